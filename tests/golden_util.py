@@ -1,0 +1,80 @@
+"""Deterministic tensors shared by tests/golden/make_golden.py and the tests, so fixtures
+hold only small inputs/outputs: every large input or weight is re-created from
+numpy RandomState(crc32(name) ^ seed), independent of iteration order."""
+import zlib
+
+import numpy as np
+import torch
+
+
+def seeded_array(name, shape, kind='randn', scale=1.0, seed=1234):
+    rs = np.random.RandomState((zlib.crc32(name.encode()) ^ seed) & 0x7FFFFFFF)
+    shape = tuple(int(s) for s in shape)
+    if kind == 'randn':
+        v = rs.randn(*shape) * scale
+    elif kind == 'rand':
+        v = rs.rand(*shape) * scale
+    else:
+        raise ValueError(kind)
+    return v.astype(np.float32)
+
+
+def seeded_tensor(name, shape, kind='randn', scale=1.0, seed=1234):
+    return torch.from_numpy(seeded_array(name, shape, kind, scale, seed))
+
+
+def seeded_state_value(name, shape, seed=1234):
+    """Non-degenerate value for a state_dict entry, chosen from its key name and shape."""
+    shape = tuple(int(s) for s in shape)
+    if name.endswith('running_var'):
+        return seeded_array(name, shape, 'rand', 0.5, seed) + 0.75
+    if name.endswith('running_mean'):
+        return seeded_array(name, shape, 'randn', 0.1, seed)
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        return seeded_array(name, shape, 'randn', float(np.sqrt(1.0 / fan_in)), seed)
+    if name.endswith('weight'):
+        return 1.0 + seeded_array(name, shape, 'randn', 0.1, seed)
+    return seeded_array(name, shape, 'randn', 0.05, seed)
+
+
+def seeded_state_dict(shapes, prefix='', seed=1234):
+    """shapes: mapping key -> shape.  Keys ending in num_batches_tracked are skipped."""
+    return {k: torch.from_numpy(seeded_state_value(prefix + k, s, seed))
+            for k, s in shapes.items() if not k.endswith('num_batches_tracked')}
+
+
+def load_seeded_(module, prefix='', seed=1234):
+    """In-place: give every parameter/buffer of `module` its seeded value (key = prefix+name)."""
+    with torch.no_grad():
+        for k, t in module.state_dict().items():
+            if k.endswith('num_batches_tracked'):
+                continue
+            t.copy_(torch.from_numpy(seeded_state_value(prefix + k, t.shape, seed)))
+    return module
+
+
+def digest(t):
+    """(sum, abs-sum, a strided sample of <=4096 values) of a tensor, float64."""
+    t = t.detach().double().reshape(-1)
+    step = max(1, t.numel() // 4096)
+    return np.array([t.sum().item(), t.abs().sum().item()]), t[::step][:4096].numpy().copy()
+
+
+def demo_inputs(B, H, W, rng, num_classes=80):
+    """Synthetic COCO-shaped batch; recipe of the reference fixture _demo_mm_inputs
+    (tests/test_models/test_forward.py:276-341) with labels in [0, num_classes)."""
+    imgs = rng.rand(B, 3, H, W).astype(np.float32)
+    gts, labels = [], []
+    for _ in range(B):
+        k = rng.randint(1, 10)
+        cx, cy, bw, bh = rng.rand(k, 4).T
+        tl_x = ((cx * W) - (W * bw / 2)).clip(0, W)
+        tl_y = ((cy * H) - (H * bh / 2)).clip(0, H)
+        br_x = ((cx * W) + (W * bw / 2)).clip(0, W)
+        br_y = ((cy * H) + (H * bh / 2)).clip(0, H)
+        gts.append(np.vstack([tl_x, tl_y, br_x, br_y]).T.astype(np.float32))
+        labels.append(rng.randint(0, num_classes, size=k).astype(np.int64))
+    return imgs, gts, labels
+
+
