@@ -46,10 +46,13 @@ def seeded_state_dict(shapes, prefix='', seed=1234):
 
 def load_seeded_(module, prefix='', seed=1234):
     """In-place: give every parameter/buffer of `module` its seeded value (key = prefix+name)."""
+    seen = set()
     with torch.no_grad():
         for k, t in module.state_dict().items():
-            if k.endswith('num_batches_tracked'):
+            # aliases of one tensor (AdptRoIExtractor.conv1 is also att.1): first key wins
+            if k.endswith('num_batches_tracked') or t.data_ptr() in seen:
                 continue
+            seen.add(t.data_ptr())
             t.copy_(torch.from_numpy(seeded_state_value(prefix + k, t.shape, seed)))
     return module
 
