@@ -1,0 +1,202 @@
+// RoIAlign forward / backward for NHWC fp32 feature maps on gfx950.
+//
+// One wavefront (64 lanes) owns one (RoI, output bin, 256-channel chunk).  The adaptive
+// sampling grid of a bin is a product grid and bilinear weights factor per axis, so the
+// bin's value is   sum_r sum_c Wy[r] * Wx[c] * feat[r][c][:]   with
+//   Wy[r] = sum_iy valid(y_iy) * max(0, 1 - |clamp(y_iy, 0, H-1) - r|)
+// i.e. every pixel of the bin's footprint is read exactly ONCE (the per-sample form of
+// mmcv's kernel reads it up to 4*grid_h*grid_w/footprint times).  Lanes run along C, so
+// every pixel access is one contiguous 1 KiB (fwd, float4/lane) or 256 B (bwd atomics,
+// the full-rate shape for global float atomics) wave transaction.  HBM-bound by design.
+#include "common.h"
+
+namespace {
+
+struct RoiGeom {
+    float start_h, start_w, bin_h, bin_w;
+    int grid_h, grid_w, batch;
+    float inv_count;
+};
+
+__device__ __forceinline__ RoiGeom roi_geometry(const float *roi, float scale, int ph, int pw,
+                                                int sampling_ratio, int aligned)
+{
+    RoiGeom g;
+    const float off = aligned ? 0.5f : 0.f;
+    g.batch = (int)roi[0];
+    g.start_w = roi[1] * scale - off;
+    g.start_h = roi[2] * scale - off;
+    const float end_w = roi[3] * scale - off, end_h = roi[4] * scale - off;
+    float rw = end_w - g.start_w, rh = end_h - g.start_h;
+    if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+    g.bin_h = rh / (float)ph;
+    g.bin_w = rw / (float)pw;
+    g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph);
+    g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw);
+    const int cnt = g.grid_h * g.grid_w;
+    g.inv_count = 1.f / (float)(cnt > 1 ? cnt : 1);
+    return g;
+}
+
+// Weight that pixel index `p` receives from the `grid` samples of one bin along one axis.
+__device__ __forceinline__ float axis_weight(float start, float bin, int bin_idx, int grid, int p,
+                                             int extent)
+{
+    float w = 0.f;
+    const float step = bin / (float)grid;
+    const float base = start + (float)bin_idx * bin;
+    for (int s = 0; s < grid; ++s) {
+        const float v = base + ((float)s + .5f) * step;
+        if (v < -1.0f || v > (float)extent) continue;
+        const float vc = fminf(fmaxf(v, 0.f), (float)(extent - 1));
+        w += fmaxf(0.f, 1.f - fabsf(vc - (float)p));
+    }
+    return w;
+}
+
+// Pixel span [lo, hi] touched by one bin along one axis (may be empty: lo > hi).
+__device__ __forceinline__ void axis_span(float start, float bin, int bin_idx, int grid, int extent,
+                                          int &lo, int &hi)
+{
+    if (grid <= 0) { lo = 0; hi = -1; return; }
+    const float step = bin / (float)grid;
+    const float base = start + (float)bin_idx * bin;
+    const float v0 = base + .5f * step, v1 = base + ((float)(grid - 1) + .5f) * step;
+    const float c0 = fminf(fmaxf(fminf(v0, v1), 0.f), (float)(extent - 1));
+    const float c1 = fminf(fmaxf(fmaxf(v0, v1), 0.f), (float)(extent - 1));
+    lo = (int)c0;
+    hi = min((int)c1 + 1, extent - 1);
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void roi_align_kernel(const float *__restrict__ feat_or_gout,
+                                                        const float *__restrict__ rois,
+                                                        const int64_t *__restrict__ roi_level, int level,
+                                                        float *__restrict__ out_or_gfeat, int64_t n,
+                                                        int B, int C, int H, int W, int ph, int pw,
+                                                        float scale, int sampling_ratio, int aligned,
+                                                        int chunks, int64_t tasks)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= tasks) return;  // whole wave exits together
+    const int chunk = (int)(task % chunks);
+    const int64_t t2 = task / chunks;
+    const int bin = (int)(t2 % (ph * pw));
+    const int64_t ri = t2 / (ph * pw);
+    const int64_t roi_row = ri;
+    if (roi_level && roi_level[ri] != (int64_t)level) return;  // wave-uniform
+    const int bi = bin / pw, bj = bin % pw;
+    const RoiGeom g = roi_geometry(rois + 5 * roi_row, scale, ph, pw, sampling_ratio, aligned);
+
+    int r0, r1, c0, c1;
+    axis_span(g.start_h, g.bin_h, bi, g.grid_h, H, r0, r1);
+    axis_span(g.start_w, g.bin_w, bj, g.grid_w, W, c0, c1);
+    if (g.batch < 0 || g.batch >= B) { r0 = 0; r1 = -1; }  // never index outside the feature map
+
+    const size_t img_base = (size_t)g.batch * H * W * C;
+    const size_t bin_off = ((size_t)roi_row * ph * pw + bin) * C;
+
+    if (!BACKWARD) {
+        const int ch = chunk * 256 + lane * 4;
+        const bool act = ch < C;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int rb = r0; rb <= r1; rb += 64) {
+            const float wy_l = (rb + lane <= r1) ? axis_weight(g.start_h, g.bin_h, bi, g.grid_h, rb + lane, H) : 0.f;
+            for (int cb = c0; cb <= c1; cb += 64) {
+                const float wx_l = (cb + lane <= c1) ? axis_weight(g.start_w, g.bin_w, bj, g.grid_w, cb + lane, W) : 0.f;
+                const int rn = min(64, r1 - rb + 1), cn = min(64, c1 - cb + 1);
+                for (int r = 0; r < rn; ++r) {
+                    const float wy = lane_bcast(wy_l, r);
+                    const float *row = feat_or_gout + img_base + ((size_t)(rb + r) * W + cb) * C + ch;
+#pragma unroll 4
+                    for (int c = 0; c < cn; ++c) {
+                        const float w = wy * lane_bcast(wx_l, c);
+                        if (act) {
+                            const float4 v = *reinterpret_cast<const float4 *>(row + (size_t)c * C);
+                            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                        }
+                    }
+                }
+            }
+        }
+        if (act) {
+            acc.x *= g.inv_count; acc.y *= g.inv_count; acc.z *= g.inv_count; acc.w *= g.inv_count;
+            *reinterpret_cast<float4 *>(out_or_gfeat + bin_off + ch) = acc;
+        }
+    } else {
+        float go[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = chunk * 256 + lane + 64 * k;
+            go[k] = ch < C ? feat_or_gout[bin_off + ch] * g.inv_count : 0.f;
+        }
+        for (int rb = r0; rb <= r1; rb += 64) {
+            const float wy_l = (rb + lane <= r1) ? axis_weight(g.start_h, g.bin_h, bi, g.grid_h, rb + lane, H) : 0.f;
+            for (int cb = c0; cb <= c1; cb += 64) {
+                const float wx_l = (cb + lane <= c1) ? axis_weight(g.start_w, g.bin_w, bj, g.grid_w, cb + lane, W) : 0.f;
+                const int rn = min(64, r1 - rb + 1), cn = min(64, c1 - cb + 1);
+                for (int r = 0; r < rn; ++r) {
+                    const float wy = lane_bcast(wy_l, r);
+                    if (wy == 0.f) continue;
+                    float *row = out_or_gfeat + img_base + ((size_t)(rb + r) * W + cb) * C + chunk * 256 + lane;
+                    for (int c = 0; c < cn; ++c) {
+                        const float w = wy * lane_bcast(wx_l, c);
+                        if (w == 0.f) continue;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (chunk * 256 + lane + 64 * k < C)
+                                atomicAdd(row + (size_t)c * C + 64 * k, w * go[k]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch(bool backward, const float *in, const float *rois, const int64_t *roi_level, int level, float *out,
+           int64_t n, int B, int C, int H, int W, int ph, int pw, float scale, int sr, int aligned,
+           void *stream)
+{
+    HTD_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0,
+                "roi_align: bad sizes n=%lld B=%d C=%d H=%d W=%d", (long long)n, B, C, H, W);
+    HTD_REQUIRE(C % 4 == 0, "roi_align: C=%d must be a multiple of 4 (float4 channel vectors)", C);
+    HTD_REQUIRE(in && rois && out, "roi_align: null pointer");
+    if (n == 0) return HTD_OK;
+    const int chunks = (C + 255) / 256;
+    const int64_t tasks = n * ph * pw * chunks;
+    const int waves_per_block = 4;
+    const int64_t blocks = htd::ceil_div(tasks, waves_per_block);
+    HTD_REQUIRE(blocks < (1ll << 31), "roi_align: too many tasks");
+    hipStream_t s = (hipStream_t)stream;
+    if (backward)
+        hipLaunchKernelGGL(roi_align_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, in, rois, roi_level, level,
+                           out, n, B, C, H, W, ph, pw, scale, sr, aligned, chunks, tasks);
+    else
+        hipLaunchKernelGGL(roi_align_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, in, rois, roi_level, level,
+                           out, n, B, C, H, W, ph, pw, scale, sr, aligned, chunks, tasks);
+    return htd::check_launch("roi_align");
+}
+
+}  // namespace
+
+extern "C" int htd_roi_align_fwd(const float *feat, const float *rois, const int64_t *roi_level, int level,
+                                 float *out, int64_t n, int B, int C, int H, int W, int ph, int pw, float spatial_scale,
+                                 int sampling_ratio, int aligned, void *stream)
+{
+    return launch(false, feat, rois, roi_level, level, out, n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio,
+                  aligned, stream);
+}
+
+extern "C" int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
+                                 float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,
+                                 float spatial_scale, int sampling_ratio, int aligned, void *stream)
+{
+    return launch(true, grad_out, rois, roi_level, level, grad_feat, n, B, C, H, W, ph, pw, spatial_scale,
+                  sampling_ratio, aligned, stream);
+}

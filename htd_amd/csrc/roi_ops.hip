@@ -1,0 +1,393 @@
+// HBM-bound per-RoI operators of the HTD head on NHWC RoI tiles [n][P][C] (P = 7*7):
+//   _fuse_global (+ alpha*enhanced), BA level fusion, global average pooling,
+//   GroupNorm(+ReLU), and the SGD-momentum update of the flat parameter buffer.
+// All are single-pass, float4-vectorised along C (16 B/lane => 1 KiB per wave access).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// ------------------------------------------------------------------ fuse_global
+__global__ __launch_bounds__(256) void fuse_global_fwd_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ rois,
+                                                              const float *__restrict__ g,
+                                                              const float *__restrict__ extra, float alpha,
+                                                              float *__restrict__ out, int64_t total4, int P,
+                                                              int C4, int B)
+{
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const int64_t i = idx / ((int64_t)P * C4);
+        int b = (int)rois[5 * i];
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+        float4 v = ld4(x + idx * 4);
+        const float4 gv = ld4(g + ((int64_t)b * C4 + c4) * 4);
+        v.x += gv.x; v.y += gv.y; v.z += gv.z; v.w += gv.w;
+        if (extra) {
+            const float4 e = ld4(extra + idx * 4);
+            v.x += alpha * e.x; v.y += alpha * e.y; v.z += alpha * e.z; v.w += alpha * e.w;
+        }
+        st4(out + idx * 4, v);
+    }
+}
+
+// grad_global[b][c] += sum_{i in image b} sum_p grad[i][p][c]; a block walks ROIS_PER_BLOCK
+// consecutive RoIs (RoIs arrive grouped by image, bbox2roi) and flushes once per image run.
+constexpr int ROIS_PER_BLOCK = 16;
+__global__ __launch_bounds__(256) void fuse_global_bwd_kernel(const float *__restrict__ grad,
+                                                              const float *__restrict__ rois,
+                                                              float *__restrict__ gg, int64_t n, int P, int C,
+                                                              int B)
+{
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t i0 = (int64_t)blockIdx.x * ROIS_PER_BLOCK;
+    const int64_t i1 = min(n, i0 + ROIS_PER_BLOCK);
+    float acc = 0.f;
+    int cur = -1;
+    for (int64_t i = i0; i < i1; ++i) {
+        int b = (int)rois[5 * i];
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+        if (b != cur) {
+            if (cur >= 0) atomicAdd(gg + (int64_t)cur * C + c, acc);
+            acc = 0.f;
+            cur = b;
+        }
+        const float *p = grad + (i * P) * C + c;
+        for (int q = 0; q < P; ++q) acc += p[(int64_t)q * C];
+    }
+    if (cur >= 0) atomicAdd(gg + (int64_t)cur * C + c, acc);
+}
+
+// ------------------------------------------------------------------ BA fusion
+struct Ptr4 { const float *p[4]; };
+struct MPtr4 { float *p[4]; };
+
+__device__ __forceinline__ void softmax4(const float *att, int L, int64_t n, int64_t i, float *w)
+{
+    float m = -INFINITY;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, att[l * n + i]);
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) { w[l] = __expf(att[l * n + i] - m); s += w[l]; }
+    const float inv = 1.f / s;
+    for (int l = 0; l < L; ++l) w[l] *= inv;
+}
+
+__device__ __forceinline__ bool on_ring(int p, int ph, int pw, int edge)
+{
+    const int y = p / pw, x = p % pw;
+    return y < edge || y >= ph - edge || x < edge || x >= pw - edge;
+}
+
+__global__ __launch_bounds__(256) void ba_fuse_fwd_kernel(Ptr4 lvl, int L, const float *__restrict__ border,
+                                                          const float *__restrict__ att, float *__restrict__ out,
+                                                          int64_t n, int ph, int pw, int C4, int edge)
+{
+    const int64_t i = blockIdx.x;
+    float w[4];
+    softmax4(att, L, n, i, w);
+    const int P = ph * pw;
+    const int64_t base = i * P * C4;
+    for (int e = threadIdx.x; e < P * C4; e += blockDim.x) {
+        const int p = e / C4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < L; ++l) {
+            const float4 v = ld4(lvl.p[l] + (base + e) * 4);
+            acc.x += w[l] * v.x; acc.y += w[l] * v.y; acc.z += w[l] * v.z; acc.w += w[l] * v.w;
+        }
+        if (on_ring(p, ph, pw, edge)) {
+            const float4 v = ld4(border + (base + e) * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        st4(out + (base + e) * 4, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_fuse_bwd_kernel(Ptr4 lvl, int L, const float *__restrict__ att,
+                                                          const float *__restrict__ go, MPtr4 glvl,
+                                                          float *__restrict__ gborder, float *__restrict__ gatt,
+                                                          int64_t n, int ph, int pw, int C4, int edge)
+{
+    const int64_t i = blockIdx.x;
+    float w[4];
+    softmax4(att, L, n, i, w);
+    const int P = ph * pw;
+    const int64_t base = i * P * C4;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = threadIdx.x; e < P * C4; e += blockDim.x) {
+        const int p = e / C4;
+        const float4 g = ld4(go + (base + e) * 4);
+        for (int l = 0; l < L; ++l) {
+            const float4 v = ld4(lvl.p[l] + (base + e) * 4);
+            d[l] += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
+            st4(glvl.p[l] + (base + e) * 4, make_float4(w[l] * g.x, w[l] * g.y, w[l] * g.z, w[l] * g.w));
+        }
+        const bool ring = on_ring(p, ph, pw, edge);
+        st4(gborder + (base + e) * 4, ring ? g : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int l = 0; l < 4; ++l) {
+        const float s = htd::wave_sum(d[l]);
+        if (lane == 0) red[wv][l] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float dl[4], dot = 0.f;
+        for (int l = 0; l < L; ++l) {
+            dl[l] = red[0][l] + red[1][l] + red[2][l] + red[3][l];
+            dot += w[l] * dl[l];
+        }
+        for (int l = 0; l < L; ++l) gatt[l * n + i] = w[l] * (dl[l] - dot);
+    }
+}
+
+// ------------------------------------------------------------------ global average pool
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float *__restrict__ x, float *__restrict__ out, int P,
+                                                      int C)
+{
+    const int64_t b = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float *p = x + b * P * C + c;
+    float acc = 0.f;
+    for (int q = 0; q < P; ++q) acc += p[(int64_t)q * C];
+    out[b * C + c] = acc / (float)P;
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ g, float *__restrict__ gx,
+                                                      int64_t total4, int P, int C4)
+{
+    const float inv = 1.f / (float)P;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const int64_t b = idx / ((int64_t)P * C4);
+        const float4 v = ld4(g + (b * C4 + c4) * 4);
+        st4(gx + idx * 4, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
+    }
+}
+
+// ------------------------------------------------------------------ GroupNorm (+ReLU)
+// One block per RoI tile; thread = channel, so a group's `cpg` channels sit on adjacent
+// lanes and the group statistics are a segmented wave reduction (cpg must divide 64).
+__global__ void gn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                              const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ mean,
+                              float *__restrict__ rstd, int P, int C, int G, float eps, int relu)
+{
+    const int64_t i = blockIdx.x;
+    const int c = threadIdx.x;
+    const int cpg = C / G;
+    const bool act = c < C;
+    const float *xp = x + i * P * C + c;
+    float s = 0.f;
+    if (act) for (int q = 0; q < P; ++q) s += xp[(int64_t)q * C];
+    for (int o = 1; o < cpg; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s / (float)(P * cpg);
+    float v = 0.f;
+    if (act) for (int q = 0; q < P; ++q) { const float d = xp[(int64_t)q * C] - mu; v += d * d; }
+    for (int o = 1; o < cpg; o <<= 1) v += __shfl_xor(v, o, 64);
+    const float rs = rsqrtf(v / (float)(P * cpg) + eps);
+    if (!act) return;
+    if (c % cpg == 0) { mean[i * G + c / cpg] = mu; rstd[i * G + c / cpg] = rs; }
+    const float ga = gamma[c] * rs, be = beta[c] - mu * gamma[c] * rs;
+    float *yp = y + i * P * C + c;
+    for (int q = 0; q < P; ++q) {
+        float t = xp[(int64_t)q * C] * ga + be;
+        if (relu) t = fmaxf(t, 0.f);
+        yp[(int64_t)q * C] = t;
+    }
+}
+
+__global__ void gn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                              const float *__restrict__ gamma, const float *__restrict__ mean,
+                              const float *__restrict__ rstd, const float *__restrict__ gy, float *__restrict__ gx,
+                              float *__restrict__ ggamma, float *__restrict__ gbeta, int P, int C, int G, int relu)
+{
+    const int64_t i = blockIdx.x;
+    const int c = threadIdx.x;
+    const int cpg = C / G;
+    const bool act = c < C;
+    const int g = act ? c / cpg : 0;
+    const float mu = mean[i * G + g], rs = rstd[i * G + g];
+    const float ga = act ? gamma[c] : 0.f;
+    const float *xp = x + i * P * C + c, *yp = y + i * P * C + c, *gp = gy + i * P * C + c;
+    float sg = 0.f, sgx = 0.f;  // sum dy, sum dy*xhat for this channel
+    if (act)
+        for (int q = 0; q < P; ++q) {
+            float d = gp[(int64_t)q * C];
+            if (relu && !(yp[(int64_t)q * C] > 0.f)) d = 0.f;
+            sg += d;
+            sgx += d * (xp[(int64_t)q * C] - mu) * rs;
+        }
+    if (act) { atomicAdd(ggamma + c, sgx); atomicAdd(gbeta + c, sg); }
+    float a = sg * ga, b = sgx * ga;
+    for (int o = 1; o < cpg; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    const float m = 1.f / (float)(P * cpg);
+    a *= m; b *= m;
+    if (!act) return;
+    float *gxp = gx + i * P * C + c;
+    for (int q = 0; q < P; ++q) {
+        float d = gp[(int64_t)q * C];
+        if (relu && !(yp[(int64_t)q * C] > 0.f)) d = 0.f;
+        const float xh = (xp[(int64_t)q * C] - mu) * rs;
+        gxp[(int64_t)q * C] = rs * (d * ga - a - xh * b);
+    }
+}
+
+// ------------------------------------------------------------------ SGD momentum
+__global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                  float *__restrict__ m, int64_t n, const float *__restrict__ lr_dev,
+                                                  float mom, float wd, float gscale)
+{
+    const float lr = *lr_dev;
+    const int64_t n4 = n >> 2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n4;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        float4 pv = ld4(p + idx * 4), mv = ld4(m + idx * 4);
+        const float4 gv = ld4(g + idx * 4);
+        mv.x = mom * mv.x + (gv.x * gscale + wd * pv.x); pv.x -= lr * mv.x;
+        mv.y = mom * mv.y + (gv.y * gscale + wd * pv.y); pv.y -= lr * mv.y;
+        mv.z = mom * mv.z + (gv.z * gscale + wd * pv.z); pv.z -= lr * mv.z;
+        mv.w = mom * mv.w + (gv.w * gscale + wd * pv.w); pv.w -= lr * mv.w;
+        st4(p + idx * 4, pv);
+        st4(m + idx * 4, mv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = n4 * 4; i < n; ++i) {
+            m[i] = mom * m[i] + (g[i] * gscale + wd * p[i]);
+            p[i] -= lr * m[i];
+        }
+}
+
+inline unsigned grid_for(int64_t work, int block = 256, int cap = 4096)
+{
+    int64_t b = htd::ceil_div(work, block);
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int htd_fuse_global_fwd(const float *roi_feats, const float *rois, const float *global_feat,
+                                   const float *extra, float alpha, float *out, int64_t n, int P, int C, int B,
+                                   void *stream)
+{
+    HTD_REQUIRE(C % 4 == 0 && P > 0 && B > 0 && n >= 0, "fuse_global: bad sizes n=%lld P=%d C=%d B=%d",
+                (long long)n, P, C, B);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(roi_feats && rois && global_feat && out, "fuse_global: null pointer");
+    const int64_t total4 = n * P * (C / 4);
+    hipLaunchKernelGGL(fuse_global_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, roi_feats,
+                       rois, global_feat, extra, alpha, out, total4, P, C / 4, B);
+    return htd::check_launch("fuse_global_fwd");
+}
+
+extern "C" int htd_fuse_global_bwd_global(const float *grad, const float *rois, float *grad_global, int64_t n, int P,
+                                          int C, int B, void *stream)
+{
+    HTD_REQUIRE(P > 0 && C > 0 && B > 0 && n >= 0, "fuse_global_bwd: bad sizes");
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(grad && rois && grad_global, "fuse_global_bwd: null pointer");
+    dim3 grid((unsigned)htd::ceil_div(n, ROIS_PER_BLOCK), (unsigned)htd::ceil_div(C, 256));
+    hipLaunchKernelGGL(fuse_global_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, grad, rois, grad_global, n, P,
+                       C, B);
+    return htd::check_launch("fuse_global_bwd");
+}
+
+extern "C" int htd_ba_fuse_fwd(const float *const *lvl, int L, const float *border, const float *att, float *out,
+                               int64_t n, int ph, int pw, int C, int edge, void *stream)
+{
+    HTD_REQUIRE(L >= 1 && L <= 4, "ba_fuse: L=%d not in [1,4]", L);
+    HTD_REQUIRE(C % 4 == 0 && ph > 0 && pw > 0 && edge >= 0, "ba_fuse: bad sizes");
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(lvl && border && att && out, "ba_fuse: null pointer");
+    Ptr4 p{};
+    for (int l = 0; l < L; ++l) p.p[l] = lvl[l];
+    hipLaunchKernelGGL(ba_fuse_fwd_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, p, L, border, att,
+                       out, n, ph, pw, C / 4, edge);
+    return htd::check_launch("ba_fuse_fwd");
+}
+
+extern "C" int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const float *grad_out,
+                               float *const *grad_lvl, float *grad_border, float *grad_att, int64_t n, int ph, int pw,
+                               int C, int edge, void *stream)
+{
+    HTD_REQUIRE(L >= 1 && L <= 4, "ba_fuse: L=%d not in [1,4]", L);
+    HTD_REQUIRE(C % 4 == 0 && ph > 0 && pw > 0 && edge >= 0, "ba_fuse: bad sizes");
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(lvl && att && grad_out && grad_lvl && grad_border && grad_att, "ba_fuse_bwd: null pointer");
+    Ptr4 p{};
+    MPtr4 g{};
+    for (int l = 0; l < L; ++l) { p.p[l] = lvl[l]; g.p[l] = grad_lvl[l]; }
+    hipLaunchKernelGGL(ba_fuse_bwd_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, p, L, att, grad_out,
+                       g, grad_border, grad_att, n, ph, pw, C / 4, edge);
+    return htd::check_launch("ba_fuse_bwd");
+}
+
+extern "C" int htd_global_avg_pool_fwd(const float *x, float *out, int64_t B, int P, int C, void *stream)
+{
+    HTD_REQUIRE(P > 0 && C > 0 && B >= 0, "global_avg_pool: bad sizes");
+    if (B == 0) return HTD_OK;
+    HTD_REQUIRE(x && out, "global_avg_pool: null pointer");
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3((unsigned)B, (unsigned)htd::ceil_div(C, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, P, C);
+    return htd::check_launch("global_avg_pool_fwd");
+}
+
+extern "C" int htd_global_avg_pool_bwd(const float *g, float *gx, int64_t B, int P, int C, void *stream)
+{
+    HTD_REQUIRE(P > 0 && C > 0 && C % 4 == 0 && B >= 0, "global_avg_pool_bwd: bad sizes");
+    if (B == 0) return HTD_OK;
+    HTD_REQUIRE(g && gx, "global_avg_pool_bwd: null pointer");
+    const int64_t total4 = B * P * (C / 4);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, g, gx, total4, P,
+                       C / 4);
+    return htd::check_launch("global_avg_pool_bwd");
+}
+
+extern "C" int htd_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                                       float *rstd, int64_t n, int P, int C, int G, float eps, int relu, void *stream)
+{
+    HTD_REQUIRE(G > 0 && C % G == 0, "group_norm: C=%d not divisible by G=%d", C, G);
+    const int cpg = C / G;
+    HTD_REQUIRE(cpg <= 64 && (cpg & (cpg - 1)) == 0, "group_norm: channels/group=%d must be a power of two <= 64", cpg);
+    HTD_REQUIRE(C <= 1024, "group_norm: C=%d > 1024", C);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(x && gamma && beta && y && mean && rstd, "group_norm: null pointer");
+    const int threads = (int)htd::ceil_div(C, 64) * 64;
+    hipLaunchKernelGGL(gn_fwd_kernel, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y,
+                       mean, rstd, P, C, G, eps, relu);
+    return htd::check_launch("group_norm_fwd");
+}
+
+extern "C" int htd_group_norm_relu_bwd(const float *x, const float *y, const float *gamma, const float *mean,
+                                       const float *rstd, const float *gy, float *gx, float *ggamma, float *gbeta,
+                                       int64_t n, int P, int C, int G, int relu, void *stream)
+{
+    HTD_REQUIRE(G > 0 && C % G == 0, "group_norm: C=%d not divisible by G=%d", C, G);
+    const int cpg = C / G;
+    HTD_REQUIRE(cpg <= 64 && (cpg & (cpg - 1)) == 0, "group_norm: channels/group=%d must be a power of two <= 64", cpg);
+    HTD_REQUIRE(C <= 1024, "group_norm: C=%d > 1024", C);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(x && y && gamma && mean && rstd && gy && gx && ggamma && gbeta, "group_norm_bwd: null pointer");
+    const int threads = (int)htd::ceil_div(C, 64) * 64;
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, y, gamma, mean,
+                       rstd, gy, gx, ggamma, gbeta, P, C, G, relu);
+    return htd::check_launch("group_norm_bwd");
+}
+
+extern "C" int htd_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, int64_t n,
+                                     const float *lr_dev, float momentum, float weight_decay, float grad_scale,
+                                     void *stream)
+{
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(param && grad && momentum_buf && lr_dev, "sgd: null pointer");
+    HTD_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0,
+                "sgd: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       momentum_buf, n, lr_dev, momentum, weight_decay, grad_scale);
+    return htd::check_launch("sgd");
+}

@@ -1,0 +1,386 @@
+"""Operator surface of the HTD hot path on MI355X.
+
+Mirrors the names, argument meaning and error behaviour of the `mmcv.ops` entry points
+the reference's modules call (mmdet/ops/__init__.py:5-16): `RoIAlign`, `roi_align`,
+`nms`, `batched_nms` (+ `soft_nms`, `DeformConv2dPack` in their own modules), and adds
+the HTD-specific fused operators (`fuse_global`, `ba_fuse`, `global_avg_pool`,
+`group_norm_relu`).  Every op calls libhtd_amd.so through the C ABI (htd_amd/capi.py);
+tensors must live on the GPU -- a CPU tensor raises NotImplementedError exactly like the
+reference wrappers (build/lib/mmdet/ops/roi_align/roi_align.py:39-40).  No fallbacks.
+
+Memory layout contract: 4-D activations are logical NCHW tensors in
+torch.channels_last memory format (= physical NHWC, what the kernels index).
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import capi
+
+CL = torch.channels_last
+
+
+def _need_gpu(t, name):
+    if not t.is_cuda:
+        raise NotImplementedError(f'{name}: only GPU tensors are supported (libhtd_amd.so has no CPU path)')
+
+
+def nhwc(x):
+    """Logical NCHW -> channels_last memory (no copy if already so)."""
+    return x.contiguous(memory_format=CL)
+
+
+def _f32(x, name):
+    if x.dtype != torch.float32:
+        raise ValueError(f'{name}: expected float32, got {x.dtype}')
+    return x
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+_S = capi.current_stream_ptr
+_P = capi.ptr
+
+
+# ====================================================================== RoIAlign
+class RoIAlignFunction(Function):
+    """mmcv.ops.roi_align semantics (avg pooling, aligned flag, sampling_ratio=0 => adaptive)."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned):
+        _need_gpu(feat, 'roi_align')
+        if rois.dim() != 2 or rois.size(1) != 5:
+            raise AssertionError('RoI must be (idx, x1, y1, x2, y2)!')  # roi_align.py:136
+        feat = nhwc(_f32(feat, 'roi_align'))
+        rois = _f32(rois, 'roi_align').contiguous()
+        ph, pw = _pair(output_size)
+        B, C, H, W = feat.shape
+        n = rois.size(0)
+        out = torch.empty((n, C, ph, pw), device=feat.device, dtype=feat.dtype).contiguous(memory_format=CL)
+        capi.call('htd_roi_align_fwd', _P(feat), _P(rois), None, 0, _P(out), n, B, C, H, W, ph, pw,
+                  float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _S())
+        ctx.save_for_backward(rois)
+        ctx.args = ((B, C, H, W), ph, pw, float(spatial_scale), int(sampling_ratio), int(bool(aligned)))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        rois, = ctx.saved_tensors
+        (B, C, H, W), ph, pw, scale, sr, aligned = ctx.args
+        grad_out = nhwc(grad_out)
+        gfeat = torch.zeros((B, C, H, W), device=grad_out.device, dtype=grad_out.dtype).contiguous(memory_format=CL)
+        capi.call('htd_roi_align_bwd', _P(grad_out), _P(rois), None, 0, _P(gfeat), rois.size(0), B, C, H, W, ph, pw,
+                  scale, sr, aligned, _S())
+        return gfeat, None, None, None, None, None
+
+
+def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True):
+    if pool_mode != 'avg':
+        raise NotImplementedError("roi_align: only pool_mode='avg' (what the HTD configs use)")
+    return RoIAlignFunction.apply(input, rois, output_size, spatial_scale, sampling_ratio, aligned)
+
+
+class RoIAlign(nn.Module):
+    """Drop-in for mmcv.ops.RoIAlign as constructed by BaseRoIExtractor.build_roi_layers
+    (roi_extractors/base_roi_extractor.py:49-56): RoIAlign(spatial_scale=1/s, output_size=7,
+    sampling_ratio=0) -> aligned=True, avg pooling."""
+
+    def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True,
+                 use_torchvision=False):
+        super().__init__()
+        self.output_size = _pair(output_size)
+        self.spatial_scale = float(spatial_scale)
+        self.sampling_ratio = int(sampling_ratio)
+        self.pool_mode = pool_mode
+        self.aligned = aligned
+
+    def forward(self, input, rois):
+        return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.pool_mode,
+                         self.aligned)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(output_size={self.output_size}, spatial_scale={self.spatial_scale}, '
+                f'sampling_ratio={self.sampling_ratio}, pool_mode={self.pool_mode}, aligned={self.aligned})')
+
+
+def roi_align_levels(feats, rois, target_lvls, output_size, scales, sampling_ratio=0, aligned=True):
+    """All pyramid levels of SingleRoIExtractor.forward (single_level_roi_extractor.py:81-99) into one
+    (N,C,ph,pw) tensor: level i's kernel only touches RoIs with target_lvls == i.  No nonzero(), no
+    scatter, no host sync.  Differentiable w.r.t. every feats[i]."""
+    return _RoIAlignLevels.apply(rois, target_lvls, output_size, tuple(scales), sampling_ratio, aligned, *feats)
+
+
+class _RoIAlignLevels(Function):
+    @staticmethod
+    def forward(ctx, rois, lvls, output_size, scales, sampling_ratio, aligned, *feats):
+        _need_gpu(feats[0], 'roi_align')
+        ph, pw = _pair(output_size)
+        rois = _f32(rois, 'roi_align').contiguous()
+        lvls = lvls.to(torch.int64).contiguous()
+        n, C = rois.size(0), feats[0].size(1)
+        out = torch.zeros((n, C, ph, pw), device=rois.device, dtype=torch.float32).contiguous(memory_format=CL)
+        shapes = []
+        for i, f in enumerate(feats):
+            f = nhwc(_f32(f, 'roi_align'))
+            B, _, H, W = f.shape
+            shapes.append((B, C, H, W))
+            capi.call('htd_roi_align_fwd', _P(f), _P(rois), _P(lvls), i, _P(out), n, B, C, H, W, ph, pw,
+                      float(scales[i]), int(sampling_ratio), int(bool(aligned)), _S())
+        ctx.save_for_backward(rois, lvls)
+        ctx.args = (shapes, ph, pw, scales, int(sampling_ratio), int(bool(aligned)))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        rois, lvls = ctx.saved_tensors
+        shapes, ph, pw, scales, sr, aligned = ctx.args
+        g = nhwc(g)
+        grads = []
+        for i, (B, C, H, W) in enumerate(shapes):
+            if not ctx.needs_input_grad[6 + i]:
+                grads.append(None)
+                continue
+            gf = torch.zeros((B, C, H, W), device=g.device, dtype=g.dtype).contiguous(memory_format=CL)
+            capi.call('htd_roi_align_bwd', _P(g), _P(rois), _P(lvls), i, _P(gf), rois.size(0), B, C, H, W, ph, pw,
+                      float(scales[i]), sr, aligned, _S())
+            grads.append(gf)
+        return (None, None, None, None, None, None, *grads)
+
+
+# ====================================================================== NMS
+def nms_sorted_mask(sorted_boxes, iou_threshold, offset=0, seg_offsets=None, max_seg=None):
+    """keep mask (uint8) for boxes already sorted by descending score.  With `seg_offsets`
+    (int64 device tensor [S+1]) the rows form S independent problems handled in one launch."""
+    _need_gpu(sorted_boxes, 'nms')
+    b = _f32(sorted_boxes, 'nms').contiguous()
+    n = b.size(0)
+    keep = torch.zeros(n, dtype=torch.uint8, device=b.device)
+    if n == 0:
+        return keep
+    if seg_offsets is None:
+        ws = torch.empty(capi.lib().htd_nms_workspace_bytes(n), dtype=torch.uint8, device=b.device)
+        capi.call('htd_nms_sorted', _P(b), _P(keep), n, float(iou_threshold), int(offset), _P(ws), _S())
+    else:
+        S = seg_offsets.numel() - 1
+        max_seg = n if max_seg is None else int(max_seg)
+        ncb = (max_seg + 63) // 64
+        ws = torch.empty(n * ncb * 8 + 64, dtype=torch.uint8, device=b.device)
+        capi.call('htd_nms_sorted_batched', _P(b), _P(seg_offsets.to(torch.int64).contiguous()), S, n, max_seg,
+                  _P(keep), float(iou_threshold), int(offset), _P(ws), _S())
+    return keep
+
+
+def nms(boxes, scores, iou_threshold, offset=0):
+    """mmcv.ops.nms: -> (dets (k,5), inds (k,) int64 in descending-score order).
+    IoU > iou_threshold suppresses; ties in score keep the lower index first."""
+    assert boxes.size(1) == 4 and boxes.size(0) == scores.size(0) and offset in (0, 1)
+    _need_gpu(boxes, 'nms')
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    keep = nms_sorted_mask(boxes[order], iou_threshold, offset)
+    inds = order[keep.bool()]
+    dets = torch.cat((boxes[inds], scores[inds].reshape(-1, 1)), dim=1)
+    return dets, inds
+
+
+def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+    """mmcv.ops.batched_nms (used at dense_heads/rpn_head.py:166-167 and
+    core/post_processing/bbox_nms.py:65).  Boxes of different `idxs` never suppress each other.
+    Like mmcv, IoUs are taken on boxes shifted by idx*(max_coordinate+1) -- the shift changes fp32
+    rounding, so it is reproduced, not optimised away -- but each class is its own segment of one
+    batched launch instead of relying on zero overlap (and there is no split_thr loop)."""
+    cfg = dict(nms_cfg)
+    class_agnostic = cfg.pop('class_agnostic', class_agnostic)
+    nms_type = cfg.pop('type', 'nms')
+    cfg.pop('split_thr', None)
+    if nms_type == 'soft_nms':
+        from .soft_nms import soft_nms_batched
+        return soft_nms_batched(boxes, scores, idxs, class_agnostic=class_agnostic, **cfg)
+    if nms_type != 'nms':
+        raise KeyError(f'unsupported nms type {nms_type}')
+    thr = cfg.pop('iou_threshold', cfg.pop('iou_thr', None))
+    offset = cfg.pop('offset', 0)
+    _need_gpu(boxes, 'batched_nms')
+    n = boxes.size(0)
+    if n == 0:
+        return boxes.new_zeros((0, 5)), boxes.new_zeros((0, ), dtype=torch.long)
+    if class_agnostic:
+        boxes_for_nms = boxes
+        idxs = torch.zeros_like(idxs)
+    else:
+        max_coordinate = boxes.max()
+        boxes_for_nms = boxes + (idxs.to(boxes) * (max_coordinate + 1))[:, None]
+    order = torch.sort(scores, descending=True, stable=True)[1]          # global score order
+    by_cls = torch.sort(idxs[order], stable=True)[1]                     # group by class, order kept inside
+    perm = order[by_cls]
+    cls_sorted = idxs[perm]
+    counts = torch.bincount(cls_sorted)
+    seg = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=boxes.device)
+    seg[1:] = torch.cumsum(counts, 0)
+    max_seg = int(counts.max().item())
+    keep_sorted = nms_sorted_mask(boxes_for_nms[perm], thr, offset, seg, max_seg)
+    keep_global = torch.zeros(n, dtype=torch.bool, device=boxes.device)
+    keep_global[perm] = keep_sorted.bool()
+    keep = order[keep_global[order]]
+    return torch.cat([boxes[keep], scores[keep, None]], -1), keep
+
+
+# ====================================================================== fuse_global
+class FuseGlobalFunction(Function):
+    """out = roi_feats + global_feat[img(roi)] (+ alpha * extra): HTDRoIHead._fuse_global
+    htd_roi_head.py:133-141, and with `extra` the x_reg + g + alpha*enhanced of htd_bbox_head.py:163,184."""
+
+    @staticmethod
+    def forward(ctx, roi_feats, rois, global_feat, extra, alpha):
+        _need_gpu(roi_feats, 'fuse_global')
+        assert roi_feats.size(0) == rois.size(0)
+        x = nhwc(_f32(roi_feats, 'fuse_global'))
+        n, C, ph, pw = x.shape
+        B = global_feat.size(0)
+        g = global_feat.reshape(B, C).contiguous()
+        e = nhwc(extra) if extra is not None else None
+        rois = rois.contiguous()
+        out = torch.empty_like(x, memory_format=CL)
+        capi.call('htd_fuse_global_fwd', _P(x), _P(rois), _P(g), _P(e), float(alpha), _P(out), n, ph * pw, C, B, _S())
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(global_feat.shape), float(alpha), extra is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        rois, = ctx.saved_tensors
+        gshape, alpha, has_extra = ctx.meta
+        go = nhwc(go)
+        n, C, ph, pw = go.shape
+        gg = None
+        if ctx.needs_input_grad[2]:
+            gg = torch.zeros(gshape[0], C, device=go.device, dtype=go.dtype)
+            capi.call('htd_fuse_global_bwd_global', _P(go), _P(rois), _P(gg), n, ph * pw, C, gshape[0], _S())
+            gg = gg.view(gshape)
+        ge = go * alpha if (has_extra and ctx.needs_input_grad[3]) else None
+        return go, None, gg, ge, None
+
+
+def fuse_global(roi_feats, rois, global_feat, extra=None, alpha=1.0):
+    return FuseGlobalFunction.apply(roi_feats, rois, global_feat, extra, alpha)
+
+
+# ====================================================================== BA fusion
+class BAFuseFunction(Function):
+    """softmax-over-levels weighted sum of the per-level RoI features + P2 border ring
+    (AdptRoIExtractor.forward adaptative_roi_extractor.py:76-91).  lvl_feats[0] is also the
+    border source (roi_layers[0] on feats[0] is evaluated once, not twice)."""
+
+    @staticmethod
+    def forward(ctx, att, edge, *lvl_feats):
+        _need_gpu(att, 'ba_fuse')
+        L = len(lvl_feats)
+        lv = [nhwc(_f32(f, 'ba_fuse')) for f in lvl_feats]
+        n, C, ph, pw = lv[0].shape
+        att = att.contiguous()
+        assert att.shape == (L, n)
+        out = torch.empty_like(lv[0], memory_format=CL)
+        arr = (ctypes.c_void_p * L)(*[f.data_ptr() for f in lv])
+        capi.call('htd_ba_fuse_fwd', arr, L, _P(lv[0]), _P(att), _P(out), n, ph, pw, C, int(edge), _S())
+        ctx.save_for_backward(att, *lv)
+        ctx.edge = int(edge)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        att, *lv = ctx.saved_tensors
+        L = len(lv)
+        n, C, ph, pw = lv[0].shape
+        go = nhwc(go)
+        glv = [torch.empty_like(f, memory_format=CL) for f in lv]
+        gborder = torch.empty_like(lv[0], memory_format=CL)
+        gatt = torch.empty_like(att)
+        arr = (ctypes.c_void_p * L)(*[f.data_ptr() for f in lv])
+        garr = (ctypes.c_void_p * L)(*[f.data_ptr() for f in glv])
+        capi.call('htd_ba_fuse_bwd', arr, L, _P(att), _P(go), garr, _P(gborder), _P(gatt), n, ph, pw, C, ctx.edge, _S())
+        glv[0] = glv[0] + gborder
+        return (gatt, None, *glv)
+
+
+def ba_fuse(att, lvl_feats, edge):
+    return BAFuseFunction.apply(att, edge, *lvl_feats)
+
+
+# ====================================================================== pooling / GN
+class GlobalAvgPoolFunction(Function):
+    """(n,C,h,w) -> (n,C,1,1) mean over h*w: nn.AdaptiveAvgPool2d(1) of SFA
+    (global_context_head.py:372,386), BA attention (adaptative_roi_extractor.py:38) and the 7x7
+    AvgPool of the reg branch (htd_bbox_head.py:122,188)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, 'global_avg_pool')
+        x = nhwc(_f32(x, 'global_avg_pool'))
+        n, C, h, w = x.shape
+        out = torch.empty(n, C, device=x.device, dtype=x.dtype)
+        capi.call('htd_global_avg_pool_fwd', _P(x), _P(out), n, h * w, C, _S())
+        ctx.shape = (n, C, h, w)
+        return out.view(n, C, 1, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        n, C, h, w = ctx.shape
+        g = g.reshape(n, C).contiguous()
+        gx = torch.empty((n, C, h, w), device=g.device, dtype=g.dtype).contiguous(memory_format=CL)
+        capi.call('htd_global_avg_pool_bwd', _P(g), _P(gx), n, h * w, C, _S())
+        return gx
+
+
+def global_avg_pool(x):
+    return GlobalAvgPoolFunction.apply(x)
+
+
+class GroupNormReLUFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, num_groups, eps, relu):
+        _need_gpu(x, 'group_norm')
+        x = nhwc(_f32(x, 'group_norm'))
+        n, C, h, w = x.shape
+        y = torch.empty_like(x, memory_format=CL)
+        mean = torch.empty(n, num_groups, device=x.device, dtype=x.dtype)
+        rstd = torch.empty_like(mean)
+        capi.call('htd_group_norm_relu_fwd', _P(x), _P(weight), _P(bias), _P(y), _P(mean), _P(rstd), n, h * w, C,
+                  int(num_groups), float(eps), int(bool(relu)), _S())
+        ctx.save_for_backward(x, y, weight, mean, rstd)
+        ctx.meta = (int(num_groups), int(bool(relu)))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        G, relu = ctx.meta
+        n, C, h, w = x.shape
+        gy = nhwc(gy)
+        gx = torch.empty_like(x, memory_format=CL)
+        gw = torch.zeros_like(weight)
+        gb = torch.zeros_like(weight)
+        capi.call('htd_group_norm_relu_bwd', _P(x), _P(y), _P(weight), _P(mean), _P(rstd), _P(gy), _P(gx), _P(gw),
+                  _P(gb), n, h * w, C, G, relu, _S())
+        return gx, gw, gb, None, None, None
+
+
+def group_norm_relu(x, weight, bias, num_groups, eps=1e-5, relu=True):
+    return GroupNormReLUFunction.apply(x, weight, bias, num_groups, eps, relu)
+
+
+# ====================================================================== optimizer step
+def sgd_momentum_step_(flat_param, flat_grad, flat_momentum, lr_dev, momentum, weight_decay, grad_scale=1.0):
+    """In-place SGD(momentum, weight_decay) on flat fp32 buffers; lr_dev is a 1-element device tensor."""
+    _need_gpu(flat_param, 'sgd')
+    capi.call('htd_sgd_momentum_step', _P(flat_param), _P(flat_grad), _P(flat_momentum), flat_param.numel(),
+              _P(lr_dev), float(momentum), float(weight_decay), float(grad_scale), _S())

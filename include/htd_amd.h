@@ -1,0 +1,136 @@
+/*
+ * htd_amd.h -- C ABI of libhtd_amd.so: the MI355X (gfx950) operator layer under the
+ * HTD detection hot path.  This is the drop-in boundary: every entry point replaces one
+ * native operator that the reference reaches through mmcv.ops / ATen.
+ *
+ * Conventions
+ *   - plain pointers + explicit sizes, no torch types; all pointers are DEVICE pointers
+ *     unless a parameter is documented as host;
+ *   - activations are NHWC fp32: feat[b][y][x][c]; RoI features are [n][ph][pw][c];
+ *     conv weights are KRSC: w[co][kh][kw][ci] (= torch channels_last of (co,ci,kh,kw));
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued there and the call
+ *     returns without synchronising; the library never allocates or frees caller-visible
+ *     memory (outputs and workspaces are caller-owned, as in the reference wrappers
+ *     build/lib/mmdet/ops/dcn/deform_conv.py:37-41, roi_align/roi_align.py:36);
+ *   - return value 0 = ok, non-zero = error; htd_last_error() gives a thread-local
+ *     message.  The Python side raises ValueError / RuntimeError from it, like the
+ *     reference wrappers (deform_conv.py:27-29, roi_align.py:39-40).  Never aborts.
+ */
+#ifndef HTD_AMD_H
+#define HTD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HTD_OK 0
+#define HTD_ERR_ARG 1
+#define HTD_ERR_LAUNCH 2
+
+const char *htd_last_error(void);
+/* ABI version, bumped on any signature change. */
+int htd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * RoIAlign (avg pooling, adaptive sampling grid when sampling_ratio == 0).
+ * Replaces mmcv.ops.RoIAlign as built at roi_extractors/base_roi_extractor.py:49-56 and
+ * called at single_level_roi_extractor.py:93, adaptative_roi_extractor.py:72,87; native
+ * signature of the reference era: roi_align_ext.forward_v2(features, rois, spatial_scale,
+ * out_h, out_w, sample_num, aligned) build/lib/mmdet/ops/roi_align/roi_align.py:28-30,
+ * backward_v2(...) :67-71.
+ *   feat  [B][H][W][C]      rois [n][5] = (batch_idx, x1, y1, x2, y2)
+ *   out   [n][ph][pw][C]    written in full
+ *   roi_level (may be NULL): int64 [n]; when given, only RoIs with roi_level[i] == level
+ *     are processed and the other rows of `out` are left untouched -- one (N,ph,pw,C)
+ *     tensor is filled level by level with no index lists and no host synchronisation
+ *     (SingleRoIExtractor.forward :81-99 does nonzero() + scatter per level).
+ * bwd: grad_feat must be zero-initialised (or hold a running sum); accumulates atomically.
+ * ---------------------------------------------------------------------------------- */
+int htd_roi_align_fwd(const float *feat, const float *rois, const int64_t *roi_level, int level,
+                      float *out, int64_t n, int B, int C, int H, int W, int ph, int pw, float spatial_scale,
+                      int sampling_ratio, int aligned, void *stream);
+int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
+                      float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,
+                      float spatial_scale, int sampling_ratio, int aligned, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Hard NMS on boxes ALREADY SORTED by descending score (ties: lower original index
+ * first).  Replaces nms_ext.nms(dets, iou_thr) build/lib/mmdet/ops/nms/nms_wrapper.py:52-55
+ * as used by batched_nms at dense_heads/rpn_head.py:166-167 and
+ * core/post_processing/bbox_nms.py:65.  Suppression rule: inter / union > iou_thr with an
+ * IEEE fp32 division (the CPU path's arithmetic), offset in {0,1}.
+ *   boxes [n][4] sorted;  keep_mask [n] uint8 out (1 = survivor);
+ *   workspace: htd_nms_workspace_bytes(n) bytes.
+ * Batched form: `segments` problems stored back to back; seg_offsets[segments+1] (device,
+ * int64) gives each problem's [begin,end) row range; one launch handles them all, no host
+ * synchronisation (per-image RPN NMS, rpn_head.py:78-168).
+ * ---------------------------------------------------------------------------------- */
+int64_t htd_nms_workspace_bytes(int64_t n_total);
+int htd_nms_sorted(const float *boxes, uint8_t *keep_mask, int64_t n, float iou_thr, int offset,
+                   void *workspace, void *stream);
+int htd_nms_sorted_batched(const float *boxes, const int64_t *seg_offsets, int segments,
+                           int64_t n_total, int64_t max_seg, uint8_t *keep_mask, float iou_thr,
+                           int offset, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * _fuse_global (htd_roi_head.py:133-141 == htd_bbox_head.py:147-155):
+ *   out[i][p][c] = roi_feats[i][p][c] + global_feat[img(i)][c],  img(i) = (int)rois[i][0]
+ * optionally + alpha * extra[i][p][c]  (x_reg + g + alpha*enhanced, htd_bbox_head.py:163,184).
+ * bwd_global: grad_global[b][c] += sum over RoIs of image b and positions of grad[i][p][c].
+ * ---------------------------------------------------------------------------------- */
+int htd_fuse_global_fwd(const float *roi_feats, const float *rois, const float *global_feat,
+                        const float *extra, float alpha, float *out, int64_t n, int P, int C,
+                        int B, void *stream);
+int htd_fuse_global_bwd_global(const float *grad, const float *rois, float *grad_global,
+                               int64_t n, int P, int C, int B, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * BA fusion (AdptRoIExtractor.forward adaptative_roi_extractor.py:76-91), given the four
+ * per-level RoIAlign outputs lvl[l] [n][P][C], the P2 border RoIAlign `border` (may alias
+ * lvl[0]) and the per-level attention logits att [L][n]:
+ *   w = softmax_l(att);  out = sum_l w[l][i]*lvl[l][i] + border[i] * ring(p)
+ * ring(p) = 1 on the outermost `edge` rows/cols of the ph x pw window, else 0.
+ * bwd: grad_lvl[l] = w[l]*g (+ ring*g added into grad_lvl[0] when border aliases lvl[0]),
+ *      grad_att[l][i] = w[l][i] * (d[l][i] - sum_m w[m][i] d[m][i]),  d[l][i] = <g[i], lvl[l][i]>.
+ * ---------------------------------------------------------------------------------- */
+int htd_ba_fuse_fwd(const float *const *lvl, int L, const float *border, const float *att,
+                    float *out, int64_t n, int ph, int pw, int C, int edge, void *stream);
+int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const float *grad_out,
+                    float *const *grad_lvl, float *grad_border, float *grad_att, int64_t n, int ph,
+                    int pw, int C, int edge, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * SFA global pooling (GlobalContextHead.forward global_context_head.py:386,
+ * nn.AdaptiveAvgPool2d(1)) and the 7x7 AvgPool of the reg branch (htd_bbox_head.py:122,188):
+ *   out[b][c] = mean over P positions of x[b][p][c];  bwd: gx[b][p][c] = g[b][c] / P.
+ * ---------------------------------------------------------------------------------- */
+int htd_global_avg_pool_fwd(const float *x, float *out, int64_t B, int P, int C, void *stream);
+int htd_global_avg_pool_bwd(const float *g, float *gx, int64_t B, int P, int C, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm + ReLU on NHWC RoI tiles (GN36 over 576 channels, htd_bbox_head.py:48,89,111):
+ *   x [n][P][C], G groups; saves mean/rstd [n][G] for backward.
+ * ---------------------------------------------------------------------------------- */
+int htd_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y,
+                            float *mean, float *rstd, int64_t n, int P, int C, int G, float eps,
+                            int relu, void *stream);
+int htd_group_norm_relu_bwd(const float *x, const float *y, const float *gamma, const float *mean,
+                            const float *rstd, const float *gy, float *gx, float *ggamma,
+                            float *gbeta, int64_t n, int P, int C, int G, int relu, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
+ * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):
+ *   g = grad*grad_scale + wd*p ; m = momentum*m + g ; p -= lr*m.     lr is a device scalar
+ *   so LR warm-up needs no re-capture.
+ * ---------------------------------------------------------------------------------- */
+int htd_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, int64_t n,
+                          const float *lr_dev, float momentum, float weight_decay,
+                          float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HTD_AMD_H */

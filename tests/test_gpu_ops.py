@@ -1,0 +1,230 @@
+"""Parity of the HIP operators (through the C ABI) against the CPU oracle, on a real MI355X.
+Bit-exact for index work (NMS keep sets / order), fp32 tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def rand_rois(gen, n, B, H, W, stride, big=False):
+    img_w, img_h = W * stride, H * stride
+    size = torch.rand(n, generator=gen) * (0.9 if big else 0.3) * min(img_w, img_h) + 2
+    ar = torch.exp(torch.rand(n, generator=gen) - 0.5)
+    w, h = size * ar, size / ar
+    cx, cy = torch.rand(n, generator=gen) * img_w, torch.rand(n, generator=gen) * img_h
+    b = torch.randint(0, B, (n, ), generator=gen).float()
+    rois = torch.stack([b, (cx - w / 2).clamp(0, img_w), (cy - h / 2).clamp(0, img_h), (cx + w / 2).clamp(0, img_w),
+                        (cy + h / 2).clamp(0, img_h)], 1)
+    return rois
+
+
+@pytest.mark.parametrize('C,H,W,stride,n,big', [(256, 40, 56, 4, 64, False), (256, 20, 28, 8, 33, True),
+                                                (8, 9, 7, 16, 20, True), (512, 12, 12, 32, 5, True)])
+def test_roi_align_fwd_bwd(dev, C, H, W, stride, n, big):
+    from htd_amd import mmcv_ops as M
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(C + n)
+    feat = torch.randn(2, C, H, W, generator=gen)
+    rois = rand_rois(gen, n, 2, H, W, stride, big)
+    rois[0, 1:] = torch.tensor([0., 0., 0., 0.])                      # degenerate: zero-size box
+    rois[1, 1:] = torch.tensor([0., 0., W * stride, H * stride])      # whole image
+    ref = O.roi_align_fwd(feat, rois, 7, 1.0 / stride, 0, True)
+    f = cl(feat.to(dev)).requires_grad_()
+    out = M.roi_align(f, rois.to(dev), 7, 1.0 / stride, 0, 'avg', True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)   # fp32, separable-weight summation order
+    go = torch.randn(out.shape, generator=gen)
+    out.backward(go.to(dev))
+    gref = O.roi_align_bwd(go, rois, feat.shape, 1.0 / stride, 0, True)
+    torch.testing.assert_close(f.grad.cpu(), gref, rtol=1e-4, atol=1e-4)
+    # aligned=False and fixed sampling_ratio
+    ref2 = O.roi_align_fwd(feat, rois, 7, 1.0 / stride, 2, False)
+    out2 = M.roi_align(f.detach(), rois.to(dev), 7, 1.0 / stride, 2, 'avg', False)
+    torch.testing.assert_close(out2.cpu(), ref2, rtol=1e-5, atol=2e-5)
+
+
+def test_roi_align_rejects_cpu_and_bad_rois(dev):
+    from htd_amd import mmcv_ops as M
+    with pytest.raises(NotImplementedError):
+        M.roi_align(torch.zeros(1, 4, 4, 4), torch.zeros(1, 5), 7)
+    with pytest.raises(AssertionError):
+        M.roi_align(torch.zeros(1, 4, 4, 4, device=dev), torch.zeros(1, 4, device=dev), 7)
+    with pytest.raises(ValueError):  # C not a multiple of 4: C-ABI argument error -> ValueError
+        M.roi_align(torch.zeros(1, 3, 4, 4, device=dev), torch.zeros(1, 5, device=dev), 7)
+    out = M.roi_align(torch.zeros(1, 4, 4, 4, device=dev), torch.zeros(0, 5, device=dev), 7)   # empty input
+    assert out.shape == (0, 4, 7, 7)
+
+
+def test_roi_align_levels_matches_per_level(dev):
+    from htd_amd import mmcv_ops as M
+    from oracle import boxes as B, detector as D
+    gen = torch.Generator().manual_seed(3)
+    feats = [torch.randn(2, 256, 64 // s, 96 // s, generator=gen) for s in (1, 2, 4, 8)]
+    rois = rand_rois(gen, 150, 2, 64, 96, 4, big=True)
+    ref = D.single_roi_extract(feats, rois)
+    lv = B.map_roi_levels(rois, 4)
+    fd = [cl(f.to(dev)).requires_grad_() for f in feats]
+    out = M.roi_align_levels(fd, rois.to(dev), lv.to(dev), 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+    go = torch.randn(out.shape, generator=gen)
+    out.backward(go.to(dev))
+    fr = [f.clone().requires_grad_() for f in feats]
+    (D.single_roi_extract(fr, rois) * go).sum().backward()
+    for a, b in zip(fd, fr):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+
+
+def clustered_boxes(gen, n, span=300.):
+    k = max(1, n // 6)
+    centers = torch.rand(k, 2, generator=gen) * span
+    c = centers[torch.randint(0, k, (n, ), generator=gen)] + torch.randn(n, 2, generator=gen) * 4
+    wh = torch.rand(n, 2, generator=gen) * 40 + 8
+    return torch.cat([c - wh / 2, c + wh / 2], 1)
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 500, 3000])
+@pytest.mark.parametrize('thr', [0.5, 0.7])
+def test_nms_bit_exact(dev, n, thr):
+    from htd_amd import mmcv_ops as M
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(n)
+    boxes = clustered_boxes(gen, n)
+    scores = torch.rand(n, generator=gen)
+    if n > 10:
+        scores[5] = scores[3]          # exact score tie: lower index first
+        boxes[7] = boxes[2]            # duplicate box
+    dets_r, keep_r = O.nms(boxes, scores, thr)
+    dets, keep = M.nms(boxes.to(dev), scores.to(dev), thr)
+    assert torch.equal(keep.cpu(), keep_r)
+    assert torch.equal(dets.cpu(), dets_r)
+    _, keep1 = M.nms(boxes.to(dev), scores.to(dev), thr, offset=1)
+    assert torch.equal(keep1.cpu(), O.nms(boxes, scores, thr, 1)[1])
+
+
+def test_nms_empty(dev):
+    from htd_amd import mmcv_ops as M
+    dets, keep = M.nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev), 0.5)
+    assert dets.shape == (0, 5) and keep.numel() == 0
+
+
+@pytest.mark.parametrize('n,ncls', [(800, 5), (5000, 80), (12000, 80)])
+def test_batched_nms_bit_exact(dev, n, ncls):
+    """incl. n >= 10000 where mmcv switches to its per-class loop (same keep set and order)."""
+    from htd_amd import mmcv_ops as M
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(n)
+    boxes = clustered_boxes(gen, n, span=800.)
+    scores = torch.rand(n, generator=gen)
+    idxs = torch.randint(0, ncls, (n, ), generator=gen)
+    cfg = dict(type='nms', iou_threshold=0.5)
+    dets_r, keep_r = O.batched_nms(boxes, scores, idxs, cfg)
+    dets, keep = M.batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), cfg)
+    assert torch.equal(keep.cpu(), keep_r)
+    assert torch.equal(dets.cpu(), dets_r)
+
+
+def test_fuse_global(dev):
+    from htd_amd import mmcv_ops as M
+    from oracle import detector as D
+    gen = torch.Generator().manual_seed(0)
+    n, C = 37, 256
+    x = torch.randn(n, C, 7, 7, generator=gen)
+    e = torch.randn(n, C, 7, 7, generator=gen)
+    g = torch.randn(3, C, 1, 1, generator=gen)
+    rois = torch.cat([torch.sort(torch.randint(0, 3, (n, 1), generator=gen).float(), 0)[0], torch.rand(n, 4, generator=gen)], 1)
+    xr, er, gr = x.clone().requires_grad_(), e.clone().requires_grad_(), g.clone().requires_grad_()
+    ref = D.fuse_global(xr, gr, rois) + 0.5 * er
+    xd, ed, gd = cl(x.to(dev)).requires_grad_(), cl(e.to(dev)).requires_grad_(), g.to(dev).requires_grad_()
+    out = M.fuse_global(xd, rois.to(dev), gd, ed, 0.5)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    go = torch.randn(out.shape, generator=gen)
+    ref.backward(go)
+    out.backward(go.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ed.grad.cpu(), er.grad, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
+    out2 = M.fuse_global(xd.detach(), rois.to(dev), gd.detach())
+    torch.testing.assert_close(out2.cpu(), D.fuse_global(x, g, rois), rtol=1e-6, atol=1e-6)
+
+
+def test_ba_fuse(dev):
+    from htd_amd import mmcv_ops as M
+    gen = torch.Generator().manual_seed(1)
+    n, C, L = 19, 256, 4
+    lv = [torch.randn(n, C, 7, 7, generator=gen) for _ in range(L)]
+    att = torch.randn(L, n, generator=gen)
+    lr = [t.clone().requires_grad_() for t in lv]
+    ar = att.clone().requires_grad_()
+    w = ar.softmax(0)
+    mask = torch.ones(7, 7)
+    mask[1:-1, 1:-1] = 0
+    ref = sum(w[l].view(n, 1, 1, 1) * lr[l] for l in range(L)) + lr[0] * mask   # adaptative_roi_extractor.py:80-91
+    ld = [cl(t.to(dev)).requires_grad_() for t in lv]
+    ad = att.to(dev).requires_grad_()
+    out = M.ba_fuse(ad, ld, 1)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+    go = torch.randn(out.shape, generator=gen)
+    ref.backward(go)
+    out.backward(go.to(dev))
+    for a, b in zip(ld, lr):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ad.grad.cpu(), ar.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_global_avg_pool_and_group_norm(dev):
+    from htd_amd import mmcv_ops as M
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(21, 576, 7, 7, generator=gen)
+    xr = x.clone().requires_grad_()
+    xd = cl(x.to(dev)).requires_grad_()
+    ref = F.adaptive_avg_pool2d(xr, 1)
+    out = M.global_avg_pool(xd)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+    go = torch.randn(ref.shape, generator=gen)
+    ref.backward(go)
+    out.backward(go.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-6, atol=1e-7)
+    # GN36 + ReLU (htd_bbox_head.py:48,89,111)
+    gamma, beta = torch.randn(576, generator=gen), torch.randn(576, generator=gen)
+    for relu in (True, False):
+        xr = x.clone().requires_grad_()
+        gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        ref = F.group_norm(xr, 36, gr, br, 1e-5)
+        ref = F.relu(ref) if relu else ref
+        xd = cl(x.to(dev)).requires_grad_()
+        gd, bd = gamma.to(dev).requires_grad_(), beta.to(dev).requires_grad_()
+        out = M.group_norm_relu(xd, gd, bd, 36, 1e-5, relu)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+        go = torch.randn(ref.shape, generator=gen)
+        ref.backward(go)
+        out.backward(go.to(dev))
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(bd.grad.cpu(), br.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_sgd_step(dev):
+    from htd_amd import mmcv_ops as M
+    gen = torch.Generator().manual_seed(4)
+    n = 100003
+    p, g = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    pr = p.clone().requires_grad_()
+    opt = torch.optim.SGD([pr], lr=0.02, momentum=0.9, weight_decay=1e-4)
+    pd, md = p.to(dev), torch.zeros(n, device=dev)
+    lr = torch.tensor([0.02], device=dev)
+    for _ in range(3):
+        pr.grad = g.clone()
+        opt.step()
+        M.sgd_momentum_step_(pd, g.to(dev), md, lr, 0.9, 1e-4)
+    torch.testing.assert_close(pd.cpu(), pr.detach(), rtol=1e-6, atol=1e-6)
