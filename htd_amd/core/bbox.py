@@ -1,0 +1,282 @@
+"""Box arithmetic of the HTD path on the device: IoU, MaxIoU assignment, random sampling,
+delta coding.  Interfaces follow the reference classes so configs build them by name:
+
+  bbox_overlaps / BboxOverlaps2D   mmdet/core/bbox/iou_calculators/iou2d_calculator.py:43-158
+  MaxIoUAssigner / AssignResult    mmdet/core/bbox/assigners/max_iou_assigner.py:10-212, assign_result.py:190-204
+  RandomSampler / SamplingResult   mmdet/core/bbox/samplers/{random_sampler,base_sampler,sampling_result}.py
+  DeltaXYWHBBoxCoder               mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:9-204
+  bbox2roi / bbox2result           mmdet/core/bbox/transforms.py:58-116
+
+Differences in *how* (not what): the per-gt Python loop of low-quality matching is one vectorised
+max-reduction; the RNG behind sampling is pluggable (`set_randperm`) so parity tests can replay the
+CPU generator the reference's CPU path would have used.
+"""
+import numpy as np
+import torch
+
+from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, BBOX_SAMPLERS, IOU_CALCULATORS, build_iou_calculator
+
+
+# ------------------------------------------------------------------ IoU
+def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
+    assert mode in ('iou', 'iof'), f'Unsupported mode {mode}'
+    assert bboxes1.size(-1) == 4 or bboxes1.size(0) == 0
+    assert bboxes2.size(-1) == 4 or bboxes2.size(0) == 0
+    rows, cols = bboxes1.size(0), bboxes2.size(0)
+    if is_aligned:
+        assert rows == cols
+    if rows * cols == 0:
+        return bboxes1.new_zeros((rows, ) if is_aligned else (rows, cols))
+    area1 = (bboxes1[:, 2] - bboxes1[:, 0]) * (bboxes1[:, 3] - bboxes1[:, 1])
+    area2 = (bboxes2[:, 2] - bboxes2[:, 0]) * (bboxes2[:, 3] - bboxes2[:, 1])
+    if is_aligned:
+        wh = (torch.min(bboxes1[:, 2:], bboxes2[:, 2:]) - torch.max(bboxes1[:, :2], bboxes2[:, :2])).clamp(min=0)
+        overlap = wh[:, 0] * wh[:, 1]
+        union = area1 + area2 - overlap if mode == 'iou' else area1
+    else:
+        wh = (torch.min(bboxes1[:, None, 2:], bboxes2[None, :, 2:]) -
+              torch.max(bboxes1[:, None, :2], bboxes2[None, :, :2])).clamp(min=0)
+        overlap = wh[..., 0] * wh[..., 1]
+        union = area1[:, None] + area2[None, :] - overlap if mode == 'iou' else area1[:, None]
+    union = torch.max(union, union.new_tensor([eps]))
+    return overlap / union
+
+
+@IOU_CALCULATORS.register_module()
+class BboxOverlaps2D:
+    def __call__(self, bboxes1, bboxes2, mode='iou', is_aligned=False):
+        assert bboxes1.size(-1) in [0, 4, 5] and bboxes2.size(-1) in [0, 4, 5]
+        if bboxes2.size(-1) == 5:
+            bboxes2 = bboxes2[..., :4]
+        if bboxes1.size(-1) == 5:
+            bboxes1 = bboxes1[..., :4]
+        return bbox_overlaps(bboxes1, bboxes2, mode, is_aligned)
+
+    def __repr__(self):
+        return self.__class__.__name__ + '()'
+
+
+# ------------------------------------------------------------------ assigner
+class AssignResult:
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+    def add_gt_(self, gt_labels):
+        self_inds = torch.arange(1, len(gt_labels) + 1, dtype=torch.long, device=gt_labels.device)
+        self.gt_inds = torch.cat([self_inds, self.gt_inds])
+        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(len(gt_labels)), self.max_overlaps])
+        if self.labels is not None:
+            self.labels = torch.cat([gt_labels, self.labels])
+
+
+@BBOX_ASSIGNERS.register_module()
+class MaxIoUAssigner:
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
+                 iou_calculator=dict(type='BboxOverlaps2D')):
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = pos_iou_thr, neg_iou_thr, min_pos_iou
+        self.gt_max_assign_all, self.ignore_iof_thr = gt_max_assign_all, ignore_iof_thr
+        self.ignore_wrt_candidates, self.gpu_assign_thr = ignore_wrt_candidates, gpu_assign_thr
+        self.match_low_quality = match_low_quality
+        self.iou_calculator = build_iou_calculator(iou_calculator)
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        overlaps = self.iou_calculator(gt_bboxes, bboxes)
+        if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
+                and bboxes.numel() > 0):
+            if self.ignore_wrt_candidates:
+                ignore_max, _ = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)
+            else:
+                ignore_max, _ = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)
+            overlaps[:, ignore_max > self.ignore_iof_thr] = -1
+        return self.assign_wrt_overlaps(overlaps, gt_labels)
+
+    def assign_wrt_overlaps(self, overlaps, gt_labels=None):
+        num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
+        if num_gts == 0 or num_bboxes == 0:
+            assigned = overlaps.new_full((num_bboxes, ), 0 if num_gts == 0 else -1, dtype=torch.long)
+            labels = None if gt_labels is None else overlaps.new_full((num_bboxes, ), -1, dtype=torch.long)
+            return AssignResult(num_gts, assigned, overlaps.new_zeros((num_bboxes, )), labels)
+        max_overlaps, argmax_overlaps = overlaps.max(dim=0)
+        assigned = overlaps.new_full((num_bboxes, ), -1, dtype=torch.long)
+        if isinstance(self.neg_iou_thr, float):
+            neg = (max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr)
+        else:
+            assert len(self.neg_iou_thr) == 2
+            neg = (max_overlaps >= self.neg_iou_thr[0]) & (max_overlaps < self.neg_iou_thr[1])
+        assigned = torch.where(neg, torch.zeros_like(assigned), assigned)
+        assigned = torch.where(max_overlaps >= self.pos_iou_thr, argmax_overlaps + 1, assigned)
+        if self.match_low_quality:
+            # max_iou_assigner.py:184-199 loops gts in order, later gts overwrite earlier ones: for every box
+            # take the LAST gt (highest index) that qualifies.
+            gt_max, gt_argmax = overlaps.max(dim=1)
+            ok = gt_max >= self.min_pos_iou
+            ids = torch.arange(1, num_gts + 1, device=overlaps.device)
+            if self.gt_max_assign_all:
+                hit = (overlaps == gt_max[:, None]) & ok[:, None]
+                low = (hit * ids[:, None]).max(dim=0)[0]
+            else:
+                # assigned[gt_argmax[i]] = i + 1 in ascending i: on duplicates the highest gt index wins
+                low = torch.zeros_like(assigned).scatter_reduce(0, gt_argmax[ok], ids[ok], 'amax', include_self=True)
+            assigned = torch.where(low > 0, low, assigned)
+        labels = None
+        if gt_labels is not None:
+            pos = assigned > 0
+            labels = torch.where(pos, gt_labels[(assigned - 1).clamp(min=0)], assigned.new_full((1, ), -1))
+        return AssignResult(num_gts, assigned, max_overlaps, labels=labels)
+
+
+# ------------------------------------------------------------------ sampler
+def _device_randperm(n, device):
+    return torch.randperm(n, device=device)
+
+
+_randperm = _device_randperm
+
+
+def set_randperm(fn=None):
+    """Replace the permutation source of RandomSampler: fn(n, device) -> int64 permutation.
+    None restores torch.randperm on the tensor's device (random_sampler.py:54).  Parity tests install
+    `lambda n, dev: torch.randperm(n).to(dev)` to replay the CPU generator."""
+    global _randperm
+    _randperm = fn or _device_randperm
+
+
+class SamplingResult:
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        if gt_bboxes.numel() == 0:
+            assert self.pos_assigned_gt_inds.numel() == 0
+            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
+        else:
+            self.pos_gt_bboxes = gt_bboxes.view(-1, 4)[self.pos_assigned_gt_inds, :]
+        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+
+    @property
+    def bboxes(self):
+        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+
+
+@BBOX_SAMPLERS.register_module()
+class RandomSampler:
+    def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
+        self.num, self.pos_fraction, self.neg_pos_ub = num, pos_fraction, neg_pos_ub
+        self.add_gt_as_proposals = add_gt_as_proposals
+        self.pos_sampler = self.neg_sampler = self
+
+    @staticmethod
+    def random_choice(gallery, num):
+        assert len(gallery) >= num
+        perm = _randperm(gallery.numel(), gallery.device)[:num]
+        return gallery[perm]
+
+    def _sample_pos(self, assign_result, num_expected, **kwargs):
+        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(1)
+        return pos_inds if pos_inds.numel() <= num_expected else self.random_choice(pos_inds, num_expected)
+
+    def _sample_neg(self, assign_result, num_expected, **kwargs):
+        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(1)
+        return neg_inds if len(neg_inds) <= num_expected else self.random_choice(neg_inds, num_expected)
+
+    def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kwargs):
+        if len(bboxes.shape) < 2:
+            bboxes = bboxes[None, :]
+        bboxes = bboxes[:, :4]
+        gt_flags = bboxes.new_zeros((bboxes.shape[0], ), dtype=torch.uint8)
+        if self.add_gt_as_proposals and len(gt_bboxes) > 0:
+            if gt_labels is None:
+                raise ValueError('gt_labels must be given when add_gt_as_proposals is True')
+            bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+            assign_result.add_gt_(gt_labels)
+            gt_flags = torch.cat([bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8), gt_flags])
+        num_expected_pos = int(self.num * self.pos_fraction)
+        pos_inds = self._sample_pos(assign_result, num_expected_pos, bboxes=bboxes, **kwargs)
+        pos_inds = torch.sort(pos_inds)[0]           # == .unique(): indices are distinct already
+        num_expected_neg = self.num - pos_inds.numel()
+        if self.neg_pos_ub >= 0:
+            num_expected_neg = min(num_expected_neg, int(self.neg_pos_ub * max(1, pos_inds.numel())))
+        neg_inds = self._sample_neg(assign_result, num_expected_neg, bboxes=bboxes, **kwargs)
+        neg_inds = torch.sort(neg_inds)[0]
+        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+
+
+# ------------------------------------------------------------------ coder
+def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+    assert proposals.size() == gt.size()
+    proposals, gt = proposals.float(), gt.float()
+    pw = proposals[..., 2] - proposals[..., 0]
+    ph = proposals[..., 3] - proposals[..., 1]
+    gw = gt[..., 2] - gt[..., 0]
+    gh = gt[..., 3] - gt[..., 1]
+    dx = ((gt[..., 0] + gt[..., 2]) * 0.5 - (proposals[..., 0] + proposals[..., 2]) * 0.5) / pw
+    dy = ((gt[..., 1] + gt[..., 3]) * 0.5 - (proposals[..., 1] + proposals[..., 3]) * 0.5) / ph
+    deltas = torch.stack([dx, dy, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
+    return deltas.sub_(deltas.new_tensor(means).unsqueeze(0)).div_(deltas.new_tensor(stds).unsqueeze(0))
+
+
+def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
+               wh_ratio_clip=16 / 1000, clip_border=True):
+    reps = deltas.size(1) // 4
+    means = deltas.new_tensor(means).view(1, -1).repeat(1, reps)
+    stds = deltas.new_tensor(stds).view(1, -1).repeat(1, reps)
+    d = deltas * stds + means
+    dx, dy, dw, dh = d[:, 0::4], d[:, 1::4], d[:, 2::4], d[:, 3::4]
+    max_ratio = np.abs(np.log(wh_ratio_clip))
+    dw = dw.clamp(min=-max_ratio, max=max_ratio)
+    dh = dh.clamp(min=-max_ratio, max=max_ratio)
+    px = ((rois[:, 0] + rois[:, 2]) * 0.5).unsqueeze(1)
+    py = ((rois[:, 1] + rois[:, 3]) * 0.5).unsqueeze(1)
+    pw = (rois[:, 2] - rois[:, 0]).unsqueeze(1)
+    ph = (rois[:, 3] - rois[:, 1]).unsqueeze(1)
+    gw, gh = pw * dw.exp(), ph * dh.exp()
+    gx, gy = px + pw * dx, py + ph * dy
+    x1, y1, x2, y2 = gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5
+    if clip_border and max_shape is not None:
+        x1 = x1.clamp(min=0, max=max_shape[1])
+        y1 = y1.clamp(min=0, max=max_shape[0])
+        x2 = x2.clamp(min=0, max=max_shape[1])
+        y2 = y2.clamp(min=0, max=max_shape[0])
+    return torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
+
+
+@BBOX_CODERS.register_module()
+class DeltaXYWHBBoxCoder:
+    def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), clip_border=True):
+        self.means, self.stds, self.clip_border = target_means, target_stds, clip_border
+
+    def encode(self, bboxes, gt_bboxes):
+        assert bboxes.size(0) == gt_bboxes.size(0)
+        assert bboxes.size(-1) == gt_bboxes.size(-1) == 4
+        return bbox2delta(bboxes, gt_bboxes, self.means, self.stds)
+
+    def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
+        assert pred_bboxes.size(0) == bboxes.size(0)
+        return delta2bbox(bboxes, pred_bboxes, self.means, self.stds, max_shape, wh_ratio_clip, self.clip_border)
+
+
+# ------------------------------------------------------------------ transforms
+def bbox2roi(bbox_list):
+    rois_list = []
+    for img_id, bboxes in enumerate(bbox_list):
+        if bboxes.size(0) > 0:
+            rois_list.append(torch.cat([bboxes.new_full((bboxes.size(0), 1), img_id), bboxes[:, :4]], dim=-1))
+        else:
+            rois_list.append(bboxes.new_zeros((0, 5)))
+    return torch.cat(rois_list, 0)
+
+
+def bbox2result(bboxes, labels, num_classes):
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)]
+    if isinstance(bboxes, torch.Tensor):
+        bboxes = bboxes.detach().cpu().numpy()
+        labels = labels.detach().cpu().numpy()
+    return [bboxes[labels == i, :] for i in range(num_classes)]

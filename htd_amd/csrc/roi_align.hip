@@ -166,8 +166,8 @@ int launch(bool backward, const float *in, const float *rois, const int64_t *roi
     HTD_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0,
                 "roi_align: bad sizes n=%lld B=%d C=%d H=%d W=%d", (long long)n, B, C, H, W);
     HTD_REQUIRE(C % 4 == 0, "roi_align: C=%d must be a multiple of 4 (float4 channel vectors)", C);
-    HTD_REQUIRE(in && rois && out, "roi_align: null pointer");
     if (n == 0) return HTD_OK;
+    HTD_REQUIRE(in && rois && out, "roi_align: null pointer");
     const int chunks = (C + 255) / 256;
     const int64_t tasks = n * ph * pw * chunks;
     const int waves_per_block = 4;

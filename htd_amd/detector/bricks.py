@@ -1,0 +1,149 @@
+"""Layer bricks the reference gets from mmcv.cnn: `build_conv_layer`, `build_norm_layer`, `ConvModule`
+and the init helpers (call sites: backbones/resnet.py:3-4,138-194, necks/fpn.py:3,69-87,
+bbox_heads/htd_bbox_head.py:77-113, global_context_head.py:358-368).  Parameters keep the reference's
+names and logical shapes (state_dict compatibility); conv weights are held in channels_last memory,
+i.e. physically [Co][kh][kw][Ci], the layout the HIP kernels index.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import mmcv_ops as M
+from ..registry import CONV_LAYERS
+
+CL = torch.channels_last
+
+
+def dense_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
+    """y = act(conv2d(x, w) + bias + residual) on NHWC activations / KRSC weights."""
+    from .. import dense
+    return dense.conv2d(x, weight, bias, stride, padding, dilation, relu, residual)
+
+
+@CONV_LAYERS.register_module('Conv')
+@CONV_LAYERS.register_module('Conv2d')
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d with KRSC (channels_last) weight storage and the fused bias/ReLU/residual epilogue."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert self.groups == 1 and self.padding_mode == 'zeros'
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+        return self
+
+    def forward(self, x, relu=False, residual=None, weight=None, bias=None):
+        w = self.weight if weight is None else weight
+        b = self.bias if bias is None else bias
+        return dense_conv2d(x, w, b, self.stride[0], self.padding[0], self.dilation[0], relu, residual)
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    cfg_ = dict(type='Conv2d') if cfg is None else dict(cfg)
+    layer_type = cfg_.pop('type')
+    cls = CONV_LAYERS.get(layer_type)
+    if cls is None:
+        raise KeyError(f'Unrecognized conv type {layer_type}')
+    return cls(*args, **kwargs, **cfg_)
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    """-> (name, layer) with mmcv's abbreviations ('bn1', 'gn')."""
+    cfg_ = dict(cfg)
+    layer_type = cfg_.pop('type')
+    requires_grad = cfg_.pop('requires_grad', True)
+    cfg_.setdefault('eps', 1e-5)
+    if layer_type in ('BN', 'BN2d'):
+        layer, abbr = nn.BatchNorm2d(num_features, **cfg_), 'bn'
+    elif layer_type == 'GN':
+        assert 'num_groups' in cfg_
+        layer, abbr = nn.GroupNorm(num_channels=num_features, **cfg_), 'gn'
+    else:
+        raise KeyError(f'Unrecognized norm type {layer_type}')
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return abbr + str(postfix), layer
+
+
+def frozen_bn_fold(conv_weight, bn):
+    """Eval-mode BatchNorm (norm_eval=True, backbones/resnet.py:640-649) folded into the preceding conv:
+    w' = w * s, b' = beta - mean * s with s = gamma / sqrt(var + eps).  Written with differentiable tensor
+    ops, so autograd returns exactly d/dgamma, d/dbeta, d/dw of the unfused conv->BN pair."""
+    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    return conv_weight * s.view(-1, 1, 1, 1), bn.bias - bn.running_mean * s
+
+
+def kaiming_init(module, a=0, mode='fan_out', nonlinearity='relu', bias=0, distribution='normal'):
+    if distribution == 'uniform':
+        nn.init.kaiming_uniform_(module.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+    else:
+        nn.init.kaiming_normal_(module.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def xavier_init(module, gain=1, bias=0, distribution='normal'):
+    if distribution == 'uniform':
+        nn.init.xavier_uniform_(module.weight, gain=gain)
+    else:
+        nn.init.xavier_normal_(module.weight, gain=gain)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def normal_init(module, mean=0, std=1, bias=0):
+    nn.init.normal_(module.weight, mean, std)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> ReLU block (mmcv.cnn.ConvModule with order conv/norm/act, bias='auto').
+    GroupNorm+ReLU runs as one fused HIP kernel; a ReLU with no norm is fused into the conv epilogue."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True, **unused):
+        super().__init__()
+        assert act_cfg is None or act_cfg['type'] == 'ReLU'
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.with_bias = bias
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation, groups=groups, bias=bias)
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            self.activate = nn.ReLU(inplace=inplace)
+        self.init_weights()
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name)
+
+    def init_weights(self):
+        kaiming_init(self.conv, a=0, nonlinearity='relu')
+        if self.with_norm:
+            constant_init(self.norm, 1, bias=0)
+
+    def forward(self, x):
+        if not self.with_norm:
+            return self.conv(x, relu=self.with_activation)
+        x = self.conv(x)
+        norm = self.norm
+        if isinstance(norm, nn.GroupNorm):
+            return M.group_norm_relu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, self.with_activation)
+        x = norm(x)
+        return F.relu(x) if self.with_activation else x

@@ -1,0 +1,55 @@
+"""FPN neck (mmdet/models/necks/fpn.py:9-216): 1x1 laterals, nearest top-down add, 3x3 output convs,
+P6 = stride-2 subsample of P5.  The HTD configs use the plain variant (no extra convs, no norm)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..registry import NECKS
+from .bricks import ConvModule, xavier_init
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False,
+                 extra_convs_on_inputs=True, relu_before_extra_convs=False, no_norm_on_lateral=False, conv_cfg=None,
+                 norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode='nearest')):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        assert not add_extra_convs, 'extra FPN convs are outside the HTD path (P6 is a subsample of P5)'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.upsample_cfg = dict(upsample_cfg)
+        if end_level == -1:
+            self.backbone_end_level = self.num_ins
+            assert num_outs >= self.num_ins - start_level
+        else:
+            self.backbone_end_level = end_level
+            assert end_level <= len(in_channels) and num_outs == end_level - start_level
+        self.start_level, self.end_level, self.add_extra_convs = start_level, end_level, add_extra_convs
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, conv_cfg=conv_cfg,
+                                                 norm_cfg=norm_cfg if not no_norm_on_lateral else None,
+                                                 act_cfg=act_cfg, inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, conv_cfg=conv_cfg,
+                                             norm_cfg=norm_cfg, act_cfg=act_cfg, inplace=False))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                xavier_init(m, distribution='uniform')
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        n = len(laterals)
+        for i in range(n - 1, 0, -1):
+            if 'scale_factor' in self.upsample_cfg:
+                up = F.interpolate(laterals[i], **self.upsample_cfg)
+            else:
+                up = F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
+            laterals[i - 1] = laterals[i - 1] + up
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
+        for _ in range(self.num_outs - n):
+            outs.append(outs[-1][:, :, ::2, ::2])      # == F.max_pool2d(x, 1, stride=2), fpn.py:197-199
+        return tuple(outs)

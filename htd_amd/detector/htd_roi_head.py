@@ -1,0 +1,186 @@
+"""HTDRoIHead: the two-stage decoupled RoI head (driver of SFA, stage 1, BA and PGraph).
+
+Reference: roi_heads/htd_roi_head.py:12-476 (+ base_roi_head.py:8-106).  Same registry name, kwargs,
+sub-module names (bbox_roi_extractor.{0,1}, bbox_head.{0,1}, glbctx_head), loss keys
+(loss_global, s0.loss_cls, s0.acc, s0.loss_bbox, s1.*) and return structures.
+
+Deliberate fixes ('F'): stage-2 positives are taken from EVERY image of the batch
+(the reference hard-codes image ids 0 and 1, :158-169,181-182 -- identical for B <= 2); `_fuse_global`
+does not round-trip through the host.
+"""
+import torch
+import torch.nn as nn
+
+from .. import mmcv_ops as M
+from ..core import bbox2result, bbox2roi
+from ..registry import HEADS, build_assigner, build_head, build_roi_extractor, build_sampler
+
+
+@HEADS.register_module()
+class HTDRoIHead(nn.Module):
+    def __init__(self, num_stages, stage_loss_weights, with_global=False, bbox_roi_extractor=None, bbox_head=None,
+                 mask_roi_extractor=None, mask_head=None, shared_head=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        assert bbox_roi_extractor is not None and bbox_head is not None
+        assert shared_head is None, 'Shared head is not supported in Cascade RCNN anymore'
+        assert mask_head is None and mask_roi_extractor is None, 'HTD configs have no mask branch'
+        self.num_stages, self.stage_loss_weights, self.with_global = num_stages, stage_loss_weights, with_global
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_bbox_head(bbox_roi_extractor, bbox_head)
+        self.init_assigner_sampler()
+
+    @property
+    def with_bbox(self):
+        return hasattr(self, 'bbox_head') and self.bbox_head is not None
+
+    @property
+    def with_mask(self):
+        return False
+
+    @property
+    def with_shared_head(self):
+        return False
+
+    def init_bbox_head(self, bbox_roi_extractor, bbox_head):
+        self.bbox_roi_extractor = nn.ModuleList()
+        self.bbox_head = nn.ModuleList()
+        if not isinstance(bbox_roi_extractor, list):
+            bbox_roi_extractor = [bbox_roi_extractor for _ in range(self.num_stages)]
+        if not isinstance(bbox_head, list):
+            bbox_head = [bbox_head for _ in range(self.num_stages)]
+        assert len(bbox_roi_extractor) == len(bbox_head) == self.num_stages
+        for ext, head in zip(bbox_roi_extractor, bbox_head):
+            self.bbox_roi_extractor.append(build_roi_extractor(ext))
+            self.bbox_head.append(build_head(head))
+        if self.with_global:
+            self.glbctx_head = build_head(dict(type='GlobalContextHead', num_ins=5, num_convs=4, in_channels=256,
+                                               conv_out_channels=256, num_classes=self.bbox_head[0].num_classes + 1,
+                                               loss_weight=3.0))
+
+    def init_assigner_sampler(self):
+        self.bbox_assigner, self.bbox_sampler = [], []
+        if self.train_cfg is not None:
+            for idx, rcnn_train_cfg in enumerate(self.train_cfg):
+                self.bbox_assigner.append(build_assigner(rcnn_train_cfg.assigner))
+                self.current_stage = idx
+                self.bbox_sampler.append(build_sampler(rcnn_train_cfg.sampler, context=self))
+
+    def init_weights(self, pretrained=None):
+        for i in range(self.num_stages):
+            self.bbox_roi_extractor[i].init_weights()
+            self.bbox_head[i].init_weights()
+        if self.with_global:
+            self.glbctx_head.init_weights()
+
+    def _fuse_global(self, roi_feats, global_feat, rois):
+        assert roi_feats.size(0) == rois.size(0)
+        return M.fuse_global(roi_feats, rois, global_feat)
+
+    # ------------------------------------------------------------------ per-stage forward
+    def _bbox_forward(self, stage, x, rois, global_feat=None, sampling_results=None, img_metas=None):
+        extractor, enhanced_extractor = self.bbox_roi_extractor[0], self.bbox_roi_extractor[1]
+        feats = x[:extractor.num_inputs]
+        if stage == 0:
+            bbox_feats = extractor(feats, rois)
+            if self.with_global:
+                bbox_feats = self._fuse_global(bbox_feats, global_feat, rois)
+            cls_score, bbox_pred = self.bbox_head[0](bbox_feats)
+            return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+        head = self.bbox_head[stage]
+        bbox_feats = extractor(feats, rois)
+        if sampling_results:
+            # training: BA + reg branch on the positives only; rows of `rois` are [pos_i, neg_i] per image
+            pos_rois = bbox2roi([res.pos_bboxes for res in sampling_results])
+            pos_rows, start = [], 0
+            for res in sampling_results:
+                npos = res.pos_bboxes.size(0)
+                pos_rows.append(torch.arange(start, start + npos, device=rois.device))
+                start += npos + res.neg_bboxes.size(0)
+            pos_rows = torch.cat(pos_rows)
+            enhanced = enhanced_extractor(feats, pos_rois)
+            pos_bbox_feat = bbox_feats[pos_rows]
+            cls_score, bbox_pred = head(bbox_feats, pos_bbox_feat, feats, rois, self.bbox_head[0].fc_cls, enhanced,
+                                        pos_rois, global_feat if self.with_global else None)
+            full = cls_score.new_zeros(cls_score.size(0), 4).index_put((pos_rows, ), bbox_pred)
+            return dict(cls_score=cls_score, bbox_pred=full)
+        enhanced = enhanced_extractor(feats, rois)
+        cls_score, bbox_pred = head(bbox_feats, bbox_feats, feats, rois, self.bbox_head[0].fc_cls, enhanced, rois,
+                                    global_feat if self.with_global else None)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred)
+
+    def _bbox_forward_train(self, stage, x, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, img_metas,
+                            global_feat=None):
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        bbox_results = self._bbox_forward(stage, x, rois, global_feat, sampling_results, img_metas)
+        bbox_targets = self.bbox_head[stage].get_targets(sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg)
+        loss_bbox = self.bbox_head[stage].loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
+                                               *bbox_targets)
+        bbox_results.update(loss_bbox=loss_bbox, rois=rois, bbox_targets=bbox_targets)
+        return bbox_results
+
+    def _assign_and_sample(self, stage, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore):
+        out = []
+        for j in range(len(proposal_list)):
+            assign_result = self.bbox_assigner[stage].assign(proposal_list[j], gt_bboxes[j], gt_bboxes_ignore[j],
+                                                             gt_labels[j])
+            out.append(self.bbox_sampler[stage].sample(assign_result, proposal_list[j], gt_bboxes[j], gt_labels[j]))
+        return out
+
+    # ------------------------------------------------------------------ train
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None):
+        losses = dict()
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None for _ in range(num_imgs)]
+        sampling_results = self._assign_and_sample(0, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore)
+        global_feat = None
+        if self.with_global:
+            mc_pred, global_feat = self.glbctx_head(x)
+            losses['loss_global'] = self.glbctx_head.loss(mc_pred, gt_labels)
+        # ---------------- stage 1: common head
+        lw = self.stage_loss_weights[0]
+        res = self._bbox_forward_train(0, x, sampling_results, gt_bboxes, gt_labels, self.train_cfg[0], img_metas,
+                                       global_feat)
+        for name, value in res['loss_bbox'].items():
+            losses[f's0.{name}'] = value * lw if 'loss' in name else value
+        with torch.no_grad():
+            roi_labels = res['bbox_targets'][0]
+            roi_labels = torch.where(roi_labels == self.bbox_head[0].num_classes,
+                                     res['cls_score'][:, :-1].argmax(1), roi_labels)
+            proposal_list = self.bbox_head[0].refine_bboxes(res['rois'], roi_labels, res['bbox_pred'],
+                                                            [r.pos_is_gt for r in sampling_results], img_metas)
+        # ---------------- stage 2: graph reasoning
+        lw = self.stage_loss_weights[1]
+        sampling_results = self._assign_and_sample(1, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore)
+        res = self._bbox_forward_train(1, x, sampling_results, gt_bboxes, gt_labels, self.train_cfg[1], img_metas,
+                                       global_feat)
+        for name, value in res['loss_bbox'].items():
+            losses[f's1.{name}'] = value * lw if 'loss' in name else value
+        return losses
+
+    # ------------------------------------------------------------------ test
+    def simple_test_bboxes(self, x, proposal_list, img_metas, rescale=False):
+        """-> (det_bboxes list, det_labels list) on the device."""
+        num_imgs = len(proposal_list)
+        rois = bbox2roi(proposal_list)
+        global_feat = self.glbctx_head(x)[1] if self.with_global else None
+        n_per = tuple(len(p) for p in proposal_list)
+        res = self._bbox_forward(0, x, rois, global_feat)
+        cls0, reg0 = res['cls_score'], res['bbox_pred']
+        # stage-1 refinement with the arg-max foreground class (:346-352); class-agnostic => label unused
+        label = cls0[:, :-1].argmax(dim=1)
+        rois = torch.cat([self.bbox_head[0].regress_by_class(r, l, p, m) for r, l, p, m in
+                          zip(rois.split(n_per), label.split(n_per), reg0.split(n_per), img_metas)])
+        res = self._bbox_forward(1, x, rois, global_feat)
+        cls_score = (cls0 + res['cls_score']) / 2.0              # logits averaged over the stages (:363-366)
+        det_bboxes, det_labels = [], []
+        for i, (r, c, p) in enumerate(zip(rois.split(n_per), cls_score.split(n_per), res['bbox_pred'].split(n_per))):
+            b, l = self.bbox_head[-1].get_bboxes(r, c, p, img_metas[i]['img_shape'], img_metas[i]['scale_factor'],
+                                                 rescale=rescale, cfg=self.test_cfg)
+            det_bboxes.append(b)
+            det_labels.append(l)
+        return det_bboxes, det_labels
+
+    def simple_test(self, x, proposal_list, img_metas, rescale=False):
+        det_bboxes, det_labels = self.simple_test_bboxes(x, proposal_list, img_metas, rescale)
+        return [bbox2result(b, l, self.bbox_head[-1].num_classes) for b, l in zip(det_bboxes, det_labels)]

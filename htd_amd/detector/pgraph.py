@@ -1,0 +1,80 @@
+"""PGraph: per (image, pyramid level) group of RoIs, local spatial aggregation followed by global
+semantic interaction (HTDBBoxHead.forward, htd_bbox_head.py:195-219).
+
+The reference runs a Python double loop over images and levels with boolean-mask gathers, `.any()`
+host syncs and five tiny mm's per group.  Here ALL groups of the call are one padded batch
+[G, n_max, .]: one stable sort puts each group's RoIs next to each other, the adjacency products are
+batched contractions, the four per-level Linear layers are applied to their groups' rows, and the
+result is scattered back -- a fixed, small number of launches with a single host read (group sizes).
+"""
+import torch
+import torch.nn.functional as F
+
+from ..core.bbox import bbox_overlaps
+
+
+def group_layout(rois, target_lvls, num_levels):
+    """Sort RoIs by (image, level).  -> perm (N,), counts (G,) with G = B*num_levels (host list), B."""
+    img = rois[:, 0].long()
+    B = int(img.max().item()) + 1 if rois.numel() else 0
+    key = img * num_levels + target_lvls
+    perm = torch.sort(key, stable=True)[1]
+    counts = torch.bincount(key, minlength=B * num_levels)
+    return perm, counts, B
+
+
+def pgraph_refine(x, sam, rois, target_lvls, graph_layers):
+    """x (N,F) fc features, sam (N,S) semantic embedding, -> refined (N,F):
+         M       = (IoU(rois_g, rois_g) with unit diagonal) > 0
+         A_local = D^-1/2 M D^-1/2,  D = rowsum(M)
+         mixed   = A_local @ x_g
+         A_glob  = softmax_row((1 - M) * (sam_g sam_g^T))
+         refined_g = ReLU(Linear_level(A_glob @ mixed))          rows in empty groups stay 0."""
+    N, Fdim = x.shape
+    L = len(graph_layers)
+    refined = x.new_zeros(N, Fdim)
+    if N == 0:
+        return refined
+    perm, counts, B = group_layout(rois, target_lvls, L)
+    counts_h = counts.tolist()                      # the one host read of this op
+    G = B * L
+    nmax = max(counts_h)
+    if nmax == 0:
+        return refined
+    # padded batch index: row r of group g  <-  sorted position start_g + r
+    starts = torch.cumsum(counts, 0) - counts
+    ar = torch.arange(nmax, device=x.device)
+    valid = ar[None, :] < counts[:, None]                                   # (G, nmax)
+    src = (starts[:, None] + ar[None, :]).clamp(max=N - 1)
+    rows = perm[src]                                                        # (G, nmax) original RoI rows
+    xg = x[rows] * valid[..., None]
+    sg = sam[rows] * valid[..., None]
+    bx = rois[rows][..., 1:5]
+    # pairwise IoU inside each group (bbox_overlaps with its eps=1e-6 union floor), unit diagonal
+    lt = torch.max(bx[:, :, None, :2], bx[:, None, :, :2])
+    rb = torch.min(bx[:, :, None, 2:], bx[:, None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area = (bx[..., 2] - bx[..., 0]) * (bx[..., 3] - bx[..., 1])
+    union = torch.max(area[:, :, None] + area[:, None, :] - inter, inter.new_tensor([1e-6]))
+    iou = inter / union
+    eye = torch.eye(nmax, device=x.device, dtype=torch.bool)[None]
+    pair = valid[:, :, None] & valid[:, None, :]
+    Mloc = (((iou > 0) | eye) & pair).to(x.dtype)                           # (G, nmax, nmax)
+    deg = Mloc.sum(-1).clamp(min=1.0)                                       # padded rows: avoid 0^-1/2
+    dinv = deg.pow(-0.5)
+    A_local = dinv[:, :, None] * Mloc * dinv[:, None, :]
+    mixed = torch.bmm(A_local, xg)
+    sim = torch.bmm(sg, sg.transpose(1, 2))
+    logits = (1.0 - Mloc) * sim
+    logits = torch.where(pair, logits, logits.new_full((1, ), float('-inf')))   # padded columns carry no mass
+    logits = torch.where(valid[:, :, None], logits, torch.zeros_like(logits))   # padded rows: finite, unused
+    A_glob = torch.softmax(logits, dim=-1)
+    A_glob = torch.where(valid[:, :, None], A_glob, torch.zeros_like(A_glob))
+    agg = torch.bmm(A_glob, mixed)                                          # (G, nmax, F)
+    agg = agg.view(B, L, nmax, Fdim)
+    outs = []
+    for i, layer in enumerate(graph_layers):
+        outs.append(F.relu(F.linear(agg[:, i], layer.weight, layer.bias)))
+    out = torch.stack(outs, 1).view(G, nmax, Fdim)
+    return refined.index_put((rows[valid], ), out[valid])

@@ -1,0 +1,203 @@
+"""RPN head of HTD: forward, targets + loss, proposal generation.
+
+Reference: dense_heads/rpn_head.py:12-168 (RPNHead), anchor_head.py:14-682 (AnchorHead: targets/loss/
+get_bboxes), base_dense_head.py:22-59 (forward_train), rpn_test_mixin.py:24-37 (simple_test_rpn).
+Same registry name, constructor kwargs, state_dict keys (rpn_conv / rpn_cls / rpn_reg) and return
+structures.  What differs is execution: proposal generation handles ALL images and levels of the batch
+together -- one stable sort per level over the (B, A_l) score matrix, one decode, ONE batched NMS
+launch whose segments are the (image, level) pairs -- instead of a Python loop over images with a
+sort + NMS each (rpn_head.py:78-168).  The kept set, its order and its values are the same.
+"""
+import torch
+import torch.nn as nn
+
+from ..core import (anchor_inside_flags, images_to_levels, multi_apply, unmap)
+from ..core.bbox import delta2bbox
+from ..mmcv_ops import nms_sorted_mask
+from ..registry import (HEADS, build_anchor_generator, build_assigner, build_bbox_coder, build_loss, build_sampler)
+from .bricks import Conv2d, normal_init
+
+
+@HEADS.register_module()
+class RPNHead(nn.Module):
+    def __init__(self, in_channels, feat_channels=256,
+                 anchor_generator=dict(type='AnchorGenerator', scales=[8, 16, 32], ratios=[0.5, 1.0, 2.0],
+                                       strides=[4, 8, 16, 32, 64]),
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True, target_means=(.0, .0, .0, .0),
+                                 target_stds=(1.0, 1.0, 1.0, 1.0)),
+                 reg_decoded_bbox=False,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0), train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.in_channels, self.num_classes, self.feat_channels = in_channels, 1, feat_channels
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        assert self.use_sigmoid_cls and not reg_decoded_bbox, 'HTD configs use a sigmoid RPN with delta targets'
+        self.sampling = True
+        self.cls_out_channels = self.num_classes
+        self.reg_decoded_bbox = reg_decoded_bbox
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if self.train_cfg:
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            self.sampler = build_sampler(self.train_cfg.sampler, context=self)
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self.rpn_conv = Conv2d(self.in_channels, self.feat_channels, 3, padding=1)
+        self.rpn_cls = Conv2d(self.feat_channels, self.num_anchors * self.cls_out_channels, 1)
+        self.rpn_reg = Conv2d(self.feat_channels, self.num_anchors * 4, 1)
+
+    def init_weights(self):
+        normal_init(self.rpn_conv, std=0.01)
+        normal_init(self.rpn_cls, std=0.01)
+        normal_init(self.rpn_reg, std=0.01)
+
+    # ------------------------------------------------------------------ forward
+    def forward_single(self, x):
+        x = self.rpn_conv(x, relu=True)
+        return self.rpn_cls(x), self.rpn_reg(x)
+
+    def forward(self, feats):
+        return multi_apply(self.forward_single, feats)
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
+                      **kwargs):
+        outs = self(x)
+        losses = self.loss(*outs, gt_bboxes, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is None:
+            return losses
+        return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
+
+    def simple_test_rpn(self, x, img_metas):
+        return self.get_bboxes(*self(x), img_metas)
+
+    # ------------------------------------------------------------------ targets + loss
+    def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
+        mlvl = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        anchor_list = [mlvl for _ in img_metas]
+        valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, m['pad_shape'], device)
+                           for m in img_metas]
+        return anchor_list, valid_flag_list
+
+    def _get_targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore, img_meta):
+        """anchor_head.py:172-269 with gt_labels=None (RPN): fg label 0, bg label num_classes (=1)."""
+        inside = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
+                                     self.train_cfg.allowed_border)
+        anchors = flat_anchors[inside, :]
+        assign_result = self.assigner.assign(anchors, gt_bboxes, gt_bboxes_ignore, None)
+        sr = self.sampler.sample(assign_result, anchors, gt_bboxes)
+        n = anchors.shape[0]
+        bbox_targets = torch.zeros_like(anchors)
+        bbox_weights = torch.zeros_like(anchors)
+        labels = anchors.new_full((n, ), self.num_classes, dtype=torch.long)
+        label_weights = anchors.new_zeros(n, dtype=torch.float)
+        if len(sr.pos_inds) > 0:
+            bbox_targets[sr.pos_inds, :] = self.bbox_coder.encode(sr.pos_bboxes, sr.pos_gt_bboxes)
+            bbox_weights[sr.pos_inds, :] = 1.0
+            labels[sr.pos_inds] = 0
+            label_weights[sr.pos_inds] = 1.0 if self.train_cfg.pos_weight <= 0 else self.train_cfg.pos_weight
+        if len(sr.neg_inds) > 0:
+            label_weights[sr.neg_inds] = 1.0
+        total = flat_anchors.size(0)
+        return (unmap(labels, total, inside, fill=self.num_classes), unmap(label_weights, total, inside),
+                unmap(bbox_targets, total, inside), unmap(bbox_weights, total, inside), sr.pos_inds, sr.neg_inds)
+
+    def get_targets(self, anchor_list, valid_flag_list, gt_bboxes_list, img_metas, gt_bboxes_ignore_list=None):
+        num_imgs = len(img_metas)
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        flat_anchors = torch.cat(anchor_list[0])
+        if gt_bboxes_ignore_list is None:
+            gt_bboxes_ignore_list = [None] * num_imgs
+        res = [self._get_targets_single(flat_anchors, torch.cat(valid_flag_list[i]), gt_bboxes_list[i],
+                                        gt_bboxes_ignore_list[i], img_metas[i]) for i in range(num_imgs)]
+        num_total_pos = sum(max(r[4].numel(), 1) for r in res)
+        num_total_neg = sum(max(r[5].numel(), 1) for r in res)
+        lv = [images_to_levels([r[k] for r in res], num_level_anchors) for k in range(4)]
+        return lv[0], lv[1], lv[2], lv[3], num_total_pos, num_total_neg
+
+    def loss_single(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, num_total_samples):
+        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+        loss_cls = self.loss_cls(cls_score, labels.reshape(-1), label_weights.reshape(-1),
+                                 avg_factor=num_total_samples)
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 4)
+        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets.reshape(-1, 4), bbox_weights.reshape(-1, 4),
+                                   avg_factor=num_total_samples)
+        return loss_cls, loss_bbox
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None):
+        featmap_sizes = [f.size()[-2:] for f in cls_scores]
+        assert len(featmap_sizes) == self.anchor_generator.num_levels
+        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=cls_scores[0].device)
+        (labels, label_weights, bbox_targets, bbox_weights, num_pos, num_neg) = self.get_targets(
+            anchor_list, valid_flag_list, gt_bboxes, img_metas, gt_bboxes_ignore_list=gt_bboxes_ignore)
+        losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, labels, label_weights,
+                                              bbox_targets, bbox_weights, num_total_samples=num_pos + num_neg)
+        return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
+
+    # ------------------------------------------------------------------ proposals
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False, with_nms=True):
+        """-> list (per image) of (k_i, 5) [x1,y1,x2,y2,score], k_i <= nms_post, descending score."""
+        cfg = self.test_cfg if cfg is None else cfg
+        assert len(cls_scores) == len(bbox_preds)
+        B = cls_scores[0].size(0)
+        dev = cls_scores[0].device
+        featmap_sizes = [c.shape[-2:] for c in cls_scores]
+        mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
+        scores_l, deltas_l, anchors_l, seg_sizes = [], [], [], []
+        for lvl in range(len(cls_scores)):
+            s = cls_scores[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
+            d = bbox_preds[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1, 4)
+            k = s.size(1) if cfg.nms_pre <= 0 else min(cfg.nms_pre, s.size(1))
+            ranked, idx = s.sort(dim=1, descending=True, stable=True)
+            ranked, idx = ranked[:, :k], idx[:, :k]
+            scores_l.append(ranked)
+            deltas_l.append(torch.gather(d, 1, idx[..., None].expand(B, k, 4)))
+            anchors_l.append(mlvl_anchors[lvl][idx])
+            seg_sizes.append(k)
+        scores = torch.cat(scores_l, 1)                       # (B, K): level-major, descending inside a level
+        K = scores.size(1)
+        deltas = torch.cat(deltas_l, 1).reshape(B * K, 4)
+        anchors = torch.cat(anchors_l, 1).reshape(B * K, 4)
+        proposals = delta2bbox(anchors, deltas, self.bbox_coder.means, self.bbox_coder.stds, None)
+        if self.bbox_coder.clip_border:
+            lim = proposals.new_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas])   # (B, 2) w,h
+            lim = lim.repeat(1, 2).view(B, 1, 4)
+            proposals = torch.min(proposals.view(B, K, 4).clamp(min=0), lim)
+        proposals = proposals.view(B, K, 4)
+        valid = None
+        if cfg.min_bbox_size > 0:
+            w = proposals[..., 2] - proposals[..., 0]
+            h = proposals[..., 3] - proposals[..., 1]
+            valid = (w >= cfg.min_bbox_size) & (h >= cfg.min_bbox_size)
+            if bool(valid.all()):
+                valid = None
+        if valid is not None:
+            # rare path (min_bbox_size is 0 in every HTD config): fall back to the per-image operator
+            from ..mmcv_ops import batched_nms
+            ids = torch.cat([scores.new_full((k, ), i, dtype=torch.long) for i, k in enumerate(seg_sizes)])
+            out = []
+            for b in range(B):
+                v = valid[b]
+                dets, _ = batched_nms(proposals[b][v], scores[b][v], ids[v], dict(type='nms', iou_threshold=cfg.nms_thr))
+                out.append(dets[:cfg.nms_post])
+            return out
+        # level id as class: shift by id*(max+1) like batched_nms does (per image), one segment per (image, level)
+        ids = torch.cat([scores.new_full((k, ), i) for i, k in enumerate(seg_sizes)])
+        max_coord = proposals.reshape(B, -1).max(dim=1)[0]
+        shifted = proposals + (ids.view(1, K) * (max_coord.view(B, 1) + 1)).unsqueeze(-1)
+        offs = [0]
+        for b in range(B):
+            for k in seg_sizes:
+                offs.append(offs[-1] + k)
+        seg = torch.tensor(offs, dtype=torch.int64, device=dev)
+        keep = nms_sorted_mask(shifted.reshape(B * K, 4), cfg.nms_thr, 0, seg, max(seg_sizes)).view(B, K).bool()
+        # survivors in descending score order (ties: lower level / lower rank first), first nms_post of them
+        masked = torch.where(keep, scores, scores.new_full((1, ), -1.0))
+        top, order = masked.sort(dim=1, descending=True, stable=True)
+        n_keep = keep.sum(1).clamp(max=cfg.nms_post).tolist()
+        order = order[:, :cfg.nms_post]
+        boxes = torch.gather(proposals, 1, order[..., None].expand(-1, -1, 4))
+        dets = torch.cat([boxes, top[:, :cfg.nms_post, None]], -1)
+        return [dets[b, :n_keep[b]] for b in range(B)]

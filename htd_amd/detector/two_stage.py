@@ -1,0 +1,177 @@
+"""FasterRCNN / TwoStageDetector / BaseDetector glue of the path.
+
+Reference: detectors/base.py:15-372 (forward :168-182, _parse_losses :184-223, train_step :225-258),
+two_stage.py:10-222 (extract_feat :80-87, forward_train :107-170, simple_test :190-211),
+faster_rcnn.py:5-24.  `_parse_losses` packs all log scalars into ONE all-reduce and ONE device->host
+copy (the reference does ~9 of each per step, base.py:216-221).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ..registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+class BaseDetector(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fp16_enabled = False
+
+    @property
+    def with_neck(self):
+        return getattr(self, 'neck', None) is not None
+
+    @property
+    def with_bbox(self):
+        return getattr(self, 'roi_head', None) is not None and self.roi_head.with_bbox
+
+    @property
+    def with_rpn(self):
+        return getattr(self, 'rpn_head', None) is not None
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        for img, img_meta in zip(imgs, img_metas):
+            for m in img_meta:
+                m['batch_intput_shape'] = tuple(img.size()[-2:])
+        if len(imgs) == 1:
+            if 'proposals' in kwargs:
+                kwargs['proposals'] = kwargs['proposals'][0]
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        raise NotImplementedError('test-time augmentation (aug_test) is outside this path')
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def _parse_losses(self, losses):
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        packed = torch.stack([v.detach().reshape(()).float() for v in log_vars.values()])
+        if dist.is_available() and dist.is_initialized():
+            packed = packed / dist.get_world_size()
+            dist.all_reduce(packed)
+        self._last_log_tensor = packed                      # rank-averaged scalars, still on the device
+        self._last_log_keys = list(log_vars.keys())
+        return loss, LazyLogVars(self._last_log_keys, packed)
+
+    def train_step(self, data, optimizer):
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+    val_step = train_step
+
+
+class LazyLogVars(OrderedDict):
+    """log_vars whose float values are fetched with a single device->host copy on first access."""
+
+    def __init__(self, keys, packed):
+        super().__init__()
+        self._keys, self._packed, self._done = keys, packed, False
+
+    def _fill(self):
+        if not self._done:
+            self._done = True
+            for k, v in zip(self._keys, self._packed.tolist()):
+                super().__setitem__(k, v)
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def keys(self):
+        return list(self._keys)
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+
+@DETECTORS.register_module()
+class TwoStageDetector(BaseDetector):
+    def __init__(self, backbone, neck=None, rpn_head=None, roi_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            self.neck = build_neck(neck)
+        if rpn_head is not None:
+            rpn_train_cfg = train_cfg.rpn if train_cfg is not None else None
+            rpn_head_ = dict(rpn_head)
+            rpn_head_.update(train_cfg=rpn_train_cfg, test_cfg=test_cfg.rpn if test_cfg is not None else None)
+            self.rpn_head = build_head(rpn_head_)
+        if roi_head is not None:
+            rcnn_train_cfg = train_cfg.rcnn if train_cfg is not None else None
+            roi_head_ = dict(roi_head)
+            roi_head_.update(train_cfg=rcnn_train_cfg, test_cfg=test_cfg.rcnn if test_cfg is not None else None)
+            self.roi_head = build_head(roi_head_)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained=pretrained)
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            self.neck.init_weights()
+        if self.with_rpn:
+            self.rpn_head.init_weights()
+        if getattr(self, 'roi_head', None) is not None:
+            self.roi_head.init_weights(pretrained)
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        return self.neck(x) if self.with_neck else x
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
+                      proposals=None, **kwargs):
+        x = self.extract_feat(img)
+        losses = dict()
+        if self.with_rpn:
+            proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+            rpn_losses, proposal_list = self.rpn_head.forward_train(x, img_metas, gt_bboxes, gt_labels=None,
+                                                                    gt_bboxes_ignore=gt_bboxes_ignore,
+                                                                    proposal_cfg=proposal_cfg)
+            losses.update(rpn_losses)
+        else:
+            proposal_list = proposals
+        losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
+                                                  gt_bboxes_ignore, gt_masks, **kwargs))
+        return losses
+
+    def simple_test(self, img, img_metas, proposals=None, rescale=False):
+        assert self.with_bbox, 'Bbox head must be implemented.'
+        x = self.extract_feat(img)
+        proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
+
+
+@DETECTORS.register_module()
+class FasterRCNN(TwoStageDetector):
+    def __init__(self, backbone, rpn_head, roi_head, train_cfg, test_cfg, neck=None, pretrained=None):
+        super().__init__(backbone=backbone, neck=neck, rpn_head=rpn_head, roi_head=roi_head, train_cfg=train_cfg,
+                         test_cfg=test_cfg, pretrained=pretrained)

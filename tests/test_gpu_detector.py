@@ -1,0 +1,137 @@
+"""Whole-path parity on a real MI355X: the product detector (HIP ops through the C ABI) against
+(1) the fixture produced by the reference's own code (tests/golden/detector.npz) and (2) the CPU
+oracle on the same seeded inputs.  Sampling replays the CPU generator."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import demo_inputs, digest, load_seeded_, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def small_cfg():
+    from htd_amd.configs import htd_config
+    cfg = htd_config(50)
+    cfg.train_cfg.rpn_proposal.update(nms_pre=200, nms_post=100, max_num=100)
+    for r in cfg.train_cfg.rcnn:
+        r.sampler.num = 48
+    cfg.test_cfg.rpn.update(nms_pre=100, nms_post=60, max_num=60)
+    cfg.test_cfg.rcnn.score_thr = 0.001
+    return cfg
+
+
+def inputs(g, dev):
+    H, W = int(g['H']), int(g['W'])
+    imgs, gts, labels = demo_inputs(2, H, W, np.random.RandomState(0))
+    imgs = (imgs - 0.5) * 4
+    iw = int(g['img_w'])
+    metas = [dict(img_shape=(H, iw, 3), pad_shape=(H, W, 3), ori_shape=(H, iw, 3),
+                  scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(2)]
+    gts = [np.minimum(x, np.array([iw, H, iw, H], dtype=np.float32)) for x in gts]
+    return T(imgs).to(dev), metas, [T(x).to(dev) for x in gts], [T(x).to(dev) for x in labels]
+
+
+@pytest.fixture(scope='module')
+def det():
+    from htd_amd.configs import build_htd_detector
+    from htd_amd.core import set_randperm
+    dev = torch.device('cuda:0')
+    model = build_htd_detector(cfg=small_cfg())
+    load_seeded_(model, 'det.')
+    model = model.to(dev)
+    set_randperm(lambda n, device: torch.randperm(n).to(device))     # replay the CPU generator
+    yield model
+    set_randperm(None)
+
+
+def check_digest(g, key, t, rtol, atol):
+    sums, sample = digest(t.detach().cpu())
+    ref = g[key + '.sample']
+    np.testing.assert_allclose(sample, ref, rtol=rtol, atol=atol * max(1.0, np.abs(ref).max()), err_msg=key)
+
+
+def test_train_step_matches_reference_fixture(det, golden):
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, gts, labels = inputs(g, dev)
+    det.train()
+    torch.manual_seed(int(g['seed_sampler']))
+    losses = det.forward_train(img, metas, gts, labels)
+    loss, log_vars = det._parse_losses(losses)
+    for k, v in log_vars.items():
+        # fp32 logits within 1e-4 => losses within a few 1e-4 relative
+        np.testing.assert_allclose(v, float(g['loss.' + k]), rtol=5e-4, atol=1e-4, err_msg=k)
+    det.zero_grad()
+    loss.backward()
+    params = dict(det.named_parameters())
+    for k in [f[5:-5] for f in g.files if f.startswith('grad.') and f.endswith('.sums')]:
+        gr = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
+        check_digest(g, 'grad.' + k, gr, rtol=1e-2, atol=2e-3)
+
+
+def test_inference_matches_reference_fixture(det, golden):
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, _, _ = inputs(g, dev)
+    det.eval()
+    with torch.no_grad():
+        feats = det.extract_feat(img)
+        for i, f in enumerate(feats):
+            np.testing.assert_allclose(f.double().abs().sum().item(), float(g[f'feat{i}_abs']), rtol=1e-5)
+        props = det.rpn_head.simple_test_rpn(feats, metas)
+        res = det.roi_head.simple_test(feats, props, metas, rescale=False)
+    for i in range(2):
+        ref_p = g[f'test_props{i}']
+        assert props[i].shape == ref_p.shape
+        np.testing.assert_allclose(props[i].cpu().numpy(), ref_p, rtol=1e-4, atol=2e-3)
+        mine = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, dtype=np.float32)], 1)
+                               for c, r in enumerate(res[i])], 0)
+        ref = g[f'test_dets{i}']
+        assert mine.shape == ref.shape
+        np.testing.assert_array_equal(mine[:, 5], ref[:, 5])
+        np.testing.assert_allclose(mine[:, :5], ref[:, :5], rtol=1e-3, atol=1e-2)
+
+
+def test_train_step_matches_oracle_other_seed(det):
+    """Fresh inputs (not in any fixture), 3 images => exercises the generalised stage-2 positives (B > 2)."""
+    from oracle import detector as D
+    dev = torch.device('cuda:0')
+    H, W, B = 96, 160, 3
+    imgs, gts, labels = demo_inputs(B, H, W, np.random.RandomState(5))
+    imgs = (imgs - 0.5) * 4
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3),
+                  scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(B)]
+    cfg = D.htd_config(50)
+    cfg['train_cfg']['rpn_proposal'].update(nms_pre=200, nms_post=100, max_num=100)
+    for r in cfg['train_cfg']['rcnn']:
+        r['sampler']['num'] = 48
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+          for k, v in seeded_state_dict(D.state_shapes(50), prefix='det.').items()}
+    torch.manual_seed(9)
+    ref_losses = D.forward_train(sd, T(imgs), metas, [T(x) for x in gts], [T(x) for x in labels], cfg)
+    ref_loss, ref_log = D.parse_losses(ref_losses)
+    ref_loss.backward()
+    det.train()
+    torch.manual_seed(9)
+    losses = det.forward_train(T(imgs).to(dev), metas, [T(x).to(dev) for x in gts], [T(x).to(dev) for x in labels])
+    loss, log_vars = det._parse_losses(losses)
+    for k, v in log_vars.items():
+        np.testing.assert_allclose(v, ref_log[k], rtol=5e-4, atol=1e-4, err_msg=k)
+    det.zero_grad()
+    loss.backward()
+    params = dict(det.named_parameters())
+    for k in ('backbone.layer2.0.conv1.weight', 'backbone.layer4.2.bn3.weight', 'neck.fpn_convs.0.conv.weight',
+              'rpn_head.rpn_cls.weight', 'roi_head.bbox_head.0.fc_cls.weight', 'roi_head.bbox_head.1.fcs.0.weight',
+              'roi_head.bbox_head.1.graph_lvl1_cls.weight', 'roi_head.bbox_head.1.convs.2.gn.bias',
+              'roi_head.bbox_roi_extractor.1.conv2.weight', 'roi_head.glbctx_head.convs.3.conv.weight'):
+        a = params[k].grad.detach().cpu() if params[k].grad is not None else torch.zeros_like(params[k]).cpu()
+        b = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-3 * scale + 1e-6, (k, (a - b).abs().max().item(), scale)
