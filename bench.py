@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the HTD-R50 train step (fwd + losses + bwd + gradient all-reduce +
+SGD update) on synthetic 1333x800 COCO-shaped batches, fp32, B=4 per MI355X (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (see the driver contract): whole-job images/sec, plus
+  roofline     -- the dominant hand-written kernel of the step, timed live with device events on the stream
+                  it is launched on, priced against its algorithmic FLOPs / bytes;
+  cpu_baseline -- the CPU oracle (reference semantics) timed on this host on a bounded sample (rank 0, N=1).
+Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0             # HBM3E peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=4, help='images per GPU (BASELINE configs[1]: 4)')
+    ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--height', type=int, default=800)
+    ap.add_argument('--width', type=int, default=1344)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-kernels', action='store_true', help='print the per-kernel-class time table')
+    return ap.parse_args()
+
+
+def cpu_baseline(depth, H, W):
+    """The CPU oracle (oracle/detector.py, pinned against reference-generated fixtures) on ONE 800x1344 image:
+    forward + losses + backward, fp32, all host threads.  ~10-30 s of CPU work."""
+    from oracle import detector as D
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from golden_util import seeded_state_dict
+    from htd_amd.runner import synthetic_batch
+    threads = torch.get_num_threads()
+    cfg = D.htd_config(depth)
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+          for k, v in seeded_state_dict(D.state_shapes(depth), prefix='det.').items()}
+    data = synthetic_batch(1, H, W, W - 11, device='cpu', seed=0)
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    losses = D.forward_train(sd, data['img'].contiguous(), data['img_metas'], data['gt_bboxes'], data['gt_labels'], cfg)
+    loss, _ = D.parse_losses(losses)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 5), unit='images/sec', cores=threads, kind='port',
+                sample=f'oracle (CPU restatement of the reference path) 1 train step fwd+loss+bwd, B=1 @{H}x{W}, '
+                       f'R{depth}, fp32, {dt:.1f} s wall')
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP ops have no CPU path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
+    assert world == args.gpus or world == 1
+
+    from htd_amd import capi
+    from htd_amd.configs import build_htd_detector
+    from htd_amd.runner import Trainer, synthetic_batch
+    capi.lib()                                              # fail loudly if the HIP library is missing
+
+    torch.manual_seed(0)
+    model = build_htd_detector(args.depth)                  # init_weights() of every module, seed 0
+    model = model.to(dev).train()
+    trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
+    data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(data)
+    sync()
+    capi.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(data)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = capi.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        return
+    ms = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+
+    from htd_amd import dense
+    roof = dense.roofline_report(prof, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS)
+    if args.profile_kernels:
+        for name, (n, tot_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            print(f'# {name:40s} calls={n:6d} total={tot_ms:9.3f} ms', file=sys.stderr)
+    out = {
+        'metric': 'images/sec (1333x800) HTD-R%d train step' % args.depth, 'value': round(value, 3),
+        'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'HTD ResNet-{args.depth} FPN fp32 train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
+                               f'{args.width - 11}x{args.height} (padded {args.width}x{args.height}), '
+                               'random-init weights, 2000 RPN proposals/img, 512 RoIs/img/stage',
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
+        'roofline': roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(args.depth, args.height, args.width)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -70,8 +70,50 @@ def check(status, what=''):
         raise HtdError(f'{what}: {msg}')
 
 
-def call(name, *args):
-    check(getattr(lib(), name)(*args), name)
+# ---------------------------------------------------------------------------------- live kernel timing
+# bench.py brackets every C-ABI call with device events recorded on the stream the kernel is launched on
+# (torch's current stream, which is the stream handed to the library), so per-kernel-class durations are
+# measured inside the timed region itself.  `work` = (kind, amount): algorithmic FLOPs ('flop') or bytes
+# ('byte') of that call, summed per entry point for the roofline line.
+_PROFILE = None
+
+
+def profile_begin():
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_end():
+    """-> {name: (calls, total_ms, work_kind, total_work)}; synchronises the device."""
+    global _PROFILE
+    import torch
+    prof, _PROFILE = _PROFILE, None
+    if prof is None:
+        return {}
+    torch.cuda.synchronize()
+    out = {}
+    for name, rec in prof.items():
+        ms = sum(a.elapsed_time(b) for a, b in rec['events'])
+        out[name] = (len(rec['events']), ms, rec['kind'], rec['work'])
+    return out
+
+
+def call(name, *args, work=None):
+    fn = getattr(lib(), name)
+    if _PROFILE is None:
+        check(fn(*args), name)
+        return
+    import torch
+    rec = _PROFILE.setdefault(name, dict(events=[], kind=None, work=0.0))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    status = fn(*args)
+    b.record()
+    rec['events'].append((a, b))
+    if work is not None:
+        rec['kind'] = work[0]
+        rec['work'] += float(work[1])
+    check(status, name)
 
 
 def current_stream_ptr():

@@ -130,8 +130,11 @@ class _RoIAlignLevels(Function):
             f = nhwc(_f32(f, 'roi_align'))
             B, _, H, W = f.shape
             shapes.append((B, C, H, W))
+            # algorithmic bytes: each RoI is pooled on ONE level: write ph*pw*C*4 B, read its
+            # footprint, mid-range 21x21 px of the 14..28 px the level mapping yields -> counted on level 0's call
+            work = ('byte', n * C * 4.0 * (ph * pw + 21 * 21)) if i == 0 else ('byte', 0.0)
             capi.call('htd_roi_align_fwd', _P(f), _P(rois), _P(lvls), i, _P(out), n, B, C, H, W, ph, pw,
-                      float(scales[i]), int(sampling_ratio), int(bool(aligned)), _S())
+                      float(scales[i]), int(sampling_ratio), int(bool(aligned)), _S(), work=work)
         ctx.save_for_backward(rois, lvls)
         ctx.args = (shapes, ph, pw, scales, int(sampling_ratio), int(bool(aligned)))
         return out

@@ -1,0 +1,203 @@
+"""Minimal training runner for the HTD path: what mmcv's EpochBasedRunner + OptimizerHook +
+MMDistributedDataParallel do around `model.train_step` (mmdet/apis/train.py:72-150,
+configs/_base_/schedules/schedule_1x.py:2-11), re-designed for one process per MI355X:
+
+  * all trainable parameters live in ONE flat fp32 buffer (params are views into it), gradients in a
+    second flat buffer, SGD momentum in a third: the optimizer is one fused HIP kernel over the flat
+    buffers (htd_sgd_momentum_step), LR comes from a device scalar so warm-up needs no re-launch setup;
+  * gradient exchange = bucketed RCCL all-reduce over xGMI of slices of the flat gradient buffer,
+    launched from autograd post-accumulate hooks on a side stream while backward is still running
+    (semantics of DDP as configured at apis/train.py:76-80 and of core/utils/dist_utils.py:10-51:
+    sum then divide by world size; the division is folded into the optimizer kernel);
+  * parameters that receive no gradient in a step (a graph_lvl{i}_cls whose level had no RoI,
+    htd_bbox_head.py:219) contribute zeros: the flat gradient buffer is zero-filled each step.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import mmcv_ops as M
+
+CL = torch.channels_last
+
+
+class FlatParams:
+    """Flattens the trainable parameters of `model` into contiguous fp32 buffers (16-byte aligned slices)."""
+
+    def __init__(self, model, bucket_mb=64):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.offsets, self.total = offs, total
+        self.flat = torch.zeros(total, device=dev)
+        self.grad = torch.zeros(total, device=dev)
+        self.momentum = torch.zeros(total, device=dev)
+        for p, o in zip(self.params, offs):
+            self._view(self.flat, p, o).copy_(p.data)
+            p.data = self._view(self.flat, p, o)
+            p.grad = self._view(self.grad, p, o)
+        # buckets in reverse parameter order (roughly the order backward produces gradients)
+        cap = bucket_mb * (1 << 20) // 4
+        self.buckets = []            # [lo, hi) slices of the flat buffers
+        self.bucket_of = {}
+        hi = total
+        lo = total
+        members = []
+        for i in range(len(self.params) - 1, -1, -1):
+            lo = offs[i]
+            members.append(i)
+            if hi - lo >= cap or i == 0:
+                b = len(self.buckets)
+                self.buckets.append((lo, hi))
+                for m in members:
+                    self.bucket_of[m] = b
+                members, hi = [], lo
+
+    @staticmethod
+    def _view(flat, p, off):
+        n = p.numel()
+        if p.dim() == 4 and p.is_contiguous(memory_format=CL) and not p.is_contiguous():
+            co, ci, kh, kw = p.shape
+            return flat[off:off + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat[off:off + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self._view(self.grad, p, o)
+
+
+class GradientExchange:
+    """Bucketed all-reduce of FlatParams.grad overlapped with backward (RCCL when the process group is nccl)."""
+
+    def __init__(self, flat, process_group=None):
+        self.flat = flat
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.enabled = self.world > 1
+        self.on_gpu = flat.grad.is_cuda
+        self.stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
+        self._pending = None
+        self._works = []
+        if self.enabled:
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            if self._pending is None:
+                return
+            b = self.flat.bucket_of[i]
+            self._pending[b].discard(i)
+            if not self._pending[b] and b not in self._launched:
+                self._launch(b)
+        return hook
+
+    def begin_step(self):
+        if not self.enabled:
+            return
+        self._pending = [set() for _ in self.flat.buckets]
+        for i, b in self.flat.bucket_of.items():
+            self._pending[b].add(i)
+        self._launched = set()
+        self._works = []
+
+    def _launch(self, b):
+        self._launched.add(b)
+        lo, hi = self.flat.buckets[b]
+        chunk = self.flat.grad[lo:hi]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(chunk, group=self.group)
+        else:
+            self._works.append(dist.all_reduce(chunk, group=self.group, async_op=True))
+
+    def finish_step(self):
+        """Reduce buckets whose parameters got no gradient this step, then join the side stream."""
+        if not self.enabled:
+            return
+        for b in range(len(self.flat.buckets)):
+            if b not in self._launched:
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._pending = None
+
+
+class WarmupStepLR:
+    """lr policy 'step' with linear warm-up (schedule_1x.py:5-10): warmup_iters=500, warmup_ratio=0.001."""
+
+    def __init__(self, base_lr, steps=(8, 11), gamma=0.1, warmup_iters=500, warmup_ratio=0.001, iters_per_epoch=7330):
+        self.base_lr, self.steps, self.gamma = base_lr, steps, gamma
+        self.warmup_iters, self.warmup_ratio, self.iters_per_epoch = warmup_iters, warmup_ratio, iters_per_epoch
+
+    def lr(self, it):
+        epoch = it // self.iters_per_epoch
+        lr = self.base_lr * self.gamma ** sum(epoch >= s for s in self.steps)
+        if it < self.warmup_iters:
+            k = (1 - it / self.warmup_iters) * (1 - self.warmup_ratio)
+            lr = lr * (1 - k)
+        return lr
+
+
+class Trainer:
+    """train_step loop: zero_grad -> losses = model(**data) -> _parse_losses -> backward (+ overlapped gradient
+    all-reduce) -> fused SGD update.  `data` = dict(img, img_metas, gt_bboxes, gt_labels)."""
+
+    def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, schedule=None, bucket_mb=64):
+        self.model = model
+        self.flat = FlatParams(model, bucket_mb)
+        self.exchange = GradientExchange(self.flat)
+        self.momentum, self.weight_decay = momentum, weight_decay
+        self.schedule = schedule or WarmupStepLR(lr)
+        self.lr_dev = torch.zeros(1, device=self.flat.flat.device)
+        self.iter = 0
+
+    def train_step(self, data):
+        self.flat.zero_grad()
+        self.exchange.begin_step()
+        out = self.model.train_step(data, None)
+        out['loss'].backward()
+        self.exchange.finish_step()
+        self.lr_dev.fill_(self.schedule.lr(self.iter))
+        if self.flat.flat.is_cuda:
+            M.sgd_momentum_step_(self.flat.flat, self.flat.grad, self.flat.momentum, self.lr_dev, self.momentum,
+                                 self.weight_decay, grad_scale=1.0 / self.exchange.world)
+        else:   # gloo / CPU rehearsal of the distributed logic only (tests): same arithmetic in torch
+            g = self.flat.grad / self.exchange.world + self.weight_decay * self.flat.flat
+            self.flat.momentum.mul_(self.momentum).add_(g)
+            self.flat.flat.add_(self.flat.momentum, alpha=-float(self.lr_dev))
+        self.iter += 1
+        return out
+
+
+def synthetic_batch(B, H=800, W=1344, img_w=1333, device='cuda', seed=0, num_classes=80):
+    """COCO-shaped synthetic batch: randn images, 1-9 random gt boxes per image (recipe of
+    the reference fixture tests/test_models/test_forward.py:311-328), labels in [0, 80)."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    img = torch.randn(B, 3, H, W, generator=g)
+    gts, labels = [], []
+    for _ in range(B):
+        k = rng.randint(1, 10)
+        cx, cy, bw, bh = rng.rand(k, 4).T
+        x1 = ((cx * img_w) - (img_w * bw / 2)).clip(0, img_w)
+        y1 = ((cy * H) - (H * bh / 2)).clip(0, H)
+        x2 = ((cx * img_w) + (img_w * bw / 2)).clip(0, img_w)
+        y2 = ((cy * H) + (H * bh / 2)).clip(0, H)
+        gts.append(torch.from_numpy(np.vstack([x1, y1, x2, y2]).T.astype(np.float32)))
+        labels.append(torch.from_numpy(rng.randint(0, num_classes, size=k).astype(np.int64)))
+    metas = [dict(img_shape=(H, img_w, 3), pad_shape=(H, W, 3), ori_shape=(H, img_w, 3),
+                  scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(B)]
+    dev = torch.device(device)
+    return dict(img=img.to(dev).contiguous(memory_format=CL), img_metas=metas,
+                gt_bboxes=[t.to(dev) for t in gts], gt_labels=[t.to(dev) for t in labels])
