@@ -102,6 +102,7 @@ def main():
         trainer.train_step(data)
     sync()
     elapsed = time.perf_counter() - t0
+    print(f'# timed region: {elapsed:.3f} s for {args.steps} steps', file=sys.stderr)
     prof = capi.profile_end()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -115,8 +116,8 @@ def main():
     from htd_amd import dense
     roof = dense.roofline_report(prof, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS)
     if args.profile_kernels:
-        for name, (n, tot_ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-            print(f'# {name:40s} calls={n:6d} total={tot_ms:9.3f} ms', file=sys.stderr)
+        for name, (n, tot_ms, kind, work) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            print(f'# {name:40s} calls={n:6d} total={tot_ms:9.3f} ms  {kind or ""} {work:.3e}', file=sys.stderr)
     out = {
         'metric': 'images/sec (1333x800) HTD-R%d train step' % args.depth, 'value': round(value, 3),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

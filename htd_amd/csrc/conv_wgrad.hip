@@ -1,0 +1,277 @@
+// Weight gradient of the NHWC convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32):
+//
+//   gw[co][kh][kw][ci] = sum over pixels k = (b, ho, wo) of gy[k][co] * x[b][ho*s-p+kh*d][wo*s-p+kw*d][ci]
+//
+// GEMM view: M = Co, N = kh*kw*Ci, reduction K = B*Ho*Wo (10^5..10^6).  Both operands are "K-major" in memory
+// (a pixel row holds all channels contiguously), so slices are staged to LDS as [k][m] / [k][n] with 16-byte
+// coalesced loads and the MFMA fragments (lane = m or n index, lane half = k parity) are conflict-free
+// ds_read_b32 reads of 32 consecutive floats.  The reduction is split over `splits` independent workgroups
+// per output tile (split-K); partial tiles go to a workspace and a second kernel sums them in a fixed order,
+// so the result is bitwise reproducible (no float atomics).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct WgradParams {
+    const float *x, *gy;
+    float *out;            // gw if splits == 1 else workspace [splits][Co][Ntot]
+    int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo;
+    int64_t K;             // B*Ho*Wo
+    int Ntot;              // kh*kw*Ci
+    int mt, nt, splits;
+    int64_t slices_per_split;
+};
+
+constexpr int BKW = 16;    // pixels per K slice
+
+// WGM x WGN waves, each wave TM x TN MFMA blocks of 32x32
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
+{
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int SA = BM + 4, SB = BN + 4;                 // LDS row strides (floats), +16 B pad
+    constexpr int VA = BM / 4, VB = BN / 4;                 // float4 per row
+    constexpr int PA = (BKW * VA + 255) / 256, PB = (BKW * VB + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[2][BKW * (SA + SB)];
+
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tile_m = tile % p.mt, tile_n = tile / p.mt;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // fixed per-thread column chunks
+    int a_col[PA], a_row[PA];
+    bool a_cok[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int v = tid + i * 256;
+        a_row[i] = v / VA;
+        a_col[i] = (v % VA) * 4;
+        a_cok[i] = (v < BKW * VA) && (m0 + a_col[i] < p.Co);
+    }
+    int b_col[PB], b_row[PB], b_dy[PB], b_dx[PB], b_ci[PB];
+    bool b_cok[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int v = tid + i * 256;
+        b_row[i] = v / VB;
+        b_col[i] = (v % VB) * 4;
+        const int n = n0 + b_col[i];
+        b_cok[i] = (v < BKW * VB) && (n < p.Ntot);
+        const int tap = b_cok[i] ? n / p.Ci : 0;
+        b_ci[i] = b_cok[i] ? n - tap * p.Ci : 0;
+        b_dy[i] = (tap / p.kw) * p.dil - p.pad;
+        b_dx[i] = (tap % p.kw) * p.dil - p.pad;
+    }
+
+    const int64_t total_slices = (p.K + BKW - 1) / BKW;
+    const int64_t s_begin = (int64_t)split * p.slices_per_split;
+    const int64_t s_end = min(total_slices, s_begin + p.slices_per_split);
+
+    float4 ra[PA], rb[PB];
+    auto load_slice = [&](int64_t s) {
+        const int64_t k0 = s * BKW;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int64_t k = k0 + a_row[i];
+            const bool ok = a_cok[i] && k < p.K;
+            // Co may not be a multiple of 4 (RPN heads): fall back to scalar loads at the edge
+            if (ok && m0 + a_col[i] + 3 < p.Co && (p.Co & 3) == 0)
+                ra[i] = *reinterpret_cast<const float4 *>(p.gy + k * p.Co + m0 + a_col[i]);
+            else if (ok) {
+                const float *g = p.gy + k * p.Co + m0 + a_col[i];
+                const int rem = p.Co - (m0 + a_col[i]);
+                ra[i] = make_float4(g[0], rem > 1 ? g[1] : 0.f, rem > 2 ? g[2] : 0.f, rem > 3 ? g[3] : 0.f);
+            } else
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int64_t k = k0 + b_row[i];
+            bool ok = b_cok[i] && k < p.K;
+            const int64_t kk = ok ? k : 0;
+            const int wo = (int)(kk % p.Wo);
+            const int64_t t = kk / p.Wo;
+            const int ho = (int)(t % p.Ho);
+            const int b = (int)(t / p.Ho);
+            const int hi = ho * p.stride + b_dy[i], wi = wo * p.stride + b_dx[i];
+            ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            rb[i] = ok ? *reinterpret_cast<const float4 *>(p.x + (((int64_t)b * p.H + hi) * p.W + wi) * p.Ci + b_ci[i])
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_slice = [&](int buf) {
+        float *la = lds[buf], *lb = lds[buf] + BKW * SA;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if (tid + i * 256 < BKW * VA) *reinterpret_cast<float4 *>(la + a_row[i] * SA + a_col[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            if (tid + i * 256 < BKW * VB) *reinterpret_cast<float4 *>(lb + b_row[i] * SB + b_col[i]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fidx = lane & 31, fhalf = lane >> 5;
+    if (s_begin < s_end) {
+        load_slice(s_begin);
+        store_slice(0);
+    }
+    __syncthreads();
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        const int cur = (int)((s - s_begin) & 1);
+        if (s + 1 < s_end) load_slice(s + 1);
+        const float *la = lds[cur] + fhalf * SA + wm * TM * 32 + fidx;
+        const float *lb = lds[cur] + BKW * SA + fhalf * SB + wn * TN * 32 + fidx;
+#pragma unroll
+        for (int t = 0; t < BKW / 2; ++t) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = la[2 * t * SA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = lb[2 * t * SB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < s_end) store_slice(cur ^ 1);
+        __syncthreads();
+    }
+
+    float *out = p.out + (int64_t)split * p.Co * p.Ntot;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + fidx;
+        if (n >= p.Ntot) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[i][j][r];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
+                                                            int64_t n, int splits)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+// column sums of a [rows][C] matrix (bias gradient), optionally fused with the ReLU-mask of the incoming
+// gradient:  gm = g * (y > 0) written back, gbias[c] = sum_rows gm.  Deterministic two-stage reduction.
+__global__ __launch_bounds__(256) void colsum_mask_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                          float *__restrict__ gm, float *__restrict__ partial,
+                                                          int64_t rows, int C, int64_t rows_per_block)
+{
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        float v = g[r * C + c];
+        if (y) {
+            v = y[r * C + c] > 0.f ? v : 0.f;
+            gm[r * C + c] = v;
+        }
+        s += v;
+    }
+    partial[(int64_t)blockIdx.x * C + c] = s;
+}
+
+struct Cfg { int splits; int mt, nt; int bm, bn; };
+
+Cfg choose(int Co, int Ntot, int64_t K)
+{
+    Cfg c;
+    c.bm = Co <= 32 ? 32 : 128;
+    c.bn = 128;
+    c.mt = (int)htd::ceil_div(Co, c.bm);
+    c.nt = (int)htd::ceil_div(Ntot, c.bn);
+    const int64_t slices = htd::ceil_div(K, BKW);
+    int64_t want = htd::ceil_div(1024, (int64_t)c.mt * c.nt);       // ~4 workgroups per CU
+    want = std::min<int64_t>(want, std::max<int64_t>(1, slices / 8)); // at least 8 slices per split
+    c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 512));
+    return c;
+}
+
+}  // namespace
+
+extern "C" int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+                                                    int pad, int dil)
+{
+    const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    const Cfg c = choose(Co, kh * kw * Ci, (int64_t)B * Ho * Wo);
+    return (int64_t)c.splits * Co * kh * kw * Ci * 4 + 256;
+}
+
+extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, int B, int H, int W, int Ci, int Co,
+                                     int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream)
+{
+    HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
+                "conv2d_bwd_weight: bad sizes");
+    HTD_REQUIRE(Ci % 4 == 0, "conv2d_bwd_weight: Ci=%d must be a multiple of 4", Ci);
+    HTD_REQUIRE(x && gy && gw && workspace, "conv2d_bwd_weight: null pointer");
+    WgradParams p{};
+    p.x = x; p.gy = gy;
+    p.B = B; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
+    p.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_bwd_weight: empty output");
+    p.K = (int64_t)B * p.Ho * p.Wo;
+    p.Ntot = kh * kw * Ci;
+    const Cfg c = choose(Co, p.Ntot, p.K);
+    p.mt = c.mt; p.nt = c.nt; p.splits = c.splits;
+    p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
+    p.out = c.splits == 1 ? gw : (float *)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)(c.mt * c.nt), (unsigned)c.splits);
+    if (c.bm == 32)
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 4, 1, 1>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    if (c.splits > 1) {
+        const int64_t n = (int64_t)Co * p.Ntot;
+        const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)workspace, gw, n,
+                           c.splits);
+    }
+    return htd::check_launch("conv2d_bwd_weight");
+}
+
+// g [rows][C], y (may be NULL) [rows][C]; gm (out, required iff y) ; gbias [C]; workspace >= 256*C*4 bytes
+extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows, int C,
+                                       void *workspace, void *stream)
+{
+    HTD_REQUIRE(rows >= 0 && C > 0, "bias_grad: bad sizes");
+    HTD_REQUIRE(g && gbias && workspace && (!y || gm), "bias_grad: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(256, htd::ceil_div(rows, 64)));
+    const int64_t rpb = htd::ceil_div(std::max<int64_t>(rows, 1), nb);
+    float *partial = (float *)workspace;
+    hipLaunchKernelGGL(colsum_mask_kernel, dim3(nb, (unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s, g, y, gm,
+                       partial, rows, C, rpb);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s,
+                       (const float *)partial, gbias, (int64_t)C, nb);
+    return htd::check_launch("bias_grad");
+}

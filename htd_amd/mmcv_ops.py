@@ -61,7 +61,7 @@ class RoIAlignFunction(Function):
         ph, pw = _pair(output_size)
         B, C, H, W = feat.shape
         n = rois.size(0)
-        out = torch.empty((n, C, ph, pw), device=feat.device, dtype=feat.dtype).contiguous(memory_format=CL)
+        out = torch.empty((n, C, ph, pw), device=feat.device, dtype=feat.dtype, memory_format=CL)
         capi.call('htd_roi_align_fwd', _P(feat), _P(rois), None, 0, _P(out), n, B, C, H, W, ph, pw,
                   float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _S())
         ctx.save_for_backward(rois)
@@ -74,7 +74,7 @@ class RoIAlignFunction(Function):
         rois, = ctx.saved_tensors
         (B, C, H, W), ph, pw, scale, sr, aligned = ctx.args
         grad_out = nhwc(grad_out)
-        gfeat = torch.zeros((B, C, H, W), device=grad_out.device, dtype=grad_out.dtype).contiguous(memory_format=CL)
+        gfeat = torch.empty((B, C, H, W), device=grad_out.device, dtype=grad_out.dtype, memory_format=CL).zero_()
         capi.call('htd_roi_align_bwd', _P(grad_out), _P(rois), None, 0, _P(gfeat), rois.size(0), B, C, H, W, ph, pw,
                   scale, sr, aligned, _S())
         return gfeat, None, None, None, None, None
@@ -124,7 +124,7 @@ class _RoIAlignLevels(Function):
         rois = _f32(rois, 'roi_align').contiguous()
         lvls = lvls.to(torch.int64).contiguous()
         n, C = rois.size(0), feats[0].size(1)
-        out = torch.zeros((n, C, ph, pw), device=rois.device, dtype=torch.float32).contiguous(memory_format=CL)
+        out = torch.empty((n, C, ph, pw), device=rois.device, dtype=torch.float32, memory_format=CL).zero_()
         shapes = []
         for i, f in enumerate(feats):
             f = nhwc(_f32(f, 'roi_align'))
@@ -150,7 +150,7 @@ class _RoIAlignLevels(Function):
             if not ctx.needs_input_grad[6 + i]:
                 grads.append(None)
                 continue
-            gf = torch.zeros((B, C, H, W), device=g.device, dtype=g.dtype).contiguous(memory_format=CL)
+            gf = torch.empty((B, C, H, W), device=g.device, dtype=g.dtype, memory_format=CL).zero_()
             capi.call('htd_roi_align_bwd', _P(g), _P(rois), _P(lvls), i, _P(gf), rois.size(0), B, C, H, W, ph, pw,
                       float(scales[i]), sr, aligned, _S())
             grads.append(gf)
@@ -338,7 +338,7 @@ class GlobalAvgPoolFunction(Function):
     def backward(ctx, g):
         n, C, h, w = ctx.shape
         g = g.reshape(n, C).contiguous()
-        gx = torch.empty((n, C, h, w), device=g.device, dtype=g.dtype).contiguous(memory_format=CL)
+        gx = torch.empty((n, C, h, w), device=g.device, dtype=g.dtype, memory_format=CL)
         capi.call('htd_global_avg_pool_bwd', _P(g), _P(gx), n, h * w, C, _S())
         return gx
 

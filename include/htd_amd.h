@@ -102,6 +102,38 @@ int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const floa
                     int pw, int C, int edge, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Dense NHWC fp32 convolution on the f32 matrix cores (v_mfma_f32_32x32x2_f32), implicit GEMM with
+ * the fused epilogue  y = act(conv(x, w) + bias + residual).  Replaces the ATen/cuDNN convolutions and
+ * GEMMs of ResNet/FPN/RPN/SFA/HTD-reg and every nn.Linear of the heads (backbones/resnet.py:260-300,
+ * necks/fpn.py:165-216, dense_heads/rpn_head.py:37-43, global_context_head.py:382-392,
+ * htd_bbox_head.py:164,186,192,194,216,227-228, convfc_bbox_head.py:147-172).
+ *   x [B][H][W][Ci]   w [Co][kh][kw][Ci]   bias [Co] or NULL   residual [B][Ho][Wo][Co] or NULL
+ *   y [B][Ho][Wo][Co];  relu in {0,1};  Ci % 8 == 0 (the 3-channel stem input is padded to 8).
+ *   A Linear layer is the 1x1 case with H = rows, W = 1.
+ * bwd_data:  gx = conv_transpose(gy, w), given wT = htd_conv2d_flip_weights(w) ([Ci][kh][kw][Co], taps
+ *            reversed).  mask_src (may be NULL, [B][H][W][Ci]): gx is zeroed where mask_src <= 0, i.e. the
+ *            backward of the ReLU that produced the conv input is fused into this epilogue.  Co % 8 == 0.
+ * bwd_weight: gw[co][kh][kw][ci] = sum_pixels gy * x; deterministic split-K through `workspace`
+ *            (htd_conv2d_wgrad_workspace_bytes); Ci % 4 == 0.
+ * bias_grad_relu_mask: gbias[c] = sum_rows gm[r][c] with gm = g * (y > 0) written out when y != NULL
+ *            (gm = g, nothing written, when y == NULL); workspace >= 256*C*4 bytes.
+ * ---------------------------------------------------------------------------------- */
+int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual,
+                   float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+                   int pad, int dil, int relu, void *stream);
+int htd_conv2d_flip_weights(const float *w, float *wT, int Co, int kh, int kw, int Ci, void *stream);
+int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, float *gx, int B,
+                        int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                        void *stream);
+int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw,
+                                         int stride, int pad, int dil);
+int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, int B, int H, int W, int Ci,
+                          int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
+                          void *stream);
+int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows,
+                            int C, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * SFA global pooling (GlobalContextHead.forward global_context_head.py:386,
  * nn.AdaptiveAvgPool2d(1)) and the 7x7 AvgPool of the reg branch (htd_bbox_head.py:122,188):
  *   out[b][c] = mean over P positions of x[b][p][c];  bwd: gx[b][p][c] = g[b][c] / P.

@@ -423,7 +423,8 @@ def roi_head_forward_train(sd, x, img_metas, proposal_list, gt_bboxes, gt_labels
         losses['s1.' + k] = v * cfg['stage_loss_weights'][1] if 'loss' in k else v
     if trace is not None:
         trace.update(rois0=B.bbox2roi([r.bboxes for r in sr0]), cls0=cls0, reg0=reg0, rois1=rois, cls1=cls1,
-                     reg1=reg1, pos_rows=pos_rows, global_feat=gfeat, mc_pred=mc_pred)
+                     reg1=reg1, pos_rows=pos_rows, global_feat=gfeat, mc_pred=mc_pred,
+                     samples=[[(r.pos_inds, r.neg_inds) for r in sr] for sr in (sr0, sr1)])
     return losses
 
 

@@ -1,0 +1,83 @@
+"""fp32 MFMA implicit-GEMM convolution / Linear kernels against a plain PyTorch fp64 CPU reference.
+Tolerance: fp32 accumulation over K terms, relative 2e-5 * sqrt(K)-ish => rtol 1e-4, atol scaled."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+CASES = [
+    # B, Ci, H, W, Co, k, stride, pad, dil
+    (2, 64, 20, 28, 64, 1, 1, 0, 1),
+    (2, 64, 20, 28, 128, 3, 1, 1, 1),
+    (1, 256, 13, 17, 256, 3, 1, 1, 1),
+    (2, 128, 21, 30, 128, 3, 2, 1, 1),
+    (2, 256, 20, 28, 512, 1, 2, 0, 1),
+    (2, 3, 32, 40, 64, 7, 2, 3, 1),
+    (1, 256, 25, 31, 15, 1, 1, 0, 1),
+    (3, 576, 7, 7, 576, 3, 1, 1, 1),
+    (1, 16, 9, 9, 40, 3, 1, 2, 2),
+    (1, 24, 5, 6, 8, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('B,Ci,H,W,Co,k,stride,pad,dil', CASES)
+@pytest.mark.parametrize('relu,with_res', [(False, False), (True, True)])
+def test_conv2d_fwd_bwd(B, Ci, H, W, Co, k, stride, pad, dil, relu, with_res):
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B * 1000 + Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride, pad, dil)
+    res = torch.randn(ref.shape, generator=g) if with_res else None
+    rr = res.double().requires_grad_() if with_res else None
+    if with_res:
+        ref = ref + rr
+    if relu:
+        ref = F.relu(ref)
+    xd = x.to(dev).contiguous(memory_format=CL).requires_grad_()
+    wd = w.to(dev).contiguous(memory_format=CL).requires_grad_()
+    bd = b.to(dev).requires_grad_()
+    rd = res.to(dev).contiguous(memory_format=CL).requires_grad_() if with_res else None
+    y = dense.conv2d(xd, wd, bd, stride, pad, dil, relu, rd)
+    assert y.shape == ref.shape
+    K = Ci * k * k
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5 * K ** 0.5)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go.double())
+    y.backward(go.to(dev))
+    npix = ref.shape[0] * ref.shape[2] * ref.shape[3]
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=2e-5 * (Co * k * k) ** 0.5)
+    torch.testing.assert_close(wd.grad.cpu().double(), wr.grad, rtol=1e-4, atol=2e-5 * npix ** 0.5)
+    torch.testing.assert_close(bd.grad.cpu().double(), br.grad, rtol=1e-4, atol=2e-5 * npix ** 0.5)
+    if with_res:
+        torch.testing.assert_close(rd.grad.cpu().double(), rr.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('M,K,N', [(37, 12544, 1024), (200, 1024, 81), (5, 256, 128), (64, 81, 1025), (1, 128, 1)])
+def test_linear(M, K, N):
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    ref = F.relu(F.linear(xr, wr, br))
+    xd, wd, bd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    y = dense.linear(xd, wd, bd, relu=True)
+    torch.testing.assert_close(y.cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5 * K ** 0.5)
+    go = torch.randn(M, N, generator=g)
+    ref.backward(go.double())
+    y.backward(go.to(dev))
+    torch.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=2e-5 * N ** 0.5)
+    torch.testing.assert_close(wd.grad.cpu().double(), wr.grad, rtol=1e-4, atol=2e-5 * M ** 0.5)
+    torch.testing.assert_close(bd.grad.cpu().double(), br.grad, rtol=1e-4, atol=2e-5 * M ** 0.5)
+
+
+def test_conv_rejects_cpu():
+    from htd_amd import dense
+    with pytest.raises(NotImplementedError):
+        dense.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1))

@@ -99,8 +99,30 @@ def test_inference_matches_reference_fixture(det, golden):
         np.testing.assert_allclose(mine[:, :5], ref[:, :5], rtol=1e-3, atol=1e-2)
 
 
+class ReplaySampler:
+    """Stands in for RandomSampler.sample with the (pos, neg) index sets the oracle drew, so that the
+    comparison below is between continuous quantities only: a one-ulp difference in a box coordinate can move
+    an IoU across its threshold, which changes the candidate count and with it the whole random permutation."""
+
+    def __init__(self, orig, picks):
+        self.orig, self.picks, self.i = orig, picks, 0
+
+    def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kw):
+        from htd_amd.core.bbox import SamplingResult
+        bboxes = bboxes[:, :4]
+        gt_flags = bboxes.new_zeros((bboxes.shape[0], ), dtype=torch.uint8)
+        if self.orig.add_gt_as_proposals and len(gt_bboxes) > 0:
+            bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+            assign_result.add_gt_(gt_labels)
+            gt_flags = torch.cat([bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8), gt_flags])
+        pos, neg = self.picks[self.i]
+        self.i += 1
+        return SamplingResult(pos.to(bboxes.device), neg.to(bboxes.device), bboxes, gt_bboxes, assign_result, gt_flags)
+
+
 def test_train_step_matches_oracle_other_seed(det):
-    """Fresh inputs (not in any fixture), 3 images => exercises the generalised stage-2 positives (B > 2)."""
+    """Fresh inputs (not in any fixture), 3 images => exercises the generalised stage-2 positives (B > 2).
+    RPN: product end to end.  RoI head: fed the oracle's proposals and sample picks (see ReplaySampler)."""
     from oracle import detector as D
     dev = torch.device('cuda:0')
     H, W, B = 96, 160, 3
@@ -115,12 +137,22 @@ def test_train_step_matches_oracle_other_seed(det):
     sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
           for k, v in seeded_state_dict(D.state_shapes(50), prefix='det.').items()}
     torch.manual_seed(9)
-    ref_losses = D.forward_train(sd, T(imgs), metas, [T(x) for x in gts], [T(x) for x in labels], cfg)
+    trace = {}
+    ref_losses = D.forward_train(sd, T(imgs), metas, [T(x) for x in gts], [T(x) for x in labels], cfg, trace)
     ref_loss, ref_log = D.parse_losses(ref_losses)
     ref_loss.backward()
     det.train()
     torch.manual_seed(9)
-    losses = det.forward_train(T(imgs).to(dev), metas, [T(x).to(dev) for x in gts], [T(x).to(dev) for x in labels])
+    gts_d, labels_d = [T(x).to(dev) for x in gts], [T(x).to(dev) for x in labels]
+    x = det.extract_feat(T(imgs).to(dev))
+    losses, _ = det.rpn_head.forward_train(x, metas, gts_d, proposal_cfg=det.train_cfg.rpn_proposal)
+    head = det.roi_head
+    saved = list(head.bbox_sampler)
+    try:
+        head.bbox_sampler = [ReplaySampler(saved[i], trace['samples'][i]) for i in range(2)]
+        losses.update(head.forward_train(x, metas, [p.to(dev) for p in trace['proposals']], gts_d, labels_d))
+    finally:
+        head.bbox_sampler = saved
     loss, log_vars = det._parse_losses(losses)
     for k, v in log_vars.items():
         np.testing.assert_allclose(v, ref_log[k], rtol=5e-4, atol=1e-4, err_msg=k)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fp32 MFMA conv kernels on the layer shapes of HTD-R50 @ B=4, 800x1344
+(fwd / data-grad / weight-grad TFLOP/s), next to ATen's convolution for reference."""
+import sys
+import os
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+from htd_amd import dense
+
+CL = torch.channels_last
+LAYERS = [  # name, Ci, H, W, Co, k, stride, pad
+    ('l1.conv2 3x3 64', 64, 200, 336, 64, 3, 1, 1),
+    ('l1.conv3 1x1 64-256', 64, 200, 336, 256, 1, 1, 0),
+    ('l2.conv2 3x3 128', 128, 100, 168, 128, 3, 1, 1),
+    ('l2.conv3 1x1 128-512', 128, 100, 168, 512, 1, 1, 0),
+    ('l3.conv2 3x3 256', 256, 50, 84, 256, 3, 1, 1),
+    ('l3.conv1 1x1 1024-256', 1024, 50, 84, 256, 1, 1, 0),
+    ('l4.conv2 3x3 512', 512, 25, 42, 512, 3, 1, 1),
+    ('fpn P2 3x3 256', 256, 200, 336, 256, 3, 1, 1),
+    ('rpn P2 1x1 256-15', 256, 200, 336, 15, 1, 1, 0),
+    ('l2.0.conv2 3x3 s2', 128, 200, 336, 128, 3, 2, 1),
+]
+
+
+def timeit(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def main():
+    B = 4
+    dev = torch.device('cuda:0')
+    print(f'{"layer":26s} {"GFLOP":>8s} | {"fwd":>7s} {"dgrad":>7s} {"wgrad":>7s} TF/s (htd) | {"fwd":>7s} {"bwd":>7s} TF/s (ATen)')
+    for name, Ci, H, W, Co, k, s, p in LAYERS:
+        x = torch.randn(B, Ci, H, W, device=dev).contiguous(memory_format=CL)
+        w = (torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5).contiguous(memory_format=CL)
+        y = dense.conv2d(x, w, None, s, p, 1)
+        g = torch.randn_like(y)
+        flop = 2.0 * y.numel() * Ci * k * k
+        t_f = timeit(lambda: dense.conv2d(x, w, None, s, p, 1))
+        xg = x.clone().requires_grad_()
+        wg = w.clone().requires_grad_()
+
+        def bwd_x():
+            yy = dense.conv2d(xg, w, None, s, p, 1)
+            yy.backward(g)
+
+        def bwd_w():
+            yy = dense.conv2d(x, wg, None, s, p, 1)
+            yy.backward(g)
+        t_x = timeit(bwd_x) - t_f
+        t_w = timeit(bwd_w) - t_f
+        t_af = timeit(lambda: F.conv2d(x, w, None, s, p))
+
+        def aten_bwd():
+            yy = F.conv2d(xg, wg, None, s, p)
+            yy.backward(g)
+        t_ab = timeit(aten_bwd) - t_af
+        print(f'{name:26s} {flop / 1e9:8.1f} | {flop / t_f / 1e12:7.1f} {flop / t_x / 1e12:7.1f} {flop / t_w / 1e12:7.1f}'
+              f'             | {flop / t_af / 1e12:7.1f} {2 * flop / t_ab / 1e12:7.1f}')
+
+
+if __name__ == '__main__':
+    main()
