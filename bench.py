@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-kernels', action='store_true', help='print the per-kernel-class time table')
+    ap.add_argument('--profile-detail', action='store_true', help='per-layer-shape time table (implies the above)')
     return ap.parse_args()
 
 
@@ -96,7 +97,7 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(data)
     sync()
-    capi.profile_begin()
+    capi.profile_begin(detail=args.profile_detail)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.train_step(data)
@@ -115,9 +116,10 @@ def main():
 
     from htd_amd import dense
     roof = dense.roofline_report(prof, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS)
-    if args.profile_kernels:
-        for name, (n, tot_ms, kind, work) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
-            print(f'# {name:40s} calls={n:6d} total={tot_ms:9.3f} ms  {kind or ""} {work:.3e}', file=sys.stderr)
+    if args.profile_kernels or args.profile_detail:
+        for name, (n, tot_ms, kind, work) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:60]:
+            rate = (work / (tot_ms * 1e-3) / 1e12) if (kind and tot_ms > 0) else 0.0
+            print(f'# {name:64s} calls={n:5d} total={tot_ms:9.3f} ms  {kind or ""} {rate:8.2f} T/s', file=sys.stderr)
     out = {
         'metric': 'images/sec (1333x800) HTD-R%d train step' % args.depth, 'value': round(value, 3),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

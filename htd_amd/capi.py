@@ -78,9 +78,14 @@ def check(status, what=''):
 _PROFILE = None
 
 
-def profile_begin():
-    global _PROFILE
+_DETAIL = False
+
+
+def profile_begin(detail=False):
+    """detail=True keys the records by entry point AND integer arguments (layer shapes)."""
+    global _PROFILE, _DETAIL
     _PROFILE = {}
+    _DETAIL = detail
 
 
 def profile_end():
@@ -104,7 +109,10 @@ def call(name, *args, work=None):
         check(fn(*args), name)
         return
     import torch
-    rec = _PROFILE.setdefault(name, dict(events=[], kind=None, work=0.0))
+    key = name
+    if _DETAIL:
+        key = name + '(' + ','.join(str(a) for a in args if isinstance(a, int) and not isinstance(a, bool)) + ')'
+    rec = _PROFILE.setdefault(key, dict(events=[], kind=None, work=0.0))
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     status = fn(*args)

@@ -34,20 +34,27 @@ struct ConvParams {
     int mt, nt;         // tiles along M, N
 };
 
-template <int BK>
+// BK: floats of K per slice; WGM x WGN: wave grid of the block; TM x TN: 32x32 MFMA blocks per wave
+template <int BK, int WGM, int WGN, int TM, int TN>
 struct Tile {
-    static constexpr int BM = 128, BN = 128;
+    static constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     static constexpr int LDS_STRIDE = BK + 4;                 // floats
     static constexpr int VEC_PER_ROW = BK / 4;                // float4 per row slice
     static constexpr int ROWS_PER_PASS = 256 / VEC_PER_ROW;   // rows covered by the 256 threads at once
-    static constexpr int PASSES = BM / ROWS_PER_PASS;         // float4 loads per thread per operand
+    static constexpr int PASSES_A = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    static constexpr int PASSES_B = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    static constexpr int MAIN_FLOATS = 2 * (BM + BN) * LDS_STRIDE;
+    static constexpr int EPI_STRIDE = BN + 4;
+    static constexpr int EPI_ROWS = WGM * 32;                 // rows staged per epilogue round
+    static constexpr int EPI_FLOATS = EPI_ROWS * EPI_STRIDE;
+    static constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
 };
 
-template <int BK>
+template <int BK, int WGM, int WGN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
 {
-    using T = Tile<BK>;
-    __shared__ __attribute__((aligned(16))) float lds[2][(T::BM + T::BN) * T::LDS_STRIDE];
+    using T = Tile<BK, WGM, WGN, TM, TN>;
+    __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
 
     // XCD-aware tile order: blocks that share an XCD (ids congruent mod 8) walk neighbouring M tiles of the
     // same N tile, so the weight panel and the overlapping input rows stay in that XCD's L2.
@@ -62,18 +69,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
     const int n0 = tile_n * T::BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // ---- per-thread staging coordinates
     const int vcol = tid % T::VEC_PER_ROW;            // which float4 of the K slice
     const int vrow = tid / T::VEC_PER_ROW;            // first row handled
-    int a_hi0[T::PASSES], a_wi0[T::PASSES];
-    int64_t a_img[T::PASSES];
-    bool a_ok[T::PASSES];
+    int a_hi0[T::PASSES_A], a_wi0[T::PASSES_A];
+    int64_t a_img[T::PASSES_A];
+    bool a_ok[T::PASSES_A];
 #pragma unroll
-    for (int i = 0; i < T::PASSES; ++i) {
-        const int64_t m = m0 + vrow + i * T::ROWS_PER_PASS;
-        a_ok[i] = m < p.M;
+    for (int i = 0; i < T::PASSES_A; ++i) {
+        const int r = vrow + i * T::ROWS_PER_PASS;
+        const int64_t m = m0 + r;
+        a_ok[i] = r < T::BM && m < p.M;
         const int64_t mm = a_ok[i] ? m : 0;
         const int wo = (int)(mm % p.Wo);
         const int64_t t = mm / p.Wo;
@@ -84,25 +92,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
         a_img[i] = (int64_t)b * p.Hx * p.Wx;
     }
     const int64_t wrow_stride = (int64_t)p.kh * p.kw * p.Ci;
-    bool b_ok[T::PASSES];
-    const float *b_ptr[T::PASSES];
+    bool b_ok[T::PASSES_B];
+    const float *b_ptr[T::PASSES_B];
 #pragma unroll
-    for (int i = 0; i < T::PASSES; ++i) {
-        const int n = n0 + vrow + i * T::ROWS_PER_PASS;
-        b_ok[i] = n < p.Co;
+    for (int i = 0; i < T::PASSES_B; ++i) {
+        const int r = vrow + i * T::ROWS_PER_PASS;
+        const int n = n0 + r;
+        b_ok[i] = r < T::BN && n < p.Co;
         b_ptr[i] = p.w + (int64_t)(b_ok[i] ? n : 0) * wrow_stride + vcol * 4;
     }
 
     const int slices_per_tap = p.Ci / BK;
     const int num_slices = p.kh * p.kw * slices_per_tap;
 
-    float4 ra[T::PASSES], rb[T::PASSES];
+    float4 ra[T::PASSES_A], rb[T::PASSES_B];
     auto load_slice = [&](int s) {
         const int tap = s / slices_per_tap;
         const int ci0 = (s - tap * slices_per_tap) * BK;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
 #pragma unroll
-        for (int i = 0; i < T::PASSES; ++i) {
+        for (int i = 0; i < T::PASSES_A; ++i) {
             int hi = a_hi0[i] + ky * p.dil, wi = a_wi0[i] + kx * p.dil;
             bool ok = a_ok[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
             if (p.in_dilate > 1) {
@@ -112,26 +121,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
             }
             ra[i] = ok ? *reinterpret_cast<const float4 *>(p.x + (a_img[i] + (int64_t)hi * p.Wx + wi) * p.Ci + ci0 + vcol * 4)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < T::PASSES_B; ++i)
             rb[i] = b_ok[i] ? *reinterpret_cast<const float4 *>(b_ptr[i] + (int64_t)tap * p.Ci + ci0)
                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
     };
     auto store_slice = [&](int buf) {
-        float *la = lds[buf];
-        float *lb = lds[buf] + T::BM * T::LDS_STRIDE;
+        float *la = (lds + buf * (T::MAIN_FLOATS / 2));
+        float *lb = (lds + buf * (T::MAIN_FLOATS / 2)) + T::BM * T::LDS_STRIDE;
 #pragma unroll
-        for (int i = 0; i < T::PASSES; ++i) {
+        for (int i = 0; i < T::PASSES_A; ++i) {
             const int r = vrow + i * T::ROWS_PER_PASS;
-            *reinterpret_cast<float4 *>(la + r * T::LDS_STRIDE + vcol * 4) = ra[i];
-            *reinterpret_cast<float4 *>(lb + r * T::LDS_STRIDE + vcol * 4) = rb[i];
+            if (r < T::BM) *reinterpret_cast<float4 *>(la + r * T::LDS_STRIDE + vcol * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < T::PASSES_B; ++i) {
+            const int r = vrow + i * T::ROWS_PER_PASS;
+            if (r < T::BN) *reinterpret_cast<float4 *>(lb + r * T::LDS_STRIDE + vcol * 4) = rb[i];
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -142,20 +157,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
     for (int s = 0; s < num_slices; ++s) {
         const int cur = s & 1;
         if (s + 1 < num_slices) load_slice(s + 1);
-        const float *la = lds[cur] + (wm * 64 + frow) * T::LDS_STRIDE + fhalf * 4;
-        const float *lb = lds[cur] + (T::BM + wn * 64 + frow) * T::LDS_STRIDE + fhalf * 4;
+        const float *la = (lds + cur * (T::MAIN_FLOATS / 2)) + (wm * TM * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
+        const float *lb = (lds + cur * (T::MAIN_FLOATS / 2)) + (T::BM + wn * TN * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 fa[2], fb[2];
+            float4 fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const float4 *>(la + i * 32 * T::LDS_STRIDE + kk * 8);
-                fb[i] = *reinterpret_cast<const float4 *>(lb + i * 32 * T::LDS_STRIDE + kk * 8);
-            }
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(la + i * 32 * T::LDS_STRIDE + kk * 8);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4 *>(lb + j * 32 * T::LDS_STRIDE + kk * 8);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
@@ -166,41 +180,87 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
         __syncthreads();
     }
 
-    // ---- epilogue: D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // ---- epilogue.  D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Accumulators go through LDS (one 32-row band per wave row per round) so that global stores -- and the
+    // residual / mask loads -- are 16 B per lane along full output rows instead of 4 B column fragments.
+    const bool vec_ok = (p.Co & 3) == 0;
+    constexpr int V = T::BN / 4;                      // float4 per staged row
+    constexpr int RPP = 256 / V;                      // staged rows written per pass
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + frow;
-        if (n >= p.Co) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (m >= p.M) continue;
-                const int64_t o = m * p.Co + n;
-                float v = acc[i][j][r] + bv;
-                if (p.residual) v += p.residual[o];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;   // data gradient through the producer's ReLU
-                p.y[o] = v;
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                lds[row * T::EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
+            }
+        __syncthreads();
+        const int c4 = tid % V;
+        const int n = n0 + c4 * 4;
+#pragma unroll
+        for (int pass = 0; pass < T::EPI_ROWS / RPP; ++pass) {
+            const int row = tid / V + pass * RPP;                    // staged row: wave-row (row >> 5), line (row & 31)
+            const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+            if (m >= p.M || n >= p.Co) continue;
+            float4 v = *reinterpret_cast<const float4 *>(lds + row * T::EPI_STRIDE + c4 * 4);
+            const int64_t o = m * p.Co + n;
+            if (vec_ok) {
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (p.residual) {
+                    const float4 rv = *reinterpret_cast<const float4 *>(p.residual + o);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.mask_src) {   // data gradient through the ReLU of the layer that produced the conv input
+                    const float4 mv = *reinterpret_cast<const float4 *>(p.mask_src + o);
+                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                    v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(p.y + o) = v;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                for (int e = 0; e < 4 && n + e < p.Co; ++e) {
+                    float t = vv[e] + (p.bias ? p.bias[n + e] : 0.f);
+                    if (p.residual) t += p.residual[o + e];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (p.mask_src) t = p.mask_src[o + e] > 0.f ? t : 0.f;
+                    p.y[o + e] = t;
+                }
             }
         }
+        if (i + 1 < TM) __syncthreads();
     }
+}
+
+template <int WGM, int WGN, int TM, int TN>
+void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
+{
+    if (p.Ci % 32 == 0 && WGN * TN * 32 + WGM * TM * 32 <= 192)
+        hipLaunchKernelGGL((conv_igemm_kernel<32, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
+    else if (p.Ci % 16 == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<8, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 int launch_conv(ConvParams p, hipStream_t s)
 {
+    // tile width follows the output-channel count: 128 (2x2 waves of 64x64), 64 or 32 columns (4x1 waves)
+    const int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
     p.mt = (int)htd::ceil_div(p.M, 128);
-    p.nt = (int)htd::ceil_div(p.Co, 128);
+    p.nt = (int)htd::ceil_div(p.Co, bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;
     HTD_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid");
-    if (p.Ci % 32 == 0)
-        hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else if (p.Ci % 16 == 0)
-        hipLaunchKernelGGL(conv_igemm_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (bn == 32)
+        launch_cfg<4, 1, 1, 1>(p, (unsigned)blocks, s);
+    else if (bn == 64)
+        launch_cfg<4, 1, 1, 2>(p, (unsigned)blocks, s);
     else
-        hipLaunchKernelGGL(conv_igemm_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+        launch_cfg<2, 2, 2, 2>(p, (unsigned)blocks, s);
     return htd::check_launch("conv2d");
 }
 

@@ -198,6 +198,43 @@ __global__ __launch_bounds__(256) void colsum_mask_kernel(const float *__restric
     partial[(int64_t)blockIdx.x * C + c] = s;
 }
 
+// float4 version for C % 4 == 0: a block's 256 threads cover R = 256 / (C/4) rows per iteration with 16-byte
+// accesses (full-rate streaming), then fold their R partial rows through LDS.
+__global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                              float *__restrict__ gm, float *__restrict__ partial,
+                                                              int64_t rows, int C, int64_t rows_per_block)
+{
+    __shared__ float4 red[256];
+    const int C4 = C >> 2;
+    const int cbase = blockIdx.y * 256;                         // float4 column chunk of this block
+    const int cw = min(256, C4 - cbase);                        // float4 columns handled here
+    const int R = 256 / cw;
+    const int c4 = threadIdx.x % cw, rsub = threadIdx.x / cw;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rsub < R)
+        for (int64_t r = r0 + rsub; r < r1; r += R) {
+            const int64_t o = r * C + (int64_t)(cbase + c4) * 4;
+            float4 v = *reinterpret_cast<const float4 *>(g + o);
+            if (y) {
+                const float4 yv = *reinterpret_cast<const float4 *>(y + o);
+                v.x = yv.x > 0.f ? v.x : 0.f; v.y = yv.y > 0.f ? v.y : 0.f;
+                v.z = yv.z > 0.f ? v.z : 0.f; v.w = yv.w > 0.f ? v.w : 0.f;
+                *reinterpret_cast<float4 *>(gm + o) = v;
+            }
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rsub == 0) {
+        for (int k = 1; k < R; ++k) {
+            const float4 t = red[k * cw + c4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4 *>(partial + (int64_t)blockIdx.x * C + (int64_t)(cbase + c4) * 4) = s;
+    }
+}
+
 struct Cfg { int splits; int mt, nt; int bm, bn; };
 
 Cfg choose(int Co, int Ntot, int64_t K)
@@ -269,8 +306,12 @@ extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(256, htd::ceil_div(rows, 64)));
     const int64_t rpb = htd::ceil_div(std::max<int64_t>(rows, 1), nb);
     float *partial = (float *)workspace;
-    hipLaunchKernelGGL(colsum_mask_kernel, dim3(nb, (unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s, g, y, gm,
-                       partial, rows, C, rpb);
+    if ((C & 3) == 0 && (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gm | (uintptr_t)partial) & 15) == 0)
+        hipLaunchKernelGGL(colsum_mask_vec_kernel, dim3(nb, (unsigned)htd::ceil_div(C / 4, 256)), dim3(256), 0, s, g, y,
+                           gm, partial, rows, C, rpb);
+    else
+        hipLaunchKernelGGL(colsum_mask_kernel, dim3(nb, (unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s, g, y, gm,
+                           partial, rows, C, rpb);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s,
                        (const float *)partial, gbias, (int64_t)C, nb);
     return htd::check_launch("bias_grad");

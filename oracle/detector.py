@@ -473,7 +473,7 @@ def parse_losses(losses):
         log_vars[k] = v.mean() if isinstance(v, torch.Tensor) else sum(t.mean() for t in v)
     loss = sum(v for k, v in log_vars.items() if 'loss' in k)
     log_vars['loss'] = loss
-    return loss, {k: float(v) for k, v in log_vars.items()}
+    return loss, {k: float(v.detach()) for k, v in log_vars.items()}
 
 
 def simple_test(sd, img, img_metas, cfg):

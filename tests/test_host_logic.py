@@ -1,0 +1,193 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol of include/htd_amd.h, the registry /
+config surface builds the HTD detector with the reference's state_dict keys, and the product's device-agnostic
+host logic (anchors, IoU, assigner, sampler, coder, losses, batched PGraph) reproduces the reference-generated
+fixtures and the CPU oracle."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import seeded_tensor, seeded_state_value
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_capi_exports_every_declared_symbol():
+    from htd_amd import capi
+    from htd_amd.csrc import build as hip_build
+    hip_build.build()
+    decl = capi.declared_functions()
+    assert len(decl) >= 20
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name, _, _ in decl:
+        assert hasattr(lib, name), f'{name} declared in include/htd_amd.h but not exported'
+    capi.lib()
+    assert capi.lib().htd_abi_version() >= 1
+    # argument errors come back as status + message, never abort (no GPU needed: rejected before any launch)
+    with pytest.raises(ValueError):
+        capi.call('htd_roi_align_fwd', None, None, None, 0, None, 5, 1, 3, 4, 4, 7, 7, 1.0, 0, 1, None)
+
+
+def test_ops_refuse_cpu_tensors():
+    from htd_amd import dense, mmcv_ops as M
+    with pytest.raises(NotImplementedError):
+        M.roi_align(torch.zeros(1, 4, 4, 4), torch.zeros(1, 5), 7)
+    with pytest.raises(NotImplementedError):
+        M.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+    with pytest.raises(NotImplementedError):
+        dense.linear(torch.zeros(2, 8), torch.zeros(4, 8))
+
+
+def test_registry_and_config_build_detector():
+    from htd_amd import Config, ConfigDict
+    from htd_amd.configs import build_htd_detector, htd_config
+    from oracle import detector as D
+    for depth in (50, 101):
+        det = build_htd_detector(depth)
+        mine = {k: tuple(v.shape) for k, v in det.state_dict().items() if not k.endswith('num_batches_tracked')}
+        ref = {k: tuple(v) for k, v in D.state_shapes(depth).items()}
+        aliases = {k for k in mine if '.att.' in k}         # AdptRoIExtractor.att.{1,3} alias conv1/conv2 (as in the reference)
+        assert set(mine) - aliases == set(ref)
+        assert all(mine[k] == ref[k] for k in ref)
+    n_all = sum(p.numel() for p in det.parameters())
+    n_train = sum(p.numel() for p in det.parameters() if p.requires_grad)
+    assert abs(n_all / 1e6 - 93.63) < 0.01 and abs(n_train / 1e6 - 93.40) < 0.01
+    cfg = htd_config(50)
+    assert isinstance(cfg.train_cfg.rcnn[1], ConfigDict) and cfg.train_cfg.rcnn[1].assigner.pos_iou_thr == 0.6
+    assert cfg.train_cfg.get('rpn_proposal').nms_post == 2000
+
+
+def test_config_fromfile_with_base(tmp_path):
+    from htd_amd import Config
+    (tmp_path / 'base.py').write_text("model = dict(type='FasterRCNN', backbone=dict(type='ResNet', depth=50))\nlr = 0.02\n")
+    (tmp_path / 'child.py').write_text("_base_ = ['./base.py']\nmodel = dict(backbone=dict(depth=101))\n")
+    cfg = Config.fromfile(str(tmp_path / 'child.py'))
+    assert cfg.model.backbone.depth == 101 and cfg.model.backbone.type == 'ResNet' and cfg.lr == 0.02
+    cfg.merge_from_dict({'model.backbone.depth': 50})
+    assert cfg.model.backbone.depth == 50
+
+
+def test_reference_config_file_loads_if_present():
+    """The reference's own config file builds through this registry (authoring container only)."""
+    path = '/root/reference/configs/htd/htd_resnet50_1x.py'
+    if not os.path.exists(path):
+        pytest.skip('reference tree not present on this machine')
+    from htd_amd import Config, build_detector
+    from htd_amd import detector  # noqa: F401
+    cfg = Config.fromfile(path)
+    model = cfg.model.to_dict()
+    model['pretrained'] = None
+    det = build_detector(model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert type(det).__name__ == 'FasterRCNN' and type(det.roi_head).__name__ == 'HTDRoIHead'
+
+
+def test_anchors_exact(golden):
+    from htd_amd.core import AnchorGenerator
+    g = golden('anchors')
+    ag = AnchorGenerator(strides=[4, 8, 16, 32, 64], ratios=[0.5, 1.0, 2.0], scales=[8])
+    sizes = [tuple(s) for s in g['sizes']]
+    anchors = ag.grid_anchors(sizes, device='cpu')
+    flags = ag.valid_flags(sizes, tuple(g['pad_shape']), device='cpu')
+    for i in range(5):
+        assert torch.equal(anchors[i], T(g[f'anchors{i}'])) and torch.equal(flags[i], T(g[f'flags{i}']))
+    kat = AnchorGenerator([10], [1.], [1.], [10]).grid_anchors([(2, 2)], device='cpu')[0]    # tests/test_anchor.py:22-40
+    assert torch.equal(kat, T(g['kat_anchor']))
+    assert torch.equal(AnchorGenerator([(10, 20)], [1.], [1.], [10]).grid_anchors([(2, 2)], device='cpu')[0],
+                       T(g['kat_anchor_xy']))
+
+
+def test_box_math_and_assigner_and_sampler(golden):
+    from htd_amd.core import (MaxIoUAssigner, RandomSampler, bbox2delta, bbox_overlaps, delta2bbox, set_randperm)
+    g = golden('box_math')
+    b1, b2 = T(g['b1']), T(g['b2'])
+    assert torch.equal(bbox_overlaps(b1, b2), T(g['iou']))
+    assert torch.equal(bbox_overlaps(b1, b2, mode='iof'), T(g['iof']))
+    assert torch.equal(bbox_overlaps(b1[:9], b2, is_aligned=True), T(g['iou_aligned']))
+    torch.testing.assert_close(bbox2delta(b1[:9], b2, (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2)), T(g['deltas']),
+                               rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(delta2bbox(b1, T(g['rnd']), (0., 0., 0., 0.), (0.1, 0.1, 0.2, 0.2), (80, 90, 3)),
+                               T(g['dec']), rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(delta2bbox(T(g['kat_rois']), T(g['kat_deltas']), max_shape=(32, 32)), T(g['kat_dec']),
+                               rtol=1e-6, atol=1e-6)
+    a = golden('assigner')
+    r = MaxIoUAssigner(0.5, 0.5).assign(T(a['kat_bboxes']), T(a['kat_gts']), gt_labels=torch.LongTensor([2, 3]))
+    assert r.gt_inds.tolist() == [1, 0, 2, 0]
+    for tag, kw in [('rpn', dict(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True)),
+                    ('rcnn', dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False))]:
+        r = MaxIoUAssigner(**kw).assign(T(a[f'{tag}_bboxes']), T(a[f'{tag}_gts']), gt_labels=T(a[f'{tag}_gt_labels']))
+        assert torch.equal(r.gt_inds, T(a[f'{tag}_gt_inds'])) and torch.equal(r.labels, T(a[f'{tag}_labels']))
+        assert torch.equal(r.max_overlaps, T(a[f'{tag}_max_overlaps']))
+    assert (MaxIoUAssigner(0.5, 0.5).assign(T(a['kat_bboxes']), torch.empty(0, 4)).gt_inds == 0).all()
+    assert MaxIoUAssigner(0.5, 0.5).assign(torch.empty(0, 4), T(a['kat_gts'])).gt_inds.numel() == 0
+    # low-quality matching, gt_max_assign_all=False: last gt wins on a shared arg-max box (sequential overwrite)
+    ov = torch.tensor([[0.4, 0.2, 0.0], [0.4, 0.1, 0.35]])
+    r = MaxIoUAssigner(0.9, 0.3, min_pos_iou=0.3, gt_max_assign_all=False).assign_wrt_overlaps(ov)
+    assert r.gt_inds.tolist() == [2, 0, -1]
+    s = golden('sampler')
+    pb, gb, gl = T(s['bboxes']), T(s['gts']), T(s['gt_labels'])
+    ar = MaxIoUAssigner(0.3, 0.3, 0.3, match_low_quality=False).assign(pb, gb, gt_labels=gl)
+    set_randperm(lambda n, dev: torch.randperm(n).to(dev))
+    try:
+        torch.manual_seed(int(s['seed']))
+        res = RandomSampler(64, 0.25, -1, True).sample(ar, pb, gb, gl)
+    finally:
+        set_randperm(None)
+    for k in ('pos_inds', 'neg_inds', 'pos_is_gt', 'pos_assigned_gt_inds', 'pos_gt_labels', 'pos_bboxes', 'neg_bboxes'):
+        assert torch.equal(getattr(res, k), T(s[k])), k
+
+
+def test_losses_match_oracle():
+    from htd_amd.detector.losses import CrossEntropyLoss, SmoothL1Loss, accuracy
+    from oracle import boxes as B
+    g = torch.Generator().manual_seed(0)
+    pred, lab, w = torch.randn(40, 81, generator=g), torch.randint(0, 81, (40, ), generator=g), torch.rand(40, generator=g)
+    torch.testing.assert_close(CrossEntropyLoss()(pred, lab, w, avg_factor=17.), B.cross_entropy(pred, lab, w, 17.))
+    p1, l1 = torch.randn(50, 1, generator=g), torch.randint(0, 2, (50, ), generator=g)
+    torch.testing.assert_close(CrossEntropyLoss(use_sigmoid=True)(p1, l1, w.new_ones(50), avg_factor=9.),
+                               B.binary_cross_entropy(p1, l1, w.new_ones(50), 9.))
+    a, b, ww = torch.randn(30, 4, generator=g), torch.randn(30, 4, generator=g), torch.rand(30, 4, generator=g)
+    torch.testing.assert_close(SmoothL1Loss(beta=1 / 9.)(a, b, ww, avg_factor=5.), B.smooth_l1_loss(a, b, ww, 1 / 9., 5.))
+    torch.testing.assert_close(accuracy(pred, lab), B.accuracy(pred, lab))
+    assert accuracy(torch.zeros(0, 81), torch.zeros(0, dtype=torch.long)).item() == 0.          # empty input
+
+
+def test_batched_pgraph_matches_reference_fixture(golden):
+    """The padded-batch PGraph (htd_amd/detector/pgraph.py) against HTDBBoxHead.forward's double loop, through
+    the fixture the reference produced: same refined features => same cls logits."""
+    import torch.nn.functional as F
+    from htd_amd.detector.pgraph import pgraph_refine
+    from htd_amd.detector.roi_extractors import map_roi_levels
+    from oracle import detector as D
+    g = golden('pgraph')
+    sd = {k: T(seeded_state_value(('head1.' if '.bbox_head.1.' in k else 'head0.') + k.split('bbox_head.')[1][2:], s))
+          for k, s in D.state_shapes().items() if '.bbox_head.' in k}
+    h, h0 = 'roi_head.bbox_head.1.', 'roi_head.bbox_head.0.'
+    rois = T(g['rois'])
+    x_cls = seeded_tensor('head1.x_cls', (40, 256, 7, 7))
+    gfeat = seeded_tensor('head1.gfeat', (2, 256, 1, 1))
+
+    def fcs(t):
+        t = F.relu(F.linear(t, sd[h + 'fcs.0.weight'], sd[h + 'fcs.0.bias']))
+        return F.relu(F.linear(t, sd[h + 'fcs.2.weight'], sd[h + 'fcs.2.bias']))
+    x = fcs(x_cls.flatten(1))
+    x_glb = fcs((x_cls + gfeat[rois[:, 0].long()]).flatten(1))
+    w0, b0 = sd[h0 + 'fc_cls.weight'], sd[h0 + 'fc_cls.bias']
+    sam = torch.mm(F.linear(x, w0, b0).softmax(-1), torch.cat((w0, b0[:, None]), 1))
+    layers = [torch.nn.Linear(1024, 1024) for _ in range(4)]
+    for i, l in enumerate(layers):
+        l.weight.data, l.bias.data = sd[f'{h}graph_lvl{i}_cls.weight'], sd[f'{h}graph_lvl{i}_cls.bias']
+    lv = map_roi_levels(rois, 4)
+    assert torch.equal(lv, T(g['target_lvls']))
+    refined = pgraph_refine(x, sam, rois, lv, layers)
+    cls = F.linear(x_glb + refined, sd[h + 'fc_cls.weight'], sd[h + 'fc_cls.bias'])
+    torch.testing.assert_close(cls, T(g['cls']), rtol=1e-4, atol=1e-4)
+    # empty groups and a single-RoI group
+    one = pgraph_refine(x[:1], sam[:1], rois[:1], lv[:1], layers)
+    assert torch.isfinite(one).all() and one.shape == (1, 1024)
+    assert pgraph_refine(x[:0], sam[:0], rois[:0], lv[:0], layers).shape == (0, 1024)
