@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
+            // the next slice's registers go to the other LDS buffer in the shadow of the remaining MFMAs:
+            // by now (one 8-float K group = 4*TM*TN MFMAs later) the global loads issued above have landed
+            if (kk == (BK / 8 > 1 ? BK / 16 - 1 : 0) && s + 1 < num_slices) store_slice(cur ^ 1);
         }
-        if (s + 1 < num_slices) store_slice(cur ^ 1);
         __syncthreads();
     }
 
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
 template <int WGM, int WGN, int TM, int TN>
 void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
 {
-    if (p.Ci % 32 == 0 && WGN * TN * 32 + WGM * TM * 32 <= 192)
+    if (p.Ci % 32 == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<32, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
     else if (p.Ci % 16 == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
@@ -250,8 +252,10 @@ void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
 int launch_conv(ConvParams p, hipStream_t s)
 {
     // tile width follows the output-channel count: 128 (2x2 waves of 64x64), 64 or 32 columns (4x1 waves)
-    const int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
+    int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
     p.mt = (int)htd::ceil_div(p.M, 128);
+    // mid-size layers: fewer than two 128x128 tiles per CU -> halve the tile width so every CU holds >= 2 blocks
+    if (bn == 128 && (int64_t)p.mt * htd::ceil_div(p.Co, 128) < 512) bn = 64;
     p.nt = (int)htd::ceil_div(p.Co, bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;
     HTD_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid");

@@ -1,0 +1,164 @@
+"""Deformable convolution layers of the path: `DeformConv2dPack` (registry name 'DCN', what
+configs/htd/htd_resnet101_dcn_2x_mstrain.py:142 asks for) and `ModulatedDeformConv2dPack` ('DCNv2').
+Interface of mmcv.ops.{DeformConv2d,DeformConv2dPack,ModulatedDeformConv2dPack} as the reference uses them
+(backbones/resnet.py:186-194, zero-initialised `conv_offset` :608-612; stale wrappers
+build/lib/mmdet/ops/dcn/deform_conv.py:257-300,385-…).  GPU only: the reference has no CPU deformable conv either
+(deform_conv.py:45-46 raises NotImplementedError).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from . import capi, dense
+from .registry import CONV_LAYERS
+
+CL = torch.channels_last
+_P, _S = capi.ptr, capi.current_stream_ptr
+
+
+class DeformConv2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, stride, padding, dilation, deform_groups):
+        if not x.is_cuda:
+            raise NotImplementedError('deform_conv2d: only GPU tensors are supported')
+        if x.dim() != 4:
+            raise ValueError(f'Expected 4D tensor as input, got {x.dim()}D tensor instead.')   # deform_conv.py:27-29
+        x = x.contiguous(memory_format=CL)
+        offset = offset.contiguous(memory_format=CL)
+        mask = mask.contiguous(memory_format=CL) if mask is not None else None
+        weight = weight.contiguous(memory_format=CL)
+        B, C, H, W = x.shape
+        Co, _, kh, kw = weight.shape
+        Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+        if offset.shape != (B, 2 * deform_groups * kh * kw, Ho, Wo):
+            raise ValueError(f'offset shape {tuple(offset.shape)} does not match output {(B, Ho, Wo)}')
+        M, K = B * Ho * Wo, kh * kw * C
+        cols = torch.empty(M, K, device=x.device, dtype=x.dtype)
+        capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
+                  dilation, deform_groups, _S(), work=('byte', 4.0 * M * K * 2))
+        y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
+        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), None, None, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1, 0, _S(),
+                  work=('flop', 2.0 * M * K * Co))
+        ctx.save_for_backward(x, offset, mask, weight)
+        ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, offset, mask, weight = ctx.saved_tensors
+        stride, padding, dilation, dg, Ho, Wo = ctx.cfg
+        B, C, H, W = x.shape
+        Co, _, kh, kw = weight.shape
+        M, K = B * Ho * Wo, kh * kw * C
+        gy = gy.contiguous(memory_format=CL)
+        gx = goff = gmask = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
+            wT = torch.empty(K * Co, device=gy.device, dtype=gy.dtype)
+            capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, 1, 1, K, _S())
+            gcol = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
+            capi.call('htd_conv2d_bwd_data', _P(gy), _P(wT), None, _P(gcol), 1, M, 1, K, Co, 1, 1, 1, 0, 1, _S(),
+                      work=('flop', 2.0 * M * K * Co))
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty((B, C, H, W), device=gy.device, dtype=gy.dtype, memory_format=CL).zero_()
+            goff = torch.empty_like(offset, memory_format=CL)
+            gmask = torch.empty_like(mask, memory_format=CL) if mask is not None else None
+            capi.call('htd_deform_col2im', _P(x), _P(offset), _P(mask), _P(gcol), _P(gx), _P(goff), _P(gmask), B, H, W,
+                      C, kh, kw, stride, padding, dilation, dg, _S())
+        if ctx.needs_input_grad[3]:
+            cols = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
+            capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
+                      dilation, dg, _S())
+            gw = torch.empty((Co, C, kh, kw), device=gy.device, dtype=gy.dtype, memory_format=CL)
+            nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(1, M, 1, K, Co, 1, 1, 1, 0, 1)
+            ws = torch.empty(nbytes // 4 + 1, device=gy.device, dtype=gy.dtype)
+            capi.call('htd_conv2d_bwd_weight', _P(cols), _P(gy), _P(gw), 1, M, 1, K, Co, 1, 1, 1, 0, 1, _P(ws), _S(),
+                      work=('flop', 2.0 * M * K * Co))
+        return gx, goff, gmask, gw, None, None, None, None
+
+
+def deform_conv2d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deform_groups=1, mask=None):
+    if groups != 1:
+        raise NotImplementedError('deform_conv2d: groups > 1 is outside the HTD path (ResNeXt is SURVEY 8f)')
+    s, p, d = _pair(stride)[0], _pair(padding)[0], _pair(dilation)[0]
+    return DeformConv2dFunction.apply(x, offset, mask, weight, s, p, d, deform_groups)
+
+
+class DeformConv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deform_groups=1, bias=False, deformable_groups=None):
+        super().__init__()
+        assert not bias, 'mmcv DeformConv2d has no bias'
+        if deformable_groups is not None:
+            deform_groups = deformable_groups
+        assert in_channels % groups == 0 and out_channels % groups == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = _pair(kernel_size), _pair(stride), \
+            _pair(padding), _pair(dilation)
+        self.groups, self.deform_groups = groups, deform_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *self.kernel_size)
+                                   .contiguous(memory_format=CL))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+        return self
+
+    def forward(self, x, offset):
+        return deform_conv2d(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                             self.deform_groups)
+
+
+@CONV_LAYERS.register_module('DCN')
+class DeformConv2dPack(DeformConv2d):
+    """Offsets predicted by a zero-initialised 3x3 conv of the same geometry (C -> deform_groups*2*kh*kw)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        from .detector.bricks import Conv2d
+        self.conv_offset = Conv2d(self.in_channels, self.deform_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                  kernel_size=self.kernel_size, stride=self.stride, padding=self.padding,
+                                  dilation=self.dilation, bias=True)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv2d(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                             self.deform_groups)
+
+
+@CONV_LAYERS.register_module('DCNv2')
+class ModulatedDeformConv2dPack(DeformConv2d):
+    """DCNv2: conv_offset predicts 2*K offsets + K mask logits; mask = sigmoid."""
+
+    def __init__(self, *args, bias=True, **kwargs):
+        super().__init__(*args, bias=False, **kwargs)
+        from .detector.bricks import Conv2d
+        self.bias = nn.Parameter(torch.zeros(self.out_channels)) if bias else None
+        taps = self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset = Conv2d(self.in_channels, self.deform_groups * 3 * taps, kernel_size=self.kernel_size,
+                                  stride=self.stride, padding=self.padding, dilation=self.dilation, bias=True)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        y = deform_conv2d(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                          self.deform_groups, mask=torch.sigmoid(mask))
+        return y if self.bias is None else y + self.bias.view(1, -1, 1, 1)

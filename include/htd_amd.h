@@ -134,6 +134,27 @@ int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gb
                             int C, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Deformable convolution v1 / v2 (mask == NULL => v1 = the 'DCN' the HTD config uses,
+ * configs/htd/htd_resnet101_dcn_2x_mstrain.py:142; built at backbones/resnet.py:186-194).  The reference-era
+ * native entry points deform_conv_forward / _backward_input / _backward_parameters
+ * (build/lib/mmdet/ops/dcn/deform_conv.py:51-56,75-81,85-91; modulated :144-167) are im2col + GEMM; here the
+ * gather/scatter halves are exported and the GEMM halves are htd_conv2d_fwd / _bwd_data / _bwd_weight (1x1)
+ * on the column matrix, so the contraction runs on the same MFMA kernels as every other convolution:
+ *   fwd:  columns = deform_im2col(x, offset, mask); y = conv2d_fwd(columns as [M][1][1][K], w[Co][K])
+ *   bwd:  gcol = conv2d_bwd_data(gy, w); (gx, goffset, gmask) = deform_col2im(gcol); gw = conv2d_bwd_weight
+ *   x [B][H][W][C]   offset [B][Ho][Wo][dg*kh*kw*2] (dy,dx pairs)   mask [B][Ho][Wo][dg*kh*kw] or NULL
+ *   columns / gcolumns [B*Ho*Wo][kh*kw*C] (tap-major: same k order as KRSC weights)
+ *   gx must be zero-initialised (atomic accumulation); gx / goffset / gmask may be NULL to skip them.
+ * ---------------------------------------------------------------------------------- */
+int64_t htd_deform_columns_bytes(int B, int H, int W, int C, int kh, int kw, int stride, int pad, int dil);
+int htd_deform_im2col(const float *x, const float *offset, const float *mask, float *columns, int B,
+                      int H, int W, int C, int kh, int kw, int stride, int pad, int dil,
+                      int deform_groups, void *stream);
+int htd_deform_col2im(const float *x, const float *offset, const float *mask, const float *gcolumns,
+                      float *gx, float *goffset, float *gmask, int B, int H, int W, int C, int kh,
+                      int kw, int stride, int pad, int dil, int deform_groups, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * SFA global pooling (GlobalContextHead.forward global_context_head.py:386,
  * nn.AdaptiveAvgPool2d(1)) and the 7x7 AvgPool of the reg branch (htd_bbox_head.py:122,188):
  *   out[b][c] = mean over P positions of x[b][p][c];  bwd: gx[b][p][c] = g[b][c] / P.

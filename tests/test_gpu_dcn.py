@@ -1,0 +1,81 @@
+"""Deformable conv (v1 'DCN' and v2) kernels against the CPU oracle (C forward, torch autograd restatement)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+@pytest.mark.parametrize('B,C,H,W,Co,stride,with_mask', [(2, 32, 11, 13, 24, 1, False), (1, 64, 9, 10, 32, 2, False),
+                                                          (2, 16, 8, 8, 16, 1, True)])
+def test_deform_conv_fwd_bwd(B, C, H, W, Co, stride, with_mask):
+    from htd_amd.dcn import deform_conv2d
+    from oracle import ops as O
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    off = torch.randn(B, 18, Ho, Wo, generator=g) * 1.5           # up to several pixels, incl. out-of-image taps
+    mask = torch.rand(B, 9, Ho, Wo, generator=g) if with_mask else None
+    ref_c = O.deform_conv2d(x, off, w, stride, 1, 1, mask=mask)
+    xr, offr, wr = x.clone().requires_grad_(), off.clone().requires_grad_(), w.clone().requires_grad_()
+    mr = mask.clone().requires_grad_() if with_mask else None
+    ref = O.deform_conv2d_autograd(xr, offr, wr, stride, 1, 1, mask=mr)
+    torch.testing.assert_close(ref.detach(), ref_c, rtol=1e-4, atol=1e-4)      # the two oracle forms agree
+    xd = x.to(dev).contiguous(memory_format=CL).requires_grad_()
+    od = off.to(dev).contiguous(memory_format=CL).requires_grad_()
+    wd = w.to(dev).contiguous(memory_format=CL).requires_grad_()
+    md = mask.to(dev).contiguous(memory_format=CL).requires_grad_() if with_mask else None
+    y = deform_conv2d(xd, od, wd, stride, 1, 1, mask=md)
+    torch.testing.assert_close(y.cpu(), ref_c, rtol=1e-4, atol=1e-4)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    y.backward(go.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(od.grad.cpu(), offr.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-3, atol=1e-3)
+    if with_mask:
+        torch.testing.assert_close(md.grad.cpu(), mr.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_zero_offsets_equal_plain_conv_and_pack_layer():
+    """conv_offset is zero-initialised (resnet.py:608-612): a fresh DCN layer is exactly the plain 3x3 conv."""
+    from htd_amd.registry import CONV_LAYERS
+    from htd_amd import detector  # noqa: F401
+    dev = torch.device('cuda:0')
+    layer = CONV_LAYERS.get('DCN')(32, 48, kernel_size=3, stride=1, padding=1, dilation=1, bias=False, deform_groups=1).to(dev)
+    assert hasattr(layer, 'conv_offset') and layer.conv_offset.weight.abs().sum().item() == 0.0
+    x = torch.randn(2, 32, 10, 12, device=dev).contiguous(memory_format=CL)
+    y = layer(x)
+    ref = F.conv2d(x.cpu().double(), layer.weight.detach().cpu().double(), None, 1, 1)
+    torch.testing.assert_close(y.detach().cpu().double(), ref, rtol=1e-4, atol=1e-4)
+    v2 = CONV_LAYERS.get('DCNv2')(32, 48, kernel_size=3, stride=1, padding=1, dilation=1, deform_groups=1).to(dev)
+    y2 = v2(x)                                              # mask = sigmoid(0) = 0.5
+    ref2 = 0.5 * F.conv2d(x.cpu().double(), v2.weight.detach().cpu().double(), None, 1, 1)
+    torch.testing.assert_close(y2.detach().cpu().double(), ref2, rtol=1e-4, atol=1e-4)
+
+
+def test_r101_dcn_backbone_block_matches_oracle():
+    """One DCN bottleneck (conv2 = DeformConv2dPack with non-zero offsets) against oracle.bottleneck."""
+    from golden_util import seeded_state_value
+    from htd_amd.detector.resnet import Bottleneck, ResLayer
+    from oracle import detector as D
+    dev = torch.device('cuda:0')
+    layer = ResLayer(Bottleneck, 64, 32, 1, stride=2, dcn=dict(type='DCN', deform_groups=1, fallback_on_stride=False),
+                     norm_cfg=dict(type='BN', requires_grad=True)).eval()
+    sd = {}
+    with torch.no_grad():
+        for k, t in layer.state_dict().items():
+            if k.endswith('num_batches_tracked'):
+                continue
+            v = torch.from_numpy(seeded_state_value('dcnblk.' + k, t.shape))
+            if 'conv_offset' in k:
+                v = v * 3.0
+            t.copy_(v)
+            sd['blk.' + k[2:]] = v.clone()
+    x = torch.randn(2, 64, 12, 14, generator=torch.Generator().manual_seed(1))
+    ref = D.bottleneck(sd, 'blk', x, 2, dcn=True)
+    y = layer.to(dev)(x.to(dev).contiguous(memory_format=CL))
+    torch.testing.assert_close(y.detach().cpu(), ref, rtol=1e-3, atol=1e-4)
