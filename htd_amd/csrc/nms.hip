@@ -173,3 +173,96 @@ extern "C" int htd_nms_sorted(const float *boxes, uint8_t *keep_mask, int64_t n,
     hipLaunchKernelGGL(write_two, dim3(1), dim3(1), 0, (hipStream_t)stream, seg, n);
     return htd_nms_sorted_batched(boxes, seg, 1, n, n, keep_mask, iou_thr, offset, workspace, stream);
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Soft-NMS (mmcv.ops.soft_nms; R101 test configs: configs/htd/htd_resnet101_2x.py:298 `type='soft_nms'`,
+// linear decay, min_score 0.05).  mmcv runs it sequentially on the CPU after a device->host copy
+// (build/lib/mmdet/ops/nms/nms_wrapper.py:62-116).  Here every (image, class) segment is one workgroup: each
+// round picks the best remaining box (block-wide arg-max), then decays / discards the rest in parallel.  Rounds are
+// inherently sequential, segments are independent.  Arithmetic as the CPU code: ovr = inter / (a_i + a_j - inter),
+// linear: w = 1 - ovr if ovr >= thr; naive: w = 0; gaussian: w = exp(-ovr^2 / sigma); box dropped when its score
+// falls below min_score.  Equal scores are resolved towards the lower row (the CPU code's swap history decides).
+namespace {
+
+constexpr int SN_THREADS = 256;
+
+__global__ __launch_bounds__(SN_THREADS) void soft_nms_kernel(const float4 *__restrict__ boxes, float *__restrict__ scores,
+                                                              const int64_t *__restrict__ seg_offsets,
+                                                              int *__restrict__ rank, float thr, float sigma,
+                                                              float min_score, int method, float off)
+{
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t begin = seg_offsets[seg];
+    const int n = (int)(seg_offsets[seg + 1] - begin);
+    const float4 *bx = boxes + begin;
+    float *sc = scores + begin;
+    int *rk = rank + begin;                      // -1 active, -2 discarded, >= 0 selection round
+    for (int i = tid; i < n; i += SN_THREADS) rk[i] = -1;
+    __shared__ float red_s[SN_THREADS / 64];
+    __shared__ int red_i[SN_THREADS / 64];
+    __shared__ int chosen;
+    __syncthreads();
+    for (int round = 0; round < n; ++round) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += SN_THREADS)
+            if (rk[i] == -1) {
+                const float v = sc[i];
+                if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { red_s[wave] = best; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < SN_THREADS / 64; ++w)
+                if (red_s[w] > best || (red_s[w] == best && red_i[w] < bi)) { best = red_s[w]; bi = red_i[w]; }
+            chosen = bi;
+            if (bi != 0x7fffffff) rk[bi] = round;
+        }
+        __syncthreads();
+        const int c = chosen;
+        if (c == 0x7fffffff) break;
+        const float4 a = bx[c];
+        const float area_a = (a.z - a.x + off) * (a.w - a.y + off);
+        for (int i = tid; i < n; i += SN_THREADS)
+            if (rk[i] == -1) {
+                const float4 b = bx[i];
+                const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+                const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+                const float w = fmaxf(0.f, xx2 - xx1 + off), h = fmaxf(0.f, yy2 - yy1 + off);
+                const float inter = w * h;
+                const float area_b = (b.z - b.x + off) * (b.w - b.y + off);
+                const float ovr = inter / (area_a + area_b - inter);
+                float weight = 1.f;
+                if (method == 0) { if (ovr >= thr) weight = 0.f; }
+                else if (method == 1) { if (ovr >= thr) weight = 1.f - ovr; }
+                else weight = expf(-(ovr * ovr) / sigma);
+                const float v = sc[i] * weight;
+                sc[i] = v;
+                if (v < min_score) rk[i] = -2;
+            }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int htd_soft_nms_segments(const float *boxes, float *scores, const int64_t *seg_offsets, int segments,
+                                     int64_t n_total, int *rank, float iou_thr, float sigma, float min_score,
+                                     int method, int offset, void *stream)
+{
+    HTD_REQUIRE(segments >= 0 && n_total >= 0, "soft_nms: negative size");
+    HTD_REQUIRE(method >= 0 && method <= 2, "soft_nms: method must be 0 (naive), 1 (linear) or 2 (gaussian)");
+    HTD_REQUIRE(offset == 0 || offset == 1, "soft_nms: offset must be 0 or 1");
+    if (segments == 0 || n_total == 0) return HTD_OK;
+    HTD_REQUIRE(boxes && scores && seg_offsets && rank, "soft_nms: null pointer");
+    hipLaunchKernelGGL(soft_nms_kernel, dim3((unsigned)segments), dim3(SN_THREADS), 0, (hipStream_t)stream,
+                       (const float4 *)boxes, scores, seg_offsets, rank, iou_thr, sigma, min_score, method, (float)offset);
+    return htd::check_launch("soft_nms");
+}

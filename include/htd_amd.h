@@ -75,6 +75,19 @@ int htd_nms_sorted_batched(const float *boxes, const int64_t *seg_offsets, int s
                            int offset, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Soft-NMS over independent segments ((image, class) groups), on the device.  Replaces
+ * nms_ext.soft_nms(dets_cpu, iou_thr, method_code, sigma, min_score)
+ * build/lib/mmdet/ops/nms/nms_wrapper.py:62-116 (sequential, CPU-only in mmcv) as selected by
+ * configs/htd/htd_resnet101_2x.py:298 through multiclass_nms (core/post_processing/bbox_nms.py:65).
+ *   boxes [n][4]; scores [n] in/out (decayed in place); seg_offsets [segments+1] device int64;
+ *   rank [n] out: selection round within the segment (>= 0, kept) or < 0 (dropped below min_score);
+ *   method 0 naive, 1 linear, 2 gaussian.
+ * ---------------------------------------------------------------------------------- */
+int htd_soft_nms_segments(const float *boxes, float *scores, const int64_t *seg_offsets, int segments,
+                          int64_t n_total, int *rank, float iou_thr, float sigma, float min_score,
+                          int method, int offset, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * _fuse_global (htd_roi_head.py:133-141 == htd_bbox_head.py:147-155):
  *   out[i][p][c] = roi_feats[i][p][c] + global_feat[img(i)][c],  img(i) = (int)rois[i][0]
  * optionally + alpha * extra[i][p][c]  (x_reg + g + alpha*enhanced, htd_bbox_head.py:163,184).
