@@ -30,6 +30,7 @@ struct ConvParams {
     int in_dilate;      // >1: the input is a zero-stuffed view of x (x sample every in_dilate pixels)
     int Hx, Wx;         // physical size of x when in_dilate > 1
     int relu;
+    int64_t w_bstride;  // >0: batched GEMM, image b uses weights w + b*w_bstride (tiles never straddle images)
     int64_t M;          // B*Ho*Wo
     int mt, nt;         // tiles along M, N
 };
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
         a_img[i] = (int64_t)b * p.Hx * p.Wx;
     }
     const int64_t wrow_stride = (int64_t)p.kh * p.kw * p.Ci;
+    const float *wbase = p.w + (p.w_bstride > 0 ? (m0 / ((int64_t)p.Ho * p.Wo)) * p.w_bstride : 0);
     bool b_ok[T::PASSES_B];
     const float *b_ptr[T::PASSES_B];
 #pragma unroll
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
         const int r = vrow + i * T::ROWS_PER_PASS;
         const int n = n0 + r;
         b_ok[i] = r < T::BN && n < p.Co;
-        b_ptr[i] = p.w + (int64_t)(b_ok[i] ? n : 0) * wrow_stride + vcol * 4;
+        b_ptr[i] = wbase + (int64_t)(b_ok[i] ? n : 0) * wrow_stride + vcol * 4;
     }
 
     const int slices_per_tap = p.Ci / BK;
@@ -287,6 +289,22 @@ extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias,
     HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_fwd: empty output");
     p.in_dilate = 1; p.Hx = H; p.Wx = W; p.relu = relu;
     p.M = (int64_t)B * p.Ho * p.Wo;
+    return launch_conv(p, (hipStream_t)stream);
+}
+
+// Batched NT GEMM on the same kernel: c[g] = a[g] @ b[g]^T, a [G][M][K], b [G][N][K], c [G][M][N].
+extern "C" int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int M, int N, int K, void *stream)
+{
+    HTD_REQUIRE(G > 0 && M > 0 && N > 0 && K > 0, "bgemm_nt: bad sizes G=%d M=%d N=%d K=%d", G, M, N, K);
+    HTD_REQUIRE(K % 8 == 0, "bgemm_nt: K=%d must be a multiple of 8", K);
+    HTD_REQUIRE(G == 1 || M % 128 == 0, "bgemm_nt: M=%d must be a multiple of 128 when G > 1 (tiles may not straddle groups)", M);
+    HTD_REQUIRE(a && b && c, "bgemm_nt: null pointer");
+    ConvParams p{};
+    p.x = a; p.w = b; p.y = c;
+    p.B = G; p.H = M; p.W = 1; p.Ci = K; p.Co = N; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+    p.Ho = M; p.Wo = 1; p.in_dilate = 1; p.Hx = M; p.Wx = 1; p.relu = 0;
+    p.w_bstride = (int64_t)N * K;
+    p.M = (int64_t)G * M;
     return launch_conv(p, (hipStream_t)stream);
 }
 

@@ -126,6 +126,44 @@ def linear(x, weight, bias=None, relu=False):
     return y.permute(0, 2, 3, 1).reshape(M, N)
 
 
+class BatchedGemmNT(Function):
+    """c[g] = a[g] @ b[g]^T on the MFMA kernel (htd_bgemm_nt).  a (G,M,K), b (G,N,K) -> (G,M,N).
+    Backward is two more NT products on transposed copies: ga = gc @ b, gb = gc^T @ a."""
+
+    @staticmethod
+    def _run(a, b):
+        G, M, K = a.shape
+        N = b.size(1)
+        c = torch.empty(G, M, N, device=a.device, dtype=a.dtype)
+        capi.call('htd_bgemm_nt', _P(a), _P(b), _P(c), G, M, N, K, _S(), work=('flop', 2.0 * G * M * N * K))
+        return c
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, 'bgemm_nt')
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b)
+        return BatchedGemmNT._run(a, b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        gc = gc.contiguous()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = BatchedGemmNT._run(gc, b.transpose(1, 2).contiguous())                 # (G,M,N) x (G,K,N)^T
+        if ctx.needs_input_grad[1]:
+            gb = BatchedGemmNT._run(gc.transpose(1, 2).contiguous(), a.transpose(1, 2).contiguous())   # (G,N,M) x (G,K,M)^T
+        return ga, gb
+
+
+def bgemm_nt(a, b):
+    """Batched a @ b^T; every dimension that becomes a row count must be a multiple of 128 when G > 1 and every
+    reduction length a multiple of 8 (PGraph pads its groups accordingly)."""
+    return BatchedGemmNT.apply(a, b)
+
+
 def roofline_report(prof, peak_tflops, peak_gbs):
     """The `roofline` object of bench.py for the dominant hand-written kernel of the timed region:
     achieved = algorithmic work of its launches / their summed device time (live HIP-event timing)."""

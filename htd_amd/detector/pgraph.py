@@ -3,14 +3,14 @@ semantic interaction (HTDBBoxHead.forward, htd_bbox_head.py:195-219).
 
 The reference runs a Python double loop over images and levels with boolean-mask gathers, `.any()`
 host syncs and five tiny mm's per group.  Here ALL groups of the call are one padded batch
-[G, n_max, .]: one stable sort puts each group's RoIs next to each other, the adjacency products are
-batched contractions, the four per-level Linear layers are applied to their groups' rows, and the
+[G, n_pad, .] (n_pad = largest group rounded up to the 128-row MFMA tile): one stable sort puts each
+group's RoIs next to each other, the three adjacency x feature contractions are three launches of the
+batched fp32-MFMA GEMM (htd_bgemm_nt), the four per-level Linear layers run on the same kernels, and the
 result is scattered back -- a fixed, small number of launches with a single host read (group sizes).
 """
 import torch
-import torch.nn.functional as F
 
-from ..core.bbox import bbox_overlaps
+from .. import dense
 
 
 def group_layout(rois, target_lvls, num_levels):
@@ -42,13 +42,16 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers):
     if nmax == 0:
         return refined
     # padded batch index: row r of group g  <-  sorted position start_g + r
+    npad = (nmax + 127) // 128 * 128
     starts = torch.cumsum(counts, 0) - counts
-    ar = torch.arange(nmax, device=x.device)
-    valid = ar[None, :] < counts[:, None]                                   # (G, nmax)
+    ar = torch.arange(npad, device=x.device)
+    valid = ar[None, :] < counts[:, None]                                   # (G, npad)
     src = (starts[:, None] + ar[None, :]).clamp(max=N - 1)
-    rows = perm[src]                                                        # (G, nmax) original RoI rows
-    xg = x[rows] * valid[..., None]
-    sg = sam[rows] * valid[..., None]
+    rows = perm[src]                                                        # (G, npad) original RoI rows
+    vf = valid[..., None].to(x.dtype)
+    xg = x[rows] * vf
+    S8 = (sam.size(1) + 7) // 8 * 8
+    sg = torch.nn.functional.pad(sam[rows] * vf, (0, S8 - sam.size(1)))
     bx = rois[rows][..., 1:5]
     # pairwise IoU inside each group (bbox_overlaps with its eps=1e-6 union floor), unit diagonal
     lt = torch.max(bx[:, :, None, :2], bx[:, None, :, :2])
@@ -57,24 +60,22 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers):
     inter = wh[..., 0] * wh[..., 1]
     area = (bx[..., 2] - bx[..., 0]) * (bx[..., 3] - bx[..., 1])
     union = torch.max(area[:, :, None] + area[:, None, :] - inter, inter.new_tensor([1e-6]))
-    iou = inter / union
-    eye = torch.eye(nmax, device=x.device, dtype=torch.bool)[None]
+    eye = torch.eye(npad, device=x.device, dtype=torch.bool)[None]
     pair = valid[:, :, None] & valid[:, None, :]
-    Mloc = (((iou > 0) | eye) & pair).to(x.dtype)                           # (G, nmax, nmax)
-    deg = Mloc.sum(-1).clamp(min=1.0)                                       # padded rows: avoid 0^-1/2
-    dinv = deg.pow(-0.5)
+    Mloc = (((inter / union > 0) | eye) & pair).to(x.dtype)                 # (G, npad, npad), symmetric
+    dinv = Mloc.sum(-1).clamp(min=1.0).pow(-0.5)                            # padded rows: avoid 0^-1/2
     A_local = dinv[:, :, None] * Mloc * dinv[:, None, :]
-    mixed = torch.bmm(A_local, xg)
-    sim = torch.bmm(sg, sg.transpose(1, 2))
+    # mixed^T[f][i] = sum_j x^T[f][j] * A_local[i][j]   (A_local @ x, kept transposed: it is the NT operand below)
+    mixedT = dense.bgemm_nt(xg.transpose(1, 2).contiguous(), A_local)       # (G, F, npad)
+    sim = dense.bgemm_nt(sg, sg)                                            # (G, npad, npad)
     logits = (1.0 - Mloc) * sim
     logits = torch.where(pair, logits, logits.new_full((1, ), float('-inf')))   # padded columns carry no mass
     logits = torch.where(valid[:, :, None], logits, torch.zeros_like(logits))   # padded rows: finite, unused
-    A_glob = torch.softmax(logits, dim=-1)
-    A_glob = torch.where(valid[:, :, None], A_glob, torch.zeros_like(A_glob))
-    agg = torch.bmm(A_glob, mixed)                                          # (G, nmax, F)
-    agg = agg.view(B, L, nmax, Fdim)
+    A_glob = torch.softmax(logits, dim=-1) * vf
+    agg = dense.bgemm_nt(A_glob, mixedT).view(B, L, npad, Fdim)             # A_glob @ mixed
     outs = []
     for i, layer in enumerate(graph_layers):
-        outs.append(F.relu(F.linear(agg[:, i], layer.weight, layer.bias)))
-    out = torch.stack(outs, 1).view(G, nmax, Fdim)
+        outs.append(dense.linear(agg[:, i].reshape(B * npad, Fdim), layer.weight, layer.bias, relu=True)
+                    .view(B, npad, Fdim))
+    out = torch.stack(outs, 1).view(G, npad, Fdim)
     return refined.index_put((rows[valid], ), out[valid])

@@ -89,8 +89,9 @@ class AdptRoIExtractor(BaseRoIExtractor):
 
     def attention_logits(self, pooled):
         """pooled (L*n, 256) -> (L*n,) : 1x1 conv 256->128, tanh, 1x1 conv 128->1 (:38-46) as two GEMVs."""
-        h = torch.tanh(torch.addmm(self.conv1.bias, pooled, self.conv1.weight.view(128, 256).t()))
-        return torch.addmv(self.conv2.bias, h, self.conv2.weight.view(128))
+        from .. import dense
+        h = torch.tanh(dense.linear(pooled, self.conv1.weight.view(128, 256), self.conv1.bias))
+        return dense.linear(h, self.conv2.weight.view(1, 128), self.conv2.bias).view(-1)
 
     def forward(self, feats, rois, roi_scale_factor=None):
         if len(feats) == 1:

@@ -134,6 +134,10 @@ int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const floa
 int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual,
                    float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
                    int pad, int dil, int relu, void *stream);
+/* Batched NT GEMM on the same MFMA kernel: c[g] = a[g] @ b[g]^T; a [G][M][K], b [G][N][K], c [G][M][N];
+ * K % 8 == 0, M % 128 == 0 when G > 1.  Carries PGraph's adjacency x feature contractions
+ * (torch.mm calls of htd_bbox_head.py:210,213,214,216 batched over all (image, level) groups). */
+int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int M, int N, int K, void *stream);
 int htd_conv2d_flip_weights(const float *w, float *wT, int Co, int kh, int kw, int Ci, void *stream);
 int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, float *gx, int B,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,

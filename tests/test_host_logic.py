@@ -155,39 +155,3 @@ def test_losses_match_oracle():
     torch.testing.assert_close(SmoothL1Loss(beta=1 / 9.)(a, b, ww, avg_factor=5.), B.smooth_l1_loss(a, b, ww, 1 / 9., 5.))
     torch.testing.assert_close(accuracy(pred, lab), B.accuracy(pred, lab))
     assert accuracy(torch.zeros(0, 81), torch.zeros(0, dtype=torch.long)).item() == 0.          # empty input
-
-
-def test_batched_pgraph_matches_reference_fixture(golden):
-    """The padded-batch PGraph (htd_amd/detector/pgraph.py) against HTDBBoxHead.forward's double loop, through
-    the fixture the reference produced: same refined features => same cls logits."""
-    import torch.nn.functional as F
-    from htd_amd.detector.pgraph import pgraph_refine
-    from htd_amd.detector.roi_extractors import map_roi_levels
-    from oracle import detector as D
-    g = golden('pgraph')
-    sd = {k: T(seeded_state_value(('head1.' if '.bbox_head.1.' in k else 'head0.') + k.split('bbox_head.')[1][2:], s))
-          for k, s in D.state_shapes().items() if '.bbox_head.' in k}
-    h, h0 = 'roi_head.bbox_head.1.', 'roi_head.bbox_head.0.'
-    rois = T(g['rois'])
-    x_cls = seeded_tensor('head1.x_cls', (40, 256, 7, 7))
-    gfeat = seeded_tensor('head1.gfeat', (2, 256, 1, 1))
-
-    def fcs(t):
-        t = F.relu(F.linear(t, sd[h + 'fcs.0.weight'], sd[h + 'fcs.0.bias']))
-        return F.relu(F.linear(t, sd[h + 'fcs.2.weight'], sd[h + 'fcs.2.bias']))
-    x = fcs(x_cls.flatten(1))
-    x_glb = fcs((x_cls + gfeat[rois[:, 0].long()]).flatten(1))
-    w0, b0 = sd[h0 + 'fc_cls.weight'], sd[h0 + 'fc_cls.bias']
-    sam = torch.mm(F.linear(x, w0, b0).softmax(-1), torch.cat((w0, b0[:, None]), 1))
-    layers = [torch.nn.Linear(1024, 1024) for _ in range(4)]
-    for i, l in enumerate(layers):
-        l.weight.data, l.bias.data = sd[f'{h}graph_lvl{i}_cls.weight'], sd[f'{h}graph_lvl{i}_cls.bias']
-    lv = map_roi_levels(rois, 4)
-    assert torch.equal(lv, T(g['target_lvls']))
-    refined = pgraph_refine(x, sam, rois, lv, layers)
-    cls = F.linear(x_glb + refined, sd[h + 'fc_cls.weight'], sd[h + 'fc_cls.bias'])
-    torch.testing.assert_close(cls, T(g['cls']), rtol=1e-4, atol=1e-4)
-    # empty groups and a single-RoI group
-    one = pgraph_refine(x[:1], sam[:1], rois[:1], lv[:1], layers)
-    assert torch.isfinite(one).all() and one.shape == (1, 1024)
-    assert pgraph_refine(x[:0], sam[:0], rois[:0], lv[:0], layers).shape == (0, 1024)
