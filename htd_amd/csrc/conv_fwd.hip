@@ -17,11 +17,19 @@
 // The same kernel serves: forward conv, Linear layers (1x1 on "pixels" = rows), and the data gradient
 // (forward conv of gy with spatially flipped, channel-transposed weights; stride-2 data gradients pass
 // `in_dilate`, which treats gy as zero-stuffed without materialising it).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// value select (a ternary between two float4 lvalues would select between ADDRESSES and push both to scratch)
+__device__ __forceinline__ float4 keep4(bool ok, float4 v)
+{
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
 
 struct ConvParams {
     const float *x, *w, *bias, *residual, *mask_src;
@@ -33,6 +41,9 @@ struct ConvParams {
     int64_t w_bstride;  // >0: batched GEMM, image b uses weights w + b*w_bstride (tiles never straddle images)
     int64_t M;          // B*Ho*Wo
     int mt, nt;         // tiles along M, N
+    int splits;         // split-K: gridDim.y workgroups share one output tile, partials go to `partial`
+    int slices_per_split;
+    float *partial;     // [splits][M][Co] raw accumulators when splits > 1
 };
 
 // BK: floats of K per slice; WGM x WGN: wave grid of the block; TM x TN: 32x32 MFMA blocks per wave
@@ -51,21 +62,22 @@ struct Tile {
     static constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
 };
 
-template <int BK, int WGM, int WGN, int TM, int TN>
+template <int BK, int WGM, int WGN, int TM, int TN, bool DIL>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
 {
     using T = Tile<BK, WGM, WGN, TM, TN>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
 
-    // XCD-aware tile order: blocks that share an XCD (ids congruent mod 8) walk neighbouring M tiles of the
-    // same N tile, so the weight panel and the overlapping input rows stay in that XCD's L2.
+    // XCD-aware tile order: blocks that share an XCD (ids congruent mod 8) get one contiguous run of tiles with
+    // the N tiles of an M tile adjacent: the A rows of an M tile are fetched into that XCD's L2 once for all its
+    // N tiles, neighbouring M tiles share their halo rows, and the (small) weight panel stays L2-resident.
     const int nblk = p.mt * p.nt;
     int bid = blockIdx.x;
     {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid / p.mt, tile_m = bid % p.mt;
+    const int tile_m = bid / p.nt, tile_n = bid % p.nt;
     const int64_t m0 = (int64_t)tile_m * T::BM;
     const int n0 = tile_n * T::BN;
 
@@ -76,58 +88,74 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
     const int vcol = tid % T::VEC_PER_ROW;            // which float4 of the K slice
     const int vrow = tid / T::VEC_PER_ROW;            // first row handled
     int a_hi0[T::PASSES_A], a_wi0[T::PASSES_A];
-    int64_t a_img[T::PASSES_A];
+    unsigned a_img[T::PASSES_A];                       // element offsets fit 32 bits (checked on the host)
     bool a_ok[T::PASSES_A];
 #pragma unroll
     for (int i = 0; i < T::PASSES_A; ++i) {
         const int r = vrow + i * T::ROWS_PER_PASS;
         const int64_t m = m0 + r;
         a_ok[i] = r < T::BM && m < p.M;
-        const int64_t mm = a_ok[i] ? m : 0;
-        const int wo = (int)(mm % p.Wo);
-        const int64_t t = mm / p.Wo;
-        const int ho = (int)(t % p.Ho);
-        const int b = (int)(t / p.Ho);
-        a_hi0[i] = ho * p.stride - p.pad;
-        a_wi0[i] = wo * p.stride - p.pad;
-        a_img[i] = (int64_t)b * p.Hx * p.Wx;
+        const unsigned mm = a_ok[i] ? (unsigned)m : 0u;
+        const unsigned wo = mm % (unsigned)p.Wo;
+        const unsigned t = mm / (unsigned)p.Wo;
+        const unsigned ho = t % (unsigned)p.Ho;
+        const unsigned b = t / (unsigned)p.Ho;
+        a_hi0[i] = (int)ho * p.stride - p.pad;
+        a_wi0[i] = (int)wo * p.stride - p.pad;
+        a_img[i] = b * (unsigned)(p.Hx * p.Wx);
     }
-    const int64_t wrow_stride = (int64_t)p.kh * p.kw * p.Ci;
+    const unsigned wrow_stride = (unsigned)(p.kh * p.kw * p.Ci);
     const float *wbase = p.w + (p.w_bstride > 0 ? (m0 / ((int64_t)p.Ho * p.Wo)) * p.w_bstride : 0);
     bool b_ok[T::PASSES_B];
-    const float *b_ptr[T::PASSES_B];
+    unsigned b_off[T::PASSES_B];
 #pragma unroll
     for (int i = 0; i < T::PASSES_B; ++i) {
         const int r = vrow + i * T::ROWS_PER_PASS;
         const int n = n0 + r;
         b_ok[i] = r < T::BN && n < p.Co;
-        b_ptr[i] = wbase + (int64_t)(b_ok[i] ? n : 0) * wrow_stride + vcol * 4;
+        b_off[i] = (unsigned)(b_ok[i] ? n : 0) * wrow_stride + vcol * 4;
     }
 
     const int slices_per_tap = p.Ci / BK;
-    const int num_slices = p.kh * p.kw * slices_per_tap;
+    const int total_slices = p.kh * p.kw * slices_per_tap;
+    const int s_begin = blockIdx.y * p.slices_per_split;
+    const int num_slices = min(total_slices, s_begin + p.slices_per_split);
+
+    // state of the NEXT slice to stage (advanced incrementally: no divisions inside the K loop)
+    int ld_ci0, ld_ky, ld_kx;
+    {
+        const int tap = s_begin / slices_per_tap;
+        ld_ci0 = (s_begin - tap * slices_per_tap) * BK;
+        ld_ky = tap / p.kw;
+        ld_kx = tap - ld_ky * p.kw;
+    }
+    unsigned ld_woff = (unsigned)s_begin * BK;          // k offset inside a weight row: slices are contiguous in k
 
     float4 ra[T::PASSES_A], rb[T::PASSES_B];
-    auto load_slice = [&](int s) {
-        const int tap = s / slices_per_tap;
-        const int ci0 = (s - tap * slices_per_tap) * BK;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+    unsigned ra_ok = 0u;                              // bit i: pass i of the staged A slice is in range
+    auto load_slice = [&]() {
+        // branch-free: out-of-range taps read element 0 (always mapped) and are replaced by zeros afterwards
 #pragma unroll
         for (int i = 0; i < T::PASSES_A; ++i) {
-            int hi = a_hi0[i] + ky * p.dil, wi = a_wi0[i] + kx * p.dil;
-            bool ok = a_ok[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-            if (p.in_dilate > 1) {
+            int hi = a_hi0[i] + ld_ky * p.dil, wi = a_wi0[i] + ld_kx * p.dil;
+            bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            if constexpr (DIL) {
                 ok = ok && (hi % p.in_dilate == 0) && (wi % p.in_dilate == 0);
                 hi /= p.in_dilate;
                 wi /= p.in_dilate;
             }
-            ra[i] = ok ? *reinterpret_cast<const float4 *>(p.x + (a_img[i] + (int64_t)hi * p.Wx + wi) * p.Ci + ci0 + vcol * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = ok ? (a_img[i] + (unsigned)hi * (unsigned)p.Wx + (unsigned)wi) * (unsigned)p.Ci + ld_ci0 + vcol * 4 : 0u;
+            ra[i] = *reinterpret_cast<const float4 *>(p.x + off);      // zeroed at store time (keeps the load in flight)
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         }
 #pragma unroll
-        for (int i = 0; i < T::PASSES_B; ++i)
-            rb[i] = b_ok[i] ? *reinterpret_cast<const float4 *>(b_ptr[i] + (int64_t)tap * p.Ci + ci0)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < T::PASSES_B; ++i) rb[i] = *reinterpret_cast<const float4 *>(wbase + b_off[i] + ld_woff);
+        ld_woff += BK;
+        ld_ci0 += BK;
+        if (ld_ci0 == p.Ci) {
+            ld_ci0 = 0;
+            if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
+        }
     };
     auto store_slice = [&](int buf) {
         float *la = (lds + buf * (T::MAIN_FLOATS / 2));
@@ -135,12 +163,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
         for (int i = 0; i < T::PASSES_A; ++i) {
             const int r = vrow + i * T::ROWS_PER_PASS;
-            if (r < T::BM) *reinterpret_cast<float4 *>(la + r * T::LDS_STRIDE + vcol * 4) = ra[i];
+            if (r < T::BM) *reinterpret_cast<float4 *>(la + r * T::LDS_STRIDE + vcol * 4) = keep4((ra_ok >> i) & 1u, ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < T::PASSES_B; ++i) {
             const int r = vrow + i * T::ROWS_PER_PASS;
-            if (r < T::BN) *reinterpret_cast<float4 *>(lb + r * T::LDS_STRIDE + vcol * 4) = rb[i];
+            if (r < T::BN) *reinterpret_cast<float4 *>(lb + r * T::LDS_STRIDE + vcol * 4) = keep4(b_ok[i], rb[i]);
         }
     };
 
@@ -153,12 +181,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fhalf = lane >> 5;
-    load_slice(0);
-    store_slice(0);
+    if (s_begin < num_slices) {
+        load_slice();
+        store_slice(0);
+    }
     __syncthreads();
-    for (int s = 0; s < num_slices; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < num_slices) load_slice(s + 1);
+    for (int s = s_begin; s < num_slices; ++s) {
+        const int cur = (s - s_begin) & 1;
+        if (s + 1 < num_slices) load_slice();
         const float *la = (lds + cur * (T::MAIN_FLOATS / 2)) + (wm * TM * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
         const float *lb = (lds + cur * (T::MAIN_FLOATS / 2)) + (T::BM + wn * TN * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
 #pragma unroll
@@ -209,6 +239,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
             if (m >= p.M || n >= p.Co) continue;
             float4 v = *reinterpret_cast<const float4 *>(lds + row * T::EPI_STRIDE + c4 * 4);
             const int64_t o = m * p.Co + n;
+            if (p.splits > 1) {          // raw partial sums; bias / residual / activation happen in the reduce pass
+                float *dst = p.partial + (int64_t)blockIdx.y * p.M * p.Co + o;
+                if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
+                else {
+                    dst[0] = v.x;
+                    if (n + 1 < p.Co) dst[1] = v.y;
+                    if (n + 2 < p.Co) dst[2] = v.z;
+                    if (n + 3 < p.Co) dst[3] = v.w;
+                }
+                continue;
+            }
             if (vec_ok) {
                 if (p.bias) {
                     const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
@@ -226,47 +267,99 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
                 }
                 *reinterpret_cast<float4 *>(p.y + o) = v;
             } else {
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-                for (int e = 0; e < 4 && n + e < p.Co; ++e) {
-                    float t = vv[e] + (p.bias ? p.bias[n + e] : 0.f);
+                auto put = [&](int e, float t) {
+                    if (n + e >= p.Co) return;
+                    t += p.bias ? p.bias[n + e] : 0.f;
                     if (p.residual) t += p.residual[o + e];
                     if (p.relu) t = fmaxf(t, 0.f);
                     if (p.mask_src) t = p.mask_src[o + e] > 0.f ? t : 0.f;
                     p.y[o + e] = t;
-                }
+                };
+                put(0, v.x); put(1, v.y); put(2, v.z); put(3, v.w);
             }
         }
         if (i + 1 < TM) __syncthreads();
     }
 }
 
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvParams p)
+{
+    const int64_t total = p.M * p.Co;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < p.splits; ++k) v += p.partial[(int64_t)k * total + o];
+        const int n = (int)(o % p.Co);
+        if (p.bias) v += p.bias[n];
+        if (p.residual) v += p.residual[o];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
+        p.y[o] = v;
+    }
+}
+
 template <int WGM, int WGN, int TM, int TN>
 void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
 {
-    if (p.Ci % 32 == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<32, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
+    const dim3 grid(blocks, p.splits);
+    if (p.in_dilate > 1) {       // strided data gradient: rare, one BK is enough
+        if (p.Ci % 16 == 0)
+            hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, true>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_igemm_kernel<8, WGM, WGN, TM, TN, true>), grid, dim3(256), 0, s, p);
+    } else if (p.Ci % 32 == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<32, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
     else if (p.Ci % 16 == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<8, WGM, WGN, TM, TN>), dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<8, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
 }
 
-int launch_conv(ConvParams p, hipStream_t s)
+// split-K plan shared by the launcher and the workspace query: only problems that cannot fill the chip
+int plan_splits(int64_t M, int Co, int Ci, int taps)
 {
-    // tile width follows the output-channel count: 128 (2x2 waves of 64x64), 64 or 32 columns (4x1 waves)
+    const int bk = Ci % 32 == 0 ? 32 : (Ci % 16 == 0 ? 16 : 8);
+    const int total_slices = taps * (Ci / bk);
+    const int64_t tiles = htd::ceil_div(M, 128) * htd::ceil_div(Co, 64);     // 128x64 tiles are used when tiles are few
+    if (tiles >= 384 || total_slices < 16) return 1;
+    int64_t want = htd::ceil_div(768, tiles);
+    want = std::min<int64_t>(want, total_slices / 8);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, 16));
+}
+
+int launch_conv(ConvParams p, hipStream_t s, void *workspace)
+{
+    // tile follows the output-channel count and the amount of work: 128x128 (2x2 waves of 64x64) for big
+    // problems, 128x64 / 128x32 (4x1 waves) for narrow outputs, 64x64 (2x2 waves of 32x32) when the problem has
+    // too few big tiles to balance 256 CUs
+    int bm = 128;
     int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
-    p.mt = (int)htd::ceil_div(p.M, 128);
-    // mid-size layers: fewer than two 128x128 tiles per CU -> halve the tile width so every CU holds >= 2 blocks
-    if (bn == 128 && (int64_t)p.mt * htd::ceil_div(p.Co, 128) < 512) bn = 64;
+    if (bn == 128 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 128) < 512) bn = 64;
+    if (bn == 64 && p.Co >= 64 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 64) < 1024 && p.M >= 2048) bm = 64;
+    p.mt = (int)htd::ceil_div(p.M, bm);
     p.nt = (int)htd::ceil_div(p.Co, bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;
     HTD_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d: bad grid");
-    if (bn == 32)
+    HTD_REQUIRE((int64_t)p.B * p.Hx * p.Wx * p.Ci < (1ll << 31) && (int64_t)p.Co * p.kh * p.kw * p.Ci < (1ll << 31) &&
+                    p.M < (1ll << 31),
+                "conv2d: operand larger than 2^31 elements (32-bit element offsets)");
+    const int bk = (p.Ci % 32 == 0 && p.in_dilate == 1) ? 32 : (p.Ci % 16 == 0 ? 16 : 8);
+    const int total_slices = p.kh * p.kw * (p.Ci / bk);
+    p.splits = (workspace && p.in_dilate == 1) ? plan_splits(p.M, p.Co, p.Ci, p.kh * p.kw) : 1;
+    p.slices_per_split = (int)htd::ceil_div(total_slices, p.splits);
+    p.splits = (int)htd::ceil_div(total_slices, p.slices_per_split);
+    p.partial = (float *)workspace;
+    if (bm == 64)
+        launch_cfg<2, 2, 1, 1>(p, (unsigned)blocks, s);
+    else if (bn == 32)
         launch_cfg<4, 1, 1, 1>(p, (unsigned)blocks, s);
     else if (bn == 64)
         launch_cfg<4, 1, 1, 2>(p, (unsigned)blocks, s);
     else
         launch_cfg<2, 2, 2, 2>(p, (unsigned)blocks, s);
+    if (p.splits > 1) {
+        const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(p.M * p.Co, 256), 4096);
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(rb), dim3(256), 0, s, p);
+    }
     return htd::check_launch("conv2d");
 }
 
@@ -274,7 +367,7 @@ int launch_conv(ConvParams p, hipStream_t s)
 
 extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, float *y,
                               int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
-                              int relu, void *stream)
+                              int relu, void *workspace, void *stream)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_fwd: bad sizes B=%d H=%d W=%d Ci=%d Co=%d k=%dx%d s=%d p=%d d=%d", B, H, W, Ci, Co, kh, kw,
@@ -289,7 +382,15 @@ extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias,
     HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_fwd: empty output");
     p.in_dilate = 1; p.Hx = H; p.Wx = W; p.relu = relu;
     p.M = (int64_t)B * p.Ho * p.Wo;
-    return launch_conv(p, (hipStream_t)stream);
+    return launch_conv(p, (hipStream_t)stream, workspace);
+}
+
+// bytes of split-K workspace htd_conv2d_fwd / htd_conv2d_bwd_data may use for this problem (0 = none needed);
+// passing workspace = NULL is always allowed and disables split-K.
+extern "C" int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw)
+{
+    const int splits = plan_splits(M, Co, Ci, kh * kw);
+    return splits > 1 ? (int64_t)splits * M * Co * 4 : 0;
 }
 
 // Batched NT GEMM on the same kernel: c[g] = a[g] @ b[g]^T, a [G][M][K], b [G][N][K], c [G][M][N].
@@ -305,14 +406,15 @@ extern "C" int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int
     p.Ho = M; p.Wo = 1; p.in_dilate = 1; p.Hx = M; p.Wx = 1; p.relu = 0;
     p.w_bstride = (int64_t)N * K;
     p.M = (int64_t)G * M;
-    return launch_conv(p, (hipStream_t)stream);
+    return launch_conv(p, (hipStream_t)stream, nullptr);
 }
 
 // Data gradient: gx[B][H][W][Ci] from gy[B][Ho][Wo][Co] and wT[Ci][kh][kw][Co] = spatially flipped,
 // channel-transposed weights (htd_conv2d_flip_weights).  mask_src (may be NULL): gx is zeroed where
 // mask_src <= 0 -- the ReLU of the layer that produced the conv input, fused into this epilogue.
 extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, float *gx, int B, int H,
-                                   int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *stream)
+                                   int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                                   void *workspace, void *stream)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_bwd_data: bad sizes");
@@ -332,7 +434,7 @@ extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float
     p.H = (Ho - 1) * stride + 1; p.W = (Wo - 1) * stride + 1;      // extent of the stuffed map
     p.Ho = H; p.Wo = W; p.relu = 0;
     p.M = (int64_t)B * H * W;
-    return launch_conv(p, (hipStream_t)stream);
+    return launch_conv(p, (hipStream_t)stream, workspace);
 }
 
 namespace {

@@ -16,6 +16,12 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// value select (a ternary between two float4 lvalues would select between ADDRESSES and push both to scratch)
+__device__ __forceinline__ float4 keep4(bool ok, float4 v)
+{
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 struct WgradParams {
     const float *x, *gy;
     float *out;            // gw if splits == 1 else workspace [splits][Co][Ntot]
@@ -39,7 +45,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
     constexpr int PA = (BKW * VA + 255) / 256, PB = (BKW * VB + 255) / 256;
     __shared__ __attribute__((aligned(16))) float lds[2][BKW * (SA + SB)];
 
-    const int tile = blockIdx.x, split = blockIdx.y;
+    // XCD-aware order: all output tiles of one K split run on the same XCD (block ids congruent mod 8 share an
+    // XCD), so the gy / x pixel slices of that split are fetched into ONE L2 and reused by every tile.
+    int tile, split;
+    {
+        const int tiles = p.mt * p.nt, L = blockIdx.x;
+        if (p.splits % 8 == 0) {
+            const int xcd = L % 8, idx = L / 8;
+            tile = idx % tiles;
+            split = (idx / tiles) * 8 + xcd;
+        } else {
+            tile = L % tiles;
+            split = L / tiles;
+        }
+    }
     const int tile_m = tile % p.mt, tile_n = tile / p.mt;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -74,46 +93,72 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
     const int64_t s_begin = (int64_t)split * p.slices_per_split;
     const int64_t s_end = min(total_slices, s_begin + p.slices_per_split);
 
+    // pixel coordinates of every staged B row, advanced by BKW pixels per slice without 64-bit divisions
+    unsigned a_k[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_k[i] = (unsigned)(s_begin * BKW) + a_row[i];
+    unsigned b_k[PB];
+    int b_b[PB], b_ho[PB], b_wo[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        b_k[i] = (unsigned)(s_begin * BKW) + b_row[i];
+        const unsigned kk = b_k[i] < (unsigned)p.K ? b_k[i] : 0u;
+        b_wo[i] = (int)(kk % (unsigned)p.Wo);
+        const unsigned t = kk / (unsigned)p.Wo;
+        b_ho[i] = (int)(t % (unsigned)p.Ho);
+        b_b[i] = (int)(t / (unsigned)p.Ho);
+    }
+    const bool co_vec = (p.Co & 3) == 0;
+
     float4 ra[PA], rb[PB];
-    auto load_slice = [&](int64_t s) {
-        const int64_t k0 = s * BKW;
+    unsigned ra_ok = 0u, rb_ok = 0u;
+    auto load_slice = [&]() {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int64_t k = k0 + a_row[i];
-            const bool ok = a_cok[i] && k < p.K;
-            // Co may not be a multiple of 4 (RPN heads): fall back to scalar loads at the edge
-            if (ok && m0 + a_col[i] + 3 < p.Co && (p.Co & 3) == 0)
-                ra[i] = *reinterpret_cast<const float4 *>(p.gy + k * p.Co + m0 + a_col[i]);
-            else if (ok) {
-                const float *g = p.gy + k * p.Co + m0 + a_col[i];
+            const bool ok = a_cok[i] && a_k[i] < (unsigned)p.K;
+            if (co_vec) {
+                ra[i] = *reinterpret_cast<const float4 *>(p.gy + (ok ? a_k[i] * (unsigned)p.Co + m0 + a_col[i] : 0u));
+                ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));       // zeroed at store time
+            } else if (ok) {      // Co not a multiple of 4 (RPN heads): scalar loads
+                const float *g = p.gy + (size_t)a_k[i] * p.Co + m0 + a_col[i];
                 const int rem = p.Co - (m0 + a_col[i]);
                 ra[i] = make_float4(g[0], rem > 1 ? g[1] : 0.f, rem > 2 ? g[2] : 0.f, rem > 3 ? g[3] : 0.f);
+                ra_ok |= 1u << i;
             } else
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                ra_ok &= ~(1u << i);
+            a_k[i] += BKW;
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int64_t k = k0 + b_row[i];
-            bool ok = b_cok[i] && k < p.K;
-            const int64_t kk = ok ? k : 0;
-            const int wo = (int)(kk % p.Wo);
-            const int64_t t = kk / p.Wo;
-            const int ho = (int)(t % p.Ho);
-            const int b = (int)(t / p.Ho);
-            const int hi = ho * p.stride + b_dy[i], wi = wo * p.stride + b_dx[i];
-            ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-            rb[i] = ok ? *reinterpret_cast<const float4 *>(p.x + (((int64_t)b * p.H + hi) * p.W + wi) * p.Ci + b_ci[i])
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int hi = b_ho[i] * p.stride + b_dy[i], wi = b_wo[i] * p.stride + b_dx[i];
+            const bool ok = b_cok[i] && b_k[i] < (unsigned)p.K && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned off = ok ? (((unsigned)b_b[i] * p.H + hi) * p.W + wi) * (unsigned)p.Ci + b_ci[i] : 0u;
+            rb[i] = *reinterpret_cast<const float4 *>(p.x + off);
+            rb_ok = ok ? (rb_ok | (1u << i)) : (rb_ok & ~(1u << i));
+            b_k[i] += BKW;
+            if (p.Wo >= BKW) {                     // incremental carry: at most one wrap per step
+                b_wo[i] += BKW;
+                if (b_wo[i] >= p.Wo) {
+                    b_wo[i] -= p.Wo;
+                    if (++b_ho[i] == p.Ho) { b_ho[i] = 0; ++b_b[i]; }
+                }
+            } else {
+                const unsigned kk = b_k[i] < (unsigned)p.K ? b_k[i] : 0u;
+                b_wo[i] = (int)(kk % (unsigned)p.Wo);
+                const unsigned t = kk / (unsigned)p.Wo;
+                b_ho[i] = (int)(t % (unsigned)p.Ho);
+                b_b[i] = (int)(t / (unsigned)p.Ho);
+            }
         }
     };
     auto store_slice = [&](int buf) {
         float *la = lds[buf], *lb = lds[buf] + BKW * SA;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            if (tid + i * 256 < BKW * VA) *reinterpret_cast<float4 *>(la + a_row[i] * SA + a_col[i]) = ra[i];
+            if (tid + i * 256 < BKW * VA) *reinterpret_cast<float4 *>(la + a_row[i] * SA + a_col[i]) = keep4((ra_ok >> i) & 1u, ra[i]);
 #pragma unroll
         for (int i = 0; i < PB; ++i)
-            if (tid + i * 256 < BKW * VB) *reinterpret_cast<float4 *>(lb + b_row[i] * SB + b_col[i]) = rb[i];
+            if (tid + i * 256 < BKW * VB) *reinterpret_cast<float4 *>(lb + b_row[i] * SB + b_col[i]) = keep4((rb_ok >> i) & 1u, rb[i]);
     };
 
     f32x16 acc[TM][TN];
@@ -126,42 +171,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
 
     const int fidx = lane & 31, fhalf = lane >> 5;
     if (s_begin < s_end) {
-        load_slice(s_begin);
+        load_slice();
         store_slice(0);
     }
     __syncthreads();
     for (int64_t s = s_begin; s < s_end; ++s) {
         const int cur = (int)((s - s_begin) & 1);
-        if (s + 1 < s_end) load_slice(s + 1);
-        const float *la = lds[cur] + fhalf * SA + wm * TM * 32 + fidx;
-        const float *lb = lds[cur] + BKW * SA + fhalf * SB + wn * TN * 32 + fidx;
+        if (s + 1 < s_end) load_slice();
+        // Fragment reads: lane (fidx, fhalf) needs, for k = 2t + fhalf, TM rows of A and TN columns of B.  MFMA block
+        // j of a wave takes the INTERLEAVED rows TM*fidx + j (not 32*j + fidx), so a lane's TM values are adjacent
+        // in the [k][m] LDS image and arrive with one ds_read_b64 (TM = 2) instead of TM ds_read_b32.
+        const float *la = lds[cur] + fhalf * SA + wm * TM * 32 + fidx * TM;
+        const float *lb = lds[cur] + BKW * SA + fhalf * SB + wn * TN * 32 + fidx * TN;
 #pragma unroll
         for (int t = 0; t < BKW / 2; ++t) {
             float fa[TM], fb[TN];
+            if constexpr (TM == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(la + 2 * t * SA);
+                fa[0] = v.x; fa[1] = v.y;
+            } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = la[2 * t * SA + i * 32];
+                for (int i = 0; i < TM; ++i) fa[i] = la[2 * t * SA + i];
+            }
+            if constexpr (TN == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(lb + 2 * t * SB);
+                fb[0] = v.x; fb[1] = v.y;
+            } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = lb[2 * t * SB + j * 32];
+                for (int j = 0; j < TN; ++j) fb[j] = lb[2 * t * SB + j];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            // next slice -> other LDS buffer in the shadow of the second half of this slice's MFMAs
+            if (t == BKW / 4 - 1 && s + 1 < s_end) store_slice(cur ^ 1);
         }
-        if (s + 1 < s_end) store_slice(cur ^ 1);
         __syncthreads();
     }
 
     float *out = p.out + (int64_t)split * p.Co * p.Ntot;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + fidx;
+        const int n = n0 + wn * TN * 32 + fidx * TN + j;                 // interleaved block columns
         if (n >= p.Ntot) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                const int m = m0 + wm * TM * 32 + ((r & 3) + 8 * (r >> 2) + 4 * fhalf) * TM + i;   // interleaved rows
                 if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[i][j][r];
             }
     }
@@ -212,8 +271,29 @@ __global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__res
     const int c4 = threadIdx.x % cw, rsub = threadIdx.x / cw;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rsub < R)
-        for (int64_t r = r0 + rsub; r < r1; r += R) {
+    if (rsub < R) {
+        // four independent row streams per thread keep 8 x 16-byte loads in flight
+        int64_t r = r0 + rsub;
+        for (; r + 3 * (int64_t)R < r1; r += 4 * (int64_t)R) {
+            float4 v[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t o = (r + u * (int64_t)R) * C + (int64_t)(cbase + c4) * 4;
+                v[u] = *reinterpret_cast<const float4 *>(g + o);
+                if (y) yv[u] = *reinterpret_cast<const float4 *>(y + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (y) {
+                    const int64_t o = (r + u * (int64_t)R) * C + (int64_t)(cbase + c4) * 4;
+                    v[u].x = yv[u].x > 0.f ? v[u].x : 0.f; v[u].y = yv[u].y > 0.f ? v[u].y : 0.f;
+                    v[u].z = yv[u].z > 0.f ? v[u].z : 0.f; v[u].w = yv[u].w > 0.f ? v[u].w : 0.f;
+                    *reinterpret_cast<float4 *>(gm + o) = v[u];
+                }
+                s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+            }
+        }
+        for (; r < r1; r += R) {
             const int64_t o = r * C + (int64_t)(cbase + c4) * 4;
             float4 v = *reinterpret_cast<const float4 *>(g + o);
             if (y) {
@@ -224,6 +304,7 @@ __global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__res
             }
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (rsub == 0) {
@@ -245,9 +326,10 @@ Cfg choose(int Co, int Ntot, int64_t K)
     c.mt = (int)htd::ceil_div(Co, c.bm);
     c.nt = (int)htd::ceil_div(Ntot, c.bn);
     const int64_t slices = htd::ceil_div(K, BKW);
-    int64_t want = htd::ceil_div(1024, (int64_t)c.mt * c.nt);       // ~4 workgroups per CU
+    int64_t want = htd::ceil_div(768, (int64_t)c.mt * c.nt);        // ~3 workgroups per CU
     want = std::min<int64_t>(want, std::max<int64_t>(1, slices / 8)); // at least 8 slices per split
-    c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 512));
+    c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 96));
+    if (c.splits >= 6) c.splits = (c.splits + 7) / 8 * 8;            // multiples of 8: one split per XCD group
     return c;
 }
 
@@ -276,13 +358,16 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
     HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_bwd_weight: empty output");
     p.K = (int64_t)B * p.Ho * p.Wo;
+    HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.K * Co < (1ll << 31),
+                "conv2d_bwd_weight: operand larger than 2^31 elements (32-bit element offsets)");
     p.Ntot = kh * kw * Ci;
     const Cfg c = choose(Co, p.Ntot, p.K);
     p.mt = c.mt; p.nt = c.nt; p.splits = c.splits;
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
     p.out = c.splits == 1 ? gw : (float *)workspace;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)(c.mt * c.nt), (unsigned)c.splits);
+    p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
+    dim3 grid((unsigned)(c.mt * c.nt * c.splits));
     if (c.bm == 32)
         hipLaunchKernelGGL((conv_wgrad_kernel<1, 4, 1, 1>), grid, dim3(256), 0, s, p);
     else
@@ -296,14 +381,14 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     return htd::check_launch("conv2d_bwd_weight");
 }
 
-// g [rows][C], y (may be NULL) [rows][C]; gm (out, required iff y) ; gbias [C]; workspace >= 256*C*4 bytes
+// g [rows][C], y (may be NULL) [rows][C]; gm (out, required iff y) ; gbias [C]; workspace >= 2048*C*4 bytes
 extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows, int C,
                                        void *workspace, void *stream)
 {
     HTD_REQUIRE(rows >= 0 && C > 0, "bias_grad: bad sizes");
     HTD_REQUIRE(g && gbias && workspace && (!y || gm), "bias_grad: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(256, htd::ceil_div(rows, 64)));
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(512, htd::ceil_div(rows, 64)));
     const int64_t rpb = htd::ceil_div(std::max<int64_t>(rows, 1), nb);
     float *partial = (float *)workspace;
     if ((C & 3) == 0 && (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gm | (uintptr_t)partial) & 15) == 0)

@@ -42,7 +42,7 @@ class DeformConv2dFunction(Function):
         capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
                   dilation, deform_groups, _S(), work=('byte', 4.0 * M * K * 2))
         y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
-        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), None, None, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1, 0, _S(),
+        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), None, None, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1, 0, None, _S(),
                   work=('flop', 2.0 * M * K * Co))
         ctx.save_for_backward(x, offset, mask, weight)
         ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo)
@@ -62,7 +62,7 @@ class DeformConv2dFunction(Function):
             wT = torch.empty(K * Co, device=gy.device, dtype=gy.dtype)
             capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, 1, 1, K, _S())
             gcol = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
-            capi.call('htd_conv2d_bwd_data', _P(gy), _P(wT), None, _P(gcol), 1, M, 1, K, Co, 1, 1, 1, 0, 1, _S(),
+            capi.call('htd_conv2d_bwd_data', _P(gy), _P(wT), None, _P(gcol), 1, M, 1, K, Co, 1, 1, 1, 0, 1, None, _S(),
                       work=('flop', 2.0 * M * K * Co))
             if ctx.needs_input_grad[0]:
                 gx = torch.empty((B, C, H, W), device=gy.device, dtype=gy.dtype, memory_format=CL).zero_()

@@ -26,6 +26,12 @@ def _need_gpu(t, name):
         raise NotImplementedError(f'{name}: only GPU tensors are supported (libhtd_amd.so has no CPU path)')
 
 
+def _splitk_ws(M, Co, Cred, kh, kw, device):
+    """Split-K scratch for a GEMM with M rows, Co columns, reduction kh*kw*Cred (None when not worth splitting)."""
+    nbytes = capi.lib().htd_conv2d_workspace_bytes(M, Co, Cred, kh, kw)
+    return torch.empty(nbytes // 4, device=device, dtype=torch.float32) if nbytes > 0 else None
+
+
 class Conv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu):
@@ -42,7 +48,8 @@ class Conv2dFunction(Function):
         b = bias.contiguous() if bias is not None else None
         flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
         capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(b), _P(res), _P(y), B, H, W, Ci, Co, kh, kw, stride, padding,
-                  dilation, int(bool(relu)), _S(), work=('flop', flops))
+                  dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
+                  work=('flop', flops))
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (stride, padding, dilation, bool(relu), bias is not None, residual is not None)
         return y
@@ -61,7 +68,7 @@ class Conv2dFunction(Function):
         if relu or (has_bias and need_b):
             gm = torch.empty_like(g, memory_format=CL) if relu else g
             gb = torch.empty(Co, device=g.device, dtype=g.dtype)
-            ws = torch.empty(256 * Co, device=g.device, dtype=g.dtype)
+            ws = torch.empty(2048 * Co, device=g.device, dtype=g.dtype)
             capi.call('htd_bias_grad_relu_mask', _P(g), _P(y) if relu else None, _P(gm) if relu else None, _P(gb),
                       B * Ho * Wo, Co, _P(ws), _S(), work=('byte', 4.0 * B * Ho * Wo * Co * (3 if relu else 1)))
             g = gm
@@ -78,7 +85,7 @@ class Conv2dFunction(Function):
             capi.call('htd_conv2d_flip_weights', _P(wd), _P(wT), Cod, kh, kw, Ci, _S())
             gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
             capi.call('htd_conv2d_bwd_data', _P(gd), _P(wT), None, _P(gx), B, H, W, Ci, Cod, kh, kw, stride, padding,
-                      dilation, _S(), work=('flop', flops))
+                      dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(), work=('flop', flops))
         if need_w:
             gw = torch.empty((Co, Ci, kh, kw), device=g.device, dtype=g.dtype, memory_format=CL)
             nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)

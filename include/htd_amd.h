@@ -123,17 +123,21 @@ int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const floa
  *   x [B][H][W][Ci]   w [Co][kh][kw][Ci]   bias [Co] or NULL   residual [B][Ho][Wo][Co] or NULL
  *   y [B][Ho][Wo][Co];  relu in {0,1};  Ci % 8 == 0 (the 3-channel stem input is padded to 8).
  *   A Linear layer is the 1x1 case with H = rows, W = 1.
+ * workspace (fwd / bwd_data): optional split-K scratch of htd_conv2d_workspace_bytes(M, Co, Ci, kh, kw) bytes
+ *            (M = output pixels, Co/Ci = output / reduction channels of that GEMM); problems too small to fill
+ *            256 CUs are split along K and summed in a second pass.  NULL disables split-K.
  * bwd_data:  gx = conv_transpose(gy, w), given wT = htd_conv2d_flip_weights(w) ([Ci][kh][kw][Co], taps
  *            reversed).  mask_src (may be NULL, [B][H][W][Ci]): gx is zeroed where mask_src <= 0, i.e. the
  *            backward of the ReLU that produced the conv input is fused into this epilogue.  Co % 8 == 0.
  * bwd_weight: gw[co][kh][kw][ci] = sum_pixels gy * x; deterministic split-K through `workspace`
  *            (htd_conv2d_wgrad_workspace_bytes); Ci % 4 == 0.
  * bias_grad_relu_mask: gbias[c] = sum_rows gm[r][c] with gm = g * (y > 0) written out when y != NULL
- *            (gm = g, nothing written, when y == NULL); workspace >= 256*C*4 bytes.
+ *            (gm = g, nothing written, when y == NULL); workspace >= 2048*C*4 bytes.
  * ---------------------------------------------------------------------------------- */
+int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw);
 int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual,
                    float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
-                   int pad, int dil, int relu, void *stream);
+                   int pad, int dil, int relu, void *workspace, void *stream);
 /* Batched NT GEMM on the same MFMA kernel: c[g] = a[g] @ b[g]^T; a [G][M][K], b [G][N][K], c [G][M][N];
  * K % 8 == 0, M % 128 == 0 when G > 1.  Carries PGraph's adjacency x feature contractions
  * (torch.mm calls of htd_bbox_head.py:210,213,214,216 batched over all (image, level) groups). */
@@ -141,7 +145,7 @@ int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int M, int N, 
 int htd_conv2d_flip_weights(const float *w, float *wT, int Co, int kh, int kw, int Ci, void *stream);
 int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, float *gx, int B,
                         int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
-                        void *stream);
+                        void *workspace, void *stream);
 int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw,
                                          int stride, int pad, int dil);
 int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, int B, int H, int W, int Ci,
