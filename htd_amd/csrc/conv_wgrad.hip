@@ -32,7 +32,7 @@ struct WgradParams {
     int64_t slices_per_split;
 };
 
-constexpr int BKW = 16;    // pixels per K slice
+constexpr int BKW = 32;    // pixels per K slice
 
 // WGM x WGN waves, each wave TM x TN MFMA blocks of 32x32
 template <int WGM, int WGN, int TM, int TN>
@@ -43,7 +43,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
     constexpr int SA = BM + 4, SB = BN + 4;                 // LDS row strides (floats), +16 B pad
     constexpr int VA = BM / 4, VB = BN / 4;                 // float4 per row
     constexpr int PA = (BKW * VA + 255) / 256, PB = (BKW * VB + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float lds[2][BKW * (SA + SB)];
+    // ONE LDS slice buffer + register prefetch: the next slice's global loads are in flight during the whole
+    // MFMA phase of the current one (64 MFMAs per wave), then written between two barriers.  Half the LDS of a
+    // double buffer => twice the resident workgroups, which is what hides the barrier bubbles.
+    __shared__ __attribute__((aligned(16))) float lds[1][BKW * (SA + SB)];
 
     // XCD-aware order: all output tiles of one K split run on the same XCD (block ids congruent mod 8 share an
     // XCD), so the gy / x pixel slices of that split are fetched into ONE L2 and reused by every tile.
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
     }
     __syncthreads();
     for (int64_t s = s_begin; s < s_end; ++s) {
-        const int cur = (int)((s - s_begin) & 1);
+        constexpr int cur = 0;
         if (s + 1 < s_end) load_slice();
         // Fragment reads: lane (fidx, fhalf) needs, for k = 2t + fhalf, TM rows of A and TN columns of B.  MFMA block
         // j of a wave takes the INTERLEAVED rows TM*fidx + j (not 32*j + fidx), so a lane's TM values are adjacent
@@ -205,10 +208,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            // next slice -> other LDS buffer in the shadow of the second half of this slice's MFMAs
-            if (t == BKW / 4 - 1 && s + 1 < s_end) store_slice(cur ^ 1);
         }
-        __syncthreads();
+        if (s + 1 < s_end) {
+            __syncthreads();               // every wave has read this slice
+            store_slice(0);
+            __syncthreads();
+        }
     }
 
     float *out = p.out + (int64_t)split * p.Co * p.Ntot;
@@ -229,11 +234,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                             int64_t n, int splits)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
-        out[i] = s;
+    // out[i] = sum_k ws[k][i] in fixed order; float4 lanes, four partial slabs in flight per thread
+    const int64_t n4 = (n & 3) == 0 ? (n >> 2) : 0;      // slabs are 16-byte aligned only when n % 4 == 0
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 3 < splits; k += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(ws + (int64_t)(k + u) * n + i * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(ws + (int64_t)k * n + i * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i * 4) = s;
     }
+    if (blockIdx.x == 0)
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
+            out[i] = s;
+        }
 }
 
 // column sums of a [rows][C] matrix (bias gradient), optionally fused with the ReLU-mask of the incoming

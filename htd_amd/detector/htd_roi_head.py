@@ -98,7 +98,7 @@ class HTDRoIHead(nn.Module):
                 start += npos + res.neg_bboxes.size(0)
             pos_rows = torch.cat(pos_rows)
             enhanced = enhanced_extractor(feats, pos_rois)
-            pos_bbox_feat = bbox_feats[pos_rows]
+            pos_bbox_feat = torch.index_select(bbox_feats, 0, pos_rows)
             cls_score, bbox_pred = head(bbox_feats, pos_bbox_feat, feats, rois, self.bbox_head[0].fc_cls, enhanced,
                                         pos_rois, global_feat if self.with_global else None)
             full = cls_score.new_zeros(cls_score.size(0), 4).index_put((pos_rows, ), bbox_pred)

@@ -49,10 +49,11 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers):
     src = (starts[:, None] + ar[None, :]).clamp(max=N - 1)
     rows = perm[src]                                                        # (G, npad) original RoI rows
     vf = valid[..., None].to(x.dtype)
-    xg = x[rows] * vf
+    flat_rows = rows.reshape(-1)
+    xg = torch.index_select(x, 0, flat_rows).view(G, npad, Fdim) * vf
     S8 = (sam.size(1) + 7) // 8 * 8
-    sg = torch.nn.functional.pad(sam[rows] * vf, (0, S8 - sam.size(1)))
-    bx = rois[rows][..., 1:5]
+    sg = torch.nn.functional.pad(torch.index_select(sam, 0, flat_rows).view(G, npad, -1) * vf, (0, S8 - sam.size(1)))
+    bx = torch.index_select(rois, 0, flat_rows).view(G, npad, -1)[..., 1:5]
     # pairwise IoU inside each group (bbox_overlaps with its eps=1e-6 union floor), unit diagonal
     lt = torch.max(bx[:, :, None, :2], bx[:, None, :, :2])
     rb = torch.min(bx[:, :, None, 2:], bx[:, None, :, 2:])
