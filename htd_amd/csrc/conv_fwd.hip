@@ -15,8 +15,8 @@
 // and B use the same permutation -- which lets one ds_read_b128 per operand block feed four MFMAs.
 //
 // The same kernel serves: forward conv, Linear layers (1x1 on "pixels" = rows), and the data gradient
-// (forward conv of gy with spatially flipped, channel-transposed weights; stride-2 data gradients pass
-// `in_dilate`, which treats gy as zero-stuffed without materialising it).
+// (forward conv of gy with spatially flipped, channel-transposed weights; a stride-s data gradient is split into
+// s*s dense sub-problems, one per output parity class, through an explicit tap table).
 #include <algorithm>
 
 #include "common.h"
@@ -35,8 +35,13 @@ struct ConvParams {
     const float *x, *w, *bias, *residual, *mask_src;
     float *y;
     int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo;
-    int in_dilate;      // >1: the input is a zero-stuffed view of x (x sample every in_dilate pixels)
-    int Hx, Wx;         // physical size of x when in_dilate > 1
+    int Hx, Wx;         // physical size of x
+    // explicit tap table (strided data gradients are split into stride*stride dense sub-problems, one per
+    // output parity class): tap t reads input pixel (i + tap_dy[t], j + tap_dx[t]) with weight tap tap_w[t],
+    // and sub-grid pixel (i, j) is written to output pixel (o_h0 + o_step*i, o_w0 + o_step*j) of an oH x oW map
+    int ntaps;
+    int tap_dy[16], tap_dx[16], tap_w[16];
+    int o_h0, o_w0, o_step, oH, oW;
     int relu;
     int64_t w_bstride;  // >0: batched GEMM, image b uses weights w + b*w_bstride (tiles never straddle images)
     int64_t M;          // B*Ho*Wo
@@ -62,7 +67,7 @@ struct Tile {
     static constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
 };
 
-template <int BK, int WGM, int WGN, int TM, int TN, bool DIL>
+template <int BK, int WGM, int WGN, int TM, int TN, bool TAPS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
 {
     using T = Tile<BK, WGM, WGN, TM, TN>;
@@ -100,8 +105,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
         const unsigned t = mm / (unsigned)p.Wo;
         const unsigned ho = t % (unsigned)p.Ho;
         const unsigned b = t / (unsigned)p.Ho;
-        a_hi0[i] = (int)ho * p.stride - p.pad;
-        a_wi0[i] = (int)wo * p.stride - p.pad;
+        a_hi0[i] = TAPS ? (int)ho : (int)ho * p.stride - p.pad;
+        a_wi0[i] = TAPS ? (int)wo : (int)wo * p.stride - p.pad;
         a_img[i] = b * (unsigned)(p.Hx * p.Wx);
     }
     const unsigned wrow_stride = (unsigned)(p.kh * p.kw * p.Ci);
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
     }
 
     const int slices_per_tap = p.Ci / BK;
-    const int total_slices = p.kh * p.kw * slices_per_tap;
+    const int total_slices = (TAPS ? p.ntaps : p.kh * p.kw) * slices_per_tap;
     const int s_begin = blockIdx.y * p.slices_per_split;
     const int num_slices = min(total_slices, s_begin + p.slices_per_split);
 
@@ -126,8 +131,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
     {
         const int tap = s_begin / slices_per_tap;
         ld_ci0 = (s_begin - tap * slices_per_tap) * BK;
-        ld_ky = tap / p.kw;
-        ld_kx = tap - ld_ky * p.kw;
+        ld_ky = TAPS ? tap : tap / p.kw;
+        ld_kx = TAPS ? 0 : tap - ld_ky * p.kw;
     }
     unsigned ld_woff = (unsigned)s_begin * BK;          // k offset inside a weight row: slices are contiguous in k
 
@@ -137,24 +142,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
         // branch-free: out-of-range taps read element 0 (always mapped) and are replaced by zeros afterwards
 #pragma unroll
         for (int i = 0; i < T::PASSES_A; ++i) {
-            int hi = a_hi0[i] + ld_ky * p.dil, wi = a_wi0[i] + ld_kx * p.dil;
-            bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            if constexpr (DIL) {
-                ok = ok && (hi % p.in_dilate == 0) && (wi % p.in_dilate == 0);
-                hi /= p.in_dilate;
-                wi /= p.in_dilate;
+            int hi, wi;
+            if constexpr (TAPS) {
+                hi = a_hi0[i] + p.tap_dy[ld_ky];        // ld_ky indexes the tap table
+                wi = a_wi0[i] + p.tap_dx[ld_ky];
+            } else {
+                hi = a_hi0[i] + ld_ky * p.dil;
+                wi = a_wi0[i] + ld_kx * p.dil;
             }
+            const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const unsigned off = ok ? (a_img[i] + (unsigned)hi * (unsigned)p.Wx + (unsigned)wi) * (unsigned)p.Ci + ld_ci0 + vcol * 4 : 0u;
             ra[i] = *reinterpret_cast<const float4 *>(p.x + off);      // zeroed at store time (keeps the load in flight)
             ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         }
+        const unsigned woff = TAPS ? (unsigned)(p.tap_w[ld_ky] * p.Ci + ld_ci0) : ld_woff;
 #pragma unroll
-        for (int i = 0; i < T::PASSES_B; ++i) rb[i] = *reinterpret_cast<const float4 *>(wbase + b_off[i] + ld_woff);
+        for (int i = 0; i < T::PASSES_B; ++i) rb[i] = *reinterpret_cast<const float4 *>(wbase + b_off[i] + woff);
         ld_woff += BK;
         ld_ci0 += BK;
         if (ld_ci0 == p.Ci) {
             ld_ci0 = 0;
-            if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
+            if (TAPS) ++ld_ky;
+            else if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
         }
     };
     auto store_slice = [&](int buf) {
@@ -238,7 +247,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
             const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
             if (m >= p.M || n >= p.Co) continue;
             float4 v = *reinterpret_cast<const float4 *>(lds + row * T::EPI_STRIDE + c4 * 4);
-            const int64_t o = m * p.Co + n;
+            int64_t o;
+            if constexpr (TAPS) {
+                const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                o = (((int64_t)b * p.oH + p.o_h0 + p.o_step * (int)ho) * p.oW + p.o_w0 + p.o_step * (int)wo) * p.Co + n;
+            } else
+                o = m * p.Co + n;
             if (p.splits > 1) {          // raw partial sums; bias / residual / activation happen in the reduce pass
                 float *dst = p.partial + (int64_t)blockIdx.y * p.M * p.Co + o;
                 if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
@@ -301,7 +316,7 @@ template <int WGM, int WGN, int TM, int TN>
 void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
 {
     const dim3 grid(blocks, p.splits);
-    if (p.in_dilate > 1) {       // strided data gradient: rare, one BK is enough
+    if (p.ntaps > 0) {           // strided data gradient sub-problem: rare, one BK is enough
         if (p.Ci % 16 == 0)
             hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, true>), grid, dim3(256), 0, s, p);
         else
@@ -342,9 +357,9 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     HTD_REQUIRE((int64_t)p.B * p.Hx * p.Wx * p.Ci < (1ll << 31) && (int64_t)p.Co * p.kh * p.kw * p.Ci < (1ll << 31) &&
                     p.M < (1ll << 31),
                 "conv2d: operand larger than 2^31 elements (32-bit element offsets)");
-    const int bk = (p.Ci % 32 == 0 && p.in_dilate == 1) ? 32 : (p.Ci % 16 == 0 ? 16 : 8);
-    const int total_slices = p.kh * p.kw * (p.Ci / bk);
-    p.splits = (workspace && p.in_dilate == 1) ? plan_splits(p.M, p.Co, p.Ci, p.kh * p.kw) : 1;
+    const int bk = (p.Ci % 32 == 0 && p.ntaps == 0) ? 32 : (p.Ci % 16 == 0 ? 16 : 8);
+    const int total_slices = (p.ntaps > 0 ? p.ntaps : p.kh * p.kw) * (p.Ci / bk);
+    p.splits = (workspace && p.ntaps == 0) ? plan_splits(p.M, p.Co, p.Ci, p.kh * p.kw) : 1;
     p.slices_per_split = (int)htd::ceil_div(total_slices, p.splits);
     p.splits = (int)htd::ceil_div(total_slices, p.slices_per_split);
     p.partial = (float *)workspace;
@@ -380,7 +395,7 @@ extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias,
     p.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
     HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_fwd: empty output");
-    p.in_dilate = 1; p.Hx = H; p.Wx = W; p.relu = relu;
+    p.Hx = H; p.Wx = W; p.relu = relu;
     p.M = (int64_t)B * p.Ho * p.Wo;
     return launch_conv(p, (hipStream_t)stream, workspace);
 }
@@ -403,7 +418,7 @@ extern "C" int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int
     ConvParams p{};
     p.x = a; p.w = b; p.y = c;
     p.B = G; p.H = M; p.W = 1; p.Ci = K; p.Co = N; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1;
-    p.Ho = M; p.Wo = 1; p.in_dilate = 1; p.Hx = M; p.Wx = 1; p.relu = 0;
+    p.Ho = M; p.Wo = 1; p.Hx = M; p.Wx = 1; p.relu = 0;
     p.w_bstride = (int64_t)N * K;
     p.M = (int64_t)G * M;
     return launch_conv(p, (hipStream_t)stream, nullptr);
@@ -424,17 +439,65 @@ extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float
     const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
     ConvParams p{};
     p.x = gy; p.w = wT; p.bias = nullptr; p.residual = nullptr; p.mask_src = mask_src; p.y = gx;
-    // a stride-1 correlation over the (zero-stuffed) gradient map: output pixel hi reads stuffed rows
-    // hi + pad' - ky'*dil with pad' = dil*(kh-1) - pad; stuffed row r is gy row r/stride when r % stride == 0
-    p.B = B; p.Ci = Co; p.Co = Ci; p.kh = kh; p.kw = kw; p.stride = 1; p.dil = dil;
-    p.pad = dil * (kh - 1) - pad;
-    HTD_REQUIRE(dil * (kw - 1) - pad == p.pad || kh == kw, "conv2d_bwd_data: square kernels only");
-    HTD_REQUIRE(p.pad >= 0, "conv2d_bwd_data: pad > dil*(k-1) unsupported");
-    p.in_dilate = stride; p.Hx = Ho; p.Wx = Wo;
-    p.H = (Ho - 1) * stride + 1; p.W = (Wo - 1) * stride + 1;      // extent of the stuffed map
-    p.Ho = H; p.Wo = W; p.relu = 0;
-    p.M = (int64_t)B * H * W;
-    return launch_conv(p, (hipStream_t)stream, workspace);
+    p.B = B; p.Ci = Co; p.Co = Ci; p.kh = kh; p.kw = kw; p.dil = dil; p.relu = 0;
+    p.Hx = Ho; p.Wx = Wo;
+    HTD_REQUIRE(kh == kw, "conv2d_bwd_data: square kernels only");
+    if (stride == 1) {
+        // a stride-1 correlation of gy with the flipped weights: pad' = dil*(k-1) - pad
+        p.stride = 1;
+        p.pad = dil * (kh - 1) - pad;
+        HTD_REQUIRE(p.pad >= 0, "conv2d_bwd_data: pad > dil*(k-1) unsupported");
+        p.H = Ho; p.W = Wo; p.Ho = H; p.Wo = W;
+        p.M = (int64_t)B * H * W;
+        return launch_conv(p, (hipStream_t)stream, workspace);
+    }
+    // stride s: output pixels fall into s*s parity classes; class (ph, pw) only receives taps with
+    // (ph + pad - ky*dil) % s == 0, and those form a dense stride-1 problem on the sub-grid hi = ph + s*i.
+    // Every tap belongs to exactly one class, so the total work is 1/s^2 of the zero-stuffed formulation.
+    HTD_REQUIRE(kh * kw <= 16 * stride * stride, "conv2d_bwd_data: kernel too large for the tap table");
+    bool need_zero = false;
+    for (int cls = 0; cls < stride * stride && !need_zero; ++cls) {
+        const int ph = cls / stride, pw = cls % stride;
+        int ny = 0, nx = 0;
+        for (int k = 0; k < kh; ++k) {
+            ny += ((ph + pad - k * dil) % stride + stride) % stride == 0;
+            nx += ((pw + pad - k * dil) % stride + stride) % stride == 0;
+        }
+        need_zero = (ny == 0 || nx == 0);
+    }
+    if (need_zero) {     // classes without taps (1x1 stride-2 shortcuts) are plain zeros
+        if (hipMemsetAsync(gx, 0, (size_t)B * H * W * Ci * 4, (hipStream_t)stream) != hipSuccess) {
+            htd::set_error("conv2d_bwd_data: memset failed");
+            return HTD_ERR_LAUNCH;
+        }
+    }
+    for (int cls = 0; cls < stride * stride; ++cls) {
+        const int ph = cls / stride, pw = cls % stride;
+        if (ph >= H || pw >= W) continue;
+        ConvParams q = p;
+        q.ntaps = 0;
+        for (int ky = 0; ky < kh; ++ky) {
+            const int ry = ph + pad - ky * dil;
+            if (((ry % stride) + stride) % stride != 0) continue;
+            for (int kx = 0; kx < kw; ++kx) {
+                const int rx = pw + pad - kx * dil;
+                if (((rx % stride) + stride) % stride != 0) continue;
+                q.tap_dy[q.ntaps] = ry >= 0 ? ry / stride : -((-ry) / stride);
+                q.tap_dx[q.ntaps] = rx >= 0 ? rx / stride : -((-rx) / stride);
+                q.tap_w[q.ntaps] = (kh - 1 - ky) * kw + (kw - 1 - kx);      // index into the flipped weights
+                ++q.ntaps;
+            }
+        }
+        if (q.ntaps == 0) continue;
+        q.stride = 1; q.pad = 0;
+        q.H = Ho; q.W = Wo;                                  // bounds of the gy map
+        q.Ho = (H - ph + stride - 1) / stride; q.Wo = (W - pw + stride - 1) / stride;
+        q.o_h0 = ph; q.o_w0 = pw; q.o_step = stride; q.oH = H; q.oW = W;
+        q.M = (int64_t)B * q.Ho * q.Wo;
+        const int st = launch_conv(q, (hipStream_t)stream, nullptr);
+        if (st) return st;
+    }
+    return HTD_OK;
 }
 
 namespace {

@@ -196,7 +196,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[i] = la[2 * t * SA + i];
             }
-            if constexpr (TN == 2) {
+            if constexpr (TN == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(lb + 2 * t * SB);
+                fb[0] = v.x; fb[1] = v.y; fb[2] = v.z; fb[3] = v.w;
+            } else if constexpr (TN == 2) {
                 const float2 v = *reinterpret_cast<const float2 *>(lb + 2 * t * SB);
                 fb[0] = v.x; fb[1] = v.y;
             } else {
@@ -394,6 +397,8 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     dim3 grid((unsigned)(c.mt * c.nt * c.splits));
     if (c.bm == 32)
         hipLaunchKernelGGL((conv_wgrad_kernel<1, 4, 1, 1>), grid, dim3(256), 0, s, p);
+    else if (c.bn == 256)
+        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 4>), grid, dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
     if (c.splits > 1) {
