@@ -209,3 +209,49 @@ def test_batched_pgraph_matches_reference_fixture(golden):
     one = pgraph_refine(x[:1].to(dev), sam[:1].to(dev), rois[:1].to(dev), lv[:1].to(dev), layers)
     assert torch.isfinite(one).all() and one.shape == (1, 1024)
     assert pgraph_refine(x[:0].to(dev), sam[:0].to(dev), rois[:0].to(dev), lv[:0].to(dev), layers).shape == (0, 1024)
+
+
+def test_rpn_batched_loss_equals_reference_order_path(det, golden):
+    """The production RPN loss (batched, host-sync-free) against the reference-order path (per image, per level,
+    unmap/index_put) on the same sample picks: assignment must be identical, losses equal to fp32 rounding."""
+    from htd_amd.core.bbox import SamplingResult
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, gts, _ = inputs(g, dev)
+    gts = [gts[0], gts[1][:0]]                      # second image WITHOUT ground truth: all-negative branch
+    det.train()
+    rpn = det.rpn_head
+    with torch.no_grad():
+        x = det.extract_feat(img)
+        cls, reg = rpn(x)
+    torch.manual_seed(3)
+    fast = rpn.loss_batched(cls, reg, gts, metas)
+    assigned, pos, neg, inside = rpn._last_rpn_sample
+    sc = rpn.train_cfg.sampler
+    n_pos, n_neg = pos.sum(1), neg.sum(1)
+    n_cand_pos, n_cand_neg = (assigned > 0).sum(1), (assigned == 0).sum(1)
+    exp_pos = torch.min(n_cand_pos, torch.full_like(n_cand_pos, int(sc.num * sc.pos_fraction)))
+    assert torch.equal(n_pos, exp_pos) and torch.equal(n_neg, torch.min(n_cand_neg, sc.num - n_pos))
+    assert not (pos & ~(assigned > 0)).any() and not (neg & ~(assigned == 0)).any()
+
+    class MaskSampler:
+        def __init__(self):
+            self.b = 0
+
+        def sample(self, assign_result, anchors, gt_bboxes, gt_labels=None, **kw):
+            ins = inside[self.b]
+            assert torch.equal(assign_result.gt_inds, assigned[self.b][ins])          # identical assignment
+            p = torch.nonzero(pos[self.b][ins], as_tuple=False).squeeze(1)
+            n = torch.nonzero(neg[self.b][ins], as_tuple=False).squeeze(1)
+            self.b += 1
+            flags = anchors.new_zeros((anchors.shape[0], ), dtype=torch.uint8)
+            return SamplingResult(p, n, anchors[:, :4], gt_bboxes, assign_result, flags)
+    saved = rpn.sampler
+    try:
+        rpn.sampler = MaskSampler()
+        ref = rpn.loss_per_image(cls, reg, gts, metas)
+    finally:
+        rpn.sampler = saved
+    for k in ('loss_rpn_cls', 'loss_rpn_bbox'):
+        a, b = sum(fast[k]).item(), sum(ref[k]).item()
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (k, a, b)
