@@ -37,6 +37,9 @@ def parse():
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--infer', action='store_true', help='inference-only throughput (BASELINE configs[4] shape): '
+                    'simple_test with --proposals RoIs per image into the RoI head')
+    ap.add_argument('--proposals', type=int, default=512)
     ap.add_argument('--profile-kernels', action='store_true', help='print the per-kernel-class time table')
     ap.add_argument('--profile-detail', action='store_true', help='per-layer-shape time table (implies the above)')
     return ap.parse_args()
@@ -84,10 +87,23 @@ def main():
     capi.lib()                                              # fail loudly if the HIP library is missing
 
     torch.manual_seed(0)
-    model = build_htd_detector(args.depth)                  # init_weights() of every module, seed 0
-    model = model.to(dev).train()
-    trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
-    data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
+    if args.infer:
+        from htd_amd.configs import htd_config
+        cfg = htd_config(args.depth, soft_nms=False)        # configs[4]: hard NMS, 512 proposals into the RoI head
+        cfg.test_cfg.rpn.update(nms_post=args.proposals, max_num=args.proposals)
+        model = build_htd_detector(cfg=cfg).to(dev).eval()
+        data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
+
+        class _Infer:                                       # same .train_step() shape as Trainer for the loop below
+            def train_step(self, d):
+                with torch.no_grad():
+                    return model.simple_test(d['img'], d['img_metas'])
+        trainer = _Infer()
+    else:
+        model = build_htd_detector(args.depth)              # init_weights() of every module, seed 0
+        model = model.to(dev).train()
+        trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
+        data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
 
     def sync():
         if world > 1:
@@ -121,17 +137,21 @@ def main():
             rate = (work / (tot_ms * 1e-3) / 1e12) if (kind and tot_ms > 0) else 0.0
             print(f'# {name:64s} calls={n:5d} total={tot_ms:9.3f} ms  {kind or ""} {rate:8.2f} T/s', file=sys.stderr)
     out = {
-        'metric': 'images/sec (1333x800) HTD-R%d train step' % args.depth, 'value': round(value, 3),
+        'metric': ('images/sec (1333x800) HTD-R%d inference' if args.infer else
+                   'images/sec (1333x800) HTD-R%d train step') % args.depth, 'value': round(value, 3),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'HTD ResNet-{args.depth} FPN fp32 train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
-                               f'{args.width - 11}x{args.height} (padded {args.width}x{args.height}), '
-                               'random-init weights, 2000 RPN proposals/img, 512 RoIs/img/stage',
+        'config': {'workload': (f'HTD ResNet-{args.depth} FPN fp32 inference (simple_test, hard NMS), batch {args.batch}/GPU '
+                                f'@ {args.width - 11}x{args.height}, {args.proposals} proposals/img into the RoI head'
+                                if args.infer else
+                                f'HTD ResNet-{args.depth} FPN fp32 train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
+                                f'{args.width - 11}x{args.height} (padded {args.width}x{args.height}), '
+                                'random-init weights, 2000 RPN proposals/img, 512 RoIs/img/stage'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
         'roofline': roof,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.infer:
         out['cpu_baseline'] = cpu_baseline(args.depth, args.height, args.width)
     print(json.dumps(out))
 

@@ -94,9 +94,16 @@ class GradientExchange:
                 return
             b = self.flat.bucket_of[i]
             self._pending[b].discard(i)
-            if not self._pending[b] and b not in self._launched:
-                self._launch(b)
+            self._advance()
         return hook
+
+    def _advance(self):
+        """Launch ready buckets strictly in bucket order.  Every rank therefore issues the same sequence of
+        collectives even when a data-dependent branch leaves some parameters without gradient on one rank only
+        (their bucket then waits for finish_step on every rank that does have it ready -- order is what matters)."""
+        while self._next < len(self.flat.buckets) and not self._pending[self._next]:
+            self._launch(self._next)
+            self._next += 1
 
     def begin_step(self):
         if not self.enabled:
@@ -106,6 +113,7 @@ class GradientExchange:
             self._pending[b].add(i)
         self._launched = set()
         self._works = []
+        self._next = 0
 
     def _launch(self, b):
         self._launched.add(b)
@@ -119,12 +127,13 @@ class GradientExchange:
             self._works.append(dist.all_reduce(chunk, group=self.group, async_op=True))
 
     def finish_step(self):
-        """Reduce buckets whose parameters got no gradient this step, then join the side stream."""
+        """Reduce the remaining buckets (parameters that got no gradient this step contribute zeros), still in
+        bucket order, then join the side stream."""
         if not self.enabled:
             return
-        for b in range(len(self.flat.buckets)):
-            if b not in self._launched:
-                self._launch(b)
+        while self._next < len(self.flat.buckets):
+            self._launch(self._next)
+            self._next += 1
         for w in self._works:
             w.wait()
         if self.stream is not None:
