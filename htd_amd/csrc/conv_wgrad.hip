@@ -186,31 +186,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
         // in the [k][m] LDS image and arrive with one ds_read_b64 (TM = 2) instead of TM ds_read_b32.
         const float *la = lds[cur] + fhalf * SA + wm * TM * 32 + fidx * TM;
         const float *lb = lds[cur] + BKW * SA + fhalf * SB + wn * TN * 32 + fidx * TN;
-#pragma unroll
-        for (int t = 0; t < BKW / 2; ++t) {
-            float fa[TM], fb[TN];
+        // fragments of k-pair t+1 are read while the MFMAs of k-pair t execute (register double buffer)
+        float fa[2][TM], fb[2][TN];
+        auto read_frag = [&](int t, float (&a)[TM], float (&b)[TN]) {
             if constexpr (TM == 2) {
                 const float2 v = *reinterpret_cast<const float2 *>(la + 2 * t * SA);
-                fa[0] = v.x; fa[1] = v.y;
+                a[0] = v.x; a[1] = v.y;
             } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = la[2 * t * SA + i];
+                for (int i = 0; i < TM; ++i) a[i] = la[2 * t * SA + i];
             }
             if constexpr (TN == 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(lb + 2 * t * SB);
-                fb[0] = v.x; fb[1] = v.y; fb[2] = v.z; fb[3] = v.w;
+                b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
             } else if constexpr (TN == 2) {
                 const float2 v = *reinterpret_cast<const float2 *>(lb + 2 * t * SB);
-                fb[0] = v.x; fb[1] = v.y;
+                b[0] = v.x; b[1] = v.y;
             } else {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = lb[2 * t * SB + j];
+                for (int j = 0; j < TN; ++j) b[j] = lb[2 * t * SB + j];
             }
+        };
+        read_frag(0, fa[0], fb[0]);
+#pragma unroll
+        for (int t = 0; t < BKW / 2; ++t) {
+            if (t + 1 < BKW / 2) read_frag(t + 1, fa[(t + 1) & 1], fb[(t + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][i], fb[t & 1][j], acc[i][j], 0, 0, 0);
         }
         if (s + 1 < s_end) {
             __syncthreads();               // every wave has read this slice
@@ -353,8 +358,8 @@ Cfg choose(int Co, int Ntot, int64_t K)
     c.mt = (int)htd::ceil_div(Co, c.bm);
     c.nt = (int)htd::ceil_div(Ntot, c.bn);
     const int64_t slices = htd::ceil_div(K, BKW);
-    int64_t want = htd::ceil_div(768, (int64_t)c.mt * c.nt);        // ~3 workgroups per CU
-    want = std::min<int64_t>(want, std::max<int64_t>(1, slices / 8)); // at least 8 slices per split
+    int64_t want = htd::ceil_div(1536, (int64_t)c.mt * c.nt);       // ~6 workgroups per CU (measured: oversubscription pays)
+    want = std::min<int64_t>(want, std::max<int64_t>(1, slices / 20)); // at least 20 slices (640 pixels) per split
     c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 96));
     if (c.splits >= 6) c.splits = (c.splits + 7) / 8 * 8;            // multiples of 8: one split per XCD group
     return c;
