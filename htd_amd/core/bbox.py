@@ -280,3 +280,141 @@ def bbox2result(bboxes, labels, num_classes):
         bboxes = bboxes.detach().cpu().numpy()
         labels = labels.detach().cpu().numpy()
     return [bboxes[labels == i, :] for i in range(num_classes)]
+
+
+# ------------------------------------------------------------------ batched, host-sync-free forms
+def batched_max_iou_assign(assigner, boxes, box_valid, gts, gt_valid):
+    """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:124-212) for B images at once.
+    boxes (A,4) shared by all images or (B,A,4); box_valid (B,A) bool; gts (B,K,4) zero-padded; gt_valid (B,K).
+    -> (assigned (B,A) int64: -1 ignore / invalid box, 0 negative, k+1 matched to gt k;  max_overlaps (B,A))."""
+    a = assigner
+    assert isinstance(a.neg_iou_thr, float) and a.ignore_iof_thr <= 0
+    if boxes.dim() == 2:
+        boxes = boxes[None]
+    B, K = gt_valid.shape
+    area_b = (boxes[..., 2] - boxes[..., 0]) * (boxes[..., 3] - boxes[..., 1])          # (1|B, A)
+    area_g = (gts[..., 2] - gts[..., 0]) * (gts[..., 3] - gts[..., 1])
+    wh = (torch.min(gts[:, :, None, 2:], boxes[:, None, :, 2:]) - torch.max(gts[:, :, None, :2], boxes[:, None, :, :2])).clamp(min=0)
+    overlap = wh[..., 0] * wh[..., 1]
+    union = torch.max(area_g[:, :, None] + area_b[:, None, :] - overlap, overlap.new_tensor([1e-6]))
+    iou = overlap / union                                                  # (B,K,A) == bbox_overlaps(gt, boxes)
+    pair_ok = gt_valid[:, :, None] & box_valid[:, None, :]
+    iou = torch.where(pair_ok, iou, iou.new_full((1, ), -1.0))             # padded gts / invalid boxes never win
+    max_ov, argmax = iou.max(dim=1)                                        # (B,A)
+    assigned = torch.full_like(argmax, -1)
+    assigned = torch.where((max_ov >= 0) & (max_ov < a.neg_iou_thr), torch.zeros_like(assigned), assigned)
+    assigned = torch.where(max_ov >= a.pos_iou_thr, argmax + 1, assigned)
+    if a.match_low_quality:
+        gt_max, gt_arg = iou.max(dim=2)                                    # (B,K)
+        ok = gt_valid & (gt_max >= a.min_pos_iou)
+        ids = torch.arange(1, K + 1, device=iou.device)
+        if a.gt_max_assign_all:
+            hit = (iou == gt_max[:, :, None]) & ok[:, :, None] & pair_ok
+            low = (hit * ids.view(1, K, 1)).max(dim=1)[0]                  # the last qualifying gt wins (:193-199)
+        else:
+            low = torch.zeros_like(assigned).scatter_reduce(1, gt_arg, (ids.view(1, K) * ok).expand(B, K), 'amax')
+        assigned = torch.where(low > 0, low, assigned)
+    has_gt = gt_valid.any(dim=1, keepdim=True)
+    assigned = torch.where(has_gt, assigned, torch.zeros_like(assigned))   # image without gt: everything negative
+    assigned = torch.where(box_valid, assigned, torch.full_like(assigned, -1))
+    return assigned, torch.where(box_valid & has_gt, max_ov.clamp(min=0), torch.zeros_like(max_ov))
+
+
+def batched_random_sample(assigned, num, pos_fraction, neg_pos_ub=-1, keys=None):
+    """RandomSampler (base_sampler.py:34-101, random_sampler.py:58-78) without host round trips: a uniformly random
+    subset of size n is the n candidates with the smallest i.i.d. random keys.  -> (pos_mask, neg_mask) (B,A)."""
+    B, A = assigned.shape
+    if keys is None:
+        keys = torch.rand(B, A, device=assigned.device)
+    is_pos, is_neg = assigned > 0, assigned == 0
+    ar = torch.arange(A, device=assigned.device).expand(B, A)
+
+    def pick(cand, limit):
+        order = torch.where(cand, keys, keys.new_full((1, ), 2.0)).argsort(dim=1)
+        rank = torch.empty_like(order).scatter_(1, order, ar)
+        return cand & (rank < limit)
+    pos_mask = pick(is_pos, torch.full((B, 1), int(num * pos_fraction), device=assigned.device))
+    n_pos = pos_mask.sum(dim=1, keepdim=True)
+    n_neg = num - n_pos
+    if neg_pos_ub >= 0:
+        n_neg = torch.min(n_neg, (neg_pos_ub * n_pos.clamp(min=1)).long())
+    return pos_mask, pick(is_neg, n_neg)
+
+
+class BatchSamplingResult:
+    """Per-image view with the attributes of SamplingResult (sampling_result.py:6-60), cut out of batched tensors."""
+
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, gt_inds, labels, gt_flags):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = gt_inds[pos_inds] - 1
+        self.pos_gt_bboxes = gt_bboxes.view(-1, 4)[self.pos_assigned_gt_inds, :] if gt_bboxes.numel() else \
+            torch.empty_like(gt_bboxes).view(-1, 4)
+        self.pos_gt_labels = labels[pos_inds] if labels is not None else None
+
+    @property
+    def bboxes(self):
+        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+
+
+def batched_assign_and_sample(assigner, sampler, proposal_list, gt_bboxes, gt_labels, keys=None):
+    """assign + sample of every image of the batch (htd_roi_head.py:254-264,292-310) with ONE device->host copy
+    (the sample counts).  Candidate order per image is [gt boxes, proposals] when add_gt_as_proposals
+    (base_sampler.py:72-81); sampled indices are ascending like `.unique()` leaves them.
+    -> (list of BatchSamplingResult, counts) with counts[b] = (n_pos, n_neg, n_pos_that_are_gt)."""
+    dev = proposal_list[0].device
+    B = len(proposal_list)
+    add_gt = sampler.add_gt_as_proposals
+    P = max(1, max(int(p.size(0)) for p in proposal_list))
+    K = max(1, max(int(g.size(0)) for g in gt_bboxes))
+    props = proposal_list[0].new_zeros(B, P, 4)
+    pvalid = torch.zeros(B, P, dtype=torch.bool, device=dev)
+    gts = proposal_list[0].new_zeros(B, K, 4)
+    gvalid = torch.zeros(B, K, dtype=torch.bool, device=dev)
+    glabels = torch.zeros(B, K, dtype=torch.long, device=dev)
+    for b in range(B):
+        n, k = proposal_list[b].size(0), gt_bboxes[b].size(0)
+        if n:
+            props[b, :n] = proposal_list[b][:, :4]
+            pvalid[b, :n] = True
+        if k:
+            gts[b, :k] = gt_bboxes[b][:, :4]
+            gvalid[b, :k] = True
+            glabels[b, :k] = gt_labels[b]
+    assigned, _ = batched_max_iou_assign(assigner, props, pvalid, gts, gvalid)
+    labels = torch.where(assigned > 0, torch.gather(glabels, 1, (assigned - 1).clamp(min=0)), torch.full_like(assigned, -1))
+    if add_gt:      # AssignResult.add_gt_: gt i is a candidate matched to itself
+        self_inds = torch.where(gvalid, torch.arange(1, K + 1, device=dev).expand(B, K), torch.full((B, K), -1, device=dev))
+        assigned = torch.cat([self_inds, assigned], 1)
+        labels = torch.cat([torch.where(gvalid, glabels, torch.full_like(glabels, -1)), labels], 1)
+        cand = torch.cat([gts, props], 1)
+        is_gt = torch.cat([gvalid, torch.zeros_like(pvalid)], 1)
+    else:
+        cand, is_gt = props, torch.zeros_like(pvalid)
+    pos, neg = batched_random_sample(assigned, sampler.num, sampler.pos_fraction, sampler.neg_pos_ub, keys)
+    # selected candidates first, ascending index inside (stable sort of the complement mask)
+    pos_order = torch.sort((~pos).to(torch.uint8), dim=1, stable=True)[1]
+    neg_order = torch.sort((~neg).to(torch.uint8), dim=1, stable=True)[1]
+    counts = torch.stack([pos.sum(1), neg.sum(1), (pos & is_gt).sum(1)], 1).tolist()        # the one host read
+    out = []
+    gt_flags = is_gt.to(torch.uint8)
+    for b in range(B):
+        npos, nneg, _ = counts[b]
+        k = gt_bboxes[b].size(0)
+        # indices refer to the padded candidate layout; remap to the reference's compact [gt_b ; proposals_b] layout
+        pi, ni = pos_order[b, :npos], neg_order[b, :nneg]
+        if add_gt and k < K:
+            shift = K - k
+            pi = torch.where(pi >= K, pi - shift, pi)
+            ni = torch.where(ni >= K, ni - shift, ni)
+            boxes_b = torch.cat([gt_bboxes[b][:, :4], proposal_list[b][:, :4]], 0)
+            inds_b = torch.cat([assigned[b, :k], assigned[b, K:K + proposal_list[b].size(0)]])
+            lab_b = torch.cat([labels[b, :k], labels[b, K:K + proposal_list[b].size(0)]])
+            flg_b = torch.cat([gt_flags[b, :k], gt_flags[b, K:K + proposal_list[b].size(0)]])
+        else:
+            n_b = (K if add_gt else 0) + proposal_list[b].size(0)
+            boxes_b, inds_b, lab_b, flg_b = cand[b, :n_b], assigned[b, :n_b], labels[b, :n_b], gt_flags[b, :n_b]
+        out.append(BatchSamplingResult(pi, ni, boxes_b, gt_bboxes[b][:, :4], inds_b, lab_b, flg_b))
+    return out, counts

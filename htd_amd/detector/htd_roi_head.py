@@ -112,13 +112,66 @@ class HTDRoIHead(nn.Module):
                             global_feat=None):
         rois = bbox2roi([res.bboxes for res in sampling_results])
         bbox_results = self._bbox_forward(stage, x, rois, global_feat, sampling_results, img_metas)
-        bbox_targets = self.bbox_head[stage].get_targets(sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg)
+        bbox_targets = self._targets(stage, sampling_results, rcnn_train_cfg)
         loss_bbox = self.bbox_head[stage].loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
                                                *bbox_targets)
         bbox_results.update(loss_bbox=loss_bbox, rois=rois, bbox_targets=bbox_targets)
         return bbox_results
 
+    def _targets(self, stage, sampling_results, cfg):
+        """BBoxHead.get_targets (bbox_head.py:85-139) for the whole batch in a handful of launches: rows are
+        [pos_i ; neg_i] per image, positives carry their gt label and encoded deltas, everything has weight 1
+        (pos_weight <= 0), negatives the background label."""
+        head = self.bbox_head[stage]
+        if cfg.pos_weight > 0 or head.reg_decoded_bbox:
+            return head.get_targets(sampling_results, None, None, cfg)
+        npos = [r.pos_bboxes.size(0) for r in sampling_results]
+        nneg = [r.neg_bboxes.size(0) for r in sampling_results]
+        N = sum(npos) + sum(nneg)
+        dev = sampling_results[0].pos_bboxes.device
+        pos_rows, start = [], 0
+        for a, b in zip(npos, nneg):
+            pos_rows.append(torch.arange(start, start + a, device=dev))
+            start += a + b
+        pos_rows = torch.cat(pos_rows)
+        pos_b = torch.cat([r.pos_bboxes for r in sampling_results])
+        labels = pos_b.new_full((N, ), head.num_classes, dtype=torch.long)
+        bbox_targets = pos_b.new_zeros(N, 4)
+        bbox_weights = pos_b.new_zeros(N, 4)
+        if pos_rows.numel():
+            labels[pos_rows] = torch.cat([r.pos_gt_labels for r in sampling_results])
+            bbox_targets[pos_rows] = head.bbox_coder.encode(pos_b, torch.cat([r.pos_gt_bboxes for r in sampling_results]))
+            bbox_weights[pos_rows] = 1
+        return labels, pos_b.new_ones(N), bbox_targets, bbox_weights
+
+    def _refine(self, rois, bbox_pred, sampling_results, img_metas):
+        """BBoxHead.refine_bboxes (bbox_head.py:227-304), class-agnostic: one decode for the whole batch (per-row
+        image limits), then per image the rows that were ground truth -- they lead each image's block because gt
+        candidates come first and sampled indices are ascending -- are dropped with a slice."""
+        head = self.bbox_head[0]
+        if not head.reg_class_agnostic or not head.bbox_coder.clip_border:
+            return None
+        from ..core.bbox import delta2bbox
+        boxes = delta2bbox(rois[:, 1:], bbox_pred, head.bbox_coder.means, head.bbox_coder.stds, None)
+        lim = boxes.new_tensor([[m['img_shape'][1], m['img_shape'][0]] * 2 for m in img_metas])      # (B,4) w,h,w,h
+        boxes = torch.min(boxes.clamp(min=0), lim[rois[:, 0].long()])
+        out, start = [], 0
+        n_gt = [int(v) for v in torch.stack([r.pos_is_gt.sum() for r in sampling_results]).tolist()]
+        for r, g in zip(sampling_results, n_gt):
+            n = r.pos_bboxes.size(0) + r.neg_bboxes.size(0)
+            out.append(boxes[start + g:start + n])
+            start += n
+        return out
+
     def _assign_and_sample(self, stage, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore):
+        """Per-image reference order when a permutation source is installed (parity tests replay the CPU RNG);
+        otherwise all images at once with a single device->host copy (core.bbox.batched_assign_and_sample)."""
+        from ..core import bbox as _bbox
+        a = self.bbox_assigner[stage]
+        if _bbox._randperm is _bbox._device_randperm and all(g is None for g in gt_bboxes_ignore) and \
+                a.ignore_iof_thr <= 0 and isinstance(a.neg_iou_thr, float) and \
+                type(self.bbox_sampler[stage]).__name__ == 'RandomSampler':
+            return _bbox.batched_assign_and_sample(a, self.bbox_sampler[stage], proposal_list, gt_bboxes, gt_labels)[0]
         out = []
         for j in range(len(proposal_list)):
             assign_result = self.bbox_assigner[stage].assign(proposal_list[j], gt_bboxes[j], gt_bboxes_ignore[j],
@@ -147,8 +200,10 @@ class HTDRoIHead(nn.Module):
             roi_labels = res['bbox_targets'][0]
             roi_labels = torch.where(roi_labels == self.bbox_head[0].num_classes,
                                      res['cls_score'][:, :-1].argmax(1), roi_labels)
-            proposal_list = self.bbox_head[0].refine_bboxes(res['rois'], roi_labels, res['bbox_pred'],
-                                                            [r.pos_is_gt for r in sampling_results], img_metas)
+            proposal_list = self._refine(res['rois'], res['bbox_pred'], sampling_results, img_metas)
+            if proposal_list is None:
+                proposal_list = self.bbox_head[0].refine_bboxes(res['rois'], roi_labels, res['bbox_pred'],
+                                                                [r.pos_is_gt for r in sampling_results], img_metas)
         # ---------------- stage 2: graph reasoning
         lw = self.stage_loss_weights[1]
         sampling_results = self._assign_and_sample(1, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore)

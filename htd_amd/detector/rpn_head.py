@@ -136,63 +136,6 @@ class RPNHead(nn.Module):
         return self.loss_per_image(cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore)
 
     # -------------------------------------------------------------- batched targets + loss (production path)
-    def batched_assign(self, flat_anchors, inside, gts, gt_valid):
-        """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:124-212) for B images at once.
-        flat_anchors (A,4); inside (B,A) bool; gts (B,K,4) zero-padded; gt_valid (B,K) bool.
-        -> assigned (B,A) int64: -1 ignore / outside the image, 0 negative, k+1 matched to gt k."""
-        a = self.assigner
-        B, K = gt_valid.shape
-        area_a = (flat_anchors[:, 2] - flat_anchors[:, 0]) * (flat_anchors[:, 3] - flat_anchors[:, 1])
-        area_g = (gts[..., 2] - gts[..., 0]) * (gts[..., 3] - gts[..., 1])
-        wh = (torch.min(gts[:, :, None, 2:], flat_anchors[None, None, :, 2:]) -
-              torch.max(gts[:, :, None, :2], flat_anchors[None, None, :, :2])).clamp(min=0)
-        overlap = wh[..., 0] * wh[..., 1]
-        union = torch.max(area_g[:, :, None] + area_a[None, None, :] - overlap, overlap.new_tensor([1e-6]))
-        iou = overlap / union                                                  # (B,K,A) == bbox_overlaps(gt, anchors)
-        pair_ok = gt_valid[:, :, None] & inside[:, None, :]
-        iou = torch.where(pair_ok, iou, iou.new_full((1, ), -1.0))             # padded gts / outside anchors never win
-        max_ov, argmax = iou.max(dim=1)                                        # (B,A)
-        assigned = torch.full_like(argmax, -1)
-        assigned = torch.where((max_ov >= 0) & (max_ov < a.neg_iou_thr), torch.zeros_like(assigned), assigned)
-        assigned = torch.where(max_ov >= a.pos_iou_thr, argmax + 1, assigned)
-        if a.match_low_quality:
-            gt_max = iou.max(dim=2)[0]                                         # (B,K)
-            ok = gt_valid & (gt_max >= a.min_pos_iou)
-            ids = torch.arange(1, K + 1, device=iou.device).view(1, K, 1)
-            if a.gt_max_assign_all:
-                hit = (iou == gt_max[:, :, None]) & ok[:, :, None] & pair_ok
-                low = (hit * ids).max(dim=1)[0]                                # last qualifying gt wins (:193-199)
-            else:
-                gt_arg = iou.max(dim=2)[1]
-                low = torch.zeros_like(assigned).scatter_reduce(1, gt_arg, (ids.view(1, K) * ok).expand(B, K), 'amax')
-            assigned = torch.where(low > 0, low, assigned)
-        has_gt = gt_valid.any(dim=1, keepdim=True)
-        assigned = torch.where(has_gt, assigned, torch.zeros_like(assigned))   # no gt in the image: all negative (:137-139)
-        return torch.where(inside, assigned, torch.full_like(assigned, -1)), max_ov
-
-    @staticmethod
-    def batched_sample(assigned, num, pos_fraction, neg_pos_ub=-1, keys=None):
-        """RandomSampler (base_sampler.py:34-101, random_sampler.py:58-78) without host round trips: a uniformly
-        random subset of size n is the n candidates with the smallest i.i.d. random keys.
-        -> (pos_mask, neg_mask) (B,A) bool."""
-        B, A = assigned.shape
-        if keys is None:
-            keys = torch.rand(B, A, device=assigned.device)
-        is_pos, is_neg = assigned > 0, assigned == 0
-        num_expected_pos = int(num * pos_fraction)
-
-        def pick(cand, limit):
-            k = torch.where(cand, keys, keys.new_full((1, ), 2.0))
-            order = k.argsort(dim=1)
-            rank = torch.empty_like(order).scatter_(1, order, torch.arange(A, device=keys.device).expand(B, A))
-            return cand & (rank < limit)
-        pos_mask = pick(is_pos, torch.full((B, 1), num_expected_pos, device=assigned.device))
-        n_pos = pos_mask.sum(dim=1, keepdim=True)
-        n_neg = num - n_pos
-        if neg_pos_ub >= 0:
-            n_neg = torch.min(n_neg, (neg_pos_ub * n_pos.clamp(min=1)).long())
-        return pos_mask, pick(is_neg, n_neg)
-
     def loss_batched(self, cls_scores, bbox_preds, gt_bboxes, img_metas, keys=None):
         dev = cls_scores[0].device
         B = cls_scores[0].size(0)
@@ -215,9 +158,10 @@ class RPNHead(nn.Module):
             if g.size(0):
                 gts[b, :g.size(0)] = g[:, :4]
                 gt_valid[b, :g.size(0)] = True
-        assigned, _ = self.batched_assign(flat_anchors, inside, gts, gt_valid)
+        from ..core.bbox import batched_max_iou_assign, batched_random_sample
+        assigned, _ = batched_max_iou_assign(self.assigner, flat_anchors, inside, gts, gt_valid)
         sc = self.train_cfg.sampler
-        pos, neg = self.batched_sample(assigned, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1), keys)
+        pos, neg = batched_random_sample(assigned, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1), keys)
         # targets (anchor_head.py:172-269): labels 0 = foreground, num_classes = background; weights 1 on samples
         gt_of = torch.gather(gts, 1, (assigned - 1).clamp(min=0)[..., None].expand(B, A, 4))
         safe_gt = torch.where(pos[..., None], gt_of, flat_anchors[None].expand(B, A, 4))   # avoid log(0) on unused rows

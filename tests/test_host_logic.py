@@ -155,3 +155,39 @@ def test_losses_match_oracle():
     torch.testing.assert_close(SmoothL1Loss(beta=1 / 9.)(a, b, ww, avg_factor=5.), B.smooth_l1_loss(a, b, ww, 1 / 9., 5.))
     torch.testing.assert_close(accuracy(pred, lab), B.accuracy(pred, lab))
     assert accuracy(torch.zeros(0, 81), torch.zeros(0, dtype=torch.long)).item() == 0.          # empty input
+
+
+def test_batched_assign_and_sample_equals_per_image_path():
+    """core.bbox.batched_assign_and_sample (one host read per stage) against MaxIoUAssigner + SamplingResult per
+    image on the same picks: identical assignment / labels / boxes, counts follow the sampler's rules.  Includes an
+    image without ground truth and ragged proposal / gt counts."""
+    from htd_amd.core.bbox import (MaxIoUAssigner, RandomSampler, SamplingResult, batched_assign_and_sample)
+    g = torch.Generator().manual_seed(0)
+
+    def boxes(n, s=200.):
+        xy = torch.rand(n, 2, generator=g) * s
+        wh = torch.rand(n, 2, generator=g) * s * 0.4 + 2
+        return torch.cat([xy, xy + wh], 1)
+    gts = [boxes(5), boxes(0), boxes(2)]
+    labels = [torch.randint(0, 80, (len(b), ), generator=g) for b in gts]
+    props = [torch.cat([boxes(300), gts[0] + 1.0]), boxes(150), torch.cat([boxes(40), gts[2] + 0.5, gts[2] - 0.5])]
+    assigner = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False)
+    sampler = RandomSampler(num=64, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    res, counts = batched_assign_and_sample(assigner, sampler, props, gts, labels)
+    for b in range(3):
+        r = res[b]
+        ar = assigner.assign(props[b], gts[b], None, labels[b])
+        cand = props[b]
+        flags = cand.new_zeros((cand.shape[0], ), dtype=torch.uint8)
+        if len(gts[b]) > 0:
+            cand = torch.cat([gts[b], cand], 0)
+            ar.add_gt_(labels[b])
+            flags = torch.cat([cand.new_ones(len(gts[b]), dtype=torch.uint8), flags])
+        n_cand_pos, n_cand_neg = int((ar.gt_inds > 0).sum()), int((ar.gt_inds == 0).sum())
+        assert counts[b][0] == min(n_cand_pos, 16) and counts[b][1] == min(n_cand_neg, 64 - counts[b][0])
+        assert (ar.gt_inds[r.pos_inds] > 0).all() and (ar.gt_inds[r.neg_inds] == 0).all()
+        assert torch.equal(torch.sort(r.pos_inds)[0], r.pos_inds) and torch.equal(torch.sort(r.neg_inds)[0], r.neg_inds)
+        ref = SamplingResult(r.pos_inds, r.neg_inds, cand, gts[b], ar, flags)
+        for k in ('pos_bboxes', 'neg_bboxes', 'pos_is_gt', 'pos_assigned_gt_inds', 'pos_gt_bboxes', 'pos_gt_labels'):
+            assert torch.equal(getattr(r, k), getattr(ref, k)), (b, k)
+        assert int(r.pos_is_gt.sum()) == counts[b][2] and r.pos_is_gt[:counts[b][2]].all()     # gt rows lead
