@@ -60,7 +60,7 @@ struct Tile {
     static constexpr int ROWS_PER_PASS = 256 / VEC_PER_ROW;   // rows covered by the 256 threads at once
     static constexpr int PASSES_A = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
     static constexpr int PASSES_B = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-    static constexpr int MAIN_FLOATS = 2 * (BM + BN) * LDS_STRIDE;
+    static constexpr int MAIN_FLOATS = (BM + BN) * LDS_STRIDE;       // ONE slice buffer + register prefetch
     static constexpr int EPI_STRIDE = BN + 4;
     static constexpr int EPI_ROWS = WGM * 32;                 // rows staged per epilogue round
     static constexpr int EPI_FLOATS = EPI_ROWS * EPI_STRIDE;
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
         }
     };
     auto store_slice = [&](int buf) {
-        float *la = (lds + buf * (T::MAIN_FLOATS / 2));
-        float *lb = (lds + buf * (T::MAIN_FLOATS / 2)) + T::BM * T::LDS_STRIDE;
+        float *la = lds;
+        float *lb = lds + T::BM * T::LDS_STRIDE;
 #pragma unroll
         for (int i = 0; i < T::PASSES_A; ++i) {
             const int r = vrow + i * T::ROWS_PER_PASS;
@@ -196,10 +196,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
     }
     __syncthreads();
     for (int s = s_begin; s < num_slices; ++s) {
-        const int cur = (s - s_begin) & 1;
         if (s + 1 < num_slices) load_slice();
-        const float *la = (lds + cur * (T::MAIN_FLOATS / 2)) + (wm * TM * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
-        const float *lb = (lds + cur * (T::MAIN_FLOATS / 2)) + (T::BM + wn * TN * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
+        const float *la = lds + (wm * TM * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
+        const float *lb = lds + (T::BM + wn * TN * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             float4 fa[TM], fb[TN];
@@ -216,9 +215,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
-            // the next slice's registers go to the other LDS buffer in the shadow of the remaining MFMAs:
-            // by now (one 8-float K group = 4*TM*TN MFMAs later) the global loads issued above have landed
-            if (kk == (BK / 8 > 1 ? BK / 16 - 1 : 0) && s + 1 < num_slices) store_slice(cur ^ 1);
+        }
+        if (s + 1 < num_slices) {
+            __syncthreads();               // every wave has read this slice
+            store_slice(0);                // the prefetched registers (global loads were in flight during the MFMAs)
         }
         __syncthreads();
     }
@@ -348,7 +348,7 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     // too few big tiles to balance 256 CUs
     int bm = 128;
     int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
-    if (bn == 128 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 128) < 512) bn = 64;
+    if (bn == 128 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 128) < 768) bn = 64;
     if (bn == 64 && p.Co >= 64 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 64) < 1024 && p.M >= 2048) bm = 64;
     p.mt = (int)htd::ceil_div(p.M, bm);
     p.nt = (int)htd::ceil_div(p.Co, bn);
