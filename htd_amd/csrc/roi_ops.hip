@@ -263,6 +263,54 @@ __global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const f
         }
 }
 
+// ------------------------------------------------------------------ frozen-statistics BatchNorm folding
+// w'[co][k] = w[co][k] * s[co],  b'[co] = beta[co] - mean[co] * s[co],  s = gamma / sqrt(var + eps)
+__global__ __launch_bounds__(256) void bn_fold_fwd_kernel(const float *__restrict__ w, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, const float *__restrict__ mean,
+                                                          const float *__restrict__ var, float eps,
+                                                          float *__restrict__ wf, float *__restrict__ bf, int K)
+{
+    const int co = blockIdx.x;
+    const float s = gamma[co] * rsqrtf(var[co] + eps);
+    if (threadIdx.x == 0) bf[co] = beta[co] - mean[co] * s;
+    const float *wr = w + (int64_t)co * K;
+    float *wo = wf + (int64_t)co * K;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const float4 v = ld4(wr + k);
+        st4(wo + k, make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+    }
+}
+
+// given G = dL/dw' and gb = dL/db':  dw = G * s,  dbeta = gb,  dgamma = (sum_k G*w - mean*gb) / sqrt(var+eps)
+__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float *__restrict__ w, const float *__restrict__ gamma,
+                                                          const float *__restrict__ mean, const float *__restrict__ var,
+                                                          float eps, const float *__restrict__ gwf,
+                                                          const float *__restrict__ gbf, float *__restrict__ gw,
+                                                          float *__restrict__ ggamma, float *__restrict__ gbeta, int K)
+{
+    const int co = blockIdx.x;
+    const float rs = rsqrtf(var[co] + eps);
+    const float s = gamma[co] * rs;
+    const float *wr = w + (int64_t)co * K, *gr = gwf + (int64_t)co * K;
+    float *go = gw + (int64_t)co * K;
+    float dot = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const float4 v = ld4(wr + k), g = ld4(gr + k);
+        dot += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
+        st4(go + k, make_float4(g.x * s, g.y * s, g.z * s, g.w * s));
+    }
+    __shared__ float red[4];
+    dot = htd::wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const float gb = gbf[co];
+        gbeta[co] = gb;
+        ggamma[co] = (tot - mean[co] * gb) * rs;
+    }
+}
+
 inline unsigned grid_for(int64_t work, int block = 256, int cap = 4096)
 {
     int64_t b = htd::ceil_div(work, block);
@@ -390,4 +438,26 @@ extern "C" int htd_sgd_momentum_step(float *param, const float *grad, float *mom
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        momentum_buf, n, lr_dev, momentum, weight_decay, grad_scale);
     return htd::check_launch("sgd");
+}
+
+extern "C" int htd_bn_fold_fwd(const float *w, const float *gamma, const float *beta, const float *mean,
+                               const float *var, float eps, float *w_folded, float *b_folded, int Co, int K,
+                               void *stream)
+{
+    HTD_REQUIRE(Co > 0 && K > 0 && K % 4 == 0, "bn_fold: bad sizes Co=%d K=%d", Co, K);
+    HTD_REQUIRE(w && gamma && beta && mean && var && w_folded && b_folded, "bn_fold: null pointer");
+    hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, mean,
+                       var, eps, w_folded, b_folded, K);
+    return htd::check_launch("bn_fold_fwd");
+}
+
+extern "C" int htd_bn_fold_bwd(const float *w, const float *gamma, const float *mean, const float *var, float eps,
+                               const float *gw_folded, const float *gb_folded, float *gw, float *ggamma, float *gbeta,
+                               int Co, int K, void *stream)
+{
+    HTD_REQUIRE(Co > 0 && K > 0 && K % 4 == 0, "bn_fold: bad sizes Co=%d K=%d", Co, K);
+    HTD_REQUIRE(w && gamma && mean && var && gw_folded && gb_folded && gw && ggamma && gbeta, "bn_fold_bwd: null pointer");
+    hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, w, gamma, mean, var,
+                       eps, gw_folded, gb_folded, gw, ggamma, gbeta, K);
+    return htd::check_launch("bn_fold_bwd");
 }

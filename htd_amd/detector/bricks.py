@@ -68,11 +68,48 @@ def build_norm_layer(cfg, num_features, postfix=''):
     return abbr + str(postfix), layer
 
 
+class _BNFold(torch.autograd.Function):
+    """One launch forward, one backward (htd_bn_fold_fwd / _bwd) instead of ~15 element-wise kernels per conv."""
+
+    @staticmethod
+    def forward(ctx, w, gamma, beta, mean, var, eps):
+        from .. import capi
+        w = w.contiguous(memory_format=CL)
+        Co = w.size(0)
+        K = w.numel() // Co
+        wf = torch.empty_like(w, memory_format=CL)
+        bf = torch.empty(Co, device=w.device, dtype=w.dtype)
+        capi.call('htd_bn_fold_fwd', capi.ptr(w), capi.ptr(gamma), capi.ptr(beta), capi.ptr(mean), capi.ptr(var),
+                  float(eps), capi.ptr(wf), capi.ptr(bf), Co, K, capi.current_stream_ptr())
+        ctx.save_for_backward(w, gamma, mean, var)
+        ctx.eps = float(eps)
+        return wf, bf
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gwf, gbf):
+        from .. import capi
+        w, gamma, mean, var = ctx.saved_tensors
+        Co = w.size(0)
+        K = w.numel() // Co
+        gwf = gwf.contiguous(memory_format=CL)
+        gbf = gbf.contiguous()
+        gw = torch.empty_like(w, memory_format=CL)
+        gg = torch.empty_like(gamma)
+        gb = torch.empty_like(gamma)
+        capi.call('htd_bn_fold_bwd', capi.ptr(w), capi.ptr(gamma), capi.ptr(mean), capi.ptr(var), ctx.eps,
+                  capi.ptr(gwf), capi.ptr(gbf), capi.ptr(gw), capi.ptr(gg), capi.ptr(gb), Co, K,
+                  capi.current_stream_ptr())
+        return gw, gg, gb, None, None, None
+
+
 def frozen_bn_fold(conv_weight, bn):
     """Eval-mode BatchNorm (norm_eval=True, backbones/resnet.py:640-649) folded into the preceding conv:
-    w' = w * s, b' = beta - mean * s with s = gamma / sqrt(var + eps).  Written with differentiable tensor
-    ops, so autograd returns exactly d/dgamma, d/dbeta, d/dw of the unfused conv->BN pair."""
-    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    w' = w * s, b' = beta - mean * s with s = gamma / sqrt(var + eps).  The backward of the fold returns exactly
+    d/dgamma, d/dbeta, d/dw of the unfused conv->BN pair (no conv output is kept for the BN backward)."""
+    if conv_weight.is_cuda and (conv_weight.numel() // conv_weight.size(0)) % 4 == 0:
+        return _BNFold.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)          # 3-channel stem (K = 147): plain tensor ops
     return conv_weight * s.view(-1, 1, 1, 1), bn.bias - bn.running_mean * s
 
 

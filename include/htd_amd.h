@@ -195,6 +195,19 @@ int htd_group_norm_relu_bwd(const float *x, const float *y, const float *gamma, 
                             float *gbeta, int64_t n, int P, int C, int G, int relu, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Frozen-statistics BatchNorm (norm_eval=True, backbones/resnet.py:640-649) folded into the preceding
+ * convolution: w'[co][k] = w[co][k]*s, b'[co] = beta - mean*s, s = gamma/sqrt(var+eps), k over kh*kw*Ci (KRSC
+ * row).  bwd maps the gradients of the folded tensors back: gw = gw'*s, gbeta = gb',
+ * ggamma = (<gw'[co], w[co]> - mean*gb') / sqrt(var+eps) -- exactly d/dgamma, d/dbeta, d/dw of conv -> BN(eval).
+ * ---------------------------------------------------------------------------------- */
+int htd_bn_fold_fwd(const float *w, const float *gamma, const float *beta, const float *mean,
+                    const float *var, float eps, float *w_folded, float *b_folded, int Co, int K,
+                    void *stream);
+int htd_bn_fold_bwd(const float *w, const float *gamma, const float *mean, const float *var, float eps,
+                    const float *gw_folded, const float *gb_folded, float *gw, float *ggamma,
+                    float *gbeta, int Co, int K, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
  * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):
  *   g = grad*grad_scale + wd*p ; m = momentum*m + g ; p -= lr*m.     lr is a device scalar

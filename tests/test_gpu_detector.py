@@ -95,8 +95,13 @@ def test_inference_matches_reference_fixture(det, golden):
                                for c, r in enumerate(res[i])], 0)
         ref = g[f'test_dets{i}']
         assert mine.shape == ref.shape
-        np.testing.assert_array_equal(mine[:, 5], ref[:, 5])
-        np.testing.assert_allclose(mine[:, :5], ref[:, :5], rtol=1e-3, atol=1e-2)
+        # one-to-one matching instead of row order: detections with (nearly) equal scores may swap ranks
+        used = np.zeros(len(mine), dtype=bool)
+        for r in ref:
+            d = np.abs(mine[:, :5] - r[:5]).max(1) + 1e3 * (mine[:, 5] != r[5]) + 1e3 * used
+            j = int(d.argmin())
+            assert d[j] <= 1e-2 + 1e-3 * np.abs(r[:4]).max(), (r, mine[j], d[j])
+            used[j] = True
 
 
 class ReplaySampler:
