@@ -68,7 +68,7 @@ struct Tile {
 };
 
 template <int BK, int WGM, int WGN, int TM, int TN, bool TAPS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p)
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel(ConvParams p)
 {
     using T = Tile<BK, WGM, WGN, TM, TN>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];

@@ -36,7 +36,7 @@ constexpr int BKW = 32;    // pixels per K slice
 
 // WGM x WGN waves, each wave TM x TN MFMA blocks of 32x32
 template <int WGM, int WGN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p)
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
 {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
