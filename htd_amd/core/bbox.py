@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, BBOX_SAMPLERS, IOU_CALCULATORS, build_iou_calculator
+from .misc import const_tensor
 
 
 # ------------------------------------------------------------------ IoU
@@ -38,7 +39,7 @@ def bbox_overlaps(bboxes1, bboxes2, mode='iou', is_aligned=False, eps=1e-6):
               torch.max(bboxes1[:, None, :2], bboxes2[None, :, :2])).clamp(min=0)
         overlap = wh[..., 0] * wh[..., 1]
         union = area1[:, None] + area2[None, :] - overlap if mode == 'iou' else area1[:, None]
-    union = torch.max(union, union.new_tensor([eps]))
+    union = torch.max(union, const_tensor([eps], union.device, union.dtype))
     return overlap / union
 
 
@@ -219,14 +220,15 @@ def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     dx = ((gt[..., 0] + gt[..., 2]) * 0.5 - (proposals[..., 0] + proposals[..., 2]) * 0.5) / pw
     dy = ((gt[..., 1] + gt[..., 3]) * 0.5 - (proposals[..., 1] + proposals[..., 3]) * 0.5) / ph
     deltas = torch.stack([dx, dy, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
-    return deltas.sub_(deltas.new_tensor(means).unsqueeze(0)).div_(deltas.new_tensor(stds).unsqueeze(0))
+    return deltas.sub_(const_tensor(means, deltas.device, deltas.dtype).unsqueeze(0)).div_(
+        const_tensor(stds, deltas.device, deltas.dtype).unsqueeze(0))
 
 
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
                wh_ratio_clip=16 / 1000, clip_border=True):
     reps = deltas.size(1) // 4
-    means = deltas.new_tensor(means).view(1, -1).repeat(1, reps)
-    stds = deltas.new_tensor(stds).view(1, -1).repeat(1, reps)
+    means = const_tensor(means, deltas.device, deltas.dtype).view(1, -1).repeat(1, reps)
+    stds = const_tensor(stds, deltas.device, deltas.dtype).view(1, -1).repeat(1, reps)
     d = deltas * stds + means
     dx, dy, dw, dh = d[:, 0::4], d[:, 1::4], d[:, 2::4], d[:, 3::4]
     max_ratio = np.abs(np.log(wh_ratio_clip))
@@ -296,7 +298,7 @@ def batched_max_iou_assign(assigner, boxes, box_valid, gts, gt_valid):
     area_g = (gts[..., 2] - gts[..., 0]) * (gts[..., 3] - gts[..., 1])
     wh = (torch.min(gts[:, :, None, 2:], boxes[:, None, :, 2:]) - torch.max(gts[:, :, None, :2], boxes[:, None, :, :2])).clamp(min=0)
     overlap = wh[..., 0] * wh[..., 1]
-    union = torch.max(area_g[:, :, None] + area_b[:, None, :] - overlap, overlap.new_tensor([1e-6]))
+    union = torch.max(area_g[:, :, None] + area_b[:, None, :] - overlap, const_tensor([1e-6], overlap.device, overlap.dtype))
     iou = overlap / union                                                  # (B,K,A) == bbox_overlaps(gt, boxes)
     pair_ok = gt_valid[:, :, None] & box_valid[:, None, :]
     iou = torch.where(pair_ok, iou, iou.new_full((1, ), -1.0))             # padded gts / invalid boxes never win
@@ -417,4 +419,5 @@ def batched_assign_and_sample(assigner, sampler, proposal_list, gt_bboxes, gt_la
             n_b = (K if add_gt else 0) + proposal_list[b].size(0)
             boxes_b, inds_b, lab_b, flg_b = cand[b, :n_b], assigned[b, :n_b], labels[b, :n_b], gt_flags[b, :n_b]
         out.append(BatchSamplingResult(pi, ni, boxes_b, gt_bboxes[b][:, :4], inds_b, lab_b, flg_b))
+        out[-1].num_pos_gt = counts[b][2]           # host copy of pos_is_gt.sum() (saves refine_bboxes a device read)
     return out, counts

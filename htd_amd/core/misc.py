@@ -14,3 +14,20 @@ def unmap(data, count, inds, fill=0):
     ret = data.new_full((count, ) + tuple(data.shape[1:]), fill)
     ret[inds.type(torch.bool)] = data
     return ret
+
+
+_CONSTS = {}
+
+
+def const_tensor(values, device, dtype=torch.float32):
+    """Device-resident constant built once per (values, device, dtype): a fresh torch.tensor(list, device=gpu)
+    is a pageable host-to-device copy, i.e. a full host/device synchronisation on every call."""
+    def freeze(v):
+        return tuple(freeze(u) for u in v) if isinstance(v, (list, tuple)) else v
+    key = (freeze(values), str(device), dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        if len(_CONSTS) > 4096:
+            _CONSTS.clear()
+        t = _CONSTS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t

@@ -18,6 +18,7 @@
 // (forward conv of gy with spatially flipped, channel-transposed weights; a stride-s data gradient is split into
 // s*s dense sub-problems, one per output parity class, through an explicit tap table).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -350,6 +351,7 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
     if (bn == 128 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 128) < 768) bn = 64;
     if (bn == 64 && p.Co >= 64 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 64) < 1024 && p.M >= 2048) bm = 64;
+    if (const char *e = getenv("HTD_CONV_TILE")) { if (atoi(e) == 128) { bm = 128; bn = 128; } }
     p.mt = (int)htd::ceil_div(p.M, bm);
     p.nt = (int)htd::ceil_div(p.Co, bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;

@@ -359,7 +359,11 @@ Cfg choose(int Co, int Ntot, int64_t K)
     c.nt = (int)htd::ceil_div(Ntot, c.bn);
     const int64_t slices = htd::ceil_div(K, BKW);
     int64_t want = htd::ceil_div(1536, (int64_t)c.mt * c.nt);       // ~6 workgroups per CU (measured: oversubscription pays)
-    want = std::min<int64_t>(want, std::max<int64_t>(1, slices / 20)); // at least 20 slices (640 pixels) per split
+    const int64_t tiles = (int64_t)c.mt * c.nt;
+    int64_t cap = std::max<int64_t>(1, slices / 20);                 // at least 20 slices (640 pixels) per split ...
+    if (tiles * cap < 256)                                           // ... unless that leaves CUs idle (short reductions)
+        cap = std::max(cap, std::min<int64_t>(htd::ceil_div(256, tiles), std::max<int64_t>(1, slices / 5)));
+    want = std::min<int64_t>(want, cap);
     c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 96));
     if (c.splits >= 6) c.splits = (c.splits + 7) / 8 * 8;            // multiples of 8: one split per XCD group
     return c;

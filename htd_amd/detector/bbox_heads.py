@@ -12,6 +12,7 @@ from torch.nn.modules.utils import _pair
 
 from .. import dense
 from ..core import multi_apply, multiclass_nms
+from ..core.misc import const_tensor
 from ..registry import HEADS, build_bbox_coder, build_loss
 from .bricks import ConvModule
 from .losses import accuracy
@@ -132,7 +133,7 @@ class BBoxHead(nn.Module):
             if isinstance(scale_factor, float):
                 bboxes = bboxes / scale_factor
             else:
-                sf = bboxes.new_tensor(scale_factor)
+                sf = const_tensor([float(v) for v in scale_factor], bboxes.device, bboxes.dtype)
                 bboxes = (bboxes.view(bboxes.size(0), -1, 4) / sf).view(bboxes.size()[0], -1)
         if cfg is None:
             return bboxes, scores

@@ -42,5 +42,5 @@ class GlobalContextHead(nn.Module):
     def loss(self, pred, labels):
         targets = pred.new_zeros(pred.size())
         for i, label in enumerate(labels):                        # multi-hot of the image's gt classes
-            targets[i, label] = 1.0
+            targets[i].index_fill_(0, label, 1.0)
         return self.loss_weight * F.binary_cross_entropy_with_logits(pred, targets)

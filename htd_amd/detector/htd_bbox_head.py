@@ -86,7 +86,8 @@ class HTDBBoxHead(BBoxHead):
             x = dense.linear(x, fc.weight, fc.bias, relu=True)
         return x
 
-    def forward(self, x_cls, x_reg, feat, rois, fc_cls_0, enhanced_feat=None, pos_rois=None, global_feat=None):
+    def forward(self, x_cls, x_reg, feat, rois, fc_cls_0, enhanced_feat=None, pos_rois=None, global_feat=None,
+                rois_per_img=None):
         from .pgraph import pgraph_refine
         prototype = torch.cat((fc_cls_0.weight, fc_cls_0.bias.unsqueeze(1)), 1).detach()
         if global_feat is not None:
@@ -101,7 +102,7 @@ class HTDBBoxHead(BBoxHead):
         x_cls = self._cls_fcs(x_cls)
         sam = torch.mm(dense.linear(x_cls, fc_cls_0.weight, fc_cls_0.bias).softmax(-1), prototype)
         target_lvls = self.map_roi_levels(rois, len(feat))
-        refined = pgraph_refine(x_cls, sam, rois, target_lvls, self.graph_layer_cls)
+        refined = pgraph_refine(x_cls, sam, rois, target_lvls, self.graph_layer_cls, rois_per_img)
         feat_cls_new = (x_cls_glb if global_feat is not None else x_cls) + refined
         cls_score = dense.linear(feat_cls_new, self.fc_cls.weight, self.fc_cls.bias) if self.with_cls else None
         bbox_pred = dense.linear(x_reg, self.fc_reg.weight, self.fc_reg.bias) if self.with_reg else None

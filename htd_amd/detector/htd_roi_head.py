@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from .. import mmcv_ops as M
 from ..core import bbox2result, bbox2roi
+from ..core.misc import const_tensor
 from ..registry import HEADS, build_assigner, build_head, build_roi_extractor, build_sampler
 
 
@@ -99,8 +100,9 @@ class HTDRoIHead(nn.Module):
             pos_rows = torch.cat(pos_rows)
             enhanced = enhanced_extractor(feats, pos_rois)
             pos_bbox_feat = torch.index_select(bbox_feats, 0, pos_rows)
+            per_img = tuple(r.pos_bboxes.size(0) + r.neg_bboxes.size(0) for r in sampling_results)
             cls_score, bbox_pred = head(bbox_feats, pos_bbox_feat, feats, rois, self.bbox_head[0].fc_cls, enhanced,
-                                        pos_rois, global_feat if self.with_global else None)
+                                        pos_rois, global_feat if self.with_global else None, rois_per_img=per_img)
             full = cls_score.new_zeros(cls_score.size(0), 4).index_put((pos_rows, ), bbox_pred)
             return dict(cls_score=cls_score, bbox_pred=full)
         enhanced = enhanced_extractor(feats, rois)
@@ -141,7 +143,7 @@ class HTDRoIHead(nn.Module):
         if pos_rows.numel():
             labels[pos_rows] = torch.cat([r.pos_gt_labels for r in sampling_results])
             bbox_targets[pos_rows] = head.bbox_coder.encode(pos_b, torch.cat([r.pos_gt_bboxes for r in sampling_results]))
-            bbox_weights[pos_rows] = 1
+            bbox_weights.index_fill_(0, pos_rows, 1.0)
         return labels, pos_b.new_ones(N), bbox_targets, bbox_weights
 
     def _refine(self, rois, bbox_pred, sampling_results, img_metas):
@@ -153,10 +155,13 @@ class HTDRoIHead(nn.Module):
             return None
         from ..core.bbox import delta2bbox
         boxes = delta2bbox(rois[:, 1:], bbox_pred, head.bbox_coder.means, head.bbox_coder.stds, None)
-        lim = boxes.new_tensor([[m['img_shape'][1], m['img_shape'][0]] * 2 for m in img_metas])      # (B,4) w,h,w,h
+        lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] * 2 for m in img_metas], boxes.device, boxes.dtype)      # (B,4) w,h,w,h
         boxes = torch.min(boxes.clamp(min=0), lim[rois[:, 0].long()])
         out, start = [], 0
-        n_gt = [int(v) for v in torch.stack([r.pos_is_gt.sum() for r in sampling_results]).tolist()]
+        if all(hasattr(r, 'num_pos_gt') for r in sampling_results):
+            n_gt = [r.num_pos_gt for r in sampling_results]
+        else:
+            n_gt = [int(v) for v in torch.stack([r.pos_is_gt.sum() for r in sampling_results]).tolist()]
         for r, g in zip(sampling_results, n_gt):
             n = r.pos_bboxes.size(0) + r.neg_bboxes.size(0)
             out.append(boxes[start + g:start + n])

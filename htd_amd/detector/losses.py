@@ -7,6 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import LOSSES
+from ..core.misc import const_tensor
 
 
 def weight_reduce_loss(loss, weight=None, reduction='mean', avg_factor=None):
@@ -51,7 +52,7 @@ class CrossEntropyLoss(nn.Module):
     def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kwargs):
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
-        cw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
+        cw = const_tensor(self.class_weight, cls_score.device, cls_score.dtype) if self.class_weight is not None else None
         return self.loss_weight * self.cls_criterion(cls_score, label, weight, class_weight=cw, reduction=reduction,
                                                      avg_factor=avg_factor, **kwargs)
 

@@ -11,34 +11,44 @@ result is scattered back -- a fixed, small number of launches with a single host
 import torch
 
 from .. import dense
+from ..core.misc import const_tensor
 
 
-def group_layout(rois, target_lvls, num_levels):
-    """Sort RoIs by (image, level).  -> perm (N,), counts (G,) with G = B*num_levels (host list), B."""
+def group_layout(rois, target_lvls, num_levels, num_imgs=None):
+    """Sort RoIs by (image, level).  -> perm (N,), counts (G,) device tensor with G = B*num_levels, B.
+    With num_imgs given nothing here reads the device (no .item(), no bincount size probe)."""
     img = rois[:, 0].long()
-    B = int(img.max().item()) + 1 if rois.numel() else 0
+    if num_imgs is None:
+        B = int(img.max().item()) + 1 if rois.numel() else 0
+    else:
+        B = num_imgs
     key = img * num_levels + target_lvls
     perm = torch.sort(key, stable=True)[1]
-    counts = torch.bincount(key, minlength=B * num_levels)
+    counts = (key[:, None] == torch.arange(B * num_levels, device=key.device)[None, :]).sum(0)
     return perm, counts, B
 
 
-def pgraph_refine(x, sam, rois, target_lvls, graph_layers):
+def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None):
     """x (N,F) fc features, sam (N,S) semantic embedding, -> refined (N,F):
          M       = (IoU(rois_g, rois_g) with unit diagonal) > 0
          A_local = D^-1/2 M D^-1/2,  D = rowsum(M)
          mixed   = A_local @ x_g
          A_glob  = softmax_row((1 - M) * (sam_g sam_g^T))
-         refined_g = ReLU(Linear_level(A_glob @ mixed))          rows in empty groups stay 0."""
+         refined_g = ReLU(Linear_level(A_glob @ mixed))          rows in empty groups stay 0.
+    rois_per_img (host ints, optional): RoIs of each image; the padded group size is then bounded by the largest
+    image instead of read back from the device, and the whole op runs without a host/device synchronisation."""
     N, Fdim = x.shape
     L = len(graph_layers)
     refined = x.new_zeros(N, Fdim)
     if N == 0:
         return refined
-    perm, counts, B = group_layout(rois, target_lvls, L)
-    counts_h = counts.tolist()                      # the one host read of this op
+    if rois_per_img is not None:
+        perm, counts, B = group_layout(rois, target_lvls, L, len(rois_per_img))
+        nmax = max(rois_per_img)
+    else:
+        perm, counts, B = group_layout(rois, target_lvls, L)
+        nmax = max(counts.tolist())                 # the one host read of this op
     G = B * L
-    nmax = max(counts_h)
     if nmax == 0:
         return refined
     # padded batch index: row r of group g  <-  sorted position start_g + r
@@ -60,7 +70,7 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers):
     wh = (rb - lt).clamp(min=0)
     inter = wh[..., 0] * wh[..., 1]
     area = (bx[..., 2] - bx[..., 0]) * (bx[..., 3] - bx[..., 1])
-    union = torch.max(area[:, :, None] + area[:, None, :] - inter, inter.new_tensor([1e-6]))
+    union = torch.max(area[:, :, None] + area[:, None, :] - inter, const_tensor([1e-6], inter.device, inter.dtype))
     eye = torch.eye(npad, device=x.device, dtype=torch.bool)[None]
     pair = valid[:, :, None] & valid[:, None, :]
     Mloc = (((inter / union > 0) | eye) & pair).to(x.dtype)                 # (G, npad, npad), symmetric
@@ -78,5 +88,7 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers):
     for i, layer in enumerate(graph_layers):
         outs.append(dense.linear(agg[:, i].reshape(B * npad, Fdim), layer.weight, layer.bias, relu=True)
                     .view(B, npad, Fdim))
-    out = torch.stack(outs, 1).view(G, npad, Fdim)
-    return refined.index_put((rows[valid], ), out[valid])
+    out = torch.stack(outs, 1).view(G * npad, Fdim)
+    # scatter back; padded rows all land on one extra row that is dropped (no boolean-mask gather = no host sync)
+    dst = torch.where(valid, rows, torch.full_like(rows, N)).reshape(-1)
+    return x.new_zeros(N + 1, Fdim).index_copy(0, dst, out)[:N]

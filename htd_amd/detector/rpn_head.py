@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from ..core import (anchor_inside_flags, images_to_levels, multi_apply, unmap)
 from ..core.bbox import delta2bbox
+from ..core.misc import const_tensor
 from ..mmcv_ops import nms_sorted_mask
 from ..registry import (HEADS, build_anchor_generator, build_assigner, build_bbox_coder, build_loss, build_sampler)
 from .bricks import Conv2d, normal_init
@@ -144,7 +145,7 @@ class RPNHead(nn.Module):
         flat_anchors = torch.cat(anchor_list[0])
         A = flat_anchors.size(0)
         valid = torch.stack([torch.cat(v) for v in valid_flag_list])                       # (B,A)
-        lim = flat_anchors.new_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas])    # (B,2) w,h
+        lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], flat_anchors.device, flat_anchors.dtype)    # (B,2) w,h
         border = self.train_cfg.allowed_border
         if border >= 0:
             inside = valid & (flat_anchors[None, :, 0] >= -border) & (flat_anchors[None, :, 1] >= -border) & \
@@ -222,7 +223,7 @@ class RPNHead(nn.Module):
         anchors = torch.cat(anchors_l, 1).reshape(B * K, 4)
         proposals = delta2bbox(anchors, deltas, self.bbox_coder.means, self.bbox_coder.stds, None)
         if self.bbox_coder.clip_border:
-            lim = proposals.new_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas])   # (B, 2) w,h
+            lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], proposals.device, proposals.dtype)   # (B, 2) w,h
             lim = lim.repeat(1, 2).view(B, 1, 4)
             proposals = torch.min(proposals.view(B, K, 4).clamp(min=0), lim)
         proposals = proposals.view(B, K, 4)
@@ -251,7 +252,7 @@ class RPNHead(nn.Module):
         for b in range(B):
             for k in seg_sizes:
                 offs.append(offs[-1] + k)
-        seg = torch.tensor(offs, dtype=torch.int64, device=dev)
+        seg = const_tensor(offs, dev, torch.int64)
         keep = nms_sorted_mask(shifted.reshape(B * K, 4), cfg.nms_thr, 0, seg, max(seg_sizes)).view(B, K).bool()
         # survivors in descending score order (ties: lower level / lower rank first), first nms_post of them
         masked = torch.where(keep, scores, scores.new_full((1, ), -1.0))

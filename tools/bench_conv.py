@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 
-from htd_amd import dense
+from htd_amd import capi, dense
 
 CL = torch.channels_last
 LAYERS = [  # name, Ci, H, W, Co, k, stride, pad
@@ -23,6 +23,11 @@ LAYERS = [  # name, Ci, H, W, Co, k, stride, pad
     ('fpn P2 3x3 256', 256, 200, 336, 256, 3, 1, 1),
     ('rpn P2 1x1 256-15', 256, 200, 336, 15, 1, 1, 0),
     ('l2.0.conv2 3x3 s2', 128, 200, 336, 128, 3, 2, 1),
+    ('fpn P3 3x3 256', 256, 100, 168, 256, 3, 1, 1),
+    ('fpn P5 3x3 256', 256, 25, 42, 256, 3, 1, 1),
+    ('fpn P6 3x3 256', 256, 13, 21, 256, 3, 1, 1),
+    ('l3.conv3 1x1 256-1024', 256, 50, 84, 1024, 1, 1, 0),
+    ('l4.conv3 1x1 512-2048', 512, 25, 42, 2048, 1, 1, 0),
 ]
 
 
@@ -36,36 +41,44 @@ def timeit(fn, n=5):
     return (time.perf_counter() - t0) / n
 
 
+def device_rates(x, w, g, s, p, flop, n=8):
+    """TF/s of the three C-ABI entry points from device events around each call (capi profile)."""
+    xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+    for it in range(n + 2):
+        if it == 2:
+            capi.profile_begin()
+        dense.conv2d(xg, wg, None, s, p, 1).backward(g)
+    prof = capi.profile_end()
+    out = []
+    for k in ('htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_bwd_weight'):
+        calls, ms, _, _ = prof[k]
+        out.append(flop / (ms / calls * 1e-3) / 1e12)
+    return out
+
+
 def main():
     B = 4
     dev = torch.device('cuda:0')
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     print(f'{"layer":26s} {"GFLOP":>8s} | {"fwd":>7s} {"dgrad":>7s} {"wgrad":>7s} TF/s (htd) | {"fwd":>7s} {"bwd":>7s} TF/s (ATen)')
     for name, Ci, H, W, Co, k, s, p in LAYERS:
+        if only and only not in name:
+            continue
         x = torch.randn(B, Ci, H, W, device=dev).contiguous(memory_format=CL)
         w = (torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5).contiguous(memory_format=CL)
         y = dense.conv2d(x, w, None, s, p, 1)
         g = torch.randn_like(y)
         flop = 2.0 * y.numel() * Ci * k * k
-        t_f = timeit(lambda: dense.conv2d(x, w, None, s, p, 1))
+        r_f, r_x, r_w = device_rates(x, w, g, s, p, flop)
         xg = x.clone().requires_grad_()
         wg = w.clone().requires_grad_()
-
-        def bwd_x():
-            yy = dense.conv2d(xg, w, None, s, p, 1)
-            yy.backward(g)
-
-        def bwd_w():
-            yy = dense.conv2d(x, wg, None, s, p, 1)
-            yy.backward(g)
-        t_x = timeit(bwd_x) - t_f
-        t_w = timeit(bwd_w) - t_f
         t_af = timeit(lambda: F.conv2d(x, w, None, s, p))
 
         def aten_bwd():
             yy = F.conv2d(xg, wg, None, s, p)
             yy.backward(g)
         t_ab = timeit(aten_bwd) - t_af
-        print(f'{name:26s} {flop / 1e9:8.1f} | {flop / t_f / 1e12:7.1f} {flop / t_x / 1e12:7.1f} {flop / t_w / 1e12:7.1f}'
+        print(f'{name:26s} {flop / 1e9:8.1f} | {r_f:7.1f} {r_x:7.1f} {r_w:7.1f}'
               f'             | {flop / t_af / 1e12:7.1f} {2 * flop / t_ab / 1e12:7.1f}')
 
 
