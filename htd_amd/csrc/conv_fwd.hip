@@ -173,12 +173,14 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
 #pragma unroll
         for (int i = 0; i < T::PASSES_A; ++i) {
             const int r = vrow + i * T::ROWS_PER_PASS;
-            if (r < T::BM) *reinterpret_cast<float4 *>(la + r * T::LDS_STRIDE + vcol * 4) = keep4((ra_ok >> i) & 1u, ra[i]);
+            if (T::BM % T::ROWS_PER_PASS == 0 || r < T::BM)
+                *reinterpret_cast<float4 *>(la + r * T::LDS_STRIDE + vcol * 4) = keep4((ra_ok >> i) & 1u, ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < T::PASSES_B; ++i) {
             const int r = vrow + i * T::ROWS_PER_PASS;
-            if (r < T::BN) *reinterpret_cast<float4 *>(lb + r * T::LDS_STRIDE + vcol * 4) = keep4(b_ok[i], rb[i]);
+            if (T::BN % T::ROWS_PER_PASS == 0 || r < T::BN)
+                *reinterpret_cast<float4 *>(lb + r * T::LDS_STRIDE + vcol * 4) = keep4(b_ok[i], rb[i]);
         }
     };
 

@@ -34,8 +34,17 @@ struct WgradParams {
 
 constexpr int BKW = 32;    // pixels per K slice
 
-// WGM x WGN waves, each wave TM x TN MFMA blocks of 32x32
-template <int WGM, int WGN, int TM, int TN>
+// how a staged pixel row finds its x address
+enum : int {
+    PIX_POINTWISE = 0,     // 1x1, stride 1, no padding: x row == pixel index (also every Linear layer)
+    PIX_WIDE = 1,          // Wo >= BKW: (b, ho, wo) advanced with at most one carry per slice, no divisions
+    PIX_GENERAL = 2        // narrow maps: decode the pixel index every slice
+};
+
+// WGM x WGN waves, each wave TM x TN MFMA blocks of 32x32.  COVEC: Co % 4 == 0 (16-byte gy loads).
+// The staging code is branch-free (selects only): a branch in front of a global load stops the scheduler from
+// issuing the slice's eight loads back to back ahead of the MFMA phase.
+template <int WGM, int WGN, int TM, int TN, int PIX, bool COVEC>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
 {
     static_assert(WGM * WGN == 4, "4 waves per block");
@@ -102,16 +111,18 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
     for (int i = 0; i < PA; ++i) a_k[i] = (unsigned)(s_begin * BKW) + a_row[i];
     unsigned b_k[PB];
     int b_b[PB], b_ho[PB], b_wo[PB];
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        b_k[i] = (unsigned)(s_begin * BKW) + b_row[i];
+    auto decode = [&](int i) {
         const unsigned kk = b_k[i] < (unsigned)p.K ? b_k[i] : 0u;
         b_wo[i] = (int)(kk % (unsigned)p.Wo);
         const unsigned t = kk / (unsigned)p.Wo;
         b_ho[i] = (int)(t % (unsigned)p.Ho);
         b_b[i] = (int)(t / (unsigned)p.Ho);
+    };
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        b_k[i] = (unsigned)(s_begin * BKW) + b_row[i];
+        if constexpr (PIX != PIX_POINTWISE) decode(i);
     }
-    const bool co_vec = (p.Co & 3) == 0;
 
     float4 ra[PA], rb[PB];
     unsigned ra_ok = 0u, rb_ok = 0u;
@@ -119,38 +130,44 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const bool ok = a_cok[i] && a_k[i] < (unsigned)p.K;
-            if (co_vec) {
-                ra[i] = *reinterpret_cast<const float4 *>(p.gy + (ok ? a_k[i] * (unsigned)p.Co + m0 + a_col[i] : 0u));
-                ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));       // zeroed at store time
-            } else if (ok) {      // Co not a multiple of 4 (RPN heads): scalar loads
-                const float *g = p.gy + (size_t)a_k[i] * p.Co + m0 + a_col[i];
-                const int rem = p.Co - (m0 + a_col[i]);
-                ra[i] = make_float4(g[0], rem > 1 ? g[1] : 0.f, rem > 2 ? g[2] : 0.f, rem > 3 ? g[3] : 0.f);
-                ra_ok |= 1u << i;
-            } else
-                ra_ok &= ~(1u << i);
+            const unsigned off = ok ? a_k[i] * (unsigned)p.Co + m0 + a_col[i] : 0u;
+            if constexpr (COVEC) {
+                ra[i] = *reinterpret_cast<const float4 *>(p.gy + off);
+            } else {              // Co not a multiple of 4 (RPN / class heads): scalar loads, clamped inside the row
+                const int rem = ok ? p.Co - (m0 + a_col[i]) : 1;
+                const float *g = p.gy + off;
+                ra[i] = make_float4(g[0], g[rem > 1 ? 1 : 0], g[rem > 2 ? 2 : 0], g[rem > 3 ? 3 : 0]);
+                ra[i].y = rem > 1 ? ra[i].y : 0.f;
+                ra[i].z = rem > 2 ? ra[i].z : 0.f;
+                ra[i].w = rem > 3 ? ra[i].w : 0.f;
+            }
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));           // zeroed at store time
             a_k[i] += BKW;
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int hi = b_ho[i] * p.stride + b_dy[i], wi = b_wo[i] * p.stride + b_dx[i];
-            const bool ok = b_cok[i] && b_k[i] < (unsigned)p.K && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned off = ok ? (((unsigned)b_b[i] * p.H + hi) * p.W + wi) * (unsigned)p.Ci + b_ci[i] : 0u;
-            rb[i] = *reinterpret_cast<const float4 *>(p.x + off);
+            bool ok = b_cok[i] && b_k[i] < (unsigned)p.K;
+            unsigned off;
+            if constexpr (PIX == PIX_POINTWISE) {
+                off = b_k[i] * (unsigned)p.Ci + b_ci[i];
+            } else {
+                const int hi = b_ho[i] * p.stride + b_dy[i], wi = b_wo[i] * p.stride + b_dx[i];
+                ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                off = (((unsigned)b_b[i] * p.H + hi) * p.W + wi) * (unsigned)p.Ci + b_ci[i];
+            }
+            rb[i] = *reinterpret_cast<const float4 *>(p.x + (ok ? off : 0u));
             rb_ok = ok ? (rb_ok | (1u << i)) : (rb_ok & ~(1u << i));
             b_k[i] += BKW;
-            if (p.Wo >= BKW) {                     // incremental carry: at most one wrap per step
-                b_wo[i] += BKW;
-                if (b_wo[i] >= p.Wo) {
-                    b_wo[i] -= p.Wo;
-                    if (++b_ho[i] == p.Ho) { b_ho[i] = 0; ++b_b[i]; }
-                }
-            } else {
-                const unsigned kk = b_k[i] < (unsigned)p.K ? b_k[i] : 0u;
-                b_wo[i] = (int)(kk % (unsigned)p.Wo);
-                const unsigned t = kk / (unsigned)p.Wo;
-                b_ho[i] = (int)(t % (unsigned)p.Ho);
-                b_b[i] = (int)(t / (unsigned)p.Ho);
+            if constexpr (PIX == PIX_WIDE) {       // incremental carry: at most one wrap per step, selects only
+                const int wo = b_wo[i] + BKW;
+                const bool c1 = wo >= p.Wo;
+                b_wo[i] = c1 ? wo - p.Wo : wo;
+                const int ho = b_ho[i] + (c1 ? 1 : 0);
+                const bool c2 = ho == p.Ho;
+                b_ho[i] = c2 ? 0 : ho;
+                b_b[i] += c2 ? 1 : 0;
+            } else if constexpr (PIX == PIX_GENERAL) {
+                decode(i);
             }
         }
     };
@@ -158,10 +175,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
         float *la = lds[buf], *lb = lds[buf] + BKW * SA;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            if (tid + i * 256 < BKW * VA) *reinterpret_cast<float4 *>(la + a_row[i] * SA + a_col[i]) = keep4((ra_ok >> i) & 1u, ra[i]);
+            if ((BKW * VA) % 256 == 0 || tid + i * 256 < BKW * VA) *reinterpret_cast<float4 *>(la + a_row[i] * SA + a_col[i]) = keep4((ra_ok >> i) & 1u, ra[i]);
 #pragma unroll
         for (int i = 0; i < PB; ++i)
-            if (tid + i * 256 < BKW * VB) *reinterpret_cast<float4 *>(lb + b_row[i] * SB + b_col[i]) = keep4((rb_ok >> i) & 1u, rb[i]);
+            if ((BKW * VB) % 256 == 0 || tid + i * 256 < BKW * VB) *reinterpret_cast<float4 *>(lb + b_row[i] * SB + b_col[i]) = keep4((rb_ok >> i) & 1u, rb[i]);
     };
 
     f32x16 acc[TM][TN];
@@ -350,6 +367,19 @@ __global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__res
 
 struct Cfg { int splits; int mt, nt; int bm, bn; };
 
+template <int WGM, int WGN, int TM, int TN>
+void launch_wgrad(int pix, bool covec, dim3 grid, hipStream_t s, const WgradParams &p)
+{
+#define HTD_WGRAD_CASE(PIX, CV)                                                                                   \
+    if (pix == PIX && covec == CV) {                                                                               \
+        hipLaunchKernelGGL((conv_wgrad_kernel<WGM, WGN, TM, TN, PIX, CV>), grid, dim3(256), 0, s, p);             \
+        return;                                                                                                    \
+    }
+    HTD_WGRAD_CASE(PIX_POINTWISE, true) HTD_WGRAD_CASE(PIX_WIDE, true) HTD_WGRAD_CASE(PIX_GENERAL, true)
+    HTD_WGRAD_CASE(PIX_POINTWISE, false) HTD_WGRAD_CASE(PIX_WIDE, false) HTD_WGRAD_CASE(PIX_GENERAL, false)
+#undef HTD_WGRAD_CASE
+}
+
 Cfg choose(int Co, int Ntot, int64_t K)
 {
     Cfg c;
@@ -404,12 +434,12 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     hipStream_t s = (hipStream_t)stream;
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
     dim3 grid((unsigned)(c.mt * c.nt * c.splits));
+    const int pix = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? PIX_POINTWISE : (p.Wo >= BKW ? PIX_WIDE : PIX_GENERAL);
+    const bool covec = (Co & 3) == 0;
     if (c.bm == 32)
-        hipLaunchKernelGGL((conv_wgrad_kernel<1, 4, 1, 1>), grid, dim3(256), 0, s, p);
-    else if (c.bn == 256)
-        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 4>), grid, dim3(256), 0, s, p);
+        launch_wgrad<1, 4, 1, 1>(pix, covec, grid, s, p);
     else
-        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+        launch_wgrad<2, 2, 2, 2>(pix, covec, grid, s, p);
     if (c.splits > 1) {
         const int64_t n = (int64_t)Co * p.Ntot;
         const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
