@@ -431,10 +431,12 @@ extern "C" int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int
 // Data gradient: gx[B][H][W][Ci] from gy[B][Ho][Wo][Co] and wT[Ci][kh][kw][Co] = spatially flipped,
 // channel-transposed weights (htd_conv2d_flip_weights).  mask_src (may be NULL): gx is zeroed where
 // mask_src <= 0 -- the ReLU of the layer that produced the conv input, fused into this epilogue.
-extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, float *gx, int B, int H,
-                                   int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+// accum (may be NULL; stride 1 only): added to the data gradient before the mask (the other branch of a residual join).
+extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx,
+                                   int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                                    void *workspace, void *stream)
 {
+    HTD_REQUIRE(!accum || stride == 1, "conv2d_bwd_data: accum needs stride 1");
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_bwd_data: bad sizes");
     HTD_REQUIRE(Co % 8 == 0, "conv2d_bwd_data: Co=%d must be a multiple of 8", Co);
@@ -442,7 +444,7 @@ extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float
     const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
     ConvParams p{};
-    p.x = gy; p.w = wT; p.bias = nullptr; p.residual = nullptr; p.mask_src = mask_src; p.y = gx;
+    p.x = gy; p.w = wT; p.bias = nullptr; p.residual = accum; p.mask_src = mask_src; p.y = gx;
     p.B = B; p.Ci = Co; p.Co = Ci; p.kh = kh; p.kw = kw; p.dil = dil; p.relu = 0;
     p.Hx = Ho; p.Wx = Wo;
     HTD_REQUIRE(kh == kw, "conv2d_bwd_data: square kernels only");

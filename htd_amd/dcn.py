@@ -62,7 +62,7 @@ class DeformConv2dFunction(Function):
             wT = torch.empty(K * Co, device=gy.device, dtype=gy.dtype)
             capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, 1, 1, K, _S())
             gcol = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
-            capi.call('htd_conv2d_bwd_data', _P(gy), _P(wT), None, _P(gcol), 1, M, 1, K, Co, 1, 1, 1, 0, 1, None, _S(),
+            capi.call('htd_conv2d_bwd_data', _P(gy), _P(wT), None, None, _P(gcol), 1, M, 1, K, Co, 1, 1, 1, 0, 1, None, _S(),
                       work=('flop', 2.0 * M * K * Co))
             if ctx.needs_input_grad[0]:
                 gx = torch.empty((B, C, H, W), device=gy.device, dtype=gy.dtype, memory_format=CL).zero_()

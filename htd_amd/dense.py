@@ -32,24 +32,74 @@ def _splitk_ws(M, Co, Cred, kh, kw, device):
     return torch.empty(nbytes // 4, device=device, dtype=torch.float32) if nbytes > 0 else None
 
 
+# ---- raw launches (no autograd): the building blocks of Conv2dFunction and ResStageFunction -------------------
+
+def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu):
+    B, Ci, H, W = x.shape
+    Co, Ci_w, kh, kw = weight.shape
+    if Ci != Ci_w:
+        raise ValueError(f'conv2d: input has {Ci} channels, weight expects {Ci_w}')
+    Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
+    y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
+    flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
+    capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), _P(y), B, H, W, Ci, Co, kh, kw, stride,
+              padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
+              work=('flop', flops))
+    return y
+
+
+def _colsum_raw(g, y=None):
+    """-> (gm, gbias): gbias = column sums of gm, gm = g * (y > 0) when y is given (else gm is g itself)."""
+    B, Co, Ho, Wo = g.shape
+    gm = torch.empty_like(g, memory_format=CL) if y is not None else g
+    gb = torch.empty(Co, device=g.device, dtype=g.dtype)
+    ws = torch.empty(2048 * Co, device=g.device, dtype=g.dtype)
+    capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm) if y is not None else None, _P(gb), B * Ho * Wo, Co,
+              _P(ws), _S(), work=('byte', 4.0 * B * Ho * Wo * Co * (3 if y is not None else 1)))
+    return gm, gb
+
+
+def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, accum=None):
+    """Data gradient of conv2d(x, weight) for gy = g, optionally + accum and masked by (mask_src > 0)."""
+    B, Ci, H, W = x_shape
+    Co, _, kh, kw = weight.shape
+    Ho, Wo = g.shape[2], g.shape[3]
+    gd, wd, Cod = g, weight, Co
+    if Co % 8 != 0:      # skinny heads (RPN cls+reg, Co=15): pad the reduction channels with zeros
+        padc = (-Co) % 8
+        gd = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
+        wd = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
+        Cod = Co + padc
+    wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
+    capi.call('htd_conv2d_flip_weights', _P(wd), _P(wT), Cod, kh, kw, Ci, _S())
+    gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+    capi.call('htd_conv2d_bwd_data', _P(gd), _P(wT), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci, Cod, kh, kw, stride,
+              padding, dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(),
+              work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
+    return gx
+
+
+def _wgrad_raw(x, g, w_shape, stride, padding, dilation):
+    B, Ci, H, W = x.shape
+    Co, _, kh, kw = w_shape
+    Ho, Wo = g.shape[2], g.shape[3]
+    gw = torch.empty((Co, Ci, kh, kw), device=g.device, dtype=g.dtype, memory_format=CL)
+    nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
+    ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
+    capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), B, H, W, Ci, Co, kh, kw, stride, padding, dilation,
+              _P(ws), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
+    return gw
+
+
 class Conv2dFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu):
         _need_gpu(x, 'conv2d')
         x = x.contiguous(memory_format=CL)
         weight = weight.contiguous(memory_format=CL)
-        B, Ci, H, W = x.shape
-        Co, Ci_w, kh, kw = weight.shape
-        if Ci != Ci_w:
-            raise ValueError(f'conv2d: input has {Ci} channels, weight expects {Ci_w}')
-        Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
-        y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
         res = residual.contiguous(memory_format=CL) if residual is not None else None
         b = bias.contiguous() if bias is not None else None
-        flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
-        capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(b), _P(res), _P(y), B, H, W, Ci, Co, kh, kw, stride, padding,
-                  dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
-                  work=('flop', flops))
+        y = _fwd_raw(x, weight, b, res, stride, padding, dilation, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (stride, padding, dilation, bool(relu), bias is not None, residual is not None)
         return y
@@ -59,41 +109,99 @@ class Conv2dFunction(Function):
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
         stride, padding, dilation, relu, has_bias, has_res = ctx.cfg
-        B, Ci, H, W = x.shape
-        Co, _, kh, kw = weight.shape
-        Ho, Wo = g.shape[2], g.shape[3]
         g = g.contiguous(memory_format=CL)
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
         gb = None
         if relu or (has_bias and need_b):
-            gm = torch.empty_like(g, memory_format=CL) if relu else g
-            gb = torch.empty(Co, device=g.device, dtype=g.dtype)
-            ws = torch.empty(2048 * Co, device=g.device, dtype=g.dtype)
-            capi.call('htd_bias_grad_relu_mask', _P(g), _P(y) if relu else None, _P(gm) if relu else None, _P(gb),
-                      B * Ho * Wo, Co, _P(ws), _S(), work=('byte', 4.0 * B * Ho * Wo * Co * (3 if relu else 1)))
-            g = gm
-        gx = gw = None
-        flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
-        if need_x:
-            gd, wd, Cod = g, weight, Co
-            if Co % 8 != 0:      # skinny heads (RPN cls+reg, Co=15): pad the reduction channels with zeros
-                padc = (-Co) % 8
-                gd = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
-                wd = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
-                Cod = Co + padc
-            wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
-            capi.call('htd_conv2d_flip_weights', _P(wd), _P(wT), Cod, kh, kw, Ci, _S())
-            gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
-            capi.call('htd_conv2d_bwd_data', _P(gd), _P(wT), None, _P(gx), B, H, W, Ci, Cod, kh, kw, stride, padding,
-                      dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(), work=('flop', flops))
-        if need_w:
-            gw = torch.empty((Co, Ci, kh, kw), device=g.device, dtype=g.dtype, memory_format=CL)
-            nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
-            ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
-            capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), B, H, W, Ci, Co, kh, kw, stride, padding,
-                      dilation, _P(ws), _S(), work=('flop', flops))
+            g, gb = _colsum_raw(g, y if relu else None)
+        gx = _dgrad_raw(g, weight, x.shape, stride, padding, dilation) if need_x else None
+        gw = _wgrad_raw(x, g, weight.shape, stride, padding, dilation) if need_w else None
         return gx, gw, (gb if (has_bias and need_b) else None), (g if (has_res and need_r) else None), None, None, \
             None, None
+
+
+class ResStageFunction(Function):
+    """A run of bottleneck blocks (one ResLayer, resnet.py:95-300 / res_layer.py:5-102) with frozen-BN-folded
+    weights as ONE autograd node.  Forward is the same four fused convolutions per block as the per-layer path.
+    The hand-written backward keeps the gradient chain inside the data-gradient epilogues:
+      * the ReLU mask of each internal activation is applied by the dgrad that produces its gradient (mask_src), so
+        only a read-only column sum remains for the bias gradient (instead of read g, read y, write g*mask);
+      * the identity / downsample branch joins through `accum` in the conv1 dgrad epilogue (no separate add);
+      * blocks after the first hand their predecessor a gradient already masked by the predecessor's output ReLU.
+    args: x, n_blocks, strides (tuple), dilation, has_ds (tuple of bool), then per block w1,b1,w2,b2,w3,b3[,wd,bd]."""
+
+    @staticmethod
+    def forward(ctx, x, strides, dilation, has_ds, *params):
+        _need_gpu(x, 'res_stage')
+        x = x.contiguous(memory_format=CL)
+        params = [t.contiguous(memory_format=CL) if t.dim() == 4 else t.contiguous() for t in params]
+        saved, k = [], 0
+        for stride, ds in zip(strides, has_ds):
+            w1, b1, w2, b2, w3, b3 = params[k:k + 6]
+            k += 6
+            h1 = _fwd_raw(x, w1, b1, None, 1, 0, 1, True)
+            h2 = _fwd_raw(h1, w2, b2, None, stride, dilation, dilation, True)
+            if ds:
+                wd, bd = params[k:k + 2]
+                k += 2
+                idn = _fwd_raw(x, wd, bd, None, stride, 0, 1, False)
+            else:
+                idn = x
+            out = _fwd_raw(h2, w3, b3, idn, 1, 0, 1, True)
+            saved += [x, h1, h2, out]
+            x = out
+        ctx.save_for_backward(*saved, *params)
+        ctx.cfg = (strides, dilation, has_ds)
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        strides, dilation, has_ds = ctx.cfg
+        nb = len(strides)
+        saved, params = ctx.saved_tensors[:4 * nb], ctx.saved_tensors[4 * nb:]
+        offs, k = [], 0
+        for ds in has_ds:
+            offs.append(k)
+            k += 8 if ds else 6
+        need = ctx.needs_input_grad
+        grads = [None] * len(params)
+        g = g.contiguous(memory_format=CL)
+        premasked = False
+        for i in range(nb - 1, -1, -1):
+            x, h1, h2, out = saved[4 * i:4 * i + 4]
+            k, stride, ds = offs[i], strides[i], has_ds[i]
+            w1, b1, w2, b2, w3, b3 = params[k:k + 6]
+            pneed = need[4 + k:4 + k + (8 if ds else 6)]
+            first = i == 0
+            need_x = need[0] if first else True
+            gm3, gb3 = _colsum_raw(g, None if premasked else out)
+            if pneed[4]:
+                grads[k + 4] = _wgrad_raw(h2, gm3, w3.shape, 1, 0, 1)
+            grads[k + 5] = gb3 if pneed[5] else None
+            gm2 = _dgrad_raw(gm3, w3, h2.shape, 1, 0, 1, mask_src=h2)
+            _, gb2 = _colsum_raw(gm2)
+            if pneed[2]:
+                grads[k + 2] = _wgrad_raw(h1, gm2, w2.shape, stride, dilation, dilation)
+            grads[k + 3] = gb2 if pneed[3] else None
+            gm1 = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1)
+            _, gb1 = _colsum_raw(gm1)
+            if pneed[0]:
+                grads[k] = _wgrad_raw(x, gm1, w1.shape, 1, 0, 1)
+            grads[k + 1] = gb1 if pneed[1] else None
+            acc = gm3
+            if ds:
+                wd = params[k + 6]
+                if pneed[6]:
+                    grads[k + 6] = _wgrad_raw(x, gm3, wd.shape, stride, 0, 1)
+                grads[k + 7] = gb3 if pneed[7] else None
+                acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1) if need_x else None
+            if need_x:
+                g = _dgrad_raw(gm1, w1, x.shape, 1, 0, 1, mask_src=None if first else x, accum=acc)
+                premasked = not first
+            else:
+                g = None
+        return (g, None, None, None, *grads)
 
 
 def _pad_channels(x, weight, mult=8):

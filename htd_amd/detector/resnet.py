@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from ..dense import ResStageFunction
 from ..registry import BACKBONES
 from .bricks import build_conv_layer, build_norm_layer, constant_init, frozen_bn_fold, kaiming_init
 
@@ -102,6 +103,29 @@ class ResLayer(nn.Sequential):
             layers.append(block(inplanes=inplanes, planes=planes, stride=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
                                 **kwargs))
         super().__init__(*layers)
+
+    def _fusable(self):
+        """All blocks plain bottlenecks (no DCN), 'pytorch' style, BN on running statistics: the whole layer runs
+        as one autograd node with the fused backward of dense.ResStageFunction."""
+        for blk in self:
+            if not isinstance(blk, Bottleneck) or blk.with_dcn or blk.style != 'pytorch':
+                return False
+            bns = [blk.norm1, blk.norm2, blk.norm3] + ([blk.downsample[1]] if blk.downsample is not None else [])
+            if any(bn.training or not isinstance(bn, nn.BatchNorm2d) for bn in bns):
+                return False
+        return True
+
+    def forward(self, x):
+        if not x.is_cuda or not self._fusable():
+            return super().forward(x)
+        params = []
+        for blk in self:
+            for conv, bn in ((blk.conv1, blk.norm1), (blk.conv2, blk.norm2), (blk.conv3, blk.norm3)):
+                params += frozen_bn_fold(conv.weight, bn)
+            if blk.downsample is not None:
+                params += frozen_bn_fold(blk.downsample[0].weight, blk.downsample[1])
+        return ResStageFunction.apply(x, tuple(blk.conv2_stride for blk in self), self[0].dilation,
+                                      tuple(blk.downsample is not None for blk in self), *params)
 
 
 @BACKBONES.register_module()

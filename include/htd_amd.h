@@ -143,8 +143,11 @@ int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const floa
  * (torch.mm calls of htd_bbox_head.py:210,213,214,216 batched over all (image, level) groups). */
 int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int M, int N, int K, void *stream);
 int htd_conv2d_flip_weights(const float *w, float *wT, int Co, int kh, int kw, int Ci, void *stream);
-int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, float *gx, int B,
-                        int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+/* gx = relu_mask(dgrad(gy) + accum): accum (may be NULL, stride 1 only) is another gradient of the same tensor (the
+ * identity branch of a residual block, basic_block/bottleneck `out += identity` resnet.py:278-282), mask_src (may be
+ * NULL) the activation whose ReLU produced the conv input (gx is zeroed where mask_src <= 0). */
+int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx,
+                        int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                         void *workspace, void *stream);
 int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw,
                                          int stride, int pad, int dil);

@@ -81,3 +81,42 @@ def test_conv_rejects_cpu():
     from htd_amd import dense
     with pytest.raises(NotImplementedError):
         dense.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('stride,dilation,needs_x', [(2, 1, True), (1, 1, False), (1, 2, True)])
+def test_res_stage_fused_backward(stride, dilation, needs_x):
+    """ResLayer as one autograd node (dense.ResStageFunction: ReLU masks and the residual join inside the dgrad
+    epilogues) against the same layer run conv by conv through autograd, and against ATen in fp64-free fp32."""
+    import torch.nn as nn
+    from htd_amd.detector.resnet import Bottleneck, ResLayer
+    torch.manual_seed(3)
+    dev = torch.device('cuda:0')
+    layer = ResLayer(Bottleneck, 64, 32, 3, stride=stride, dilation=dilation).to(dev)
+    for m in layer.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    layer.eval()                                                     # frozen statistics, parameters still trainable
+    x = torch.randn(2, 64, 20, 28, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(needs_x)
+    gy = None
+    results = []
+    for fused in (True, False):
+        layer.zero_grad()
+        if x.grad is not None:
+            x.grad = None
+        y = layer(x) if fused else nn.Sequential.forward(layer, x)
+        if gy is None:
+            gy = torch.randn_like(y)
+        y.backward(gy)
+        results.append((y.detach().clone(), None if not needs_x else x.grad.clone(),
+                        {n: p.grad.clone() for n, p in layer.named_parameters()}))
+    (y0, gx0, gp0), (y1, gx1, gp1) = results
+    assert torch.equal(y0, y1)
+    if needs_x:
+        torch.testing.assert_close(gx0, gx1, rtol=1e-5, atol=1e-6)
+    assert set(gp0) == set(gp1) and len(gp0) > 0
+    for n in gp0:
+        torch.testing.assert_close(gp0[n], gp1[n], rtol=1e-5, atol=1e-5 * float(gp1[n].abs().max()), msg=n)
