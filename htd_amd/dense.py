@@ -32,6 +32,43 @@ def _splitk_ws(M, Co, Cred, kh, kw, device):
     return torch.empty(nbytes // 4, device=device, dtype=torch.float32) if nbytes > 0 else None
 
 
+# ---- gradient sinks ------------------------------------------------------------------------------------------
+# runner.FlatParams registers, for every leaf parameter, its slice of the flat gradient buffer.  A kernel that
+# produces the gradient of such a parameter writes it straight into that slice and returns an alias of it, so
+# autograd's AccumulateGrad adopts the tensor instead of launching `grad += new` once per parameter (~230 launches
+# per step).  A slice is handed out once per step; further gradients of the same parameter (shared RPN convs, the
+# stage-1 classifier reused by stage 2) use fresh tensors, autograd sums them, and FlatParams.collect() copies any
+# gradient that did not end up in its slice.
+_GRAD_SINK = {}
+_SINK_USED = set()
+
+
+def register_grad_sinks(mapping):
+    _GRAD_SINK.clear()
+    _GRAD_SINK.update(mapping)
+    _SINK_USED.clear()
+
+
+def reset_grad_sinks():
+    _SINK_USED.clear()
+
+
+def grad_out(like):
+    """Tensor to write the gradient of `like` into: an alias of its registered flat-gradient slice, else a new one."""
+    key = like.data_ptr()
+    v = _GRAD_SINK.get(key)
+    if v is not None and key not in _SINK_USED and v.numel() == like.numel() and torch.is_grad_enabled() is False:
+        if v.shape == like.shape and v.stride() == like.stride():
+            _SINK_USED.add(key)
+            return v.view_as(v)
+        if like.dim() == 4 and v.dim() == 2 and like.shape[2:] == (1, 1) and like.shape[:2] == v.shape:
+            _SINK_USED.add(key)                       # Linear weight seen as a 1x1 conv (channels_last view)
+            return v.view(v.size(0), 1, 1, v.size(1)).permute(0, 3, 1, 2)
+    if like.dim() == 4:
+        return torch.empty(like.shape, device=like.device, dtype=like.dtype, memory_format=CL)
+    return torch.empty_like(like)
+
+
 # ---- raw launches (no autograd): the building blocks of Conv2dFunction and ResStageFunction -------------------
 
 def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu):
@@ -48,11 +85,11 @@ def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu):
     return y
 
 
-def _colsum_raw(g, y=None):
+def _colsum_raw(g, y=None, bias=None):
     """-> (gm, gbias): gbias = column sums of gm, gm = g * (y > 0) when y is given (else gm is g itself)."""
     B, Co, Ho, Wo = g.shape
     gm = torch.empty_like(g, memory_format=CL) if y is not None else g
-    gb = torch.empty(Co, device=g.device, dtype=g.dtype)
+    gb = grad_out(bias) if bias is not None else torch.empty(Co, device=g.device, dtype=g.dtype)
     ws = torch.empty(2048 * Co, device=g.device, dtype=g.dtype)
     capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm) if y is not None else None, _P(gb), B * Ho * Wo, Co,
               _P(ws), _S(), work=('byte', 4.0 * B * Ho * Wo * Co * (3 if y is not None else 1)))
@@ -79,11 +116,11 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
     return gx
 
 
-def _wgrad_raw(x, g, w_shape, stride, padding, dilation):
+def _wgrad_raw(x, g, weight, stride, padding, dilation):
     B, Ci, H, W = x.shape
-    Co, _, kh, kw = w_shape
+    Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
-    gw = torch.empty((Co, Ci, kh, kw), device=g.device, dtype=g.dtype, memory_format=CL)
+    gw = grad_out(weight)
     nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
     ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
     capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), B, H, W, Ci, Co, kh, kw, stride, padding, dilation,
@@ -102,6 +139,7 @@ class Conv2dFunction(Function):
         y = _fwd_raw(x, weight, b, res, stride, padding, dilation, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (stride, padding, dilation, bool(relu), bias is not None, residual is not None)
+        ctx.bias_ref = b                                  # only its address is used (gradient sink lookup)
         return y
 
     @staticmethod
@@ -113,9 +151,9 @@ class Conv2dFunction(Function):
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
         gb = None
         if relu or (has_bias and need_b):
-            g, gb = _colsum_raw(g, y if relu else None)
+            g, gb = _colsum_raw(g, y if relu else None, ctx.bias_ref if (has_bias and need_b) else None)
         gx = _dgrad_raw(g, weight, x.shape, stride, padding, dilation) if need_x else None
-        gw = _wgrad_raw(x, g, weight.shape, stride, padding, dilation) if need_w else None
+        gw = _wgrad_raw(x, g, weight, stride, padding, dilation) if need_w else None
         return gx, gw, (gb if (has_bias and need_b) else None), (g if (has_res and need_r) else None), None, None, \
             None, None
 
@@ -177,23 +215,23 @@ class ResStageFunction(Function):
             need_x = need[0] if first else True
             gm3, gb3 = _colsum_raw(g, None if premasked else out)
             if pneed[4]:
-                grads[k + 4] = _wgrad_raw(h2, gm3, w3.shape, 1, 0, 1)
+                grads[k + 4] = _wgrad_raw(h2, gm3, w3, 1, 0, 1)
             grads[k + 5] = gb3 if pneed[5] else None
             gm2 = _dgrad_raw(gm3, w3, h2.shape, 1, 0, 1, mask_src=h2)
             _, gb2 = _colsum_raw(gm2)
             if pneed[2]:
-                grads[k + 2] = _wgrad_raw(h1, gm2, w2.shape, stride, dilation, dilation)
+                grads[k + 2] = _wgrad_raw(h1, gm2, w2, stride, dilation, dilation)
             grads[k + 3] = gb2 if pneed[3] else None
             gm1 = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1)
             _, gb1 = _colsum_raw(gm1)
             if pneed[0]:
-                grads[k] = _wgrad_raw(x, gm1, w1.shape, 1, 0, 1)
+                grads[k] = _wgrad_raw(x, gm1, w1, 1, 0, 1)
             grads[k + 1] = gb1 if pneed[1] else None
             acc = gm3
             if ds:
                 wd = params[k + 6]
                 if pneed[6]:
-                    grads[k + 6] = _wgrad_raw(x, gm3, wd.shape, stride, 0, 1)
+                    grads[k + 6] = _wgrad_raw(x, gm3, wd, stride, 0, 1)
                 grads[k + 7] = gb3 if pneed[7] else None
                 acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1) if need_x else None
             if need_x:

@@ -83,6 +83,7 @@ class _BNFold(torch.autograd.Function):
                   float(eps), capi.ptr(wf), capi.ptr(bf), Co, K, capi.current_stream_ptr())
         ctx.save_for_backward(w, gamma, mean, var)
         ctx.eps = float(eps)
+        ctx.beta_ref = beta                               # only its address is used (gradient sink lookup)
         return wf, bf
 
     @staticmethod
@@ -94,9 +95,8 @@ class _BNFold(torch.autograd.Function):
         K = w.numel() // Co
         gwf = gwf.contiguous(memory_format=CL)
         gbf = gbf.contiguous()
-        gw = torch.empty_like(w, memory_format=CL)
-        gg = torch.empty_like(gamma)
-        gb = torch.empty_like(gamma)
+        from ..dense import grad_out
+        gw, gg, gb = grad_out(w), grad_out(gamma), grad_out(ctx.beta_ref)
         capi.call('htd_bn_fold_bwd', capi.ptr(w), capi.ptr(gamma), capi.ptr(mean), capi.ptr(var), ctx.eps,
                   capi.ptr(gwf), capi.ptr(gbf), capi.ptr(gw), capi.ptr(gg), capi.ptr(gb), Co, K,
                   capi.current_stream_ptr())

@@ -17,6 +17,7 @@ import math
 import torch
 import torch.distributed as dist
 
+from . import dense
 from . import mmcv_ops as M
 
 CL = torch.channels_last
@@ -56,6 +57,8 @@ class FlatParams:
                 for m in members:
                     self.bucket_of[m] = b
                 members, hi = [], lo
+        self.grad_views = [self._view(self.grad, p, o) for p, o in zip(self.params, offs)]
+        dense.register_grad_sinks({p.data_ptr(): v for p, v in zip(self.params, self.grad_views)})
 
     @staticmethod
     def _view(flat, p, off):
@@ -66,10 +69,24 @@ class FlatParams:
         return flat[off:off + n].view(p.shape)
 
     def zero_grad(self):
+        """Zero the flat gradient buffer and detach .grad: the kernels that produce parameter gradients write them
+        straight into their slice (dense.grad_out) and autograd adopts that tensor; collect() repairs the rest."""
         self.grad.zero_()
-        for p, o in zip(self.params, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self._view(self.grad, p, o)
+        dense.reset_grad_sinks()
+        for p in self.params:
+            p.grad = None
+
+    def collect_one(self, i):
+        p, v = self.params[i], self.grad_views[i]
+        g = p.grad
+        if g is not None and g.data_ptr() != v.data_ptr():
+            v.copy_(g)
+        p.grad = v
+
+    def collect(self):
+        """After backward: every .grad is its slice of the flat buffer again (missing gradients = zeros)."""
+        for i in range(len(self.params)):
+            self.collect_one(i)
 
 
 class GradientExchange:
@@ -92,6 +109,7 @@ class GradientExchange:
         def hook(param):
             if self._pending is None:
                 return
+            self.flat.collect_one(i)
             b = self.flat.bucket_of[i]
             self._pending[b].discard(i)
             self._advance()
@@ -129,6 +147,7 @@ class GradientExchange:
     def finish_step(self):
         """Reduce the remaining buckets (parameters that got no gradient this step contribute zeros), still in
         bucket order, then join the side stream."""
+        self.flat.collect()              # every .grad is its flat slice again (unused parameters: zeros)
         if not self.enabled:
             return
         while self._next < len(self.flat.buckets):
