@@ -322,6 +322,23 @@ def batched_max_iou_assign(assigner, boxes, box_valid, gts, gt_valid):
     return assigned, torch.where(box_valid & has_gt, max_ov.clamp(min=0), torch.zeros_like(max_ov))
 
 
+_key_source = None
+
+
+def set_sample_keys(fn=None):
+    """Source of the i.i.d. keys behind the batched samplers: fn(candidate_boxes (B,A,4)) -> (B,A) floats in [0,1).
+    None = torch.rand on the device.  Tests install a function of the box coordinates so that differently padded
+    layouts of the same candidates draw the same sample."""
+    global _key_source
+    _key_source = fn
+
+
+def sample_keys(cand):
+    if _key_source is not None:
+        return _key_source(cand)
+    return torch.rand(cand.shape[:2], device=cand.device)
+
+
 def batched_random_sample(assigned, num, pos_fraction, neg_pos_ub=-1, keys=None):
     """RandomSampler (base_sampler.py:34-101, random_sampler.py:58-78) without host round trips: a uniformly random
     subset of size n is the n candidates with the smallest i.i.d. random keys.  -> (pos_mask, neg_mask) (B,A)."""
@@ -395,7 +412,8 @@ def batched_assign_and_sample(assigner, sampler, proposal_list, gt_bboxes, gt_la
         is_gt = torch.cat([gvalid, torch.zeros_like(pvalid)], 1)
     else:
         cand, is_gt = props, torch.zeros_like(pvalid)
-    pos, neg = batched_random_sample(assigned, sampler.num, sampler.pos_fraction, sampler.neg_pos_ub, keys)
+    pos, neg = batched_random_sample(assigned, sampler.num, sampler.pos_fraction, sampler.neg_pos_ub,
+                                     keys if keys is not None else sample_keys(cand))
     # selected candidates first, ascending index inside (stable sort of the complement mask)
     pos_order = torch.sort((~pos).to(torch.uint8), dim=1, stable=True)[1]
     neg_order = torch.sort((~neg).to(torch.uint8), dim=1, stable=True)[1]
@@ -421,3 +439,65 @@ def batched_assign_and_sample(assigner, sampler, proposal_list, gt_bboxes, gt_la
         out.append(BatchSamplingResult(pi, ni, boxes_b, gt_bboxes[b][:, :4], inds_b, lab_b, flg_b))
         out[-1].num_pos_gt = counts[b][2]           # host copy of pos_is_gt.sum() (saves refine_bboxes a device read)
     return out, counts
+
+
+class StaticSamples:
+    """Sampling result of a whole batch in FIXED slots: S = sampler.num rows per image, the sampled positives first
+    (ascending candidate index), then the sampled negatives -- the order of SamplingResult.bboxes
+    (sampling_result.py:40-43) -- then unused slots.  Every member is a device tensor of static shape, so the RoI
+    head that consumes it never has to read a count back to the host."""
+
+    def __init__(self, boxes, valid, is_pos, npos, nneg, pos_gt_bboxes, pos_gt_labels, pos_is_gt):
+        self.boxes, self.valid, self.is_pos = boxes, valid, is_pos                  # (B,S,4), (B,S), (B,S)
+        self.npos, self.nneg = npos, nneg                                          # (B,)
+        self.pos_gt_bboxes, self.pos_gt_labels, self.pos_is_gt = pos_gt_bboxes, pos_gt_labels, pos_is_gt
+
+    @property
+    def rois(self):
+        B, S = self.valid.shape
+        img = torch.arange(B, device=self.boxes.device, dtype=self.boxes.dtype).view(B, 1, 1).expand(B, S, 1)
+        return torch.cat([img, self.boxes], -1).view(B * S, 5)
+
+
+def static_assign_and_sample(assigner, sampler, props, pvalid, gt_bboxes, gt_labels):
+    """MaxIoUAssigner + RandomSampler for every image (htd_roi_head.py:254-264,292-310) with NO device->host
+    copy: props (B,P,4) zero-padded with validity mask pvalid (B,P).  -> StaticSamples."""
+    dev = props.device
+    B, P = pvalid.shape
+    S = sampler.num
+    K = max(1, max(int(g.size(0)) for g in gt_bboxes))
+    gts = props.new_zeros(B, K, 4)
+    gvalid = torch.zeros(B, K, dtype=torch.bool, device=dev)
+    glabels = torch.zeros(B, K, dtype=torch.long, device=dev)
+    for b in range(B):
+        k = gt_bboxes[b].size(0)
+        if k:
+            gts[b, :k] = gt_bboxes[b][:, :4]
+            gvalid[b, :k] = True
+            glabels[b, :k] = gt_labels[b]
+    assigned, _ = batched_max_iou_assign(assigner, props, pvalid, gts, gvalid)
+    if sampler.add_gt_as_proposals:      # AssignResult.add_gt_: gt i is a candidate matched to itself
+        self_inds = torch.where(gvalid, torch.arange(1, K + 1, device=dev).expand(B, K), torch.full((B, K), -1, device=dev))
+        assigned = torch.cat([self_inds, assigned], 1)
+        cand = torch.cat([gts, props], 1)
+        is_gt = torch.cat([gvalid, torch.zeros_like(pvalid)], 1)
+    else:
+        cand, is_gt = props, torch.zeros_like(pvalid)
+    A = cand.size(1)
+    if A < S:                            # fewer candidates than slots: pad with candidates that can never be drawn
+        cand = torch.cat([cand, cand.new_zeros(B, S - A, 4)], 1)
+        assigned = torch.cat([assigned, assigned.new_full((B, S - A), -1)], 1)
+        is_gt = torch.cat([is_gt, is_gt.new_zeros(B, S - A)], 1)
+        A = S
+    pos, neg = batched_random_sample(assigned, sampler.num, sampler.pos_fraction, sampler.neg_pos_ub, sample_keys(cand))
+    ar = torch.arange(A, device=dev).expand(B, A)
+    order = torch.where(pos, ar, torch.where(neg, ar + A, ar + 2 * A)).argsort(dim=1)[:, :S]      # (B,S)
+    npos, nneg = pos.sum(1), neg.sum(1)
+    slot = torch.arange(S, device=dev).expand(B, S)
+    valid = slot < (npos + nneg)[:, None]
+    is_pos = slot < npos[:, None]
+    boxes = torch.gather(cand, 1, order[..., None].expand(B, S, 4)) * valid[..., None].to(cand.dtype)
+    gt_idx = (torch.gather(assigned, 1, order) - 1).clamp(min=0)
+    return StaticSamples(boxes, valid, is_pos, npos, nneg,
+                         torch.gather(gts, 1, gt_idx[..., None].expand(B, S, 4)), torch.gather(glabels, 1, gt_idx),
+                         torch.gather(is_gt, 1, order) & is_pos)

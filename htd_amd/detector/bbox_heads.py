@@ -92,7 +92,9 @@ class BBoxHead(nn.Module):
 
     # ---------------------------------------------------------------- loss
     def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
-             reduction_override=None):
+             reduction_override=None, num_samples=None):
+        """num_samples (device scalar, optional): number of real rows when the batch carries unused sample slots
+        (static-shape training path); rows with label_weight 0 are then excluded from `acc` as well."""
         losses = dict()
         if cls_score is not None:
             # avg_factor stays on the device (the reference calls .item() here: one host sync per stage)
@@ -100,7 +102,11 @@ class BBoxHead(nn.Module):
             if cls_score.numel() > 0:
                 losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
                                                    reduction_override=reduction_override)
-                losses['acc'] = accuracy(cls_score, labels)
+                if num_samples is None:
+                    losses['acc'] = accuracy(cls_score, labels)
+                else:
+                    hit = (cls_score.argmax(1) == labels) & (label_weights > 0)
+                    losses['acc'] = (hit.sum().float() * 100.0 / num_samples.float().clamp(min=1)).view(1)
         if bbox_pred is not None:
             pos = (labels >= 0) & (labels < self.num_classes)
             # masked form of bbox_head.py:165-185: rows of non-positives get weight 0, so no boolean gather
@@ -113,8 +119,9 @@ class BBoxHead(nn.Module):
                 idx = labels.clamp(max=self.num_classes - 1).view(-1, 1, 1).expand(-1, 1, 4)
                 pred = torch.gather(bbox_pred.view(bbox_pred.size(0), -1, 4), 1, idx).squeeze(1)
             w = bbox_weights * pos[:, None].to(bbox_weights.dtype)
-            losses['loss_bbox'] = self.loss_bbox(pred, bbox_targets, w, avg_factor=bbox_targets.size(0),
-                                                 reduction_override=reduction_override)
+            losses['loss_bbox'] = self.loss_bbox(pred, bbox_targets, w, reduction_override=reduction_override,
+                                                 avg_factor=bbox_targets.size(0) if num_samples is None else
+                                                 num_samples.to(pred.dtype).clamp(min=1))
         return losses
 
     # ---------------------------------------------------------------- inference / refinement

@@ -86,24 +86,32 @@ class HTDBBoxHead(BBoxHead):
             x = dense.linear(x, fc.weight, fc.bias, relu=True)
         return x
 
-    def forward(self, x_cls, x_reg, feat, rois, fc_cls_0, enhanced_feat=None, pos_rois=None, global_feat=None,
-                rois_per_img=None):
-        from .pgraph import pgraph_refine
-        prototype = torch.cat((fc_cls_0.weight, fc_cls_0.bias.unsqueeze(1)), 1).detach()
+    def forward_reg(self, x_reg, enhanced_feat, pos_rois=None, global_feat=None):
+        """Regression branch (htd_bbox_head.py:157-190): BA-enhanced positives -> 3 GN convs -> pool -> fc_reg."""
         if global_feat is not None:
-            x_cls_glb = self._cls_fcs(self._fuse_global(x_cls, global_feat, rois))
             # x_reg + g[img] + alpha*enhanced in one pass (:163,184)
             x_reg = M.fuse_global(x_reg, pos_rois, global_feat, enhanced_feat, self.alpha)
         else:
             x_reg = x_reg + self.alpha * enhanced_feat
         x_reg = self.convs(x_reg)
         x_reg = M.global_avg_pool(x_reg).view(x_reg.size(0), -1)           # AvgPool2d(7) on a 7x7 map
-        # cls head
+        return dense.linear(x_reg, self.fc_reg.weight, self.fc_reg.bias) if self.with_reg else None
+
+    def forward_cls(self, x_cls, feat, rois, fc_cls_0, global_feat=None, rois_per_img=None, roi_valid=None):
+        """Classification branch (:192-226): fcs (applied to the plain and to the global-fused tiles), semantic
+        embedding from the stage-1 classifier, PGraph refinement, fc_cls."""
+        from .pgraph import pgraph_refine
+        prototype = torch.cat((fc_cls_0.weight, fc_cls_0.bias.unsqueeze(1)), 1).detach()
+        x_cls_glb = self._cls_fcs(self._fuse_global(x_cls, global_feat, rois)) if global_feat is not None else None
         x_cls = self._cls_fcs(x_cls)
         sam = torch.mm(dense.linear(x_cls, fc_cls_0.weight, fc_cls_0.bias).softmax(-1), prototype)
         target_lvls = self.map_roi_levels(rois, len(feat))
-        refined = pgraph_refine(x_cls, sam, rois, target_lvls, self.graph_layer_cls, rois_per_img)
+        refined = pgraph_refine(x_cls, sam, rois, target_lvls, self.graph_layer_cls, rois_per_img, roi_valid)
         feat_cls_new = (x_cls_glb if global_feat is not None else x_cls) + refined
-        cls_score = dense.linear(feat_cls_new, self.fc_cls.weight, self.fc_cls.bias) if self.with_cls else None
-        bbox_pred = dense.linear(x_reg, self.fc_reg.weight, self.fc_reg.bias) if self.with_reg else None
+        return dense.linear(feat_cls_new, self.fc_cls.weight, self.fc_cls.bias) if self.with_cls else None
+
+    def forward(self, x_cls, x_reg, feat, rois, fc_cls_0, enhanced_feat=None, pos_rois=None, global_feat=None,
+                rois_per_img=None, roi_valid=None):
+        bbox_pred = self.forward_reg(x_reg, enhanced_feat, pos_rois, global_feat)
+        cls_score = self.forward_cls(x_cls, feat, rois, fc_cls_0, global_feat, rois_per_img, roi_valid)
         return cls_score, bbox_pred

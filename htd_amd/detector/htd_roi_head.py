@@ -218,6 +218,109 @@ class HTDRoIHead(nn.Module):
             losses[f's1.{name}'] = value * lw if 'loss' in name else value
         return losses
 
+    # ------------------------------------------------------------------ train, static shapes
+    def can_train_static(self, gt_bboxes_ignore=None):
+        """The sync-free training path covers the HTD configs: MaxIoUAssigner without ignore regions and
+        RandomSampler in both stages, a class-agnostic stage-1 regressor."""
+        from ..core import bbox as _bbox
+        if not getattr(self, 'static_shapes', True) or _bbox._randperm is not _bbox._device_randperm:
+            return False
+        if gt_bboxes_ignore is not None and any(g is not None for g in gt_bboxes_ignore):
+            return False
+        for a, smp in zip(self.bbox_assigner, self.bbox_sampler):
+            if a.ignore_iof_thr > 0 or not isinstance(a.neg_iou_thr, float) or type(smp).__name__ != 'RandomSampler':
+                return False
+        h = self.bbox_head[0]
+        return h.reg_class_agnostic and h.bbox_coder.clip_border and not h.reg_decoded_bbox and \
+            all(c.pos_weight <= 0 for c in self.train_cfg)
+
+    def _static_targets(self, stage, S):
+        """bbox_head.get_targets (bbox_head.py:85-146) on fixed slots: unused slots carry weight 0."""
+        head = self.bbox_head[stage]
+        from ..core.bbox import bbox2delta
+        B, n = S.valid.shape
+        labels = torch.where(S.is_pos, S.pos_gt_labels, torch.full_like(S.pos_gt_labels, head.num_classes)).view(-1)
+        label_weights = S.valid.to(S.boxes.dtype).view(-1)
+        # rows that are not positives encode a unit box onto itself (no log(0) / 0-division; weight 0 anyway)
+        src = S.boxes.view(-1, 4)
+        tgt = S.pos_gt_bboxes.view(-1, 4)
+        dead = ~S.is_pos.view(-1, 1)
+        one = const_tensor([0., 0., 1., 1.], src.device, src.dtype)
+        src = torch.where(dead, one, src)
+        tgt = torch.where(dead, one, tgt)
+        bbox_targets = bbox2delta(src, tgt, head.bbox_coder.means, head.bbox_coder.stds)
+        bbox_weights = S.is_pos.to(S.boxes.dtype).view(-1, 1).expand(-1, 4)
+        return labels, label_weights, bbox_targets * bbox_weights, bbox_weights
+
+    def forward_train_static(self, x, img_metas, proposals, n_keep, gt_bboxes, gt_labels):
+        """forward_train (htd_roi_head.py:240-349) on fixed-size tensors: proposals (B,P,5) zero-padded past
+        n_keep (B,) [device].  Numerically the per-image path with the same samples.  The only host read is the
+        number of stage-2 positives, fetched asynchronously behind queued device work."""
+        from ..core.bbox import delta2bbox, static_assign_and_sample
+        losses = dict()
+        B, P = proposals.shape[:2]
+        dev = proposals.device
+        pvalid = torch.arange(P, device=dev)[None, :] < n_keep[:, None]
+        S0 = static_assign_and_sample(self.bbox_assigner[0], self.bbox_sampler[0], proposals[..., :4], pvalid,
+                                      gt_bboxes, gt_labels)
+        global_feat = None
+        if self.with_global:
+            mc_pred, global_feat = self.glbctx_head(x)
+            losses['loss_global'] = self.glbctx_head.loss(mc_pred, gt_labels)
+        # ---------------- stage 1: common head
+        rois = S0.rois
+        res = self._bbox_forward(0, x, rois, global_feat)
+        t0 = self._static_targets(0, S0)
+        loss0 = self.bbox_head[0].loss(res['cls_score'], res['bbox_pred'], rois, *t0, num_samples=S0.valid.sum())
+        lw = self.stage_loss_weights[0]
+        for name, value in loss0.items():
+            losses[f's0.{name}'] = value * lw if 'loss' in name else value
+        with torch.no_grad():            # refine_bboxes (bbox_head.py:227-304): decode, clip, drop the gt-born rows
+            head = self.bbox_head[0]
+            boxes = delta2bbox(rois[:, 1:], res['bbox_pred'], head.bbox_coder.means, head.bbox_coder.stds, None)
+            lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] * 2 for m in img_metas], dev, boxes.dtype)
+            n = S0.valid.size(1)
+            boxes = torch.min(boxes.view(B, n, 4).clamp(min=0), lim[:, None, :])
+            keep = S0.valid & ~S0.pos_is_gt
+            boxes = boxes * keep[..., None].to(boxes.dtype)
+        # ---------------- stage 2: graph reasoning
+        S1 = static_assign_and_sample(self.bbox_assigner[1], self.bbox_sampler[1], boxes, keep, gt_bboxes, gt_labels)
+        rois = S1.rois
+        n = S1.valid.size(1)
+        extractor, enhanced_extractor = self.bbox_roi_extractor[0], self.bbox_roi_extractor[1]
+        feats = x[:extractor.num_inputs]
+        bbox_feats = extractor(feats, rois)
+        # The regression branch runs on the positives only.  Their count is the one number of the step the host
+        # needs: it is copied to pinned memory asynchronously now and read AFTER the classification branch has been
+        # queued, so the device still has that work to do while the host waits for the copy (no idle gap), and the
+        # host never waits for more than the sampling kernels.
+        npos_host = torch.empty(B, dtype=S1.npos.dtype).pin_memory()
+        npos_host.copy_(S1.npos, non_blocking=True)
+        npos_ready = torch.cuda.Event()
+        npos_ready.record()
+        head = self.bbox_head[1]
+        gf = global_feat if self.with_global else None
+        cls_score = head.forward_cls(bbox_feats, feats, rois, self.bbox_head[0].fc_cls, gf, rois_per_img=(n, ) * B,
+                                     roi_valid=S1.valid.view(-1))
+        npos_ready.synchronize()
+        npos = [int(v) for v in npos_host.tolist()]
+        full = cls_score.new_zeros(cls_score.size(0), 4)
+        if sum(npos) > 0:
+            pos_rows = torch.cat([torch.arange(b * n, b * n + k, device=dev) for b, k in enumerate(npos)])
+            pos_rois = torch.index_select(rois, 0, pos_rows)
+            enhanced = enhanced_extractor(feats, pos_rois)
+            bbox_pred = head.forward_reg(torch.index_select(bbox_feats, 0, pos_rows), enhanced, pos_rois, gf)
+            full = full.index_copy(0, pos_rows, bbox_pred)
+        else:
+            full = full + 0 * sum(p.sum() for p in head.parameters())      # keep every parameter in the graph
+        t1 = self._static_targets(1, S1)
+        loss1 = self.bbox_head[1].loss(cls_score, full, rois, *t1, num_samples=S1.valid.sum())
+        lw = self.stage_loss_weights[1]
+        for name, value in loss1.items():
+            losses[f's1.{name}'] = value * lw if 'loss' in name else value
+        self._last_static = (S0, S1)          # exposed for tests
+        return losses
+
     # ------------------------------------------------------------------ test
     def simple_test_bboxes(self, x, proposal_list, img_metas, rescale=False):
         """-> (det_bboxes list, det_labels list) on the device."""

@@ -14,7 +14,7 @@ from .. import dense
 from ..core.misc import const_tensor
 
 
-def group_layout(rois, target_lvls, num_levels, num_imgs=None):
+def group_layout(rois, target_lvls, num_levels, num_imgs=None, roi_valid=None):
     """Sort RoIs by (image, level).  -> perm (N,), counts (G,) device tensor with G = B*num_levels, B.
     With num_imgs given nothing here reads the device (no .item(), no bincount size probe)."""
     img = rois[:, 0].long()
@@ -23,12 +23,14 @@ def group_layout(rois, target_lvls, num_levels, num_imgs=None):
     else:
         B = num_imgs
     key = img * num_levels + target_lvls
+    if roi_valid is not None:                      # unused sample slots: a group of their own past the real ones
+        key = torch.where(roi_valid, key, torch.full_like(key, B * num_levels))
     perm = torch.sort(key, stable=True)[1]
     counts = (key[:, None] == torch.arange(B * num_levels, device=key.device)[None, :]).sum(0)
     return perm, counts, B
 
 
-def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None):
+def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, roi_valid=None):
     """x (N,F) fc features, sam (N,S) semantic embedding, -> refined (N,F):
          M       = (IoU(rois_g, rois_g) with unit diagonal) > 0
          A_local = D^-1/2 M D^-1/2,  D = rowsum(M)
@@ -43,7 +45,7 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None):
     if N == 0:
         return refined
     if rois_per_img is not None:
-        perm, counts, B = group_layout(rois, target_lvls, L, len(rois_per_img))
+        perm, counts, B = group_layout(rois, target_lvls, L, len(rois_per_img), roi_valid)
         nmax = max(rois_per_img)
     else:
         perm, counts, B = group_layout(rois, target_lvls, L)

@@ -68,7 +68,7 @@ class RPNHead(nn.Module):
         losses = self.loss(*outs, gt_bboxes, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
         if proposal_cfg is None:
             return losses
-        return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg)
+        return losses, self.get_bboxes(*outs, img_metas, cfg=proposal_cfg, padded=kwargs.get('padded', False))
 
     def simple_test_rpn(self, x, img_metas):
         return self.get_bboxes(*self(x), img_metas)
@@ -159,9 +159,11 @@ class RPNHead(nn.Module):
             if g.size(0):
                 gts[b, :g.size(0)] = g[:, :4]
                 gt_valid[b, :g.size(0)] = True
-        from ..core.bbox import batched_max_iou_assign, batched_random_sample
+        from ..core.bbox import batched_max_iou_assign, batched_random_sample, sample_keys
         assigned, _ = batched_max_iou_assign(self.assigner, flat_anchors, inside, gts, gt_valid)
         sc = self.train_cfg.sampler
+        if keys is None:
+            keys = sample_keys(flat_anchors[None].expand(B, A, 4))
         pos, neg = batched_random_sample(assigned, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1), keys)
         # targets (anchor_head.py:172-269): labels 0 = foreground, num_classes = background; weights 1 on samples
         gt_of = torch.gather(gts, 1, (assigned - 1).clamp(min=0)[..., None].expand(B, A, 4))
@@ -198,8 +200,9 @@ class RPNHead(nn.Module):
 
     # ------------------------------------------------------------------ proposals
     @torch.no_grad()
-    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False, with_nms=True):
-        """-> list (per image) of (k_i, 5) [x1,y1,x2,y2,score], k_i <= nms_post, descending score."""
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False, with_nms=True, padded=False):
+        """-> list (per image) of (k_i, 5) [x1,y1,x2,y2,score], k_i <= nms_post, descending score.
+        padded=True: -> (dets (B, nms_post, 5) zero rows past k_i, k (B,) on the device) without reading k back."""
         cfg = self.test_cfg if cfg is None else cfg
         assert len(cls_scores) == len(bbox_preds)
         B = cls_scores[0].size(0)
@@ -243,6 +246,9 @@ class RPNHead(nn.Module):
                 v = valid[b]
                 dets, _ = batched_nms(proposals[b][v], scores[b][v], ids[v], dict(type='nms', iou_threshold=cfg.nms_thr))
                 out.append(dets[:cfg.nms_post])
+            if padded:
+                n_keep = const_tensor([int(d.size(0)) for d in out], dev, torch.int64)
+                return torch.stack([torch.nn.functional.pad(d, (0, 0, 0, cfg.nms_post - d.size(0))) for d in out]), n_keep
             return out
         # level id as class: shift by id*(max+1) like batched_nms does (per image), one segment per (image, level)
         ids = torch.cat([scores.new_full((k, ), i) for i, k in enumerate(seg_sizes)])
@@ -257,8 +263,15 @@ class RPNHead(nn.Module):
         # survivors in descending score order (ties: lower level / lower rank first), first nms_post of them
         masked = torch.where(keep, scores, scores.new_full((1, ), -1.0))
         top, order = masked.sort(dim=1, descending=True, stable=True)
-        n_keep = keep.sum(1).clamp(max=cfg.nms_post).tolist()
+        n_keep = keep.sum(1).clamp(max=cfg.nms_post)
         order = order[:, :cfg.nms_post]
         boxes = torch.gather(proposals, 1, order[..., None].expand(-1, -1, 4))
         dets = torch.cat([boxes, top[:, :cfg.nms_post, None]], -1)
+        if padded:
+            live = torch.arange(dets.size(1), device=dev)[None, :] < n_keep[:, None]
+            if dets.size(1) < cfg.nms_post:
+                dets = torch.nn.functional.pad(dets, (0, 0, 0, cfg.nms_post - dets.size(1)))
+                live = torch.nn.functional.pad(live, (0, cfg.nms_post - live.size(1)))
+            return dets * live[..., None].to(dets.dtype), n_keep
+        n_keep = n_keep.tolist()
         return [dets[b, :n_keep[b]] for b in range(B)]

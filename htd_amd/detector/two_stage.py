@@ -153,10 +153,15 @@ class TwoStageDetector(BaseDetector):
         losses = dict()
         if self.with_rpn:
             proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
+            static = x[0].is_cuda and gt_masks is None and not kwargs and \
+                getattr(self.roi_head, 'can_train_static', lambda *_: False)(gt_bboxes_ignore)
             rpn_losses, proposal_list = self.rpn_head.forward_train(x, img_metas, gt_bboxes, gt_labels=None,
                                                                     gt_bboxes_ignore=gt_bboxes_ignore,
-                                                                    proposal_cfg=proposal_cfg)
+                                                                    proposal_cfg=proposal_cfg, padded=static)
             losses.update(rpn_losses)
+            if static:       # fixed-shape RoI head: the whole train step runs without a host/device synchronisation
+                losses.update(self.roi_head.forward_train_static(x, img_metas, *proposal_list, gt_bboxes, gt_labels))
+                return losses
         else:
             proposal_list = proposals
         losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,

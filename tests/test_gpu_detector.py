@@ -260,3 +260,52 @@ def test_rpn_batched_loss_equals_reference_order_path(det, golden):
     for k in ('loss_rpn_cls', 'loss_rpn_bbox'):
         a, b = sum(fast[k]).item(), sum(ref[k]).item()
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (k, a, b)
+
+
+def test_static_shape_train_path_matches_per_image_path(det, golden):
+    """The production train step runs on fixed-size tensors with no host/device synchronisation
+    (HTDRoIHead.forward_train_static, padded RPN proposals).  With the sampler keys made a function of the candidate
+    boxes, it must draw the same samples as the per-image-list path and give the same losses and gradients."""
+    from htd_amd.core import set_randperm
+    from htd_amd.core.bbox import set_sample_keys
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, gts, labels = inputs(g, dev)
+    coef = torch.tensor([12.9898, 78.233, 37.719, 93.989], device=dev)
+
+    def box_keys(cand):
+        return torch.frac(torch.sin((cand * coef).sum(-1)) * 43758.5453).abs()
+    det.train()
+    set_randperm(None)                       # the batched samplers (keys), not the replayed CPU permutation
+    set_sample_keys(box_keys)
+    out = {}
+    try:
+        for static in (True, False):
+            det.roi_head.static_shapes = static
+            det.zero_grad()
+            losses = det(img=img, img_metas=metas, gt_bboxes=gts, gt_labels=labels)
+            loss, log_vars = det._parse_losses(losses)
+            loss.backward()
+            grads = {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None}
+            out[static] = ({k: float(v) for k, v in log_vars.items()}, grads)
+        assert hasattr(det.roi_head, '_last_static')
+        S0, S1 = det.roi_head._last_static
+        assert int(S0.valid.sum()) > 0 and int(S1.is_pos.sum()) > 0
+    finally:
+        det.roi_head.static_shapes = True
+        set_sample_keys(None)
+        set_randperm(lambda n, device: torch.randperm(n).to(device))
+    (l_s, g_s), (l_d, g_d) = out[True], out[False]
+    assert set(l_s) == set(l_d)
+    for k in l_d:
+        assert abs(l_s[k] - l_d[k]) <= 2e-5 * max(1.0, abs(l_d[k])), (k, l_s[k], l_d[k])
+    assert set(g_s) == set(g_d)
+    errs = []
+    for n in g_d:
+        scale = float(g_d[n].abs().max())
+        if scale == 0.0:
+            assert float(g_s[n].abs().max()) == 0.0, n
+            continue
+        errs.append((float((g_s[n] - g_d[n]).abs().max()) / max(scale, 1e-5), n, scale))
+    errs.sort(reverse=True)
+    assert errs[0][0] < 2e-4, errs[:8]
