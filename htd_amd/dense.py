@@ -61,9 +61,12 @@ def grad_out(like):
         if v.shape == like.shape and v.stride() == like.stride():
             _SINK_USED.add(key)
             return v.view_as(v)
-        if like.dim() == 4 and v.dim() == 2 and like.shape[2:] == (1, 1) and like.shape[:2] == v.shape:
-            _SINK_USED.add(key)                       # Linear weight seen as a 1x1 conv (channels_last view)
-            return v.view(v.size(0), 1, 1, v.size(1)).permute(0, 3, 1, 2)
+        if like.dim() == 4 and like.shape[2:] == (1, 1) and like.size(0) == v.size(0):
+            if v.dim() == 4 and v.is_contiguous(memory_format=CL):       # TileLinear: (out,C,h,w) stored (out,h,w,C)
+                v = v.permute(0, 2, 3, 1).reshape(v.size(0), -1)
+            if v.dim() == 2 and v.is_contiguous():
+                _SINK_USED.add(key)                   # Linear weight seen as a 1x1 conv (channels_last view)
+                return v.view(v.size(0), 1, 1, v.size(1)).permute(0, 3, 1, 2)
     if like.dim() == 4:
         return torch.empty(like.shape, device=like.device, dtype=like.dtype, memory_format=CL)
     return torch.empty_like(like)

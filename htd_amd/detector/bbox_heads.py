@@ -18,13 +18,61 @@ from .bricks import ConvModule
 from .losses import accuracy
 
 
+class TileLinear(nn.Linear):
+    """The first fully connected layer of a RoI head (convfc_bbox_head.py:118-129, htd_bbox_head.py:53): a Linear over
+    the flattened (C,h,w) RoI tile.  Logically (and in checkpoints: key, shape, element order) it is the reference's
+    (out, C*h*w) matrix; physically the parameter is stored (out, h, w, C) -- a 4-D channels_last tensor -- which is
+    the order the NHWC RoI tiles arrive in, so neither the 51 MB weight nor its gradient is ever permuted."""
+
+    def __init__(self, channels, tile, out_features, bias=True):
+        h, w = tile
+        super().__init__(channels * h * w, out_features, bias)
+        self.tile_shape = (channels, h, w)
+        self.weight = nn.Parameter(self.weight.data.view(out_features, channels, h, w).contiguous(
+            memory_format=torch.channels_last))
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+        return self
+
+    def weight_hwc(self):
+        """(out, h*w*C) zero-copy view in physical order."""
+        w = self.weight
+        assert w.is_contiguous(memory_format=torch.channels_last)
+        return w.permute(0, 2, 3, 1).reshape(w.size(0), -1)
+
+    def forward(self, x):            # reference-order 2-D input (tests / tools): logical matrix
+        return F.linear(x, self.weight.reshape(self.out_features, -1), self.bias)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        destination[prefix + 'weight'] = destination[prefix + 'weight'].reshape(self.out_features, -1)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + 'weight'
+        if key in state_dict and state_dict[key].dim() == 2:
+            state_dict = dict(state_dict)
+            state_dict[key] = state_dict[key].view(self.out_features, *self.tile_shape)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def xavier_uniform_(self):
+        w2 = torch.empty(self.out_features, self.in_features, device=self.weight.device)
+        nn.init.xavier_uniform_(w2)
+        with torch.no_grad():
+            self.weight.copy_(w2.view(self.out_features, *self.tile_shape))
+
+
 def fc_on_roi_tiles(x, fc, relu=True):
     """Linear over flattened (n,C,h,w) RoI features held NHWC.  The reference flattens in (c,h,w)
     order (convfc_bbox_head.py:147); here x is read in its physical (h,w,c) order and the weight is
-    viewed in the matching order."""
+    viewed in the matching order (free for a TileLinear, a permuted copy for a plain nn.Linear)."""
     n, C, h, w = x.shape
     xf = x.permute(0, 2, 3, 1).reshape(n, h * w * C)
-    wt = fc.weight.view(-1, C, h * w).transpose(1, 2).reshape(-1, h * w * C)
+    if isinstance(fc, TileLinear):
+        wt = fc.weight_hwc()
+    else:
+        wt = fc.weight.view(-1, C, h * w).transpose(1, 2).reshape(-1, h * w * C)
     return dense.linear(xf, wt, fc.bias, relu)
 
 
@@ -213,8 +261,12 @@ class ConvFCBBoxHead(BBoxHead):
         if num_branch_fcs > 0:
             if (is_shared or self.num_shared_fcs == 0) and not self.with_avg_pool:
                 last *= self.roi_feat_area
+            on_tiles = (is_shared or self.num_shared_fcs == 0) and not self.with_avg_pool
             for i in range(num_branch_fcs):
-                fcs.append(nn.Linear(last if i == 0 else self.fc_out_channels, self.fc_out_channels))
+                if i == 0 and on_tiles:
+                    fcs.append(TileLinear(last // self.roi_feat_area, self.roi_feat_size, self.fc_out_channels))
+                else:
+                    fcs.append(nn.Linear(last if i == 0 else self.fc_out_channels, self.fc_out_channels))
             last = self.fc_out_channels
         return convs, fcs, last
 
@@ -222,7 +274,10 @@ class ConvFCBBoxHead(BBoxHead):
         super().init_weights()
         for module_list in [self.shared_fcs, self.cls_fcs, self.reg_fcs]:
             for m in module_list.modules():
-                if isinstance(m, nn.Linear):
+                if isinstance(m, TileLinear):
+                    m.xavier_uniform_()
+                    nn.init.constant_(m.bias, 0)
+                elif isinstance(m, nn.Linear):
                     nn.init.xavier_uniform_(m.weight)
                     nn.init.constant_(m.bias, 0)
 

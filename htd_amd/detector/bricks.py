@@ -123,7 +123,9 @@ def kaiming_init(module, a=0, mode='fan_out', nonlinearity='relu', bias=0, distr
 
 
 def xavier_init(module, gain=1, bias=0, distribution='normal'):
-    if distribution == 'uniform':
+    if distribution == 'uniform' and gain == 1 and hasattr(module, 'tile_shape'):
+        module.xavier_uniform_()                 # TileLinear: fans of the logical 2-D matrix
+    elif distribution == 'uniform':
         nn.init.xavier_uniform_(module.weight, gain=gain)
     else:
         nn.init.xavier_normal_(module.weight, gain=gain)

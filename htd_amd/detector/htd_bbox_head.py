@@ -15,7 +15,7 @@ import torch.nn as nn
 from .. import dense
 from .. import mmcv_ops as M
 from ..registry import HEADS
-from .bbox_heads import BBoxHead, fc_on_roi_tiles
+from .bbox_heads import BBoxHead, TileLinear, fc_on_roi_tiles
 from .bricks import ConvModule, normal_init, xavier_init
 from .roi_extractors import map_roi_levels
 
@@ -50,8 +50,8 @@ class HTDBBoxHead(BBoxHead):
         self.convs = nn.Sequential(*convs)
         fcs = []
         for i in range(self.num_cls_fcs):
-            fcs.append(nn.Linear(self.in_channels * self.roi_feat_area if i == 0 else self.fc_out_channels,
-                                 self.fc_out_channels))
+            fcs.append(TileLinear(self.in_channels, self.roi_feat_size, self.fc_out_channels) if i == 0 else
+                       nn.Linear(self.fc_out_channels, self.fc_out_channels))
             fcs.append(self.relu)
         self.fcs = nn.Sequential(*fcs)
         self.avg_pool = nn.AvgPool2d(self.roi_feat_size)
@@ -102,8 +102,12 @@ class HTDBBoxHead(BBoxHead):
         embedding from the stage-1 classifier, PGraph refinement, fc_cls."""
         from .pgraph import pgraph_refine
         prototype = torch.cat((fc_cls_0.weight, fc_cls_0.bias.unsqueeze(1)), 1).detach()
-        x_cls_glb = self._cls_fcs(self._fuse_global(x_cls, global_feat, rois)) if global_feat is not None else None
-        x_cls = self._cls_fcs(x_cls)
+        if global_feat is not None:
+            # the fcs run on the plain and on the global-fused tiles (:198,201): one batched pass over both
+            both = self._cls_fcs(torch.cat([x_cls, self._fuse_global(x_cls, global_feat, rois)], 0))
+            x_cls, x_cls_glb = both[:x_cls.size(0)], both[x_cls.size(0):]
+        else:
+            x_cls, x_cls_glb = self._cls_fcs(x_cls), None
         sam = torch.mm(dense.linear(x_cls, fc_cls_0.weight, fc_cls_0.bias).softmax(-1), prototype)
         target_lvls = self.map_roi_levels(rois, len(feat))
         refined = pgraph_refine(x_cls, sam, rois, target_lvls, self.graph_layer_cls, rois_per_img, roi_valid)

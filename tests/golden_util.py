@@ -47,13 +47,21 @@ def seeded_state_dict(shapes, prefix='', seed=1234):
 def load_seeded_(module, prefix='', seed=1234):
     """In-place: give every parameter/buffer of `module` its seeded value (key = prefix+name)."""
     seen = set()
+    live = {t.data_ptr() for t in list(module.parameters()) + list(module.buffers())}
+    detached = {}
     with torch.no_grad():
         for k, t in module.state_dict().items():
             # aliases of one tensor (AdptRoIExtractor.conv1 is also att.1): first key wins
             if k.endswith('num_batches_tracked') or t.data_ptr() in seen:
                 continue
             seen.add(t.data_ptr())
-            t.copy_(torch.from_numpy(seeded_state_value(prefix + k, t.shape, seed)))
+            v = torch.from_numpy(seeded_state_value(prefix + k, t.shape, seed))
+            if t.data_ptr() in live:
+                t.copy_(v)
+            else:       # state_dict entry is a re-laid-out copy (TileLinear saves its logical 2-D matrix)
+                detached[k] = v
+    if detached:
+        module.load_state_dict(detached, strict=False)
     return module
 
 

@@ -170,6 +170,7 @@ def test_train_step_matches_oracle_other_seed(det):
               'roi_head.bbox_roi_extractor.1.conv2.weight', 'roi_head.glbctx_head.convs.3.conv.weight'):
         a = params[k].grad.detach().cpu() if params[k].grad is not None else torch.zeros_like(params[k]).cpu()
         b = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        a = a.reshape(b.shape)                           # TileLinear keeps its (out, C*h*w) matrix as (out, C, h, w)
         scale = max(b.abs().max().item(), 1e-6)
         assert (a - b).abs().max().item() <= 2e-3 * scale + 1e-6, (k, (a - b).abs().max().item(), scale)
 
