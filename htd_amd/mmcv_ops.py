@@ -124,7 +124,8 @@ class _RoIAlignLevels(Function):
         rois = _f32(rois, 'roi_align').contiguous()
         lvls = lvls.to(torch.int64).contiguous()
         n, C = rois.size(0), feats[0].size(1)
-        out = torch.empty((n, C, ph, pw), device=rois.device, dtype=torch.float32, memory_format=CL).zero_()
+        # every RoI is written by exactly one level's launch (map_roi_levels clamps to [0, L)): no zero fill
+        out = torch.empty((n, C, ph, pw), device=rois.device, dtype=torch.float32, memory_format=CL)
         shapes = []
         for i, f in enumerate(feats):
             f = nhwc(_f32(f, 'roi_align'))
