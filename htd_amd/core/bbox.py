@@ -285,12 +285,39 @@ def bbox2result(bboxes, labels, num_classes):
 
 
 # ------------------------------------------------------------------ batched, host-sync-free forms
+def _max_iou_assign_device(a, boxes, box_valid, gts, gt_valid):
+    """htd_max_iou_assign (csrc/box_ops.hip): the whole assignment in one launch (two with low-quality matching)."""
+    from .. import capi
+    B, K = gt_valid.shape
+    A = boxes.size(-2)
+    shared = boxes.dim() == 2
+    boxes = boxes.float().contiguous()
+    gts = gts.float().contiguous()
+    bv = box_valid.to(torch.uint8).contiguous()
+    gv = gt_valid.to(torch.uint8).contiguous()
+    assigned = torch.empty(B, A, dtype=torch.int64, device=boxes.device)
+    max_ov = torch.empty(B, A, dtype=torch.float32, device=boxes.device)
+    ws = torch.empty(B * K, dtype=torch.int32, device=boxes.device) if a.match_low_quality else None
+    capi.call('htd_max_iou_assign', capi.ptr(boxes), int(shared), capi.ptr(bv), capi.ptr(gts), capi.ptr(gv), B, A, K,
+              float(a.pos_iou_thr), float(a.neg_iou_thr), float(a.min_pos_iou), int(bool(a.match_low_quality)),
+              capi.ptr(assigned), capi.ptr(max_ov), capi.ptr(ws), capi.current_stream_ptr())
+    return assigned, max_ov
+
+
 def batched_max_iou_assign(assigner, boxes, box_valid, gts, gt_valid):
     """MaxIoUAssigner.assign_wrt_overlaps (max_iou_assigner.py:124-212) for B images at once.
     boxes (A,4) shared by all images or (B,A,4); box_valid (B,A) bool; gts (B,K,4) zero-padded; gt_valid (B,K).
     -> (assigned (B,A) int64: -1 ignore / invalid box, 0 negative, k+1 matched to gt k;  max_overlaps (B,A))."""
     a = assigner
     assert isinstance(a.neg_iou_thr, float) and a.ignore_iof_thr <= 0
+    if boxes.is_cuda and (a.gt_max_assign_all or not a.match_low_quality):
+        return _max_iou_assign_device(a, boxes, box_valid, gts, gt_valid)
+    return _batched_max_iou_assign_tensor(a, boxes, box_valid, gts, gt_valid)
+
+
+def _batched_max_iou_assign_tensor(a, boxes, box_valid, gts, gt_valid):
+    """The same assignment written with tensor ops (host-side logic tests on CPU tensors; the rare
+    gt_max_assign_all=False configuration)."""
     if boxes.dim() == 2:
         boxes = boxes[None]
     B, K = gt_valid.shape

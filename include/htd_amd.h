@@ -211,6 +211,21 @@ int htd_bn_fold_bwd(const float *w, const float *gamma, const float *mean, const
                     float *gbeta, int Co, int K, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * MaxIoUAssigner for a whole batch (replaces MaxIoUAssigner.assign / assign_wrt_overlaps,
+ * mmdet/core/bbox/assigners/max_iou_assigner.py:60-212, and its bbox_overlaps call,
+ * iou_calculators/iou2d_calculator.py:43-158, run per image on the k x A IoU matrix).
+ *   boxes [B][A][4] (box_shared = 0) or [A][4] shared by every image (RPN anchors); box_valid [B][A];
+ *   gts [B][K][4] zero padded, gt_valid [B][K].
+ *   assigned [B][A] int64: -1 ignore / invalid box, 0 negative, k+1 matched to gt k;  max_overlaps [B][A].
+ *   match_low_quality follows gt_max_assign_all = True (:187-199).  workspace: B*K*4 bytes when match_low_quality.
+ * IoU arithmetic is the reference's fp32 expression evaluated without FMA contraction: assignments are bit-exact.
+ * ---------------------------------------------------------------------------------- */
+int htd_max_iou_assign(const float *boxes, int box_shared, const uint8_t *box_valid, const float *gts,
+                       const uint8_t *gt_valid, int B, int A, int K, float pos_iou_thr, float neg_iou_thr,
+                       float min_pos_iou, int match_low_quality, int64_t *assigned, float *max_overlaps,
+                       void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
  * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):
  *   g = grad*grad_scale + wd*p ; m = momentum*m + g ; p -= lr*m.     lr is a device scalar

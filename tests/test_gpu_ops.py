@@ -252,3 +252,47 @@ def test_soft_nms_matches_oracle(dev, method):
     dets, keep = batched_nms(boxes.to(dev), scores.to(dev), idxs.to(dev), cfg)
     assert torch.equal(keep.cpu(), keep_r)
     torch.testing.assert_close(dets.cpu(), dets_r, **tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shared,low_quality,K', [(True, True, 5), (False, False, 7), (False, True, 150), (True, True, 1)])
+def test_max_iou_assign_kernel_matches_tensor_formulation(shared, low_quality, K):
+    """htd_max_iou_assign against the tensor-op formulation of MaxIoUAssigner (itself pinned to the reference's
+    known-answer tests on the CPU): identical assignment incl. ties (duplicate gts, boxes equal to gts),
+    padded gts, invalid boxes, an image without gt."""
+    import htd_amd.core.bbox as cb
+    from htd_amd.core.bbox import MaxIoUAssigner
+    torch.manual_seed(5)
+    dev = torch.device('cuda:0')
+    B, A = 3, 5000
+    a = MaxIoUAssigner(pos_iou_thr=0.7 if low_quality else 0.5, neg_iou_thr=0.3 if low_quality else 0.5,
+                       min_pos_iou=0.3 if low_quality else 0.5, match_low_quality=low_quality, ignore_iof_thr=-1)
+    xy = torch.rand(B, A, 2) * 300
+    wh = torch.rand(B, A, 2) * 120 + 2
+    boxes = torch.cat([xy, xy + wh], -1)
+    gxy = torch.rand(B, K, 2) * 300
+    gwh = torch.rand(B, K, 2) * 150 + 4
+    gts = torch.cat([gxy, gxy + gwh], -1)
+    if K > 2:
+        gts[:, 1] = gts[:, 0]                        # duplicate gt: argmax / low-quality ties
+    boxes[:, :K] = gts if not shared else gts[:1]    # boxes equal to gts: IoU exactly 1
+    gt_valid = torch.ones(B, K, dtype=torch.bool)
+    gt_valid[1, K // 2:] = False                     # padded gts
+    gt_valid[2] = False                              # image without gt
+    gts = gts * gt_valid[..., None]
+    box_valid = torch.rand(B, A) > 0.1
+    if shared:
+        boxes = boxes[0]
+    boxes, gts, gt_valid, box_valid = boxes.to(dev), gts.to(dev), gt_valid.to(dev), box_valid.to(dev)
+    got, got_ov = cb.batched_max_iou_assign(a, boxes, box_valid, gts, gt_valid)
+    saved = cb._max_iou_assign_device
+    try:
+        cb._max_iou_assign_device = None             # force the tensor formulation
+        a2 = MaxIoUAssigner(pos_iou_thr=a.pos_iou_thr, neg_iou_thr=a.neg_iou_thr, min_pos_iou=a.min_pos_iou,
+                            match_low_quality=low_quality, ignore_iof_thr=-1)
+        ref, ref_ov = cb._batched_max_iou_assign_tensor(a2, boxes, box_valid, gts, gt_valid)
+    finally:
+        cb._max_iou_assign_device = saved
+    assert torch.equal(got, ref)
+    assert torch.equal(got_ov, ref_ov)
+    assert int((got > 0).sum()) > 0 and int((got == 0).sum()) > 0
