@@ -249,6 +249,46 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     return torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
 
 
+def _f4(vals):
+    import ctypes
+    return (ctypes.c_float * 4)(*[float(v) for v in vals])
+
+
+def delta2bbox_clip_device(rois, deltas, means, stds, lim_wh=None, keep=None, rows_per_img=None,
+                           wh_ratio_clip=16 / 1000):
+    """delta2bbox for (N,4) deltas + clip to per-image limits lim_wh (B,2) [w,h] (row // rows_per_img) + zeroing of
+    rows with keep == False, one launch (htd_delta2bbox_clip)."""
+    from .. import capi
+    n = rois.size(0)
+    rois, deltas = rois.float().contiguous(), deltas.float().contiguous()
+    out = torch.empty(n, 4, device=rois.device, dtype=torch.float32)
+    lim = lim_wh.float().contiguous() if lim_wh is not None else None
+    kp = keep.to(torch.uint8).contiguous() if keep is not None else None
+    capi.call('htd_delta2bbox_clip', capi.ptr(rois), capi.ptr(deltas), capi.ptr(lim), capi.ptr(kp), n,
+              int(rows_per_img or max(n, 1)), _f4(means), _f4(stds), float(wh_ratio_clip), capi.ptr(out),
+              capi.current_stream_ptr())
+    return out
+
+
+def roi_targets_device(boxes, gt_boxes, gt_labels, is_pos, valid, num_classes, means, stds):
+    """-> labels (N,), label_weights (N,), bbox_targets (N,4), bbox_weights (N,4) in one launch (htd_roi_targets)."""
+    from .. import capi
+    n = boxes.size(0)
+    dev = boxes.device
+    labels = torch.empty(n, dtype=torch.int64, device=dev)
+    lw = torch.empty(n, dtype=torch.float32, device=dev)
+    bt = torch.empty(n, 4, dtype=torch.float32, device=dev)
+    bw = torch.empty(n, 4, dtype=torch.float32, device=dev)
+    # converted operands stay referenced until the launch is queued (a freed temporary's block would be reused)
+    boxes, gt_boxes = boxes.float().contiguous(), gt_boxes.float().contiguous()
+    gt_labels = gt_labels.to(torch.int64).contiguous()
+    pos8, val8 = is_pos.to(torch.uint8).contiguous(), valid.to(torch.uint8).contiguous()
+    capi.call('htd_roi_targets', capi.ptr(boxes), capi.ptr(gt_boxes), capi.ptr(gt_labels), capi.ptr(pos8),
+              capi.ptr(val8), n, int(num_classes), _f4(means), _f4(stds), capi.ptr(labels), capi.ptr(lw), capi.ptr(bt),
+              capi.ptr(bw), capi.current_stream_ptr())
+    return labels, lw, bt, bw
+
+
 @BBOX_CODERS.register_module()
 class DeltaXYWHBBoxCoder:
     def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), clip_border=True):

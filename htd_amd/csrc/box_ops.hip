@@ -144,3 +144,103 @@ extern "C" int htd_max_iou_assign(const float *boxes, int box_shared, const uint
     if (match_low_quality) hipLaunchKernelGGL(assign_pass2_kernel, grid, dim3(256), 0, s, p);
     return htd::check_launch("max_iou_assign");
 }
+
+namespace {
+
+struct Vec4 { float v[4]; };
+
+// bbox_head.get_targets on fixed sample slots: label / weights / encoded regression target of every slot.
+__global__ __launch_bounds__(256) void roi_targets_kernel(const float *__restrict__ boxes, const float *__restrict__ gt,
+                                                          const int64_t *__restrict__ gt_labels,
+                                                          const uint8_t *__restrict__ is_pos,
+                                                          const uint8_t *__restrict__ valid, int64_t n, int num_classes,
+                                                          Vec4 means, Vec4 stds, int64_t *__restrict__ labels,
+                                                          float *__restrict__ label_w, float *__restrict__ targets,
+                                                          float *__restrict__ bbox_w)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool pos = is_pos[i] != 0;
+    labels[i] = pos ? gt_labels[i] : (int64_t)num_classes;
+    label_w[i] = valid[i] ? 1.f : 0.f;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos) {      // bbox2delta (delta_xywh_bbox_coder.py:78-120)
+        const float4 p = *reinterpret_cast<const float4 *>(boxes + i * 4);
+        const float4 g = *reinterpret_cast<const float4 *>(gt + i * 4);
+        const float px = (p.x + p.z) * 0.5f, py = (p.y + p.w) * 0.5f, pw = p.z - p.x, ph = p.w - p.y;
+        const float gx = (g.x + g.z) * 0.5f, gy = (g.y + g.w) * 0.5f, gw = g.z - g.x, gh = g.w - g.y;
+        t.x = ((gx - px) / pw - means.v[0]) / stds.v[0];
+        t.y = ((gy - py) / ph - means.v[1]) / stds.v[1];
+        t.z = (logf(gw / pw) - means.v[2]) / stds.v[2];
+        t.w = (logf(gh / ph) - means.v[3]) / stds.v[3];
+    }
+    *reinterpret_cast<float4 *>(targets + i * 4) = t;
+    const float w = pos ? 1.f : 0.f;
+    *reinterpret_cast<float4 *>(bbox_w + i * 4) = make_float4(w, w, w, w);
+}
+
+// delta2bbox (delta_xywh_bbox_coder.py:123-204) for 4-column deltas, clipped to the image of each row
+// (row / rows_per_img), rows with keep == 0 zeroed.
+__global__ __launch_bounds__(256) void decode_clip_kernel(const float *__restrict__ rois, const float *__restrict__ deltas,
+                                                          const float *__restrict__ lim_wh,
+                                                          const uint8_t *__restrict__ keep, int64_t n,
+                                                          int64_t rows_per_img, Vec4 means, Vec4 stds, float max_ratio,
+                                                          float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!keep || keep[i]) {
+        const float4 r = *reinterpret_cast<const float4 *>(rois + i * 4);
+        const float4 d0 = *reinterpret_cast<const float4 *>(deltas + i * 4);
+        const float dx = d0.x * stds.v[0] + means.v[0], dy = d0.y * stds.v[1] + means.v[1];
+        float dw = d0.z * stds.v[2] + means.v[2], dh = d0.w * stds.v[3] + means.v[3];
+        dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+        dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+        const float px = (r.x + r.z) * 0.5f, py = (r.y + r.w) * 0.5f, pw = r.z - r.x, ph = r.w - r.y;
+        const float gw = pw * expf(dw), gh = ph * expf(dh);
+        const float gx = px + pw * dx, gy = py + ph * dy;
+        o = make_float4(gx - gw * 0.5f, gy - gh * 0.5f, gx + gw * 0.5f, gy + gh * 0.5f);
+        if (lim_wh) {
+            const int64_t b = i / rows_per_img;
+            const float W = lim_wh[2 * b], H = lim_wh[2 * b + 1];
+            o.x = fminf(fmaxf(o.x, 0.f), W); o.y = fminf(fmaxf(o.y, 0.f), H);
+            o.z = fminf(fmaxf(o.z, 0.f), W); o.w = fminf(fmaxf(o.w, 0.f), H);
+        }
+    }
+    *reinterpret_cast<float4 *>(out + i * 4) = o;
+}
+
+}  // namespace
+
+extern "C" int htd_roi_targets(const float *boxes, const float *gt_boxes, const int64_t *gt_labels, const uint8_t *is_pos,
+                               const uint8_t *valid, int64_t n, int num_classes, const float *means4,
+                               const float *stds4, int64_t *labels, float *label_weights, float *bbox_targets,
+                               float *bbox_weights, void *stream)
+{
+    HTD_REQUIRE(n >= 0 && num_classes > 0, "roi_targets: bad sizes");
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(boxes && gt_boxes && gt_labels && is_pos && valid && means4 && stds4 && labels && label_weights &&
+                    bbox_targets && bbox_weights, "roi_targets: null pointer");
+    Vec4 m, sd;
+    for (int k = 0; k < 4; ++k) { m.v[k] = means4[k]; sd.v[k] = stds4[k]; }
+    hipLaunchKernelGGL(roi_targets_kernel, dim3((unsigned)htd::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       boxes, gt_boxes, gt_labels, is_pos, valid, n, num_classes, m, sd, labels, label_weights,
+                       bbox_targets, bbox_weights);
+    return htd::check_launch("roi_targets");
+}
+
+extern "C" int htd_delta2bbox_clip(const float *rois, const float *deltas, const float *lim_wh, const uint8_t *keep,
+                                   int64_t n, int64_t rows_per_img, const float *means4, const float *stds4,
+                                   float wh_ratio_clip, float *out, void *stream)
+{
+    HTD_REQUIRE(n >= 0 && rows_per_img > 0 && wh_ratio_clip > 0.f, "delta2bbox_clip: bad sizes");
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(rois && deltas && means4 && stds4 && out, "delta2bbox_clip: null pointer");
+    Vec4 m, sd;
+    for (int k = 0; k < 4; ++k) { m.v[k] = means4[k]; sd.v[k] = stds4[k]; }
+    const float max_ratio = fabsf(logf(wh_ratio_clip));
+    hipLaunchKernelGGL(decode_clip_kernel, dim3((unsigned)htd::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rois, deltas, lim_wh, keep, n, rows_per_img, m, sd, max_ratio, out);
+    return htd::check_launch("delta2bbox_clip");
+}

@@ -237,26 +237,16 @@ class HTDRoIHead(nn.Module):
     def _static_targets(self, stage, S):
         """bbox_head.get_targets (bbox_head.py:85-146) on fixed slots: unused slots carry weight 0."""
         head = self.bbox_head[stage]
-        from ..core.bbox import bbox2delta
-        B, n = S.valid.shape
-        labels = torch.where(S.is_pos, S.pos_gt_labels, torch.full_like(S.pos_gt_labels, head.num_classes)).view(-1)
-        label_weights = S.valid.to(S.boxes.dtype).view(-1)
-        # rows that are not positives encode a unit box onto itself (no log(0) / 0-division; weight 0 anyway)
-        src = S.boxes.view(-1, 4)
-        tgt = S.pos_gt_bboxes.view(-1, 4)
-        dead = ~S.is_pos.view(-1, 1)
-        one = const_tensor([0., 0., 1., 1.], src.device, src.dtype)
-        src = torch.where(dead, one, src)
-        tgt = torch.where(dead, one, tgt)
-        bbox_targets = bbox2delta(src, tgt, head.bbox_coder.means, head.bbox_coder.stds)
-        bbox_weights = S.is_pos.to(S.boxes.dtype).view(-1, 1).expand(-1, 4)
-        return labels, label_weights, bbox_targets * bbox_weights, bbox_weights
+        from ..core.bbox import roi_targets_device
+        return roi_targets_device(S.boxes.view(-1, 4), S.pos_gt_bboxes.view(-1, 4), S.pos_gt_labels.view(-1),
+                                  S.is_pos.view(-1), S.valid.view(-1), head.num_classes, head.bbox_coder.means,
+                                  head.bbox_coder.stds)
 
     def forward_train_static(self, x, img_metas, proposals, n_keep, gt_bboxes, gt_labels):
         """forward_train (htd_roi_head.py:240-349) on fixed-size tensors: proposals (B,P,5) zero-padded past
         n_keep (B,) [device].  Numerically the per-image path with the same samples.  The only host read is the
         number of stage-2 positives, fetched asynchronously behind queued device work."""
-        from ..core.bbox import delta2bbox, static_assign_and_sample
+        from ..core.bbox import delta2bbox_clip_device, static_assign_and_sample
         losses = dict()
         B, P = proposals.shape[:2]
         dev = proposals.device
@@ -277,12 +267,11 @@ class HTDRoIHead(nn.Module):
             losses[f's0.{name}'] = value * lw if 'loss' in name else value
         with torch.no_grad():            # refine_bboxes (bbox_head.py:227-304): decode, clip, drop the gt-born rows
             head = self.bbox_head[0]
-            boxes = delta2bbox(rois[:, 1:], res['bbox_pred'], head.bbox_coder.means, head.bbox_coder.stds, None)
-            lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] * 2 for m in img_metas], dev, boxes.dtype)
+            lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], dev, torch.float32)
             n = S0.valid.size(1)
-            boxes = torch.min(boxes.view(B, n, 4).clamp(min=0), lim[:, None, :])
             keep = S0.valid & ~S0.pos_is_gt
-            boxes = boxes * keep[..., None].to(boxes.dtype)
+            boxes = delta2bbox_clip_device(S0.boxes.view(-1, 4), res['bbox_pred'], head.bbox_coder.means,
+                                           head.bbox_coder.stds, lim, keep.view(-1), n).view(B, n, 4)
         # ---------------- stage 2: graph reasoning
         S1 = static_assign_and_sample(self.bbox_assigner[1], self.bbox_sampler[1], boxes, keep, gt_bboxes, gt_labels)
         rois = S1.rois

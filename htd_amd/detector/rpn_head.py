@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..core import (anchor_inside_flags, images_to_levels, multi_apply, unmap)
-from ..core.bbox import delta2bbox
+from ..core.bbox import delta2bbox, delta2bbox_clip_device
 from ..core.misc import const_tensor
 from ..mmcv_ops import nms_sorted_mask
 from ..registry import (HEADS, build_anchor_generator, build_assigner, build_bbox_coder, build_loss, build_sampler)
@@ -224,12 +224,10 @@ class RPNHead(nn.Module):
         K = scores.size(1)
         deltas = torch.cat(deltas_l, 1).reshape(B * K, 4)
         anchors = torch.cat(anchors_l, 1).reshape(B * K, 4)
-        proposals = delta2bbox(anchors, deltas, self.bbox_coder.means, self.bbox_coder.stds, None)
-        if self.bbox_coder.clip_border:
-            lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], proposals.device, proposals.dtype)   # (B, 2) w,h
-            lim = lim.repeat(1, 2).view(B, 1, 4)
-            proposals = torch.min(proposals.view(B, K, 4).clamp(min=0), lim)
-        proposals = proposals.view(B, K, 4)
+        lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], dev, torch.float32) \
+            if self.bbox_coder.clip_border else None                                      # (B, 2) w,h
+        proposals = delta2bbox_clip_device(anchors, deltas, self.bbox_coder.means, self.bbox_coder.stds, lim, None,
+                                           K).view(B, K, 4)
         valid = None
         if cfg.min_bbox_size > 0:
             w = proposals[..., 2] - proposals[..., 0]

@@ -176,7 +176,8 @@ def nms_sorted_mask(sorted_boxes, iou_threshold, offset=0, seg_offsets=None, max
         max_seg = n if max_seg is None else int(max_seg)
         ncb = (max_seg + 63) // 64
         ws = torch.empty(n * ncb * 8 + 64, dtype=torch.uint8, device=b.device)
-        capi.call('htd_nms_sorted_batched', _P(b), _P(seg_offsets.to(torch.int64).contiguous()), S, n, max_seg,
+        seg64 = seg_offsets.to(torch.int64).contiguous()      # referenced until the launch is queued
+        capi.call('htd_nms_sorted_batched', _P(b), _P(seg64), S, n, max_seg,
                   _P(keep), float(iou_threshold), int(offset), _P(ws), _S())
     return keep
 

@@ -11,7 +11,8 @@ def _run(boxes_for_nms, scores, seg, iou_threshold, sigma, min_score, method, of
     n = boxes_for_nms.size(0)
     new_scores = scores.clone().float().contiguous()
     rank = torch.empty(n, dtype=torch.int32, device=scores.device)
-    capi.call('htd_soft_nms_segments', _P(boxes_for_nms.float().contiguous()), _P(new_scores), _P(seg),
+    boxes_f = boxes_for_nms.float().contiguous()      # referenced until the launch is queued
+    capi.call('htd_soft_nms_segments', _P(boxes_f), _P(new_scores), _P(seg),
               seg.numel() - 1, n, _P(rank), float(iou_threshold), float(sigma), float(min_score), _METHOD[method],
               int(offset), _S())
     return new_scores, rank

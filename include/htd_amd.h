@@ -225,6 +225,19 @@ int htd_max_iou_assign(const float *boxes, int box_shared, const uint8_t *box_va
                        float min_pos_iou, int match_low_quality, int64_t *assigned, float *max_overlaps,
                        void *workspace, void *stream);
 
+/* BBoxHead.get_targets / _get_target_single (bbox_heads/bbox_head.py:85-146) on fixed sample slots: labels
+ * (background = num_classes unless the slot is a positive), label weights (1 on used slots), bbox2delta targets
+ * (delta_xywh_bbox_coder.py:78-120; means4 / stds4 are HOST arrays) and their weights (1 on positives).  n rows. */
+int htd_roi_targets(const float *boxes, const float *gt_boxes, const int64_t *gt_labels, const uint8_t *is_pos,
+                    const uint8_t *valid, int64_t n, int num_classes, const float *means4, const float *stds4,
+                    int64_t *labels, float *label_weights, float *bbox_targets, float *bbox_weights, void *stream);
+/* delta2bbox (delta_xywh_bbox_coder.py:123-204) for 4-column deltas + clip to the image of each row
+ * (row / rows_per_img -> lim_wh [img][2] = (w, h) on the device; NULL = no clip) + rows with keep == 0 zeroed
+ * (keep may be NULL): RPN proposal decode (rpn_head.py:122-140) and BBoxHead.refine_bboxes (bbox_head.py:227-304). */
+int htd_delta2bbox_clip(const float *rois, const float *deltas, const float *lim_wh, const uint8_t *keep, int64_t n,
+                        int64_t rows_per_img, const float *means4, const float *stds4, float wh_ratio_clip,
+                        float *out, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
  * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):
