@@ -244,3 +244,91 @@ extern "C" int htd_delta2bbox_clip(const float *rois, const float *deltas, const
                        rois, deltas, lim_wh, keep, n, rows_per_img, m, sd, max_ratio, out);
     return htd::check_launch("delta2bbox_clip");
 }
+
+namespace {
+
+constexpr int RPN_LOSS_BLOCKS = 1024;
+
+// RPN loss of the whole batch in one pass (anchor_head.py:373-418 loss_single summed over levels and images, with
+// the targets of _get_targets_single :172-269 formed on the fly): per anchor row
+//   cls:  w * BCEWithLogits(x, t),  t = 1 on sampled positives, w = 1 (pos_weight on positives) on sampled rows
+//   box:  SmoothL1_beta(reg - bbox2delta(anchor, gt[assigned-1])) summed over 4, on sampled positives
+// and, in the same pass, d(sum)/dx and d(sum)/dreg (the backward only scales them).  Sums are written as per-block
+// partials in a fixed grid and reduced in a fixed order afterwards (bitwise reproducible).
+__global__ __launch_bounds__(256) void rpn_loss_kernel(const float *__restrict__ cls, const float *__restrict__ reg,
+                                                       const float *__restrict__ anchors,
+                                                       const float *__restrict__ gts,
+                                                       const int64_t *__restrict__ assigned,
+                                                       const uint8_t *__restrict__ pos, const uint8_t *__restrict__ neg,
+                                                       int64_t rows, int A, int K, Vec4 means, Vec4 stds, float beta,
+                                                       float pos_weight, float *__restrict__ partial,
+                                                       float *__restrict__ gcls, float *__restrict__ greg)
+{
+    __shared__ float red[2][4];
+    float s_cls = 0.f, s_box = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.x * 256) {
+        const bool p = pos[i] != 0, n = neg[i] != 0;
+        float gx = 0.f;
+        float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p || n) {
+            const float x = cls[i], t = p ? 1.f : 0.f;
+            const float w = (p && pos_weight > 0.f) ? pos_weight : 1.f;
+            s_cls += w * (fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
+            gx = w * (1.f / (1.f + expf(-x)) - t);
+        }
+        if (p) {
+            const int64_t b = i / A;
+            const int a = (int)(i - b * A);
+            const float4 an = *reinterpret_cast<const float4 *>(anchors + (int64_t)a * 4);
+            const float4 g = *reinterpret_cast<const float4 *>(gts + (b * K + (assigned[i] - 1)) * 4);
+            const float px = (an.x + an.z) * 0.5f, py = (an.y + an.w) * 0.5f, pw = an.z - an.x, ph = an.w - an.y;
+            const float cx = (g.x + g.z) * 0.5f, cy = (g.y + g.w) * 0.5f, gw = g.z - g.x, gh = g.w - g.y;
+            float tgt[4];
+            tgt[0] = ((cx - px) / pw - means.v[0]) / stds.v[0];
+            tgt[1] = ((cy - py) / ph - means.v[1]) / stds.v[1];
+            tgt[2] = (logf(gw / pw) - means.v[2]) / stds.v[2];
+            tgt[3] = (logf(gh / ph) - means.v[3]) / stds.v[3];
+            const float4 r = *reinterpret_cast<const float4 *>(reg + i * 4);
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+            float go[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = rr[k] - tgt[k], ad = fabsf(d);
+                if (ad < beta) { s_box += 0.5f * ad * ad / beta; go[k] = d / beta; }
+                else { s_box += ad - 0.5f * beta; go[k] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+            }
+            gr = make_float4(go[0], go[1], go[2], go[3]);
+        }
+        gcls[i] = gx;
+        *reinterpret_cast<float4 *>(greg + i * 4) = gr;
+    }
+    s_cls = htd::wave_sum(s_cls);
+    s_box = htd::wave_sum(s_box);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s_cls; red[1][wave] = s_box; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int htd_rpn_loss_partial_rows(void) { return RPN_LOSS_BLOCKS; }
+
+extern "C" int htd_rpn_loss(const float *cls, const float *reg, const float *anchors, const float *gts,
+                            const int64_t *assigned, const uint8_t *pos, const uint8_t *neg, int B, int A, int K,
+                            const float *means4, const float *stds4, float beta, float pos_weight, float *partial,
+                            float *grad_cls, float *grad_reg, void *stream)
+{
+    HTD_REQUIRE(B > 0 && A > 0 && K > 0 && beta > 0.f, "rpn_loss: bad sizes");
+    HTD_REQUIRE(cls && reg && anchors && gts && assigned && pos && neg && means4 && stds4 && partial && grad_cls &&
+                    grad_reg, "rpn_loss: null pointer");
+    Vec4 m, sd;
+    for (int k = 0; k < 4; ++k) { m.v[k] = means4[k]; sd.v[k] = stds4[k]; }
+    hipLaunchKernelGGL(rpn_loss_kernel, dim3(RPN_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, cls, reg, anchors,
+                       gts, assigned, pos, neg, (int64_t)B * A, A, K, m, sd, beta, pos_weight, partial, grad_cls,
+                       grad_reg);
+    return htd::check_launch("rpn_loss");
+}

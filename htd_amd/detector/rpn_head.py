@@ -19,6 +19,36 @@ from ..registry import (HEADS, build_anchor_generator, build_assigner, build_bbo
 from .bricks import Conv2d, normal_init
 
 
+class _RPNLossFunction(torch.autograd.Function):
+    """(sum of weighted BCE, sum of SmoothL1 on positives) over every anchor of the batch: one launch forward
+    (htd_rpn_loss, which also leaves the derivatives), two scalings backward."""
+
+    @staticmethod
+    def forward(ctx, cls, reg, anchors, gts, assigned, pos, neg, means, stds, beta, pos_weight):
+        from .. import capi
+        from ..core.bbox import _f4
+        B, A = assigned.shape
+        K = gts.size(1)
+        cls, reg = cls.float().contiguous(), reg.float().contiguous()
+        anchors, gts = anchors.float().contiguous(), gts.float().contiguous()
+        assigned = assigned.contiguous()
+        pos8, neg8 = pos.to(torch.uint8).contiguous(), neg.to(torch.uint8).contiguous()
+        partial = torch.empty(capi.lib().htd_rpn_loss_partial_rows(), 2, device=cls.device, dtype=torch.float32)
+        gcls, greg = torch.empty_like(cls), torch.empty_like(reg)
+        capi.call('htd_rpn_loss', capi.ptr(cls), capi.ptr(reg), capi.ptr(anchors), capi.ptr(gts), capi.ptr(assigned),
+                  capi.ptr(pos8), capi.ptr(neg8), B, A, K, _f4(means), _f4(stds), beta, pos_weight, capi.ptr(partial),
+                  capi.ptr(gcls), capi.ptr(greg), capi.current_stream_ptr())
+        ctx.save_for_backward(gcls, greg)
+        sums = partial.sum(0)
+        return sums[0], sums[1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_cls, g_box):
+        gcls, greg = ctx.saved_tensors
+        return (gcls * g_cls, greg * g_box) + (None, ) * 9
+
+
 @HEADS.register_module()
 class RPNHead(nn.Module):
     def __init__(self, in_channels, feat_channels=256,
@@ -165,6 +195,17 @@ class RPNHead(nn.Module):
         if keys is None:
             keys = sample_keys(flat_anchors[None].expand(B, A, 4))
         pos, neg = batched_random_sample(assigned, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1), keys)
+        n_pos, n_neg = pos.sum(1), neg.sum(1)
+        num_total = (n_pos.clamp(min=1) + n_neg.clamp(min=1)).sum().to(torch.float32)       # anchor_head.py:354-355
+        cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
+        reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
+        self._last_rpn_sample = (assigned, pos, neg, inside)  # exposed for tests
+        if self._fused_loss_ok():
+            s_cls, s_box = _RPNLossFunction.apply(cls.reshape(-1), reg.reshape(-1, 4), flat_anchors, gts, assigned,
+                                                  pos, neg, tuple(self.bbox_coder.means), tuple(self.bbox_coder.stds),
+                                                  float(self.loss_bbox.beta), float(self.train_cfg.pos_weight))
+            return dict(loss_rpn_cls=[self.loss_cls.loss_weight * s_cls / num_total],
+                        loss_rpn_bbox=[self.loss_bbox.loss_weight * s_box / num_total])
         # targets (anchor_head.py:172-269): labels 0 = foreground, num_classes = background; weights 1 on samples
         gt_of = torch.gather(gts, 1, (assigned - 1).clamp(min=0)[..., None].expand(B, A, 4))
         safe_gt = torch.where(pos[..., None], gt_of, flat_anchors[None].expand(B, A, 4))   # avoid log(0) on unused rows
@@ -175,17 +216,21 @@ class RPNHead(nn.Module):
         if self.train_cfg.pos_weight > 0:
             label_weights = torch.where(pos, label_weights.new_full((1, ), self.train_cfg.pos_weight), label_weights)
         labels = torch.where(pos, torch.zeros_like(assigned), torch.full_like(assigned, self.num_classes))
-        n_pos, n_neg = pos.sum(1), neg.sum(1)
-        num_total = (n_pos.clamp(min=1) + n_neg.clamp(min=1)).sum().to(bbox_targets.dtype)  # anchor_head.py:354-355
         # one pass over all levels: sum_l loss_l == loss on the level-concatenated tensors (same avg_factor)
-        cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
-        reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
         loss_cls = self.loss_cls(cls.reshape(-1, self.cls_out_channels), labels.reshape(-1), label_weights.reshape(-1),
                                  avg_factor=num_total)
         loss_bbox = self.loss_bbox(reg.reshape(-1, 4), (bbox_targets * posf[..., None]).reshape(-1, 4),
                                    posf[..., None].expand(B, A, 4).reshape(-1, 4), avg_factor=num_total)
-        self._last_rpn_sample = (assigned, pos, neg, inside)  # exposed for tests
         return dict(loss_rpn_cls=[loss_cls], loss_rpn_bbox=[loss_bbox])
+
+    def _fused_loss_ok(self):
+        """htd_rpn_loss covers the RPN of every HTD config: one sigmoid channel, BCE without class weights,
+        SmoothL1 on encoded deltas."""
+        lc, lb = self.loss_cls, self.loss_bbox
+        return getattr(self, 'fused_loss', True) and self.cls_out_channels == 1 and \
+            type(lc).__name__ == 'CrossEntropyLoss' and lc.use_sigmoid and lc.class_weight is None and \
+            lc.reduction == 'mean' and type(lb).__name__ == 'SmoothL1Loss' and lb.reduction == 'mean' and \
+            not getattr(self, 'reg_decoded_bbox', False)
 
     # -------------------------------------------------------------- reference-order path
     def loss_per_image(self, cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None):

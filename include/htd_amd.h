@@ -238,6 +238,16 @@ int htd_delta2bbox_clip(const float *rois, const float *deltas, const float *lim
                         int64_t rows_per_img, const float *means4, const float *stds4, float wh_ratio_clip,
                         float *out, void *stream);
 
+/* RPN loss of the whole batch in one pass (AnchorHead.loss / loss_single, dense_heads/anchor_head.py:373-488, with the
+ * targets of _get_targets_single :172-269 and bbox2delta formed on the fly).  cls [B*A] logits (one sigmoid channel),
+ * reg [B*A][4], anchors [A][4], gts [B][K][4], assigned [B][A] (MaxIoUAssigner output), pos / neg [B][A] sample masks.
+ * partial [htd_rpn_loss_partial_rows()][2] = per-block (sum BCE, sum SmoothL1) -- reduce over rows in order;
+ * grad_cls [B*A], grad_reg [B*A][4] = derivatives of those sums (scale by 1/avg_factor * loss_weight). */
+int htd_rpn_loss_partial_rows(void);
+int htd_rpn_loss(const float *cls, const float *reg, const float *anchors, const float *gts, const int64_t *assigned,
+                 const uint8_t *pos, const uint8_t *neg, int B, int A, int K, const float *means4, const float *stds4,
+                 float beta, float pos_weight, float *partial, float *grad_cls, float *grad_reg, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
  * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):

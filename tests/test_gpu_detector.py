@@ -263,15 +263,22 @@ def test_rpn_batched_loss_equals_reference_order_path(det, golden):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (k, a, b)
 
 
-def test_static_shape_train_path_matches_per_image_path(det, golden):
+@pytest.mark.parametrize('scenario', ['plain', 'no_gt_image_and_few_proposals'])
+def test_static_shape_train_path_matches_per_image_path(det, golden, scenario):
     """The production train step runs on fixed-size tensors with no host/device synchronisation
     (HTDRoIHead.forward_train_static, padded RPN proposals).  With the sampler keys made a function of the candidate
-    boxes, it must draw the same samples as the per-image-list path and give the same losses and gradients."""
+    boxes, it must draw the same samples as the per-image-list path and give the same losses and gradients.
+    Second scenario: one image without ground truth and fewer proposals than sampler slots (unused slots must not
+    leak into losses, PGraph groups or gradients)."""
     from htd_amd.core import set_randperm
     from htd_amd.core.bbox import set_sample_keys
     g = golden('detector')
     dev = torch.device('cuda:0')
     img, metas, gts, labels = inputs(g, dev)
+    saved_post = det.train_cfg.rpn_proposal.nms_post
+    if scenario != 'plain':
+        gts, labels = [gts[0], gts[1][:0]], [labels[0], labels[1][:0]]
+        det.train_cfg.rpn_proposal.nms_post = 30          # < sampler.num = 48
     coef = torch.tensor([12.9898, 78.233, 37.719, 93.989], device=dev)
 
     def box_keys(cand):
@@ -292,7 +299,10 @@ def test_static_shape_train_path_matches_per_image_path(det, golden):
         assert hasattr(det.roi_head, '_last_static')
         S0, S1 = det.roi_head._last_static
         assert int(S0.valid.sum()) > 0 and int(S1.is_pos.sum()) > 0
+        if scenario != 'plain':
+            assert int((~S0.valid).sum()) > 0 and int((~S1.valid).sum()) > 0      # unused slots really occur
     finally:
+        det.train_cfg.rpn_proposal.nms_post = saved_post
         det.roi_head.static_shapes = True
         set_sample_keys(None)
         set_randperm(lambda n, device: torch.randperm(n).to(device))
@@ -310,3 +320,39 @@ def test_static_shape_train_path_matches_per_image_path(det, golden):
         errs.append((float((g_s[n] - g_d[n]).abs().max()) / max(scale, 1e-5), n, scale))
     errs.sort(reverse=True)
     assert errs[0][0] < 2e-4, errs[:8]
+
+
+def test_fused_rpn_loss_matches_tensor_formulation(det, golden):
+    """htd_rpn_loss (targets + BCE + SmoothL1 + their derivatives in one launch) against the tensor-op formulation
+    of the same batched loss: values and gradients w.r.t. every level's cls / reg maps."""
+    from htd_amd.core.bbox import set_sample_keys
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, gts, _ = inputs(g, dev)
+    det.train()
+    rpn = det.rpn_head
+    with torch.no_grad():
+        x = det.extract_feat(img)
+        cls0, reg0 = rpn(x)
+    coef = torch.tensor([12.9898, 78.233, 37.719, 93.989], device=dev)
+    set_sample_keys(lambda cand: torch.frac(torch.sin((cand * coef).sum(-1)) * 43758.5453).abs())
+    out = {}
+    try:
+        for fused in (True, False):
+            rpn.fused_loss = fused
+            cls = [c.clone().requires_grad_() for c in cls0]
+            reg = [r.clone().requires_grad_() for r in reg0]
+            losses = rpn.loss_batched(cls, reg, gts, metas)
+            total = sum(losses['loss_rpn_cls']) + 2.0 * sum(losses['loss_rpn_bbox'])
+            total.backward()
+            out[fused] = ([float(sum(losses[k]).detach()) for k in ('loss_rpn_cls', 'loss_rpn_bbox')],
+                          [t.grad.clone() for t in cls + reg])
+    finally:
+        rpn.fused_loss = True
+        set_sample_keys(None)
+    (lf, gf), (lt, gt_) = out[True], out[False]
+    for a, b in zip(lf, lt):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (lf, lt)
+    assert lt[1] > 0
+    for a, b in zip(gf, gt_):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * max(1.0, float(b.abs().max())))
