@@ -81,6 +81,11 @@ _PROFILE = None
 _DETAIL = False
 
 
+def profiling():
+    """True while bench.py's per-call device-event timing is active (calls must then stay on one stream)."""
+    return _PROFILE is not None
+
+
 def profile_begin(detail=False):
     """detail=True keys the records by entry point AND integer arguments (layer shapes)."""
     global _PROFILE, _DETAIL

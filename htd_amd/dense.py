@@ -51,25 +51,67 @@ def register_grad_sinks(mapping):
 
 def reset_grad_sinks():
     _SINK_USED.clear()
+    _SIDE_CONSUMED.clear()
 
 
 def grad_out(like):
     """Tensor to write the gradient of `like` into: an alias of its registered flat-gradient slice, else a new one."""
+    return grad_out2(like)[0]
+
+
+def grad_out2(like):
+    """-> (tensor, is_sink)."""
     key = like.data_ptr()
     v = _GRAD_SINK.get(key)
     if v is not None and key not in _SINK_USED and v.numel() == like.numel() and torch.is_grad_enabled() is False:
         if v.shape == like.shape and v.stride() == like.stride():
             _SINK_USED.add(key)
-            return v.view_as(v)
+            return v.view_as(v), True
         if like.dim() == 4 and like.shape[2:] == (1, 1) and like.size(0) == v.size(0):
             if v.dim() == 4 and v.is_contiguous(memory_format=CL):       # TileLinear: (out,C,h,w) stored (out,h,w,C)
                 v = v.permute(0, 2, 3, 1).reshape(v.size(0), -1)
             if v.dim() == 2 and v.is_contiguous():
                 _SINK_USED.add(key)                   # Linear weight seen as a 1x1 conv (channels_last view)
-                return v.view(v.size(0), 1, 1, v.size(1)).permute(0, 3, 1, 2)
+                return v.view(v.size(0), 1, 1, v.size(1)).permute(0, 3, 1, 2), True
     if like.dim() == 4:
-        return torch.empty(like.shape, device=like.device, dtype=like.dtype, memory_format=CL)
-    return torch.empty_like(like)
+        return torch.empty(like.shape, device=like.device, dtype=like.dtype, memory_format=CL), False
+    return torch.empty_like(like), False
+
+
+# ---- weight-gradient stream --------------------------------------------------------------------------------------
+# In backward the data gradients form the critical chain; weight gradients (wgrad -> split-K sum -> BN-fold gradient ->
+# flat gradient buffer) are only needed by the optimizer.  They are queued on a second HIP stream: their small reduce /
+# fold kernels and the tail waves of the big ones then overlap with the data-gradient kernels of the main stream
+# instead of leaving CUs idle.  Rules: the side stream waits for the main stream before every launch (operands ready);
+# a result that autograd will consume on the main stream (not a flat-buffer sink, not an input of a BN fold that itself
+# runs on the side stream) makes the main stream wait at once; runner joins the streams after backward.
+# Measured (HTD-R50, B=4): 75.2 -> 74.0 ms per step, while every overlapped kernel's own duration grows (they share
+# the CUs), which blurs the per-kernel roofline timing of bench.py -- so it is opt-in: HTD_OVERLAP_WGRAD=1.
+OVERLAP_WGRAD = bool(int(__import__('os').environ.get('HTD_OVERLAP_WGRAD', '0')))
+_OVERLAP_IN_PROFILE = True
+_SIDE = {}
+_SIDE_CONSUMED = set()          # data_ptr of folded weights whose gradient is consumed by _BNFold.backward (side stream)
+
+
+def side_stream(device=None):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def mark_side_consumed(t):
+    _SIDE_CONSUMED.add(t.data_ptr())
+
+
+def join_side_stream():
+    """Main stream waits for everything queued on the weight-gradient stream (call after backward)."""
+    if _SIDE:
+        cur = torch.cuda.current_stream()
+        s = _SIDE.get(cur.device.index)
+        if s is not None:
+            cur.wait_stream(s)
 
 
 # ---- raw launches (no autograd): the building blocks of Conv2dFunction and ResStageFunction -------------------
@@ -119,15 +161,30 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
     return gx
 
 
-def _wgrad_raw(x, g, weight, stride, padding, dilation):
+def _wgrad_launch(x, g, weight, stride, padding, dilation):
     B, Ci, H, W = x.shape
     Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
-    gw = grad_out(weight)
+    gw, is_sink = grad_out2(weight)
     nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
     ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
     capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), B, H, W, Ci, Co, kh, kw, stride, padding, dilation,
               _P(ws), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
+    return gw, is_sink
+
+
+def _wgrad_raw(x, g, weight, stride, padding, dilation):
+    if not OVERLAP_WGRAD or (capi.profiling() and not _OVERLAP_IN_PROFILE):
+        return _wgrad_launch(x, g, weight, stride, padding, dilation)[0]
+    main, side = torch.cuda.current_stream(), side_stream(g.device)
+    side.wait_stream(main)
+    x.record_stream(side)
+    g.record_stream(side)
+    with torch.cuda.stream(side):
+        gw, is_sink = _wgrad_launch(x, g, weight, stride, padding, dilation)
+    if not is_sink and weight.data_ptr() not in _SIDE_CONSUMED:
+        gw.record_stream(main)
+        main.wait_stream(side)          # autograd consumes this gradient on the main stream
     return gw
 
 

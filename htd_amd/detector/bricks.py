@@ -84,6 +84,8 @@ class _BNFold(torch.autograd.Function):
         ctx.save_for_backward(w, gamma, mean, var)
         ctx.eps = float(eps)
         ctx.beta_ref = beta                               # only its address is used (gradient sink lookup)
+        from .. import dense
+        dense.mark_side_consumed(wf)                      # its gradient is read by backward() below, on the side stream
         return wf, bf
 
     @staticmethod
@@ -95,12 +97,28 @@ class _BNFold(torch.autograd.Function):
         K = w.numel() // Co
         gwf = gwf.contiguous(memory_format=CL)
         gbf = gbf.contiguous()
-        from ..dense import grad_out
-        gw, gg, gb = grad_out(w), grad_out(gamma), grad_out(ctx.beta_ref)
-        capi.call('htd_bn_fold_bwd', capi.ptr(w), capi.ptr(gamma), capi.ptr(mean), capi.ptr(var), ctx.eps,
-                  capi.ptr(gwf), capi.ptr(gbf), capi.ptr(gw), capi.ptr(gg), capi.ptr(gb), Co, K,
-                  capi.current_stream_ptr())
-        return gw, gg, gb, None, None, None
+        from .. import dense
+
+        def launch():
+            (gw, s1), (gg, s2), (gb, s3) = dense.grad_out2(w), dense.grad_out2(gamma), dense.grad_out2(ctx.beta_ref)
+            capi.call('htd_bn_fold_bwd', capi.ptr(w), capi.ptr(gamma), capi.ptr(mean), capi.ptr(var), ctx.eps,
+                      capi.ptr(gwf), capi.ptr(gbf), capi.ptr(gw), capi.ptr(gg), capi.ptr(gb), Co, K,
+                      capi.current_stream_ptr())
+            return (gw, gg, gb), s1 and s2 and s3
+        if not dense.OVERLAP_WGRAD or (capi.profiling() and not dense._OVERLAP_IN_PROFILE):
+            return launch()[0] + (None, None, None)
+        # weight-gradient stream (dense.py): gwf was produced there; gbf comes from the main stream
+        main, side = torch.cuda.current_stream(), dense.side_stream(gwf.device)
+        side.wait_stream(main)
+        gwf.record_stream(side)
+        gbf.record_stream(side)
+        with torch.cuda.stream(side):
+            outs, all_sinks = launch()
+        if not all_sinks:
+            for t in outs:
+                t.record_stream(main)
+            main.wait_stream(side)
+        return outs + (None, None, None)
 
 
 def frozen_bn_fold(conv_weight, bn):

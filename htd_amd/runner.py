@@ -139,6 +139,8 @@ class GradientExchange:
         chunk = self.flat.grad[lo:hi]
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
+            if dense._SIDE:
+                self.stream.wait_stream(dense.side_stream(chunk.device))
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(chunk, group=self.group)
         else:
@@ -147,6 +149,7 @@ class GradientExchange:
     def finish_step(self):
         """Reduce the remaining buckets (parameters that got no gradient this step contribute zeros), still in
         bucket order, then join the side stream."""
+        dense.join_side_stream()         # weight gradients are produced on dense's second stream
         self.flat.collect()              # every .grad is its flat slice again (unused parameters: zeros)
         if not self.enabled:
             return

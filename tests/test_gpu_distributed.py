@@ -72,3 +72,37 @@ def test_trainer_world2_on_gpu():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+@pytest.mark.gpu
+def test_weight_gradient_stream_gives_identical_step():
+    """dense.OVERLAP_WGRAD queues weight gradients on a second HIP stream; one optimizer step must leave the parameters of
+    the single-stream run (same kernels, same order per tensor)."""
+    import copy
+    from htd_amd import dense
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.runner import Trainer, synthetic_batch
+    dev = torch.device('cuda:0')
+    cfg = htd_config(50)
+    cfg.train_cfg.rpn_proposal.update(nms_pre=300, nms_post=200, max_num=200)
+    for r in cfg.train_cfg.rcnn:
+        r.sampler.num = 64
+    torch.manual_seed(0)
+    base = build_htd_detector(cfg=cfg).to(dev).train()
+    data = synthetic_batch(2, 256, 320, 311, device=dev, seed=3)
+    flats = []
+    saved = dense.OVERLAP_WGRAD
+    try:
+        for overlap in (False, True):
+            dense.OVERLAP_WGRAD = overlap
+            model = copy.deepcopy(base)
+            tr = Trainer(model, lr=0.01)
+            torch.manual_seed(11)
+            tr.train_step(data)
+            torch.cuda.synchronize()
+            flats.append(tr.flat.flat.clone())
+    finally:
+        dense.OVERLAP_WGRAD = saved
+    assert torch.isfinite(flats[0]).all()
+    # float atomics of the RoIAlign backward make the gradients reproducible to rounding only
+    torch.testing.assert_close(flats[0], flats[1], rtol=0, atol=1e-6)
