@@ -113,9 +113,16 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(data)
     sync()
-    capi.profile_begin(detail=args.profile_detail)
+    # live device-event timing of the matrix-core entry points (the roofline kernels); every entry point with
+    # --profile-kernels (costs ~6 % of the step)
+    everything = args.profile_kernels or args.profile_detail
+    capi.profile_begin(detail=args.profile_detail, only=None if everything else (
+        'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_bwd_weight', 'htd_bgemm_nt'))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # kernel events on every 4th step of the timed region (all steps with --profile-kernels): their queue
+        # barriers cost ~2 ms per timed step, which would otherwise be charged to the throughput being measured
+        capi.profile_pause(not everything and i % 4 != 0)
         trainer.train_step(data)
     sync()
     elapsed = time.perf_counter() - t0
