@@ -388,7 +388,7 @@ Cfg choose(int Co, int Ntot, int64_t K)
     c.mt = (int)htd::ceil_div(Co, c.bm);
     c.nt = (int)htd::ceil_div(Ntot, c.bn);
     const int64_t slices = htd::ceil_div(K, BKW);
-    int64_t want = htd::ceil_div(1536, (int64_t)c.mt * c.nt);       // ~6 workgroups per CU (measured: oversubscription pays)
+    int64_t want = htd::ceil_div(2304, (int64_t)c.mt * c.nt);       // ~9 workgroups per CU (measured 768..6144: flat from 2304)
     const int64_t tiles = (int64_t)c.mt * c.nt;
     int64_t cap = std::max<int64_t>(1, slices / 20);                 // at least 20 slices (640 pixels) per split ...
     if (tiles * cap < 256)                                           // ... unless that leaves CUs idle (short reductions)
