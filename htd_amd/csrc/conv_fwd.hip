@@ -18,7 +18,6 @@
 // (forward conv of gy with spatially flipped, channel-transposed weights; a stride-s data gradient is split into
 // s*s dense sub-problems, one per output parity class, through an explicit tap table).
 #include <algorithm>
-#include <cstdlib>
 
 #include "common.h"
 
@@ -351,9 +350,10 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     // too few big tiles to balance 256 CUs
     int bm = 128;
     int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
-    if (bn == 128 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 128) < 768) bn = 64;
-    if (bn == 64 && p.Co >= 64 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 64) < 1024 && p.M >= 2048) bm = 64;
-    if (const char *e = getenv("HTD_CONV_TILE")) { if (atoi(e) == 128) { bm = 128; bn = 128; } }
+    // thresholds swept on the HTD-R50 layer set (768..5000 / 600..6000): below ~8 big tiles per CU the finer tiles'
+    // better balance across 256 CUs outweighs their extra L2 traffic
+    if (bn == 128 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 128) < 2200) bn = 64;
+    if (bn == 64 && p.Co >= 64 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 64) < 4400 && p.M >= 2048) bm = 64;
     p.mt = (int)htd::ceil_div(p.M, bm);
     p.nt = (int)htd::ceil_div(p.Co, bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;
