@@ -66,7 +66,11 @@ __global__ __launch_bounds__(256) void assign_pass1_kernel(AssignParams p)
             if (v > best) { best = v; arg = k0 + k; }
             if (p.low_quality) {
                 const float m = htd::wave_max(v);
-                if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(p.gt_max + (int64_t)b * p.K + k0 + k, __float_as_uint(m));
+                // plain read first: the stored maximum only grows, so a wave whose value cannot raise it skips the
+                // atomic (thousands of waves per gt would otherwise serialise on B*K addresses)
+                unsigned *dst = p.gt_max + (int64_t)b * p.K + k0 + k;
+                if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) > __atomic_load_n(dst, __ATOMIC_RELAXED))
+                    atomicMax(dst, __float_as_uint(m));
             }
         }
     }

@@ -285,6 +285,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         }
 }
 
+// out[c] = sum_k ws[k][c] for FEW columns and MANY partial rows (second stage of the bias gradient: n = C <= 2048,
+// rows = up to 512 block partials).  splitk_reduce_kernel would walk the rows serially in one or two workgroups;
+// here a workgroup takes 16 columns and spreads the rows over 16 thread groups, folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restrict__ ws, float *__restrict__ out, int n,
+                                                          int rows)
+{
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + col;
+    float s = 0.f;
+    if (c < n)
+        for (int k = grp; k < rows; k += 16) s += ws[(int64_t)k * n + c];
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && c < n) {
+        float t = red[0][col];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][col];
+        out[c] = t;
+    }
+}
+
 // column sums of a [rows][C] matrix (bias gradient), optionally fused with the ReLU-mask of the incoming
 // gradient:  gm = g * (y > 0) written back, gbias[c] = sum_rows gm.  Deterministic two-stage reduction.
 __global__ __launch_bounds__(256) void colsum_mask_kernel(const float *__restrict__ g, const float *__restrict__ y,
@@ -465,7 +487,7 @@ extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm
     else
         hipLaunchKernelGGL(colsum_mask_kernel, dim3(nb, (unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s, g, y, gm,
                            partial, rows, C, rpb);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s,
-                       (const float *)partial, gbias, (int64_t)C, nb);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)htd::ceil_div(C, 16)), dim3(256), 0, s,
+                       (const float *)partial, gbias, C, nb);
     return htd::check_launch("bias_grad");
 }
