@@ -337,7 +337,8 @@ def _max_iou_assign_device(a, boxes, box_valid, gts, gt_valid):
     gv = gt_valid.to(torch.uint8).contiguous()
     assigned = torch.empty(B, A, dtype=torch.int64, device=boxes.device)
     max_ov = torch.empty(B, A, dtype=torch.float32, device=boxes.device)
-    ws = torch.empty(B * K, dtype=torch.int32, device=boxes.device) if a.match_low_quality else None
+    ws = torch.empty(capi.lib().htd_max_iou_assign_workspace_bytes(B, A, K) // 4, dtype=torch.float32,
+                     device=boxes.device) if a.match_low_quality else None
     capi.call('htd_max_iou_assign', capi.ptr(boxes), int(shared), capi.ptr(bv), capi.ptr(gts), capi.ptr(gv), B, A, K,
               float(a.pos_iou_thr), float(a.neg_iou_thr), float(a.min_pos_iou), int(bool(a.match_low_quality)),
               capi.ptr(assigned), capi.ptr(max_ov), capi.ptr(ws), capi.current_stream_ptr())

@@ -18,7 +18,8 @@ struct AssignParams {
     int low_quality;
     int64_t *assigned;           // [B][A]
     float *max_ov;               // [B][A]
-    unsigned *gt_max;            // [B][K] float bits (IoU >= 0), zero-initialised by pass 1's caller
+    float *gt_max;               // [B][K] best IoU of each gt over the valid boxes (-1: none)
+    float *block_max;            // [B][blocks][K] per-workgroup maxima of pass 1
 };
 
 __device__ __forceinline__ float iou_of(float4 g, float ga, float4 b, float ba)
@@ -32,13 +33,13 @@ __device__ __forceinline__ float iou_of(float4 g, float ga, float4 b, float ba)
 
 constexpr int GT_CHUNK = 128;
 
-// pass 1: per box the best gt (first maximum), thresholds; per gt the best IoU over the valid boxes (wave max -> one
-// integer atomicMax per wave: IoUs are non-negative, so their bit patterns order like the floats).
+// pass 1: per box the best gt (first maximum), thresholds; per gt this workgroup's best IoU over its valid boxes.
 __global__ __launch_bounds__(256) void assign_pass1_kernel(AssignParams p)
 {
     __shared__ float4 sg[GT_CHUNK];
     __shared__ float sga[GT_CHUNK];
     __shared__ int sok[GT_CHUNK];
+    __shared__ float swave[4][GT_CHUNK];
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
     const bool in = a < p.A;
@@ -66,11 +67,16 @@ __global__ __launch_bounds__(256) void assign_pass1_kernel(AssignParams p)
             if (v > best) { best = v; arg = k0 + k; }
             if (p.low_quality) {
                 const float m = htd::wave_max(v);
-                // plain read first: the stored maximum only grows, so a wave whose value cannot raise it skips the
-                // atomic (thousands of waves per gt would otherwise serialise on B*K addresses)
-                unsigned *dst = p.gt_max + (int64_t)b * p.K + k0 + k;
-                if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) > __atomic_load_n(dst, __ATOMIC_RELAXED))
-                    atomicMax(dst, __float_as_uint(m));
+                if ((threadIdx.x & 63) == 0) swave[threadIdx.x >> 6][k] = m;
+            }
+        }
+        if (p.low_quality) {                 // this block's best IoU per gt of the chunk (no atomics: B*K hot addresses)
+            __syncthreads();
+            if (threadIdx.x < kn) {
+                const float m = sok[threadIdx.x]
+                    ? fmaxf(fmaxf(swave[0][threadIdx.x], swave[1][threadIdx.x]), fmaxf(swave[2][threadIdx.x], swave[3][threadIdx.x]))
+                    : -1.f;
+                p.block_max[((int64_t)b * gridDim.x + blockIdx.x) * p.K + k0 + threadIdx.x] = m;
             }
         }
     }
@@ -82,6 +88,23 @@ __global__ __launch_bounds__(256) void assign_pass1_kernel(AssignParams p)
     if (!bvalid) out = -1;
     p.assigned[(int64_t)b * p.A + a] = out;
     p.max_ov[(int64_t)b * p.A + a] = (bvalid && any_gt) ? fmaxf(best, 0.f) : 0.f;
+}
+
+// best IoU of every gt over all workgroups of its image
+__global__ __launch_bounds__(256) void assign_gtmax_kernel(AssignParams p, int blocks)
+{
+    __shared__ float red[256];
+    const int64_t bk = blockIdx.x;                       // b * K + k
+    const int64_t b = bk / p.K, k = bk - b * p.K;
+    float m = -1.f;
+    for (int i = threadIdx.x; i < blocks; i += 256) m = fmaxf(m, p.block_max[(b * blocks + i) * p.K + k]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.gt_max[bk] = red[0];
 }
 
 // pass 2 (match_low_quality, gt_max_assign_all: max_iou_assigner.py:187-199): every box whose IoU with gt k equals
@@ -107,7 +130,7 @@ __global__ __launch_bounds__(256) void assign_pass2_kernel(AssignParams p)
             const float4 g = *reinterpret_cast<const float4 *>(p.gts + gi * 4);
             sg[threadIdx.x] = g;
             sga[threadIdx.x] = (g.z - g.x) * (g.w - g.y);
-            const float m = __uint_as_float(p.gt_max[gi]);
+            const float m = p.gt_max[gi];
             smax[threadIdx.x] = (p.gt_valid[gi] && m >= p.min_pos) ? m : -1.f;
         }
         __syncthreads();
@@ -123,7 +146,13 @@ __global__ __launch_bounds__(256) void assign_pass2_kernel(AssignParams p)
 // MaxIoUAssigner.assign_wrt_overlaps (core/bbox/assigners/max_iou_assigner.py:124-212) with gt_max_assign_all for B
 // images in one or two launches.  boxes [B][A][4] (box_shared = 0) or [A][4] shared by all images (box_shared = 1);
 // box_valid [B][A]; gts [B][K][4] zero-padded with gt_valid [B][K].  assigned [B][A] int64: -1 ignore / invalid box,
-// 0 negative, k+1 matched to gt k; max_overlaps [B][A].  workspace: B*K*4 bytes when match_low_quality.
+// 0 negative, k+1 matched to gt k; max_overlaps [B][A].  workspace: htd_max_iou_assign_workspace_bytes when
+// match_low_quality.
+extern "C" int64_t htd_max_iou_assign_workspace_bytes(int B, int A, int K)
+{
+    return ((int64_t)B * K + (int64_t)B * htd::ceil_div(A, 256) * K) * 4;
+}
+
 extern "C" int htd_max_iou_assign(const float *boxes, int box_shared, const uint8_t *box_valid, const float *gts,
                                   const uint8_t *gt_valid, int B, int A, int K, float pos_iou_thr, float neg_iou_thr,
                                   float min_pos_iou, int match_low_quality, int64_t *assigned, float *max_overlaps,
@@ -132,20 +161,21 @@ extern "C" int htd_max_iou_assign(const float *boxes, int box_shared, const uint
     HTD_REQUIRE(B >= 0 && A >= 0 && K >= 1, "max_iou_assign: bad sizes B=%d A=%d K=%d", B, A, K);
     if (B == 0 || A == 0) return HTD_OK;
     HTD_REQUIRE(boxes && box_valid && gts && gt_valid && assigned && max_overlaps, "max_iou_assign: null pointer");
-    HTD_REQUIRE(!match_low_quality || workspace, "max_iou_assign: match_low_quality needs a B*K*4 byte workspace");
+    HTD_REQUIRE(!match_low_quality || workspace, "max_iou_assign: match_low_quality needs a workspace");
     AssignParams p{};
     p.boxes = boxes; p.box_bstride = box_shared ? 0 : (int64_t)A * 4; p.box_valid = box_valid;
     p.gts = gts; p.gt_valid = gt_valid; p.A = A; p.K = K;
     p.pos_thr = pos_iou_thr; p.neg_thr = neg_iou_thr; p.min_pos = min_pos_iou; p.low_quality = match_low_quality;
-    p.assigned = assigned; p.max_ov = max_overlaps; p.gt_max = (unsigned *)workspace;
+    p.assigned = assigned; p.max_ov = max_overlaps;
+    p.gt_max = (float *)workspace;
+    p.block_max = p.gt_max + (int64_t)B * K;
     hipStream_t s = (hipStream_t)stream;
-    if (match_low_quality && hipMemsetAsync(workspace, 0, (size_t)B * K * 4, s) != hipSuccess) {
-        htd::set_error("max_iou_assign: memset failed");
-        return HTD_ERR_LAUNCH;
-    }
     const dim3 grid((unsigned)htd::ceil_div(A, 256), (unsigned)B);
     hipLaunchKernelGGL(assign_pass1_kernel, grid, dim3(256), 0, s, p);
-    if (match_low_quality) hipLaunchKernelGGL(assign_pass2_kernel, grid, dim3(256), 0, s, p);
+    if (match_low_quality) {
+        hipLaunchKernelGGL(assign_gtmax_kernel, dim3((unsigned)(B * K)), dim3(256), 0, s, p, (int)grid.x);
+        hipLaunchKernelGGL(assign_pass2_kernel, grid, dim3(256), 0, s, p);
+    }
     return htd::check_launch("max_iou_assign");
 }
 

@@ -217,9 +217,11 @@ int htd_bn_fold_bwd(const float *w, const float *gamma, const float *mean, const
  *   boxes [B][A][4] (box_shared = 0) or [A][4] shared by every image (RPN anchors); box_valid [B][A];
  *   gts [B][K][4] zero padded, gt_valid [B][K].
  *   assigned [B][A] int64: -1 ignore / invalid box, 0 negative, k+1 matched to gt k;  max_overlaps [B][A].
- *   match_low_quality follows gt_max_assign_all = True (:187-199).  workspace: B*K*4 bytes when match_low_quality.
+ *   match_low_quality follows gt_max_assign_all = True (:187-199); it needs a workspace of
+ *   htd_max_iou_assign_workspace_bytes(B, A, K) bytes.
  * IoU arithmetic is the reference's fp32 expression evaluated without FMA contraction: assignments are bit-exact.
  * ---------------------------------------------------------------------------------- */
+int64_t htd_max_iou_assign_workspace_bytes(int B, int A, int K);
 int htd_max_iou_assign(const float *boxes, int box_shared, const uint8_t *box_valid, const float *gts,
                        const uint8_t *gt_valid, int B, int A, int K, float pos_iou_thr, float neg_iou_thr,
                        float min_pos_iou, int match_low_quality, int64_t *assigned, float *max_overlaps,
