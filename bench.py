@@ -143,14 +143,14 @@ def main():
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:
         tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
-        cls = 'conv_wgrad' if 'bwd_weight' in roof['kernel'] else 'conv_igemm'
-        if roof and 'conv2d' in roof['kernel']:
+        cls = 'conv_wgrad' if 'wgrad' in roof['kernel'] else 'conv_igemm'
+        if roof and 'conv' in roof['kernel']:
             roof['traffic'] = tr[cls]['hbm_bytes_per_launch_corrected']
             roof['traffic_unit'] = 'bytes/launch (rocprofv3 PMC, profiles/r01_hbm_traffic.json)'
     except Exception:
         pass
     if args.profile_kernels or args.profile_detail:
-        for name, (n, tot_ms, kind, work) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:60]:
+        for name, (n, tot_ms, kind, work, _) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:60]:
             rate = (work / (tot_ms * 1e-3) / 1e12) if (kind and tot_ms > 0) else 0.0
             print(f'# {name:64s} calls={n:5d} total={tot_ms:9.3f} ms  {kind or ""} {rate:8.2f} T/s', file=sys.stderr)
     out = {

@@ -108,7 +108,7 @@ def profile_begin(detail=False, only=None):
 
 
 def profile_end():
-    """-> {name: (calls, total_ms, work_kind, total_work)}; synchronises the device."""
+    """-> {name: (calls, total_ms, work_kind, total_work, total_algorithmic_bytes)}; synchronises the device."""
     global _PROFILE
     import torch
     prof, _PROFILE = _PROFILE, None
@@ -118,7 +118,7 @@ def profile_end():
     out = {}
     for name, rec in prof.items():
         ms = sum(a.elapsed_time(b) for a, b in rec['events'])
-        out[name] = (len(rec['events']), ms, rec['kind'], rec['work'])
+        out[name] = (len(rec['events']), ms, rec['kind'], rec['work'], rec['bytes'])
     return out
 
 
@@ -131,7 +131,7 @@ def call(name, *args, work=None):
     key = name
     if _DETAIL:
         key = name + '(' + ','.join(str(a) for a in args if isinstance(a, int) and not isinstance(a, bool)) + ')'
-    rec = _PROFILE.setdefault(key, dict(events=[], kind=None, work=0.0))
+    rec = _PROFILE.setdefault(key, dict(events=[], kind=None, work=0.0, bytes=0.0))
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     status = fn(*args)
@@ -140,6 +140,8 @@ def call(name, *args, work=None):
     if work is not None:
         rec['kind'] = work[0]
         rec['work'] += float(work[1])
+        if len(work) > 2:
+            rec['bytes'] += float(work[2])              # algorithmic HBM bytes of the call (operands once)
     check(status, name)
 
 

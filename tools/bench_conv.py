@@ -51,7 +51,7 @@ def device_rates(x, w, g, s, p, flop, n=8):
     prof = capi.profile_end()
     out = []
     for k in ('htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_bwd_weight'):
-        calls, ms, _, _ = prof[k]
+        calls, ms = prof[k][:2]
         out.append(flop / (ms / calls * 1e-3) / 1e12)
     return out
 
