@@ -25,6 +25,7 @@ __device__ __forceinline__ float4 keep4(bool ok, float4 v)
 struct WgradParams {
     const float *x, *gy;
     float *out;            // gw if splits == 1 else workspace [splits][Co][Ntot]
+    float *bias_out;       // NULL, or column sums of gy: gbias if splits == 1 else workspace [splits][Co]
     int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo;
     int64_t K;             // B*Ho*Wo
     int Ntot;              // kh*kw*Ci
@@ -171,11 +172,19 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
             }
         }
     };
+    // bias gradient = column sums of gy: the tiles of the first N column already stage every gy element of their
+    // (M tile, K split) once, so they add it up on the way into LDS (saves a separate pass over gy per layer)
+    const bool do_bias = p.bias_out != nullptr && tile_n == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_slice = [&](int buf) {
         float *la = lds[buf], *lb = lds[buf] + BKW * SA;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            if ((BKW * VA) % 256 == 0 || tid + i * 256 < BKW * VA) *reinterpret_cast<float4 *>(la + a_row[i] * SA + a_col[i]) = keep4((ra_ok >> i) & 1u, ra[i]);
+            if ((BKW * VA) % 256 == 0 || tid + i * 256 < BKW * VA) {
+                const float4 v = keep4((ra_ok >> i) & 1u, ra[i]);
+                *reinterpret_cast<float4 *>(la + a_row[i] * SA + a_col[i]) = v;
+                if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+            }
 #pragma unroll
         for (int i = 0; i < PB; ++i)
             if ((BKW * VB) % 256 == 0 || tid + i * 256 < BKW * VB) *reinterpret_cast<float4 *>(lb + b_row[i] * SB + b_col[i]) = keep4((rb_ok >> i) & 1u, rb[i]);
@@ -241,6 +250,26 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
         }
     }
 
+    if (do_bias) {          // threads sharing a column quad (tid % VA) fold their row partials in a fixed order
+        static_assert(256 % VA == 0, "column quads repeat every VA threads");
+        __syncthreads();
+        float4 *red = reinterpret_cast<float4 *>(&lds[0][0]);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < VA) {
+            float4 t = red[tid];
+            for (int r = 1; r < 256 / VA; ++r) {
+                const float4 v = red[r * VA + tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            float *dst = p.bias_out + (int64_t)split * p.Co;
+            const int m = m0 + tid * 4;
+            if (m < p.Co) dst[m] = t.x;
+            if (m + 1 < p.Co) dst[m + 1] = t.y;
+            if (m + 2 < p.Co) dst[m + 2] = t.z;
+            if (m + 3 < p.Co) dst[m + 3] = t.w;
+        }
+    }
     float *out = p.out + (int64_t)split * p.Co * p.Ntot;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -257,8 +286,16 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
-                                                            int64_t n, int splits)
+                                                            int64_t n, int splits, const float *__restrict__ ws2 = nullptr,
+                                                            float *__restrict__ out2 = nullptr, int n2 = 0)
 {
+    // a second, small set of partials (bias gradient [splits][n2]) rides along in the last workgroup
+    if (out2 && blockIdx.x == gridDim.x - 1)
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += ws2[(int64_t)k * n2 + i];
+            out2[i] = s;
+        }
     // out[i] = sum_k ws[k][i] in fixed order; float4 lanes, four partial slabs in flight per thread
     const int64_t n4 = (n & 3) == 0 ? (n >> 2) : 0;      // slabs are 16-byte aligned only when n % 4 == 0
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -325,7 +362,7 @@ __global__ __launch_bounds__(256) void colsum_mask_kernel(const float *__restric
         }
         s += v;
     }
-    partial[(int64_t)blockIdx.x * C + c] = s;
+    if (partial) partial[(int64_t)blockIdx.x * C + c] = s;
 }
 
 // float4 version for C % 4 == 0: a block's 256 threads cover R = 256 / (C/4) rows per iteration with 16-byte
@@ -376,6 +413,7 @@ __global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__res
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
+    if (!partial) return;                                       // mask-only call: no column sums wanted
     red[threadIdx.x] = s;
     __syncthreads();
     if (rsub == 0) {
@@ -429,11 +467,13 @@ extern "C" int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci,
     const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
     const Cfg c = choose(Co, kh * kw * Ci, (int64_t)B * Ho * Wo);
-    return (int64_t)c.splits * Co * kh * kw * Ci * 4 + 256;
+    return (int64_t)c.splits * Co * (kh * kw * Ci + 1) * 4 + 256;      // weight partials + bias partials
 }
 
-extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, int B, int H, int W, int Ci, int Co,
-                                     int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream)
+// gbias (may be NULL): also returns the bias gradient, column sums of gy, accumulated by the same kernel.
+extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W,
+                                     int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
+                                     void *stream)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_bwd_weight: bad sizes");
@@ -453,6 +493,8 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     p.mt = c.mt; p.nt = c.nt; p.splits = c.splits;
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
     p.out = c.splits == 1 ? gw : (float *)workspace;
+    float *bias_partial = (float *)workspace + (int64_t)c.splits * Co * p.Ntot;
+    p.bias_out = !gbias ? nullptr : (c.splits == 1 ? gbias : bias_partial);
     hipStream_t s = (hipStream_t)stream;
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
     dim3 grid((unsigned)(c.mt * c.nt * c.splits));
@@ -466,7 +508,7 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         const int64_t n = (int64_t)Co * p.Ntot;
         const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)workspace, gw, n,
-                           c.splits);
+                           c.splits, (const float *)(gbias ? bias_partial : nullptr), gbias, Co);
     }
     return htd::check_launch("conv2d_bwd_weight");
 }
@@ -476,18 +518,19 @@ extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm
                                        void *workspace, void *stream)
 {
     HTD_REQUIRE(rows >= 0 && C > 0, "bias_grad: bad sizes");
-    HTD_REQUIRE(g && gbias && workspace && (!y || gm), "bias_grad: null pointer");
+    HTD_REQUIRE(g && (gbias || y) && (!gbias || workspace) && (!y || gm), "bias_grad: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(512, htd::ceil_div(rows, 64)));
     const int64_t rpb = htd::ceil_div(std::max<int64_t>(rows, 1), nb);
-    float *partial = (float *)workspace;
+    float *partial = gbias ? (float *)workspace : nullptr;          // gbias == NULL: ReLU mask only
     if ((C & 3) == 0 && (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gm | (uintptr_t)partial) & 15) == 0)
         hipLaunchKernelGGL(colsum_mask_vec_kernel, dim3(nb, (unsigned)htd::ceil_div(C / 4, 256)), dim3(256), 0, s, g, y,
                            gm, partial, rows, C, rpb);
     else
         hipLaunchKernelGGL(colsum_mask_kernel, dim3(nb, (unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s, g, y, gm,
                            partial, rows, C, rpb);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)htd::ceil_div(C, 16)), dim3(256), 0, s,
-                       (const float *)partial, gbias, C, nb);
+    if (gbias)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)htd::ceil_div(C, 16)), dim3(256), 0, s,
+                           (const float *)partial, gbias, C, nb);
     return htd::check_launch("bias_grad");
 }

@@ -77,7 +77,7 @@ class DeformConv2dFunction(Function):
             gw = torch.empty((Co, C, kh, kw), device=gy.device, dtype=gy.dtype, memory_format=CL)
             nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(1, M, 1, K, Co, 1, 1, 1, 0, 1)
             ws = torch.empty(nbytes // 4 + 1, device=gy.device, dtype=gy.dtype)
-            capi.call('htd_conv2d_bwd_weight', _P(cols), _P(gy), _P(gw), 1, M, 1, K, Co, 1, 1, 1, 0, 1, _P(ws), _S(),
+            capi.call('htd_conv2d_bwd_weight', _P(cols), _P(gy), _P(gw), None, 1, M, 1, K, Co, 1, 1, 1, 0, 1, _P(ws), _S(),
                       work=('flop', 2.0 * M * K * Co))
         return gx, goff, gmask, gw, None, None, None, None
 

@@ -141,6 +141,15 @@ def _colsum_raw(g, y=None, bias=None):
     return gm, gb
 
 
+def _mask_raw(g, y):
+    """g * (y > 0): the ReLU backward alone (the bias gradient of the layer comes out of its wgrad launch)."""
+    B, Co, Ho, Wo = g.shape
+    gm = torch.empty_like(g, memory_format=CL)
+    capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm), None, B * Ho * Wo, Co, None, _S(),
+              work=('byte', 12.0 * B * Ho * Wo * Co))
+    return gm
+
+
 def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, accum=None):
     """Data gradient of conv2d(x, weight) for gy = g, optionally + accum and masked by (mask_src > 0)."""
     B, Ci, H, W = x_shape
@@ -162,32 +171,39 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
     return gx
 
 
-def _wgrad_launch(x, g, weight, stride, padding, dilation):
+def _wgrad_launch(x, g, weight, stride, padding, dilation, bias):
     B, Ci, H, W = x.shape
     Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
-    gw, is_sink = grad_out2(weight)
+    gw, sink_w = grad_out2(weight)
+    gb, sink_b = (None, True)
+    if bias is not None:            # True: bias gradient wanted, no parameter to look a sink up for
+        gb, sink_b = grad_out2(bias) if torch.is_tensor(bias) else (torch.empty(Co, device=g.device, dtype=g.dtype), False)
     nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
     ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
-    capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), B, H, W, Ci, Co, kh, kw, stride, padding, dilation,
-              _P(ws), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
-                                  4.0 * (x.numel() + g.numel() + gw.numel())))
-    return gw, is_sink
+    capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, stride, padding,
+              dilation, _P(ws), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
+                                            4.0 * (x.numel() + g.numel() + gw.numel())))
+    return gw, gb, sink_w and sink_b
 
 
-def _wgrad_raw(x, g, weight, stride, padding, dilation):
+def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None):
+    """-> (gw, gbias); gbias = column sums of g from the same launch when `bias` is given (the bias tensor, whose flat
+    gradient slice is then written in place, or True), else None."""
     if not OVERLAP_WGRAD or (capi.profiling() and not _OVERLAP_IN_PROFILE):
-        return _wgrad_launch(x, g, weight, stride, padding, dilation)[0]
+        return _wgrad_launch(x, g, weight, stride, padding, dilation, bias)[:2]
     main, side = torch.cuda.current_stream(), side_stream(g.device)
     side.wait_stream(main)
     x.record_stream(side)
     g.record_stream(side)
     with torch.cuda.stream(side):
-        gw, is_sink = _wgrad_launch(x, g, weight, stride, padding, dilation)
-    if not is_sink and weight.data_ptr() not in _SIDE_CONSUMED:
+        gw, gb, sinks = _wgrad_launch(x, g, weight, stride, padding, dilation, bias)
+    if not sinks and weight.data_ptr() not in _SIDE_CONSUMED:
         gw.record_stream(main)
-        main.wait_stream(side)          # autograd consumes this gradient on the main stream
-    return gw
+        if gb is not None:
+            gb.record_stream(main)
+        main.wait_stream(side)          # autograd consumes these gradients on the main stream
+    return gw, gb
 
 
 class Conv2dFunction(Function):
@@ -211,11 +227,19 @@ class Conv2dFunction(Function):
         stride, padding, dilation, relu, has_bias, has_res = ctx.cfg
         g = g.contiguous(memory_format=CL)
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
-        gb = None
-        if relu or (has_bias and need_b):
-            g, gb = _colsum_raw(g, y if relu else None, ctx.bias_ref if (has_bias and need_b) else None)
+        gb = gw = None
+        want_b = has_bias and need_b
+        # the bias gradient is a by-product of the wgrad launch; without a weight gradient: stand-alone column sums
+        if relu:
+            if want_b and not need_w:
+                g, gb = _colsum_raw(g, y, ctx.bias_ref)
+            else:
+                g = _mask_raw(g, y)
+        elif want_b and not need_w:
+            gb = _colsum_raw(g, None, ctx.bias_ref)[1]
         gx = _dgrad_raw(g, weight, x.shape, stride, padding, dilation) if need_x else None
-        gw = _wgrad_raw(x, g, weight, stride, padding, dilation) if need_w else None
+        if need_w:
+            gw, gb = _wgrad_raw(x, g, weight, stride, padding, dilation, ctx.bias_ref if want_b else None)
         return gx, gw, (gb if (has_bias and need_b) else None), (g if (has_res and need_r) else None), None, None, \
             None, None
 
@@ -224,8 +248,8 @@ class ResStageFunction(Function):
     """A run of bottleneck blocks (one ResLayer, resnet.py:95-300 / res_layer.py:5-102) with frozen-BN-folded
     weights as ONE autograd node.  Forward is the same four fused convolutions per block as the per-layer path.
     The hand-written backward keeps the gradient chain inside the data-gradient epilogues:
-      * the ReLU mask of each internal activation is applied by the dgrad that produces its gradient (mask_src), so
-        only a read-only column sum remains for the bias gradient (instead of read g, read y, write g*mask);
+      * the ReLU mask of each internal activation is applied by the dgrad that produces its gradient (mask_src) and
+        the bias gradients come out of the wgrad launches: no separate pass over any gradient map;
       * the identity / downsample branch joins through `accum` in the conv1 dgrad epilogue (no separate add);
       * blocks after the first hand their predecessor a gradient already masked by the predecessor's output ReLU.
     args: x, n_blocks, strides (tuple), dilation, has_ds (tuple of bool), then per block w1,b1,w2,b2,w3,b3[,wd,bd]."""
@@ -275,25 +299,32 @@ class ResStageFunction(Function):
             pneed = need[4 + k:4 + k + (8 if ds else 6)]
             first = i == 0
             need_x = need[0] if first else True
-            gm3, gb3 = _colsum_raw(g, None if premasked else out)
+            # bias gradients are by-products of the wgrad launches (column sums of the staged gy tiles); a conv whose
+            # weight needs no gradient falls back to stand-alone column sums
+            gm3 = g if premasked else _mask_raw(g, out)
+            gb3 = None
             if pneed[4]:
-                grads[k + 4] = _wgrad_raw(h2, gm3, w3, 1, 0, 1)
+                grads[k + 4], gb3 = _wgrad_raw(h2, gm3, w3, 1, 0, 1, True if (pneed[5] or (ds and pneed[7])) else None)
+            elif pneed[5] or (ds and pneed[7]):
+                gb3 = _colsum_raw(gm3)[1]
             grads[k + 5] = gb3 if pneed[5] else None
             gm2 = _dgrad_raw(gm3, w3, h2.shape, 1, 0, 1, mask_src=h2)
-            _, gb2 = _colsum_raw(gm2)
             if pneed[2]:
-                grads[k + 2] = _wgrad_raw(h1, gm2, w2, stride, dilation, dilation)
+                grads[k + 2], gb2 = _wgrad_raw(h1, gm2, w2, stride, dilation, dilation, True if pneed[3] else None)
+            else:
+                gb2 = _colsum_raw(gm2)[1] if pneed[3] else None
             grads[k + 3] = gb2 if pneed[3] else None
             gm1 = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1)
-            _, gb1 = _colsum_raw(gm1)
             if pneed[0]:
-                grads[k] = _wgrad_raw(x, gm1, w1, 1, 0, 1)
+                grads[k], gb1 = _wgrad_raw(x, gm1, w1, 1, 0, 1, True if pneed[1] else None)
+            else:
+                gb1 = _colsum_raw(gm1)[1] if pneed[1] else None
             grads[k + 1] = gb1 if pneed[1] else None
             acc = gm3
             if ds:
                 wd = params[k + 6]
                 if pneed[6]:
-                    grads[k + 6] = _wgrad_raw(x, gm3, wd, stride, 0, 1)
+                    grads[k + 6] = _wgrad_raw(x, gm3, wd, stride, 0, 1)[0]
                 grads[k + 7] = gb3 if pneed[7] else None
                 acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1) if need_x else None
             if need_x:

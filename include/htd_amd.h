@@ -130,9 +130,11 @@ int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const floa
  *            reversed).  mask_src (may be NULL, [B][H][W][Ci]): gx is zeroed where mask_src <= 0, i.e. the
  *            backward of the ReLU that produced the conv input is fused into this epilogue.  Co % 8 == 0.
  * bwd_weight: gw[co][kh][kw][ci] = sum_pixels gy * x; deterministic split-K through `workspace`
- *            (htd_conv2d_wgrad_workspace_bytes); Ci % 4 == 0.
+ *            (htd_conv2d_wgrad_workspace_bytes); Ci % 4 == 0.  gbias (may be NULL, [Co]): the bias gradient
+ *            sum_pixels gy is accumulated by the same kernel (the tiles of the first N column see every gy element).
  * bias_grad_relu_mask: gbias[c] = sum_rows gm[r][c] with gm = g * (y > 0) written out when y != NULL
- *            (gm = g, nothing written, when y == NULL); workspace >= 2048*C*4 bytes.
+ *            (gm = g, nothing written, when y == NULL); workspace >= 2048*C*4 bytes.  gbias == NULL (y required):
+ *            ReLU mask only.
  * ---------------------------------------------------------------------------------- */
 int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw);
 int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual,
@@ -151,8 +153,8 @@ int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src,
                         void *workspace, void *stream);
 int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw,
                                          int stride, int pad, int dil);
-int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, int B, int H, int W, int Ci,
-                          int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
+int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W,
+                          int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
                           void *stream);
 int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows,
                             int C, void *workspace, void *stream);
