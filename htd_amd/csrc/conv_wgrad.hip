@@ -289,16 +289,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
                                                             int64_t n, int splits, const float *__restrict__ ws2 = nullptr,
                                                             float *__restrict__ out2 = nullptr, int n2 = 0)
 {
-    // a second, small set of partials (bias gradient [splits][n2]) rides along in the last workgroup
-    if (out2 && blockIdx.x == gridDim.x - 1)
-        for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+    // a second, small set of partials (bias gradient [splits][n2]) rides along in ceil(n2/256) extra workgroups
+    // appended to the grid: one column per thread, four loads in flight
+    const int extra = out2 ? (n2 + 255) / 256 : 0;
+    if ((int)blockIdx.x >= (int)gridDim.x - extra) {
+        const int i = ((int)blockIdx.x - ((int)gridDim.x - extra)) * 256 + threadIdx.x;
+        if (i < n2) {
             float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += ws2[(int64_t)k * n2 + i];
+            int k = 0;
+            for (; k + 3 < splits; k += 4) {
+                const float a = ws2[(int64_t)k * n2 + i], b = ws2[(int64_t)(k + 1) * n2 + i];
+                const float c = ws2[(int64_t)(k + 2) * n2 + i], d = ws2[(int64_t)(k + 3) * n2 + i];
+                s += a; s += b; s += c; s += d;
+            }
+            for (; k < splits; ++k) s += ws2[(int64_t)k * n2 + i];
             out2[i] = s;
         }
+        return;
+    }
+    const unsigned main_blocks = gridDim.x - extra;
     // out[i] = sum_k ws[k][i] in fixed order; float4 lanes, four partial slabs in flight per thread
     const int64_t n4 = (n & 3) == 0 ? (n >> 2) : 0;      // slabs are 16-byte aligned only when n % 4 == 0
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)main_blocks * blockDim.x) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         int k = 0;
         for (; k + 3 < splits; k += 4) {
@@ -507,7 +519,8 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     if (c.splits > 1) {
         const int64_t n = (int64_t)Co * p.Ntot;
         const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)workspace, gw, n,
+        const unsigned extra = gbias ? (unsigned)htd::ceil_div(Co, 256) : 0u;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + extra), dim3(256), 0, s, (const float *)workspace, gw, n,
                            c.splits, (const float *)(gbias ? bias_partial : nullptr), gbias, Co);
     }
     return htd::check_launch("conv2d_bwd_weight");
