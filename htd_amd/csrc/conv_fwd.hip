@@ -337,7 +337,7 @@ int plan_splits(int64_t M, int Co, int Ci, int taps)
     const int bk = Ci % 32 == 0 ? 32 : (Ci % 16 == 0 ? 16 : 8);
     const int total_slices = taps * (Ci / bk);
     const int64_t tiles = htd::ceil_div(M, 128) * htd::ceil_div(Co, 64);     // 128x64 tiles are used when tiles are few
-    if (tiles >= 384 || total_slices < 16) return 1;
+    if (tiles <= 0 || tiles >= 384 || total_slices < 16) return 1;
     int64_t want = htd::ceil_div(768, tiles);
     want = std::min<int64_t>(want, total_slices / 8);
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, 16));

@@ -123,6 +123,8 @@ def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu):
         raise ValueError(f'conv2d: input has {Ci} channels, weight expects {Ci_w}')
     Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
     y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
+    if y.numel() == 0:              # empty batch (a stage without positive RoIs): nothing to launch
+        return y
     flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
     capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), _P(y), B, H, W, Ci, Co, kh, kw, stride,
               padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
@@ -135,6 +137,8 @@ def _colsum_raw(g, y=None, bias=None):
     B, Co, Ho, Wo = g.shape
     gm = torch.empty_like(g, memory_format=CL) if y is not None else g
     gb = grad_out(bias) if bias is not None else torch.empty(Co, device=g.device, dtype=g.dtype)
+    if g.numel() == 0:
+        return gm, gb.zero_()
     ws = torch.empty(2048 * Co, device=g.device, dtype=g.dtype)
     capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm) if y is not None else None, _P(gb), B * Ho * Wo, Co,
               _P(ws), _S(), work=('byte', 4.0 * B * Ho * Wo * Co * (3 if y is not None else 1)))
@@ -145,6 +149,8 @@ def _mask_raw(g, y):
     """g * (y > 0): the ReLU backward alone (the bias gradient of the layer comes out of its wgrad launch)."""
     B, Co, Ho, Wo = g.shape
     gm = torch.empty_like(g, memory_format=CL)
+    if g.numel() == 0:
+        return gm
     capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm), None, B * Ho * Wo, Co, None, _S(),
               work=('byte', 12.0 * B * Ho * Wo * Co))
     return gm
@@ -161,6 +167,8 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
         gd = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
         wd = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
         Cod = Co + padc
+    if B == 0:
+        return torch.empty((0, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
     wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
     capi.call('htd_conv2d_flip_weights', _P(wd), _P(wT), Cod, kh, kw, Ci, _S())
     gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
@@ -179,6 +187,11 @@ def _wgrad_launch(x, g, weight, stride, padding, dilation, bias):
     gb, sink_b = (None, True)
     if bias is not None:            # True: bias gradient wanted, no parameter to look a sink up for
         gb, sink_b = grad_out2(bias) if torch.is_tensor(bias) else (torch.empty(Co, device=g.device, dtype=g.dtype), False)
+    if B * Ho * Wo == 0:            # no pixels: the gradients are zeros
+        gw.zero_()
+        if gb is not None:
+            gb.zero_()
+        return gw, gb, sink_w and sink_b
     nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
     ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
     capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, stride, padding,

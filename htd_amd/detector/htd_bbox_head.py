@@ -94,7 +94,7 @@ class HTDBBoxHead(BBoxHead):
         else:
             x_reg = x_reg + self.alpha * enhanced_feat
         x_reg = self.convs(x_reg)
-        x_reg = M.global_avg_pool(x_reg).view(x_reg.size(0), -1)           # AvgPool2d(7) on a 7x7 map
+        x_reg = M.global_avg_pool(x_reg).view(x_reg.size(0), x_reg.size(1))   # AvgPool2d(7) on a 7x7 map
         return dense.linear(x_reg, self.fc_reg.weight, self.fc_reg.bias) if self.with_reg else None
 
     def forward_cls(self, x_cls, feat, rois, fc_cls_0, global_feat=None, rois_per_img=None, roi_valid=None):

@@ -300,8 +300,7 @@ class HTDRoIHead(nn.Module):
             enhanced = enhanced_extractor(feats, pos_rois)
             bbox_pred = head.forward_reg(torch.index_select(bbox_feats, 0, pos_rows), enhanced, pos_rois, gf)
             full = full.index_copy(0, pos_rows, bbox_pred)
-        else:
-            full = full + 0 * sum(p.sum() for p in head.parameters())      # keep every parameter in the graph
+        # no positive in the whole batch: the regression branch gets no gradient this step (zeros in the flat buffer)
         t1 = self._static_targets(1, S1)
         loss1 = self.bbox_head[1].loss(cls_score, full, rois, *t1, num_samples=S1.valid.sum())
         lw = self.stage_loss_weights[1]
