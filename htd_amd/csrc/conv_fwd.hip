@@ -43,6 +43,10 @@ struct ConvParams {
     int tap_dy[16], tap_dx[16], tap_w[16];
     int o_h0, o_w0, o_step, oH, oW;
     int relu;
+    // res_H > 0: `residual` is a coarser [B][res_H][res_W][Co] map read through nearest-neighbour up-sampling
+    // (the FPN top-down path): source row = min(floor(ho * res_sh), res_H - 1), ATen's nearest rule
+    int res_H, res_W;
+    float res_sh, res_sw;
     int64_t w_bstride;  // >0: batched GEMM, image b uses weights w + b*w_bstride (tiles never straddle images)
     int64_t M;          // B*Ho*Wo
     int mt, nt;         // tiles along M, N
@@ -273,7 +277,15 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 }
                 if (p.residual) {
-                    const float4 rv = *reinterpret_cast<const float4 *>(p.residual + o);
+                    int64_t ro = o;
+                    if (p.res_H > 0) {
+                        const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                        const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                        const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                        ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
+                    }
+                    const float4 rv = *reinterpret_cast<const float4 *>(p.residual + ro);
                     v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                 }
                 if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -307,7 +319,18 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvParams p)
         for (int k = 0; k < p.splits; ++k) v += p.partial[(int64_t)k * total + o];
         const int n = (int)(o % p.Co);
         if (p.bias) v += p.bias[n];
-        if (p.residual) v += p.residual[o];
+        if (p.residual) {
+            int64_t ro = o;
+            if (p.res_H > 0) {
+                const int64_t m = o / p.Co;
+                const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
+            }
+            v += p.residual[ro];
+        }
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
         p.y[o] = v;
@@ -384,10 +407,14 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
 
 }  // namespace
 
-extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, float *y,
-                              int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
-                              int relu, void *workspace, void *stream)
+// res_h / res_w > 0: residual is a [B][res_h][res_w][Co] map added through nearest-neighbour up-sampling to the
+// output size (0, 0: residual has the output's shape).
+extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, int res_h,
+                              int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+                              int pad, int dil, int relu, void *workspace, void *stream)
 {
+    HTD_REQUIRE((res_h > 0) == (res_w > 0) && res_h >= 0 && (res_h == 0 || ((Co & 3) == 0 && residual)),
+                "conv2d_fwd: bad residual up-sampling arguments");
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_fwd: bad sizes B=%d H=%d W=%d Ci=%d Co=%d k=%dx%d s=%d p=%d d=%d", B, H, W, Ci, Co, kh, kw,
                 stride, pad, dil);
@@ -401,6 +428,10 @@ extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias,
     HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_fwd: empty output");
     p.Hx = H; p.Wx = W; p.relu = relu;
     p.M = (int64_t)B * p.Ho * p.Wo;
+    if (res_h > 0) {
+        p.res_H = res_h; p.res_W = res_w;
+        p.res_sh = (float)res_h / (float)p.Ho; p.res_sw = (float)res_w / (float)p.Wo;
+    }
     return launch_conv(p, (hipStream_t)stream, workspace);
 }
 

@@ -42,7 +42,7 @@ class DeformConv2dFunction(Function):
         capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
                   dilation, deform_groups, _S(), work=('byte', 4.0 * M * K * 2))
         y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
-        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), None, None, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1, 0, None, _S(),
+        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), None, None, 0, 0, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1, 0, None, _S(),
                   work=('flop', 2.0 * M * K * Co))
         ctx.save_for_backward(x, offset, mask, weight)
         ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo)

@@ -116,7 +116,7 @@ def join_side_stream():
 
 # ---- raw launches (no autograd): the building blocks of Conv2dFunction and ResStageFunction -------------------
 
-def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu):
+def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu, res_up=False):
     B, Ci, H, W = x.shape
     Co, Ci_w, kh, kw = weight.shape
     if Ci != Ci_w:
@@ -126,7 +126,8 @@ def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu):
     if y.numel() == 0:              # empty batch (a stage without positive RoIs): nothing to launch
         return y
     flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
-    capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), _P(y), B, H, W, Ci, Co, kh, kw, stride,
+    rh, rw = (residual.size(2), residual.size(3)) if (res_up and residual is not None) else (0, 0)
+    capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), rh, rw, _P(y), B, H, W, Ci, Co, kh, kw, stride,
               padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
               work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
     return y
@@ -221,15 +222,16 @@ def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None):
 
 class Conv2dFunction(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu):
+    def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu, res_up=False):
         _need_gpu(x, 'conv2d')
         x = x.contiguous(memory_format=CL)
         weight = weight.contiguous(memory_format=CL)
         res = residual.contiguous(memory_format=CL) if residual is not None else None
         b = bias.contiguous() if bias is not None else None
-        y = _fwd_raw(x, weight, b, res, stride, padding, dilation, relu)
+        y = _fwd_raw(x, weight, b, res, stride, padding, dilation, relu, res_up)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (stride, padding, dilation, bool(relu), bias is not None, residual is not None)
+        ctx.res_up = tuple(res.shape) if (res_up and res is not None) else None
         ctx.bias_ref = b                                  # only its address is used (gradient sink lookup)
         return y
 
@@ -253,8 +255,12 @@ class Conv2dFunction(Function):
         gx = _dgrad_raw(g, weight, x.shape, stride, padding, dilation) if need_x else None
         if need_w:
             gw, gb = _wgrad_raw(x, g, weight, stride, padding, dilation, ctx.bias_ref if want_b else None)
-        return gx, gw, (gb if (has_bias and need_b) else None), (g if (has_res and need_r) else None), None, None, \
-            None, None
+        gr = None
+        if has_res and need_r:
+            gr = g
+            if ctx.res_up is not None:      # residual came in through nearest up-sampling: sum the gradient back down
+                gr = torch.ops.aten.upsample_nearest2d_backward(g, [g.size(2), g.size(3)], list(ctx.res_up), None, None)
+        return gx, gw, (gb if (has_bias and need_b) else None), gr, None, None, None, None, None
 
 
 class ResStageFunction(Function):
@@ -359,13 +365,15 @@ def _pad_channels(x, weight, mult=8):
     return x.contiguous(memory_format=CL), weight.contiguous(memory_format=CL)
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
-    """y = act(conv2d(x, w) + bias + residual); x (B,Ci,H,W) channels_last, weight (Co,Ci,kh,kw) channels_last."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False):
+    """y = act(conv2d(x, w) + bias + residual); x (B,Ci,H,W) channels_last, weight (Co,Ci,kh,kw) channels_last.
+    residual_up: residual is a coarser map, added through nearest-neighbour up-sampling to the output size."""
     if isinstance(stride, (tuple, list)):
         stride, padding, dilation = stride[0], padding[0], dilation[0]
     if x.size(1) % 8 != 0:
         x, weight = _pad_channels(x, weight)
-    return Conv2dFunction.apply(x, weight, bias, residual, int(stride), int(padding), int(dilation), relu)
+    return Conv2dFunction.apply(x, weight, bias, residual, int(stride), int(padding), int(dilation), relu,
+                                bool(residual_up))
 
 
 def linear(x, weight, bias=None, relu=False):

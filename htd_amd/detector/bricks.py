@@ -14,10 +14,10 @@ from ..registry import CONV_LAYERS
 CL = torch.channels_last
 
 
-def dense_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
+def dense_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False):
     """y = act(conv2d(x, w) + bias + residual) on NHWC activations / KRSC weights."""
     from .. import dense
-    return dense.conv2d(x, weight, bias, stride, padding, dilation, relu, residual)
+    return dense.conv2d(x, weight, bias, stride, padding, dilation, relu, residual, residual_up)
 
 
 @CONV_LAYERS.register_module('Conv')
@@ -35,10 +35,10 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
         return self
 
-    def forward(self, x, relu=False, residual=None, weight=None, bias=None):
+    def forward(self, x, relu=False, residual=None, weight=None, bias=None, residual_up=False):
         w = self.weight if weight is None else weight
         b = self.bias if bias is None else bias
-        return dense_conv2d(x, w, b, self.stride[0], self.padding[0], self.dilation[0], relu, residual)
+        return dense_conv2d(x, w, b, self.stride[0], self.padding[0], self.dilation[0], relu, residual, residual_up)
 
 
 def build_conv_layer(cfg, *args, **kwargs):

@@ -39,16 +39,37 @@ class FPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution='uniform')
 
+    def _fused_top_down(self, inputs):
+        """Plain lateral convs (no norm / activation) on GPU tensors, nearest up-sampling to the finer level's size."""
+        if not inputs[0].is_cuda or self.upsample_cfg.get('mode', 'nearest') != 'nearest' or \
+                self.out_channels % 4 != 0 or not getattr(self, 'fused_top_down', True):
+            return False
+        if 'scale_factor' in self.upsample_cfg:      # must land exactly on the finer level's size
+            sf = self.upsample_cfg['scale_factor']
+            shapes = [t.shape[2:] for t in inputs[self.start_level:self.backbone_end_level]]
+            if any(int(b[0] * sf) != a[0] or int(b[1] * sf) != a[1] for a, b in zip(shapes[:-1], shapes[1:])):
+                return False
+        return all(not m.with_norm and not m.with_activation for m in self.lateral_convs)
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
-        n = len(laterals)
-        for i in range(n - 1, 0, -1):
-            if 'scale_factor' in self.upsample_cfg:
-                up = F.interpolate(laterals[i], **self.upsample_cfg)
-            else:
-                up = F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
-            laterals[i - 1] = laterals[i - 1] + up
+        n = len(self.lateral_convs)
+        if self._fused_top_down(inputs):
+            # top-down pathway (fpn.py:176-189) inside the lateral convolutions: level i-1's 1x1 conv adds the
+            # nearest-up-sampled level i in its epilogue (no up-sampled map, no separate add)
+            laterals = [None] * n
+            for i in range(n - 1, -1, -1):
+                m = self.lateral_convs[i]
+                up = laterals[i + 1] if i + 1 < n else None
+                laterals[i] = m.conv(inputs[i + self.start_level], residual=up, residual_up=up is not None)
+        else:
+            laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+            for i in range(n - 1, 0, -1):
+                if 'scale_factor' in self.upsample_cfg:
+                    up = F.interpolate(laterals[i], **self.upsample_cfg)
+                else:
+                    up = F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
+                laterals[i - 1] = laterals[i - 1] + up
         outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
         for _ in range(self.num_outs - n):
             outs.append(outs[-1][:, :, ::2, ::2])      # == F.max_pool2d(x, 1, stride=2), fpn.py:197-199

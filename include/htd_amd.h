@@ -120,7 +120,9 @@ int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const floa
  * GEMMs of ResNet/FPN/RPN/SFA/HTD-reg and every nn.Linear of the heads (backbones/resnet.py:260-300,
  * necks/fpn.py:165-216, dense_heads/rpn_head.py:37-43, global_context_head.py:382-392,
  * htd_bbox_head.py:164,186,192,194,216,227-228, convfc_bbox_head.py:147-172).
- *   x [B][H][W][Ci]   w [Co][kh][kw][Ci]   bias [Co] or NULL   residual [B][Ho][Wo][Co] or NULL
+ *   x [B][H][W][Ci]   w [Co][kh][kw][Ci]   bias [Co] or NULL   residual [B][Ho][Wo][Co] or NULL;
+ *   res_h, res_w > 0: residual is a coarser [B][res_h][res_w][Co] map added through nearest-neighbour up-sampling
+ *   (the FPN top-down `laterals[i-1] += F.interpolate(laterals[i], mode='nearest')`, necks/fpn.py:176-189)
  *   y [B][Ho][Wo][Co];  relu in {0,1};  Ci % 8 == 0 (the 3-channel stem input is padded to 8).
  *   A Linear layer is the 1x1 case with H = rows, W = 1.
  * workspace (fwd / bwd_data): optional split-K scratch of htd_conv2d_workspace_bytes(M, Co, Ci, kh, kw) bytes
@@ -137,8 +139,8 @@ int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const floa
  *            ReLU mask only.
  * ---------------------------------------------------------------------------------- */
 int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw);
-int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual,
-                   float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, int res_h,
+                   int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
                    int pad, int dil, int relu, void *workspace, void *stream);
 /* Batched NT GEMM on the same MFMA kernel: c[g] = a[g] @ b[g]^T; a [G][M][K], b [G][N][K], c [G][M][N];
  * K % 8 == 0, M % 128 == 0 when G > 1.  Carries PGraph's adjacency x feature contractions

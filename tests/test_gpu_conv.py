@@ -120,3 +120,35 @@ def test_res_stage_fused_backward(stride, dilation, needs_x):
     assert set(gp0) == set(gp1) and len(gp0) > 0
     for n in gp0:
         torch.testing.assert_close(gp0[n], gp1[n], rtol=1e-5, atol=1e-5 * float(gp1[n].abs().max()), msg=n)
+
+
+@pytest.mark.gpu
+def test_fpn_fused_top_down_matches_interpolate_add():
+    """FPN with the top-down `laterals[i-1] += interpolate(laterals[i])` folded into the lateral conv epilogues
+    (residual read through nearest up-sampling, incl. an odd size 25 -> 13) against the unfused module."""
+    from htd_amd.detector.fpn import FPN
+    torch.manual_seed(4)
+    dev = torch.device('cuda:0')
+    fpn = FPN([32, 64, 128, 256], 64, 5).to(dev)
+    fpn.init_weights()
+    sizes = [(50, 84), (25, 42), (13, 21), (7, 11)]
+    xs = [torch.randn(2, c, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+          for c, (h, w) in zip([32, 64, 128, 256], sizes)]
+    res = []
+    for fused in (True, False):
+        fpn.fused_top_down = fused
+        fpn.zero_grad()
+        for x in xs:
+            x.grad = None
+        outs = fpn(xs)
+        loss = sum((o * torch.linspace(0.5, 1.5, o.numel(), device=dev).view_as(o)).sum() for o in outs)
+        loss.backward()
+        res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+                    {n: p.grad.clone() for n, p in fpn.named_parameters()}))
+    (o1, g1, p1), (o2, g2, p2) = res
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+    for n in p2:
+        torch.testing.assert_close(p1[n], p2[n], rtol=1e-4, atol=1e-4 * float(p2[n].abs().max()), msg=n)
