@@ -8,6 +8,8 @@
 // mmcv's kernel reads it up to 4*grid_h*grid_w/footprint times).  Lanes run along C, so
 // every pixel access is one contiguous 1 KiB (fwd, float4/lane) or 256 B (bwd atomics,
 // the full-rate shape for global float atomics) wave transaction.  HBM-bound by design.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -159,6 +161,94 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float *__restrict_
     }
 }
 
+// Backward, row-wise: one wavefront owns (RoI, footprint row mod row_slots, 256-channel chunk); row_slots grows when
+// there are few RoIs (BA pools two dozen large RoIs from every level) so that the launch still fills the chip.  For its row r it
+// first folds the bins along y,  T[q][:] = sum_p Wy[p][r] * gout[p][q][:] / count  (registers), then walks the row's
+// columns with  gfeat[r][c][:] += sum_q Wx[q][c] * T[q][:]:  ONE atomic per footprint pixel and channel.  The bin-wise
+// form above issues one per (bin, pixel of the bin's span), i.e. about twice as many, because neighbouring bins'
+// bilinear spans overlap -- and the 1.3 TB/s float-atomic rate is what bounds this kernel.
+constexpr int MAXP = 8;
+
+__global__ __launch_bounds__(256) void roi_align_bwd_rows_kernel(const float *__restrict__ gout,
+                                                                 const float *__restrict__ rois,
+                                                                 const int64_t *__restrict__ roi_level, int level,
+                                                                 float *__restrict__ gfeat, int64_t n, int B, int C,
+                                                                 int H, int W, int ph, int pw, float scale,
+                                                                 int sampling_ratio, int aligned, int chunks,
+                                                                 int row_slots, int64_t tasks)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= tasks) return;  // whole wave exits together
+    const int chunk = (int)(task % chunks);
+    const int64_t t2 = task / chunks;
+    const int slot = (int)(t2 % row_slots);
+    const int64_t ri = t2 / row_slots;
+    if (roi_level && roi_level[ri] != (int64_t)level) return;  // wave-uniform
+    const RoiGeom g = roi_geometry(rois + 5 * ri, scale, ph, pw, sampling_ratio, aligned);
+    if (g.batch < 0 || g.batch >= B) return;
+    int r_lo, r_hi, c_lo, c_hi, t0, t1;
+    axis_span(g.start_h, g.bin_h, 0, g.grid_h, H, r_lo, t0);
+    axis_span(g.start_h, g.bin_h, ph - 1, g.grid_h, H, t1, r_hi);
+    if (t0 < r_lo || r_hi < t1) return;                          // empty spans (degenerate RoI)
+    axis_span(g.start_w, g.bin_w, 0, g.grid_w, W, c_lo, t0);
+    axis_span(g.start_w, g.bin_w, pw - 1, g.grid_w, W, t1, c_hi);
+    if (t0 < c_lo || c_hi < t1) return;
+    const size_t img_base = (size_t)g.batch * H * W * C;
+    const float *go = gout + (size_t)ri * ph * pw * C + chunk * 256 + lane;
+    bool chk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) chk[k] = chunk * 256 + lane + 64 * k < C;
+
+    for (int r = r_lo + slot; r <= r_hi; r += row_slots) {
+        const float wy_l = lane < ph ? axis_weight(g.start_h, g.bin_h, lane, g.grid_h, r, H) : 0.f;
+        float T[MAXP][4];
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) T[q][k] = 0.f;
+        bool any_row = false;
+        for (int p = 0; p < ph; ++p) {
+            const float wy = lane_bcast(wy_l, p) * g.inv_count;
+            if (wy == 0.f) continue;
+            any_row = true;
+#pragma unroll
+            for (int q = 0; q < MAXP; ++q)
+                if (q < pw) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (chk[k]) T[q][k] += wy * go[((size_t)p * pw + q) * C + 64 * k];
+                }
+        }
+        if (!any_row) continue;
+        for (int cb = c_lo; cb <= c_hi; cb += 64) {
+            float wx_l[MAXP];
+#pragma unroll
+            for (int q = 0; q < MAXP; ++q)
+                wx_l[q] = (q < pw && cb + lane <= c_hi) ? axis_weight(g.start_w, g.bin_w, q, g.grid_w, cb + lane, W) : 0.f;
+            const int cn = min(64, c_hi - cb + 1);
+            float *row = gfeat + img_base + ((size_t)r * W + cb) * C + chunk * 256 + lane;
+            for (int c = 0; c < cn; ++c) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < MAXP; ++q) {
+                    const float w = lane_bcast(wx_l[q], c);
+                    if (w != 0.f) {
+                        any = true;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += w * T[q][k];
+                    }
+                }
+                if (!any) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (chk[k]) atomicAdd(row + (size_t)c * C + 64 * k, v[k]);
+            }
+        }
+    }
+}
+
 int launch(bool backward, const float *in, const float *rois, const int64_t *roi_level, int level, float *out,
            int64_t n, int B, int C, int H, int W, int ph, int pw, float scale, int sr, int aligned,
            void *stream)
@@ -169,11 +259,22 @@ int launch(bool backward, const float *in, const float *rois, const int64_t *roi
     if (n == 0) return HTD_OK;
     HTD_REQUIRE(in && rois && out, "roi_align: null pointer");
     const int chunks = (C + 255) / 256;
-    const int64_t tasks = n * ph * pw * chunks;
     const int waves_per_block = 4;
+    hipStream_t s = (hipStream_t)stream;
+    // few RoIs (BA: two dozen large ones on every level): the bin-wise kernel has 49 waves per RoI to spread a large
+    // footprint over; many RoIs: the row-wise kernel halves the atomics
+    if (backward && ph <= MAXP && pw <= MAXP && n * chunks >= 256) {
+        const int row_slots = (int)std::min<int64_t>(H, std::max<int64_t>(8, htd::ceil_div(16384, n * chunks)));   // >= 16k waves
+        const int64_t tasks = n * row_slots * chunks;
+        const int64_t blocks = htd::ceil_div(tasks, waves_per_block);
+        HTD_REQUIRE(blocks < (1ll << 31), "roi_align: too many tasks");
+        hipLaunchKernelGGL(roi_align_bwd_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, rois, roi_level,
+                           level, out, n, B, C, H, W, ph, pw, scale, sr, aligned, chunks, row_slots, tasks);
+        return htd::check_launch("roi_align");
+    }
+    const int64_t tasks = n * ph * pw * chunks;
     const int64_t blocks = htd::ceil_div(tasks, waves_per_block);
     HTD_REQUIRE(blocks < (1ll << 31), "roi_align: too many tasks");
-    hipStream_t s = (hipStream_t)stream;
     if (backward)
         hipLaunchKernelGGL(roi_align_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, in, rois, roi_level, level,
                            out, n, B, C, H, W, ph, pw, scale, sr, aligned, chunks, tasks);

@@ -30,7 +30,9 @@ def rand_rois(gen, n, B, H, W, stride, big=False):
 
 
 @pytest.mark.parametrize('C,H,W,stride,n,big', [(256, 40, 56, 4, 64, False), (256, 20, 28, 8, 33, True),
-                                                (8, 9, 7, 16, 20, True), (512, 12, 12, 32, 5, True)])
+                                                (8, 9, 7, 16, 20, True), (512, 12, 12, 32, 5, True),
+                                                # >= 256 RoIs: the row-wise backward kernel (one atomic per pixel)
+                                                (256, 40, 56, 4, 300, False), (64, 20, 28, 8, 400, True)])
 def test_roi_align_fwd_bwd(dev, C, H, W, stride, n, big):
     from htd_amd import mmcv_ops as M
     from oracle import ops as O
