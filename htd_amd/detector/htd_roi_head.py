@@ -78,9 +78,11 @@ class HTDRoIHead(nn.Module):
         return M.fuse_global(roi_feats, rois, global_feat)
 
     # ------------------------------------------------------------------ per-stage forward
-    def _bbox_forward(self, stage, x, rois, global_feat=None, sampling_results=None, img_metas=None):
+    def _bbox_forward(self, stage, x, rois, global_feat=None, sampling_results=None, img_metas=None, taps=None):
+        """taps (training): mmcv_ops.PyramidTaps over the pyramid levels -- the three RoIAlign consumers of a step
+        (both extractors and BA) then share one gradient map per level instead of summing three."""
         extractor, enhanced_extractor = self.bbox_roi_extractor[0], self.bbox_roi_extractor[1]
-        feats = x[:extractor.num_inputs]
+        feats = taps if taps is not None else x[:extractor.num_inputs]
         if stage == 0:
             bbox_feats = extractor(feats, rois)
             if self.with_global:
@@ -111,9 +113,9 @@ class HTDRoIHead(nn.Module):
         return dict(cls_score=cls_score, bbox_pred=bbox_pred)
 
     def _bbox_forward_train(self, stage, x, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, img_metas,
-                            global_feat=None):
+                            global_feat=None, taps=None):
         rois = bbox2roi([res.bboxes for res in sampling_results])
-        bbox_results = self._bbox_forward(stage, x, rois, global_feat, sampling_results, img_metas)
+        bbox_results = self._bbox_forward(stage, x, rois, global_feat, sampling_results, img_metas, taps)
         bbox_targets = self._targets(stage, sampling_results, rcnn_train_cfg)
         loss_bbox = self.bbox_head[stage].loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois,
                                                *bbox_targets)
@@ -197,8 +199,9 @@ class HTDRoIHead(nn.Module):
             losses['loss_global'] = self.glbctx_head.loss(mc_pred, gt_labels)
         # ---------------- stage 1: common head
         lw = self.stage_loss_weights[0]
+        taps = M.PyramidTaps(x[:self.bbox_roi_extractor[0].num_inputs])
         res = self._bbox_forward_train(0, x, sampling_results, gt_bboxes, gt_labels, self.train_cfg[0], img_metas,
-                                       global_feat)
+                                       global_feat, taps)
         for name, value in res['loss_bbox'].items():
             losses[f's0.{name}'] = value * lw if 'loss' in name else value
         with torch.no_grad():
@@ -213,7 +216,7 @@ class HTDRoIHead(nn.Module):
         lw = self.stage_loss_weights[1]
         sampling_results = self._assign_and_sample(1, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore)
         res = self._bbox_forward_train(1, x, sampling_results, gt_bboxes, gt_labels, self.train_cfg[1], img_metas,
-                                       global_feat)
+                                       global_feat, taps)
         for name, value in res['loss_bbox'].items():
             losses[f's1.{name}'] = value * lw if 'loss' in name else value
         return losses
@@ -259,7 +262,8 @@ class HTDRoIHead(nn.Module):
             losses['loss_global'] = self.glbctx_head.loss(mc_pred, gt_labels)
         # ---------------- stage 1: common head
         rois = S0.rois
-        res = self._bbox_forward(0, x, rois, global_feat)
+        taps = M.PyramidTaps(x[:self.bbox_roi_extractor[0].num_inputs])
+        res = self._bbox_forward(0, x, rois, global_feat, taps=taps)
         t0 = self._static_targets(0, S0)
         loss0 = self.bbox_head[0].loss(res['cls_score'], res['bbox_pred'], rois, *t0, num_samples=S0.valid.sum())
         lw = self.stage_loss_weights[0]
@@ -277,7 +281,7 @@ class HTDRoIHead(nn.Module):
         rois = S1.rois
         n = S1.valid.size(1)
         extractor, enhanced_extractor = self.bbox_roi_extractor[0], self.bbox_roi_extractor[1]
-        feats = x[:extractor.num_inputs]
+        feats = taps
         bbox_feats = extractor(feats, rois)
         # The regression branch runs on the positives only.  Their count is the one number of the step the host
         # needs: it is copied to pinned memory asynchronously now and read AFTER the classification branch has been

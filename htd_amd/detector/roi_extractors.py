@@ -68,7 +68,7 @@ class SingleRoIExtractor(BaseRoIExtractor):
         lvls = self.map_roi_levels(rois, len(feats))
         if roi_scale_factor is not None:
             rois = self.roi_rescale(rois, roi_scale_factor)
-        return M.roi_align_levels(list(feats), rois, lvls, l0.output_size,
+        return M.roi_align_levels(feats if isinstance(feats, M.PyramidTaps) else list(feats), rois, lvls, l0.output_size,
                                   [l.spatial_scale for l in self.roi_layers], l0.sampling_ratio, l0.aligned)
 
 
@@ -103,7 +103,13 @@ class AdptRoIExtractor(BaseRoIExtractor):
         if roi_scale_factor is not None:
             rois = self.roi_rescale(rois, roi_scale_factor)
         L = len(feats)
-        lvl_feats = [self.roi_layers[i](feats[i], rois) for i in range(L)]
+        if isinstance(feats, M.PyramidTaps):          # chained gradient maps (see mmcv_ops.PyramidTaps)
+            lvl_feats = []
+            for i in range(L):
+                f, feats.levels[i] = self.roi_layers[i](feats.levels[i], rois, chain=True)
+                lvl_feats.append(f)
+        else:
+            lvl_feats = [self.roi_layers[i](feats[i], rois) for i in range(L)]
         pooled = torch.cat([M.global_avg_pool(f).view(n, -1) for f in lvl_feats], 0)
         att = self.attention_logits(pooled).view(L, n)          # n == 1 keeps its axis (reference .squeeze() bug)
         # roi_layers[0](feats[0], rois) of :87 equals lvl_feats[0]: evaluated once

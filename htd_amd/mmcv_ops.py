@@ -48,14 +48,44 @@ _P = capi.ptr
 
 
 # ====================================================================== RoIAlign
+class PyramidTaps:
+    """The FPN levels as seen by a SEQUENCE of RoIAlign consumers (stage-1 extractor, stage-2 extractor, BA).  Each
+    consumer reads `levels`, and replaces them by identity aliases that its autograd node outputs; the next consumer
+    therefore hangs off the previous one instead of off the pyramid itself.  In backward the gradient map of a level
+    is then handed from node to node and every node scatter-adds into it IN PLACE: one zero fill and no
+    `grad += other` per level instead of one of each per consumer."""
+
+    def __init__(self, feats):
+        self.levels = list(feats)
+
+    def __len__(self):
+        return len(self.levels)
+
+    def __getitem__(self, i):
+        return self.levels[i] if not isinstance(i, slice) else self.levels[i]
+
+
+def _grad_buffer(galias, shape, device, dtype):
+    """Gradient map to scatter into: the one handed down the tap chain when usable, else fresh zeros."""
+    if galias is not None and galias.dtype == dtype and tuple(galias.shape) == tuple(shape) and \
+            galias.is_contiguous(memory_format=CL):
+        return galias
+    buf = torch.empty(shape, device=device, dtype=dtype, memory_format=CL).zero_()
+    if galias is not None:
+        buf += galias
+    return buf
+
+
 class RoIAlignFunction(Function):
-    """mmcv.ops.roi_align semantics (avg pooling, aligned flag, sampling_ratio=0 => adaptive)."""
+    """mmcv.ops.roi_align semantics (avg pooling, aligned flag, sampling_ratio=0 => adaptive).  chain=True also
+    returns an identity alias of `feat` (see PyramidTaps)."""
 
     @staticmethod
-    def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned):
+    def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned, chain=False):
         _need_gpu(feat, 'roi_align')
         if rois.dim() != 2 or rois.size(1) != 5:
             raise AssertionError('RoI must be (idx, x1, y1, x2, y2)!')  # roi_align.py:136
+        src = feat
         feat = nhwc(_f32(feat, 'roi_align'))
         rois = _f32(rois, 'roi_align').contiguous()
         ph, pw = _pair(output_size)
@@ -66,24 +96,31 @@ class RoIAlignFunction(Function):
                   float(spatial_scale), int(sampling_ratio), int(bool(aligned)), _S())
         ctx.save_for_backward(rois)
         ctx.args = ((B, C, H, W), ph, pw, float(spatial_scale), int(sampling_ratio), int(bool(aligned)))
-        return out
+        ctx.chain = bool(chain)
+        ctx.set_materialize_grads(False)      # an unused alias must arrive as None, not as a full-size zero map
+        return (out, src.view_as(src)) if chain else out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, galias=None):
         rois, = ctx.saved_tensors
         (B, C, H, W), ph, pw, scale, sr, aligned = ctx.args
+        if not ctx.needs_input_grad[0] or (grad_out is None and galias is None):
+            return (None, ) * 7
+        if grad_out is None:
+            return (galias, ) + (None, ) * 6
         grad_out = nhwc(grad_out)
-        gfeat = torch.empty((B, C, H, W), device=grad_out.device, dtype=grad_out.dtype, memory_format=CL).zero_()
+        gfeat = _grad_buffer(galias if ctx.chain else None, (B, C, H, W), grad_out.device, grad_out.dtype)
         capi.call('htd_roi_align_bwd', _P(grad_out), _P(rois), None, 0, _P(gfeat), rois.size(0), B, C, H, W, ph, pw,
                   scale, sr, aligned, _S())
-        return gfeat, None, None, None, None, None
+        return gfeat, None, None, None, None, None, None
 
 
-def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True):
+def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True,
+              chain=False):
     if pool_mode != 'avg':
         raise NotImplementedError("roi_align: only pool_mode='avg' (what the HTD configs use)")
-    return RoIAlignFunction.apply(input, rois, output_size, spatial_scale, sampling_ratio, aligned)
+    return RoIAlignFunction.apply(input, rois, output_size, spatial_scale, sampling_ratio, aligned, chain)
 
 
 class RoIAlign(nn.Module):
@@ -100,9 +137,9 @@ class RoIAlign(nn.Module):
         self.pool_mode = pool_mode
         self.aligned = aligned
 
-    def forward(self, input, rois):
+    def forward(self, input, rois, chain=False):
         return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.pool_mode,
-                         self.aligned)
+                         self.aligned, chain)
 
     def __repr__(self):
         return (f'{self.__class__.__name__}(output_size={self.output_size}, spatial_scale={self.spatial_scale}, '
@@ -112,14 +149,21 @@ class RoIAlign(nn.Module):
 def roi_align_levels(feats, rois, target_lvls, output_size, scales, sampling_ratio=0, aligned=True):
     """All pyramid levels of SingleRoIExtractor.forward (single_level_roi_extractor.py:81-99) into one
     (N,C,ph,pw) tensor: level i's kernel only touches RoIs with target_lvls == i.  No nonzero(), no
-    scatter, no host sync.  Differentiable w.r.t. every feats[i]."""
-    return _RoIAlignLevels.apply(rois, target_lvls, output_size, tuple(scales), sampling_ratio, aligned, *feats)
+    scatter, no host sync.  Differentiable w.r.t. every feats[i].  feats may be a PyramidTaps (chained gradients)."""
+    if isinstance(feats, PyramidTaps):
+        n = len(scales)
+        res = _RoIAlignLevels.apply(rois, target_lvls, output_size, tuple(scales), sampling_ratio, aligned, True,
+                                    *feats.levels[:n])
+        feats.levels[:n] = list(res[1:])
+        return res[0]
+    return _RoIAlignLevels.apply(rois, target_lvls, output_size, tuple(scales), sampling_ratio, aligned, False, *feats)
 
 
 class _RoIAlignLevels(Function):
     @staticmethod
-    def forward(ctx, rois, lvls, output_size, scales, sampling_ratio, aligned, *feats):
+    def forward(ctx, rois, lvls, output_size, scales, sampling_ratio, aligned, chain, *feats):
         _need_gpu(feats[0], 'roi_align')
+        srcs = feats
         ph, pw = _pair(output_size)
         rois = _f32(rois, 'roi_align').contiguous()
         lvls = lvls.to(torch.int64).contiguous()
@@ -138,24 +182,28 @@ class _RoIAlignLevels(Function):
                       float(scales[i]), int(sampling_ratio), int(bool(aligned)), _S(), work=work)
         ctx.save_for_backward(rois, lvls)
         ctx.args = (shapes, ph, pw, scales, int(sampling_ratio), int(bool(aligned)))
-        return out
+        ctx.chain = bool(chain)
+        ctx.set_materialize_grads(False)      # unused aliases must arrive as None, not as full-size zero maps
+        return (out, *[f.view_as(f) for f in srcs]) if chain else out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, *galias):
         rois, lvls = ctx.saved_tensors
         shapes, ph, pw, scales, sr, aligned = ctx.args
+        if g is None:                            # pooled features unused: hand the chained maps on unchanged
+            return (None, ) * 7 + tuple(galias[i] if (ctx.chain and i < len(galias)) else None for i in range(len(shapes)))
         g = nhwc(g)
         grads = []
         for i, (B, C, H, W) in enumerate(shapes):
-            if not ctx.needs_input_grad[6 + i]:
+            if not ctx.needs_input_grad[7 + i]:
                 grads.append(None)
                 continue
-            gf = torch.empty((B, C, H, W), device=g.device, dtype=g.dtype, memory_format=CL).zero_()
+            gf = _grad_buffer(galias[i] if (ctx.chain and i < len(galias)) else None, (B, C, H, W), g.device, g.dtype)
             capi.call('htd_roi_align_bwd', _P(g), _P(rois), _P(lvls), i, _P(gf), rois.size(0), B, C, H, W, ph, pw,
                       float(scales[i]), sr, aligned, _S())
             grads.append(gf)
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 # ====================================================================== NMS
