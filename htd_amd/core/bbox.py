@@ -509,6 +509,26 @@ def batched_assign_and_sample(assigner, sampler, proposal_list, gt_bboxes, gt_la
     return out, counts
 
 
+def pad_gt_batch(gt_bboxes, gt_labels=None):
+    """Per-image gt lists -> zero-padded (B,K,4) boxes, (B,K) validity [, (B,K) labels] with two launches instead of
+    three slice assignments per image: one cat, one gather through an index built from the (host-known) list sizes."""
+    dev = gt_bboxes[0].device
+    sizes = tuple(int(g.size(0)) for g in gt_bboxes)
+    B, K, tot = len(sizes), max(1, max(sizes)), sum(sizes)
+    idx, off = [], 0
+    for k in sizes:
+        idx.append(list(range(off, off + k)) + [tot] * (K - k))      # `tot` = the appended all-zero row
+        off += k
+    idx_t = const_tensor(idx, dev, torch.int64)
+    valid = const_tensor([[j < k for j in range(K)] for k in sizes], dev, torch.bool)
+    flat = torch.cat([g[:, :4] for g in gt_bboxes] + [gt_bboxes[0].new_zeros(1, 4)])
+    gts = flat[idx_t.view(-1)].view(B, K, 4)
+    if gt_labels is None:
+        return gts, valid
+    lab = torch.cat(list(gt_labels) + [gt_labels[0].new_zeros(1)])
+    return gts, valid, lab[idx_t.view(-1)].view(B, K).long()
+
+
 class StaticSamples:
     """Sampling result of a whole batch in FIXED slots: S = sampler.num rows per image, the sampled positives first
     (ascending candidate index), then the sampled negatives -- the order of SamplingResult.bboxes
@@ -533,16 +553,8 @@ def static_assign_and_sample(assigner, sampler, props, pvalid, gt_bboxes, gt_lab
     dev = props.device
     B, P = pvalid.shape
     S = sampler.num
-    K = max(1, max(int(g.size(0)) for g in gt_bboxes))
-    gts = props.new_zeros(B, K, 4)
-    gvalid = torch.zeros(B, K, dtype=torch.bool, device=dev)
-    glabels = torch.zeros(B, K, dtype=torch.long, device=dev)
-    for b in range(B):
-        k = gt_bboxes[b].size(0)
-        if k:
-            gts[b, :k] = gt_bboxes[b][:, :4]
-            gvalid[b, :k] = True
-            glabels[b, :k] = gt_labels[b]
+    gts, gvalid, glabels = pad_gt_batch(gt_bboxes, gt_labels)
+    K = gts.size(1)
     assigned, _ = batched_max_iou_assign(assigner, props, pvalid, gts, gvalid)
     if sampler.add_gt_as_proposals:      # AssignResult.add_gt_: gt i is a candidate matched to itself
         self_inds = torch.where(gvalid, torch.arange(1, K + 1, device=dev).expand(B, K), torch.full((B, K), -1, device=dev))

@@ -166,29 +166,37 @@ class RPNHead(nn.Module):
             return self.loss_batched(cls_scores, bbox_preds, gt_bboxes, img_metas)
         return self.loss_per_image(cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore)
 
+    def _anchors_inside(self, featmap_sizes, img_metas, dev):
+        """(A,4) level-concatenated anchors and the (B,A) mask of anchors that are valid and inside their image
+        (anchor_head.py:200-207, core/anchor/utils.py:20-46): constants of (feature sizes, image shapes), cached."""
+        border = self.train_cfg.allowed_border
+        key = (tuple(tuple(int(v) for v in f) for f in featmap_sizes),
+               tuple((tuple(m['img_shape'][:2]), tuple(m['pad_shape'][:2])) for m in img_metas), str(dev), border)
+        cache = self.__dict__.setdefault('_inside_cache', {})
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=dev)
+            flat_anchors = torch.cat(anchor_list[0])
+            valid = torch.stack([torch.cat(v) for v in valid_flag_list])                   # (B,A)
+            lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], dev, flat_anchors.dtype)
+            if border >= 0:
+                inside = valid & (flat_anchors[None, :, 0] >= -border) & (flat_anchors[None, :, 1] >= -border) & \
+                    (flat_anchors[None, :, 2] < lim[:, 0:1] + border) & (flat_anchors[None, :, 3] < lim[:, 1:2] + border)
+            else:
+                inside = valid
+            cache[key] = (flat_anchors, inside)
+        return cache[key]
+
     # -------------------------------------------------------------- batched targets + loss (production path)
     def loss_batched(self, cls_scores, bbox_preds, gt_bboxes, img_metas, keys=None):
         dev = cls_scores[0].device
         B = cls_scores[0].size(0)
         featmap_sizes = [f.size()[-2:] for f in cls_scores]
-        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=dev)
-        flat_anchors = torch.cat(anchor_list[0])
+        flat_anchors, inside = self._anchors_inside(featmap_sizes, img_metas, dev)
         A = flat_anchors.size(0)
-        valid = torch.stack([torch.cat(v) for v in valid_flag_list])                       # (B,A)
-        lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], flat_anchors.device, flat_anchors.dtype)    # (B,2) w,h
-        border = self.train_cfg.allowed_border
-        if border >= 0:
-            inside = valid & (flat_anchors[None, :, 0] >= -border) & (flat_anchors[None, :, 1] >= -border) & \
-                (flat_anchors[None, :, 2] < lim[:, 0:1] + border) & (flat_anchors[None, :, 3] < lim[:, 1:2] + border)
-        else:
-            inside = valid
-        K = max(1, max(int(g.size(0)) for g in gt_bboxes))
-        gts = flat_anchors.new_zeros(B, K, 4)
-        gt_valid = torch.zeros(B, K, dtype=torch.bool, device=dev)
-        for b, g in enumerate(gt_bboxes):
-            if g.size(0):
-                gts[b, :g.size(0)] = g[:, :4]
-                gt_valid[b, :g.size(0)] = True
+        from ..core.bbox import pad_gt_batch
+        gts, gt_valid = pad_gt_batch(gt_bboxes)
         from ..core.bbox import batched_max_iou_assign, batched_random_sample, sample_keys
         assigned, _ = batched_max_iou_assign(self.assigner, flat_anchors, inside, gts, gt_valid)
         sc = self.train_cfg.sampler
