@@ -7,12 +7,15 @@
 // every B row contiguous in the same k order, so both operands are staged global -> registers -> LDS as
 // 16-byte vectors with no im2col buffer (im2col happens in the address arithmetic; padding = zero fill).
 //
-// Tiling (64-wide wavefronts): block = 256 threads = 4 waves in a 2x2 grid, each wave owns a 64x64
-// accumulator tile = 2x2 MFMA 32x32 blocks (64 accumulator VGPRs).  K is walked in BK-float slices,
-// double-buffered in LDS (one barrier per slice).  LDS rows are padded by 16 B so the ds_read_b128
-// fragment reads (lane = row, two K-halves per wave) are bank-conflict free for BK in {8,16,32}.
-// The MFMA k index is permuted (lane half h takes floats 4h..4h+3 of an 8-float group) -- legal because A
-// and B use the same permutation -- which lets one ds_read_b128 per operand block feed four MFMAs.
+// Tiling (64-wide wavefronts): block = 256 threads = 4 waves.  128x128 tile: 2x2 waves, each wave a 64x64
+// accumulator tile = 2x2 MFMA 32x32 blocks (64 accumulator VGPRs); 128x64 / 128x32: 4x1 waves; 64x64: 2x2 waves of
+// 32x32.  K is walked in BK-float slices through ONE LDS slice buffer plus a register prefetch: the next slice's
+// global loads are issued before the MFMAs of the current slice and written to LDS between two barriers (half the LDS
+// of a double buffer => three resident workgroups per CU; a double-buffered variant measured the same 119 TF/s).
+// LDS rows are padded by 16 B so the ds_read_b128 fragment reads (lane = row, two K-halves per wave) are
+// bank-conflict free for BK in {8,16,32}.  The MFMA k index is permuted (lane half h takes floats 4h..4h+3 of an
+// 8-float group) -- legal because A and B use the same permutation -- which lets one ds_read_b128 per operand block
+// feed four MFMAs.  __launch_bounds__(256, 3) keeps the accumulators in architectural VGPRs (no AGPR moves).
 //
 // The same kernel serves: forward conv, Linear layers (1x1 on "pixels" = rows), and the data gradient
 // (forward conv of gy with spatially flipped, channel-transposed weights; a stride-s data gradient is split into

@@ -4,10 +4,11 @@
 //
 // GEMM view: M = Co, N = kh*kw*Ci, reduction K = B*Ho*Wo (10^5..10^6).  Both operands are "K-major" in memory
 // (a pixel row holds all channels contiguously), so slices are staged to LDS as [k][m] / [k][n] with 16-byte
-// coalesced loads and the MFMA fragments (lane = m or n index, lane half = k parity) are conflict-free
-// ds_read_b32 reads of 32 consecutive floats.  The reduction is split over `splits` independent workgroups
-// per output tile (split-K); partial tiles go to a workspace and a second kernel sums them in a fixed order,
-// so the result is bitwise reproducible (no float atomics).
+// coalesced loads; MFMA block j of a wave takes the interleaved rows TM*lane + j, so a lane's operands are adjacent
+// in the [k][m] image and arrive with one conflict-free ds_read_b64.  The reduction is split over `splits`
+// independent workgroups per output tile (split-K); partial tiles go to a workspace and a second kernel sums them in
+// a fixed order, so the result is bitwise reproducible (no float atomics).  The tiles of the first N column also
+// add up the gy elements they stage: the bias gradient is a by-product of the same launch.
 #include <algorithm>
 
 #include "common.h"

@@ -2,8 +2,10 @@
 
 `conv2d` / `linear` are the single entry points every module uses.  They run the hand-written fp32
 matrix-core implicit-GEMM kernels of libhtd_amd.so (htd_conv2d_fwd / _bwd_data / _bwd_weight,
-csrc/conv_fwd.hip, csrc/conv_wgrad.hip) through the C ABI.  Activations NHWC, weights KRSC; the fused
-epilogue carries bias, residual add and ReLU, and the backward fuses the ReLU mask with the bias gradient.
+csrc/conv_fwd.hip, csrc/conv_wgrad.hip) through the C ABI.  Activations NHWC, weights KRSC; the forward epilogue
+carries bias, residual add (optionally through nearest up-sampling) and ReLU; in backward the ReLU masks and residual
+joins live in the data-gradient epilogues (ResStageFunction), bias gradients come out of the weight-gradient launch
+and parameter gradients are written straight into the flat gradient buffer (gradient sinks).
 GPU tensors only -- there is no other path.
 """
 import torch
