@@ -191,3 +191,45 @@ def test_batched_assign_and_sample_equals_per_image_path():
         for k in ('pos_bboxes', 'neg_bboxes', 'pos_is_gt', 'pos_assigned_gt_inds', 'pos_gt_bboxes', 'pos_gt_labels'):
             assert torch.equal(getattr(r, k), getattr(ref, k)), (b, k)
         assert int(r.pos_is_gt.sum()) == counts[b][2] and r.pos_is_gt[:counts[b][2]].all()     # gt rows lead
+
+
+def test_checkpoint_wire_format_round_trip(tmp_path):
+    """A checkpoint in the reference's format (state_dict with the reference's keys and logical shapes, `module.`
+    prefix, meta, foreign keys) loads into the re-laid-out model (KRSC conv weights, (out,h,w,C) TileLinear) and a
+    saved checkpoint has the reference's keys / shapes again."""
+    from htd_amd.checkpoint import load_checkpoint, save_checkpoint
+    from htd_amd.configs import build_htd_detector, htd_config
+    from oracle import detector as D
+    from golden_util import seeded_state_dict
+    model = build_htd_detector(cfg=htd_config(50))
+    ref = seeded_state_dict(D.state_shapes(50), prefix='ckpt.')
+    ref = {k: torch.as_tensor(v) for k, v in ref.items()}
+    ex = 'roi_head.bbox_roi_extractor.1.'           # a real reference file also holds the aliases att.1 / att.3
+    for a, b in (('att.1', 'conv1'), ('att.3', 'conv2')):
+        for t in ('weight', 'bias'):
+            ref[f'{ex}{a}.{t}'] = ref[f'{ex}{b}.{t}']
+    src = {'module.' + k: v for k, v in ref.items()}
+    torch.save(dict(meta=dict(epoch=12), state_dict=src), tmp_path / 'ref.pth')
+    ckpt = load_checkpoint(model, str(tmp_path / 'ref.pth'), strict=True)
+    assert ckpt['meta']['epoch'] == 12
+    w = model.roi_head.bbox_head[0].shared_fcs[0].weight                      # TileLinear: stored (out, C, h, w)
+    assert w.shape == (1024, 256, 7, 7)
+    assert torch.equal(w.reshape(1024, -1), ref['roi_head.bbox_head.0.shared_fcs.0.weight'])
+    cw = model.backbone.layer2[0].conv2.weight
+    assert cw.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(cw, ref['backbone.layer2.0.conv2.weight'])
+    # foreign / missing keys: reported, not fatal unless strict
+    partial = {k: v for k, v in ref.items() if k.startswith('backbone.')}
+    bb = {k[len('backbone.'):]: v for k, v in partial.items() if k.startswith('backbone.')}
+    bb['fc.weight'] = torch.zeros(3, 3)                                       # torchvision's classifier head
+    torch.save(bb, tmp_path / 'resnet50.pth')
+    model.backbone.init_weights(pretrained=str(tmp_path / 'resnet50.pth'))    # the reference's call site
+    with pytest.raises(RuntimeError):
+        load_checkpoint(model.backbone, str(tmp_path / 'resnet50.pth'), strict=True)
+    with pytest.raises(IOError):
+        load_checkpoint(model, 'torchvision://resnet50')
+    save_checkpoint(model, str(tmp_path / 'out' / 'epoch_1.pth'), meta=dict(epoch=1))
+    saved = torch.load(tmp_path / 'out' / 'epoch_1.pth', weights_only=False)
+    got = {k: tuple(v.shape) for k, v in saved['state_dict'].items() if not k.endswith('num_batches_tracked')}
+    assert got == {k: tuple(v.shape) for k, v in ref.items()}
+    assert torch.equal(saved['state_dict']['roi_head.bbox_head.1.fcs.0.weight'], ref['roi_head.bbox_head.1.fcs.0.weight'])
