@@ -108,7 +108,8 @@ class HTDBBoxHead(BBoxHead):
             x_cls, x_cls_glb = both[:x_cls.size(0)], both[x_cls.size(0):]
         else:
             x_cls, x_cls_glb = self._cls_fcs(x_cls), None
-        sam = torch.mm(dense.linear(x_cls, fc_cls_0.weight, fc_cls_0.bias).softmax(-1), prototype)
+        # semantic embedding (:203-204): class posterior of the stage-1 classifier times its (detached) weights
+        sam = dense.linear(dense.linear(x_cls, fc_cls_0.weight, fc_cls_0.bias).softmax(-1), prototype.t().contiguous())
         target_lvls = self.map_roi_levels(rois, len(feat))
         refined = pgraph_refine(x_cls, sam, rois, target_lvls, self.graph_layer_cls, rois_per_img, roi_valid)
         feat_cls_new = (x_cls_glb if global_feat is not None else x_cls) + refined
