@@ -2,6 +2,8 @@
 //   _fuse_global (+ alpha*enhanced), BA level fusion, global average pooling,
 //   GroupNorm(+ReLU), and the SGD-momentum update of the flat parameter buffer.
 // All are single-pass, float4-vectorised along C (16 B/lane => 1 KiB per wave access).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -513,4 +515,107 @@ extern "C" int htd_bn_fold_bwd(const float *w, const float *gamma, const float *
     hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, w, gamma, mean, var,
                        eps, gw_folded, gb_folded, gw, ggamma, gbeta, K);
     return htd::check_launch("bn_fold_bwd");
+}
+
+// ------------------------------------------------------------------ max pooling (ResNet stem, NHWC)
+// nn.MaxPool2d(kernel k, stride s, padding p) of backbones/resnet.py:509 on [B][H][W][C] maps: a thread owns four
+// channels of one output pixel (16-byte accesses), padding = -inf.  idx (optional) records the flat input pixel
+// (hi*W + wi) of the FIRST maximum in window scan order, which is where ATen sends the gradient.
+namespace {
+
+__global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           int *__restrict__ idx, int B, int H, int W, int C4, int Ho,
+                                                           int Wo, int k, int s, int p)
+{
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(t % C4);
+        int64_t r = t / C4;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho), b = (int)(r / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int4 am = make_int4(-1, -1, -1, -1);
+        for (int i = 0; i < k; ++i) {
+            const int hi = ho * s - p + i;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int j = 0; j < k; ++j) {
+                const int wi = wo * s - p + j;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = reinterpret_cast<const float4 *>(x)[(((int64_t)b * H + hi) * W + wi) * C4 + c4];
+                const int pix = hi * W + wi;
+                // NaN propagates like ATen's `(val > max) || isnan(val)`
+                if (v.x > m.x || v.x != v.x) { m.x = v.x; am.x = pix; }
+                if (v.y > m.y || v.y != v.y) { m.y = v.y; am.y = pix; }
+                if (v.z > m.z || v.z != v.z) { m.z = v.z; am.z = pix; }
+                if (v.w > m.w || v.w != v.w) { m.w = v.w; am.w = pix; }
+            }
+        }
+        reinterpret_cast<float4 *>(y)[t] = m;
+        if (idx) reinterpret_cast<int4 *>(idx)[t] = am;
+    }
+}
+
+// gather form of the backward: an input pixel sums the gradients of the (at most ceil(k/s)^2) windows that contain
+// it and elected it -- no atomics, bitwise reproducible.
+__global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float *__restrict__ g, const int *__restrict__ idx,
+                                                           float *__restrict__ gx, int B, int H, int W, int C4, int Ho,
+                                                           int Wo, int k, int s, int p)
+{
+    const int64_t total = (int64_t)B * H * W * C4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(t % C4);
+        int64_t r = t / C4;
+        const int wi = (int)(r % W);
+        r /= W;
+        const int hi = (int)(r % H), b = (int)(r / H);
+        const int pix = hi * W + wi;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ho_lo = max(0, (hi + p - k + s) / s), ho_hi = min(Ho - 1, (hi + p) / s);
+        const int wo_lo = max(0, (wi + p - k + s) / s), wo_hi = min(Wo - 1, (wi + p) / s);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho)
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                const int64_t o = (((int64_t)b * Ho + ho) * Wo + wo) * C4 + c4;
+                const int4 am = reinterpret_cast<const int4 *>(idx)[o];
+                const float4 gv = reinterpret_cast<const float4 *>(g)[o];
+                if (am.x == pix) acc.x += gv.x;
+                if (am.y == pix) acc.y += gv.y;
+                if (am.z == pix) acc.z += gv.z;
+                if (am.w == pix) acc.w += gv.w;
+            }
+        reinterpret_cast<float4 *>(gx)[t] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride,
+                                  int pad, void *stream)
+{
+    HTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k,
+                "max_pool2d: bad sizes");
+    HTD_REQUIRE(C % 4 == 0, "max_pool2d: C=%d must be a multiple of 4", C);
+    HTD_REQUIRE((int64_t)H * W < (1ll << 31), "max_pool2d: map too large");
+    HTD_REQUIRE(x && y, "max_pool2d: null pointer");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    HTD_REQUIRE(Ho > 0 && Wo > 0, "max_pool2d: empty output");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 65536);
+    hipLaunchKernelGGL(max_pool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, idx, B, H, W, C / 4,
+                       Ho, Wo, k, stride, pad);
+    return htd::check_launch("max_pool2d_fwd");
+}
+
+extern "C" int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, int W, int C, int k,
+                                  int stride, int pad, void *stream)
+{
+    HTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && C % 4 == 0,
+                "max_pool2d_bwd: bad sizes");
+    HTD_REQUIRE(g && idx && gx, "max_pool2d_bwd: null pointer");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 65536);
+    hipLaunchKernelGGL(max_pool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, idx, gx, B, H, W, C / 4,
+                       Ho, Wo, k, stride, pad);
+    return htd::check_launch("max_pool2d_bwd");
 }

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from .. import mmcv_ops as M
 from ..dense import ResStageFunction
 from ..registry import BACKBONES
 from .bricks import build_conv_layer, build_norm_layer, constant_init, frozen_bn_fold, kaiming_init
@@ -218,7 +219,11 @@ class ResNet(nn.Module):
     def forward(self, x):
         x = x.contiguous(memory_format=CL)
         x = conv_bn(self.conv1, self.norm1, x, relu=True)
-        x = self.maxpool(x)
+        mp = self.maxpool
+        if x.is_cuda and x.size(1) % 4 == 0 and not mp.ceil_mode and mp.dilation == 1:
+            x = M.max_pool2d(x, mp.kernel_size, mp.stride, mp.padding)      # NHWC kernel of libhtd_amd.so
+        else:
+            x = mp(x)
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

@@ -206,6 +206,38 @@ class _RoIAlignLevels(Function):
         return (None, None, None, None, None, None, None, *grads)
 
 
+# ====================================================================== max pooling (ResNet stem)
+class MaxPool2dFunction(Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        _need_gpu(x, 'max_pool2d')
+        x = nhwc(_f32(x, 'max_pool2d'))
+        B, C, H, W = x.shape
+        Ho, Wo = (H + 2 * padding - kernel) // stride + 1, (W + 2 * padding - kernel) // stride + 1
+        y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
+        need = ctx.needs_input_grad[0]
+        idx = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.int32) if need else None
+        capi.call('htd_max_pool2d_fwd', _P(x), _P(y), _P(idx), B, H, W, C, kernel, stride, padding, _S())
+        ctx.save_for_backward(idx)
+        ctx.args = ((B, C, H, W), kernel, stride, padding)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        (B, C, H, W), kernel, stride, padding = ctx.args
+        g = nhwc(g)
+        gx = torch.empty((B, C, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+        capi.call('htd_max_pool2d_bwd', _P(g), _P(idx), _P(gx), B, H, W, C, kernel, stride, padding, _S())
+        return gx, None, None, None
+
+
+def max_pool2d(x, kernel_size, stride, padding=0):
+    """nn.MaxPool2d(kernel_size, stride, padding) on NHWC maps (the ResNet stem pool)."""
+    return MaxPool2dFunction.apply(x, int(kernel_size), int(stride), int(padding))
+
+
 # ====================================================================== NMS
 def nms_sorted_mask(sorted_boxes, iou_threshold, offset=0, seg_offsets=None, max_seg=None):
     """keep mask (uint8) for boxes already sorted by descending score.  With `seg_offsets`

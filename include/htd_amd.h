@@ -254,6 +254,15 @@ int htd_rpn_loss(const float *cls, const float *reg, const float *anchors, const
                  const uint8_t *pos, const uint8_t *neg, int B, int A, int K, const float *means4, const float *stds4,
                  float beta, float pos_weight, float *partial, float *grad_cls, float *grad_reg, void *stream);
 
+/* nn.MaxPool2d(kernel, stride, padding) of the ResNet stem (backbones/resnet.py:509,629) on NHWC maps
+ * x [B][H][W][C] -> y [B][Ho][Wo][C], C % 4 == 0, padding = -inf, floor mode.  idx (may be NULL for inference; int32
+ * [B][Ho][Wo][C]) records the input pixel hi*W+wi of the first maximum of each window; bwd sends the gradient there
+ * (gather form, no atomics). */
+int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride, int pad,
+                       void *stream);
+int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, int W, int C, int k, int stride,
+                       int pad, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
  * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):

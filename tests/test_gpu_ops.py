@@ -298,3 +298,20 @@ def test_max_iou_assign_kernel_matches_tensor_formulation(shared, low_quality, K
     assert torch.equal(got, ref)
     assert torch.equal(got_ov, ref_ov)
     assert int((got > 0).sum()) > 0 and int((got == 0).sum()) > 0
+
+
+@pytest.mark.parametrize('k,s,p,H,W', [(3, 2, 1, 37, 52), (2, 2, 0, 16, 24), (3, 1, 1, 9, 11)])
+def test_max_pool2d_matches_aten(dev, k, s, p, H, W):
+    """The stem's max pooling on NHWC maps: values and gradient routing (first maximum of the window, ties included)."""
+    from htd_amd import mmcv_ops as M
+    gen = torch.Generator().manual_seed(k * 10 + s)
+    x = (torch.randn(2, 8, H, W, generator=gen) * 2).round() / 2          # quantised: many ties inside windows
+    a = cl(x.to(dev)).requires_grad_()
+    b = x.clone().requires_grad_()
+    ya = M.max_pool2d(a, k, s, p)
+    yb = torch.nn.functional.max_pool2d(b, k, s, p)
+    assert torch.equal(ya.cpu(), yb)
+    g = torch.randn(yb.shape, generator=gen)
+    ya.backward(g.to(dev))
+    yb.backward(g)
+    torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=0, atol=1e-6)
