@@ -126,7 +126,16 @@ def frozen_bn_fold(conv_weight, bn):
     w' = w * s, b' = beta - mean * s with s = gamma / sqrt(var + eps).  The backward of the fold returns exactly
     d/dgamma, d/dbeta, d/dw of the unfused conv->BN pair (no conv output is kept for the BN backward)."""
     if conv_weight.is_cuda and (conv_weight.numel() // conv_weight.size(0)) % 4 == 0:
-        return _BNFold.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        if torch.is_grad_enabled():
+            return _BNFold.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        # inference: the folded pair is a constant of the parameters -- keep it until they change
+        key = (M.PARAM_EPOCH, conv_weight.data_ptr(), conv_weight._version, bn.weight._version, bn.bias._version,
+               bn.running_mean._version, bn.running_var._version)
+        cached = bn.__dict__.get('_htd_fold_cache')
+        if cached is None or cached[0] != key:
+            cached = (key, _BNFold.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))
+            bn.__dict__['_htd_fold_cache'] = cached
+        return cached[1]
     s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)          # 3-channel stem (K = 147): plain tensor ops
     return conv_weight * s.view(-1, 1, 1, 1), bn.bias - bn.running_mean * s
 

@@ -464,8 +464,13 @@ def group_norm_relu(x, weight, bias, num_groups, eps=1e-5, relu=True):
 
 
 # ====================================================================== optimizer step
+PARAM_EPOCH = 0
+
+
 def sgd_momentum_step_(flat_param, flat_grad, flat_momentum, lr_dev, momentum, weight_decay, grad_scale=1.0):
     """In-place SGD(momentum, weight_decay) on flat fp32 buffers; lr_dev is a 1-element device tensor."""
     _need_gpu(flat_param, 'sgd')
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1        # parameters change behind autograd's version counters: invalidates folded-weight caches
     capi.call('htd_sgd_momentum_step', _P(flat_param), _P(flat_grad), _P(flat_momentum), flat_param.numel(),
               _P(lr_dev), float(momentum), float(weight_decay), float(grad_scale), _S())
