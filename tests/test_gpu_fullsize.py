@@ -1,0 +1,112 @@
+"""BASELINE configs[1] sizes (B = 4 @ 800x1344, HTD-R50) -- far beyond what the CPU oracle finishes in seconds -- checked
+through size-independent properties: adjoint identities of the three convolution kernels, mass conservation of RoIAlign,
+agreement of independent code paths (batched vs per-segment NMS, assign kernel vs tensor formulation, static-shape vs
+per-image-list train step), order / range invariants of the proposals."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def test_conv_adjoint_identities_on_the_largest_layer():
+    """<conv(x, w), g> == <x, dgrad(g, w)> == <w, wgrad(x, g)> and linearity, FPN/RPN 3x3 256->256 at 200x336, B = 4
+    (317 GFLOP per pass): ties the forward, data-gradient and weight-gradient kernels to one another at full size."""
+    from htd_amd import dense
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    x = torch.randn(4, 256, 200, 336, device=dev).contiguous(memory_format=CL).requires_grad_()
+    w = (torch.randn(256, 256, 3, 3, device=dev) / 48).contiguous(memory_format=CL).requires_grad_()
+    b = torch.randn(256, device=dev).requires_grad_()
+    y = dense.conv2d(x, w, b, 1, 1, 1)
+    g = torch.randn_like(y)
+    y.backward(g)
+    lhs = (y.detach().double() * g.double()).sum()
+    via_x = (x.detach().double() * x.grad.double()).sum() + (b.detach().double() * b.grad.double()).sum()
+    via_w = (w.detach().double() * w.grad.double()).sum() + (b.detach().double() * b.grad.double()).sum()
+    assert abs(float(lhs - via_x)) <= 2e-5 * abs(float(lhs)) + 1.0
+    assert abs(float(lhs - via_w)) <= 2e-5 * abs(float(lhs)) + 1.0
+    torch.testing.assert_close(b.grad, g.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    with torch.no_grad():
+        x2 = torch.randn_like(x)
+        lin = dense.conv2d(0.5 * x + 2.0 * x2, w, None, 1, 1, 1)
+        ref = 0.5 * dense.conv2d(x, w, None, 1, 1, 1) + 2.0 * dense.conv2d(x2, w, None, 1, 1, 1)
+        torch.testing.assert_close(lin, ref, rtol=1e-4, atol=1e-3)
+
+
+def test_roi_align_partition_of_unity_and_mass_conservation():
+    """2048 RoIs on a (4,256,200,336) map: pooling a constant map gives that constant for RoIs inside the image, and
+    the backward (row-wise kernel) spreads exactly the incoming gradient mass."""
+    from htd_amd import mmcv_ops as M
+    torch.manual_seed(1)
+    dev = torch.device('cuda:0')
+    n = 2048
+    cx, cy = torch.rand(n) * 1000 + 150, torch.rand(n) * 500 + 150
+    w, h = torch.rand(n) * 100 + 12, torch.rand(n) * 100 + 12
+    rois = torch.stack([torch.randint(0, 4, (n, )).float(), cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).to(dev)
+    feat = torch.full((4, 256, 200, 336), 3.0, device=dev).contiguous(memory_format=CL).requires_grad_()
+    out = M.roi_align(feat, rois, 7, 0.25, 0, 'avg', True)
+    torch.testing.assert_close(out, torch.full_like(out, 3.0), rtol=1e-5, atol=1e-5)
+    g = torch.rand_like(out)
+    out.backward(g)
+    assert abs(float(feat.grad.double().sum() - g.double().sum())) <= 1e-5 * float(g.double().sum())
+
+
+def test_full_size_train_step_paths_agree_and_proposals_are_ordered():
+    from htd_amd.configs import build_htd_detector
+    from htd_amd.core.bbox import _batched_max_iou_assign_tensor, batched_max_iou_assign, set_sample_keys
+    from htd_amd.mmcv_ops import nms
+    from htd_amd.runner import synthetic_batch
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    model = build_htd_detector(50).to(dev).train()
+    data = synthetic_batch(4, device=dev)
+    coef = torch.tensor([12.9898, 78.233, 37.719, 93.989], device=dev)
+    set_sample_keys(lambda cand: torch.frac(torch.sin((cand * coef).sum(-1)) * 43758.5453).abs())
+    out = {}
+    try:
+        for static in (True, False):
+            model.roi_head.static_shapes = static
+            model.zero_grad()
+            losses = model(img=data['img'], img_metas=data['img_metas'], gt_bboxes=data['gt_bboxes'],
+                           gt_labels=data['gt_labels'])
+            loss, log_vars = model._parse_losses(losses)
+            loss.backward()
+            out[static] = ({k: float(v) for k, v in log_vars.items()},
+                           model.backbone.layer2[0].conv1.weight.grad.detach().clone())
+    finally:
+        model.roi_head.static_shapes = True
+        set_sample_keys(None)
+    for k, v in out[False][0].items():
+        assert v == v and abs(out[True][0][k] - v) <= 5e-5 * max(1.0, abs(v)), (k, out[True][0][k], v)
+    scale = float(out[False][1].abs().max())
+    assert float((out[True][1] - out[False][1]).abs().max()) <= 5e-4 * scale
+
+    # proposals of the full-size step: order, range, and the batched NMS against one NMS call per (image, level)
+    with torch.no_grad():
+        x = model.extract_feat(data['img'])
+        cls, reg = model.rpn_head(x)
+        dets, n_keep = model.rpn_head.get_bboxes(cls, reg, data['img_metas'], cfg=model.train_cfg.rpn_proposal,
+                                                 padded=True)
+        plist = model.rpn_head.get_bboxes(cls, reg, data['img_metas'], cfg=model.train_cfg.rpn_proposal)
+    assert dets.shape == (4, 2000, 5)
+    for b_ in range(4):
+        k = int(n_keep[b_])
+        p = plist[b_]
+        assert p.size(0) == k and torch.equal(dets[b_, :k], p) and float(dets[b_, k:].abs().sum()) == 0.0
+        assert bool((p[:-1, 4] >= p[1:, 4]).all())                                   # descending scores
+        assert float(p[:, :4].min()) >= 0 and float(p[:, 2].max()) <= 1333 and float(p[:, 3].max()) <= 800
+        # NMS survivors are mutually compatible: one more NMS pass over them (single class) with the same threshold
+        # can only remove cross-level pairs, never reorder what it keeps
+        _, keep = nms(p[:, :4].contiguous(), p[:, 4].contiguous(), 0.7)
+        assert bool((keep[:-1] < keep[1:]).all())
+
+    # assigner at full size (4 x 268 569 anchors): kernel == tensor formulation, bit for bit
+    anchors, inside = model.rpn_head._anchors_inside([c.shape[-2:] for c in cls], data['img_metas'], dev)
+    from htd_amd.core.bbox import pad_gt_batch
+    gts, gvalid = pad_gt_batch(data['gt_bboxes'])
+    a = model.rpn_head.assigner
+    got = batched_max_iou_assign(a, anchors, inside, gts, gvalid)
+    ref = _batched_max_iou_assign_tensor(a, anchors, inside, gts, gvalid)
+    assert anchors.size(0) == 268569
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
