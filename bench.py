@@ -34,6 +34,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4, help='images per GPU (BASELINE configs[1]: 4)')
     ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--dcn', action='store_true', help='ResNet-DCN backbone (BASELINE configs[3] architecture, fp32 here)')
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -100,7 +101,7 @@ def main():
                     return model.simple_test(d['img'], d['img_metas'])
         trainer = _Infer()
     else:
-        model = build_htd_detector(args.depth)              # init_weights() of every module, seed 0
+        model = build_htd_detector(args.depth, dcn=args.dcn)  # init_weights() of every module, seed 0
         model = model.to(dev).train()
         trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
         data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
@@ -162,7 +163,7 @@ def main():
         'config': {'workload': (f'HTD ResNet-{args.depth} FPN fp32 inference (simple_test, hard NMS), batch {args.batch}/GPU '
                                 f'@ {args.width - 11}x{args.height}, {args.proposals} proposals/img into the RoI head'
                                 if args.infer else
-                                f'HTD ResNet-{args.depth} FPN fp32 train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
+                                f'HTD ResNet-{args.depth}{"-DCN" if args.dcn else ""} FPN fp32 train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
                                 f'{args.width - 11}x{args.height} (padded {args.width}x{args.height}), '
                                 'random-init weights, 2000 RPN proposals/img, 512 RoIs/img/stage'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
