@@ -22,7 +22,7 @@ _P, _S = capi.ptr, capi.current_stream_ptr
 
 class DeformConv2dFunction(Function):
     @staticmethod
-    def forward(ctx, x, offset, mask, weight, stride, padding, dilation, deform_groups):
+    def forward(ctx, x, offset, mask, weight, stride, padding, dilation, deform_groups, bias=None, relu=False):
         if not x.is_cuda:
             raise NotImplementedError('deform_conv2d: only GPU tensors are supported')
         if x.dim() != 4:
@@ -42,22 +42,27 @@ class DeformConv2dFunction(Function):
         capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
                   dilation, deform_groups, _S(), work=('byte', 4.0 * M * K * 2))
         y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
-        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), None, None, 0, 0, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1, 0, None, _S(),
-                  work=('flop', 2.0 * M * K * Co))
-        ctx.save_for_backward(x, offset, mask, weight)
-        ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo)
+        bias = bias.contiguous() if bias is not None else None
+        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), _P(bias), None, 0, 0, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1,
+                  int(bool(relu)), None, _S(), work=('flop', 2.0 * M * K * Co))     # bias / ReLU in the GEMM epilogue
+        ctx.save_for_backward(x, offset, mask, weight, y if relu else None)
+        ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo, bias is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, offset, mask, weight = ctx.saved_tensors
-        stride, padding, dilation, dg, Ho, Wo = ctx.cfg
+        x, offset, mask, weight, y = ctx.saved_tensors
+        stride, padding, dilation, dg, Ho, Wo, has_bias = ctx.cfg
         B, C, H, W = x.shape
         Co, _, kh, kw = weight.shape
         M, K = B * Ho * Wo, kh * kw * C
         gy = gy.contiguous(memory_format=CL)
-        gx = goff = gmask = gw = None
+        if y is not None:
+            from .dense import _mask_raw
+            gy = _mask_raw(gy, y)
+        gx = goff = gmask = gw = gb = None
+        want_b = has_bias and ctx.needs_input_grad[8]
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
             wT = torch.empty(K * Co, device=gy.device, dtype=gy.dtype)
             capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, 1, 1, K, _S())
@@ -77,16 +82,21 @@ class DeformConv2dFunction(Function):
             gw = torch.empty((Co, C, kh, kw), device=gy.device, dtype=gy.dtype, memory_format=CL)
             nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(1, M, 1, K, Co, 1, 1, 1, 0, 1)
             ws = torch.empty(nbytes // 4 + 1, device=gy.device, dtype=gy.dtype)
-            capi.call('htd_conv2d_bwd_weight', _P(cols), _P(gy), _P(gw), None, 1, M, 1, K, Co, 1, 1, 1, 0, 1, _P(ws), _S(),
-                      work=('flop', 2.0 * M * K * Co))
-        return gx, goff, gmask, gw, None, None, None, None
+            gb = torch.empty(Co, device=gy.device, dtype=gy.dtype) if want_b else None
+            capi.call('htd_conv2d_bwd_weight', _P(cols), _P(gy), _P(gw), _P(gb), 1, M, 1, K, Co, 1, 1, 1, 0, 1, _P(ws),
+                      _S(), work=('flop', 2.0 * M * K * Co))
+        elif want_b:
+            gb = gy.sum((0, 2, 3))
+        return gx, goff, gmask, gw, None, None, None, None, gb, None
 
 
-def deform_conv2d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deform_groups=1, mask=None):
+def deform_conv2d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deform_groups=1, mask=None,
+                  bias=None, relu=False):
+    """mmcv.ops.deform_conv2d; bias / relu (extensions): folded-BN bias and ReLU in the epilogue of the GEMM half."""
     if groups != 1:
         raise NotImplementedError('deform_conv2d: groups > 1 is outside the HTD path (ResNeXt is SURVEY 8f)')
     s, p, d = _pair(stride)[0], _pair(padding)[0], _pair(dilation)[0]
-    return DeformConv2dFunction.apply(x, offset, mask, weight, s, p, d, deform_groups)
+    return DeformConv2dFunction.apply(x, offset, mask, weight, s, p, d, deform_groups, bias, relu)
 
 
 class DeformConv2d(nn.Module):
@@ -135,10 +145,12 @@ class DeformConv2dPack(DeformConv2d):
         self.conv_offset.weight.data.zero_()
         self.conv_offset.bias.data.zero_()
 
-    def forward(self, x):
+    def forward(self, x, relu=False, weight=None, bias=None):
+        """weight / bias / relu: the frozen-BN-folded pair and the activation that follow this layer in a bottleneck
+        (the offsets are always predicted from the layer's own parameters)."""
         offset = self.conv_offset(x)
-        return deform_conv2d(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
-                             self.deform_groups)
+        return deform_conv2d(x, offset, self.weight if weight is None else weight, self.stride, self.padding,
+                             self.dilation, self.groups, self.deform_groups, bias=bias, relu=relu)
 
 
 @CONV_LAYERS.register_module('DCNv2')

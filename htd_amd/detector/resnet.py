@@ -79,8 +79,13 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         out = conv_bn(self.conv1, self.norm1, x, relu=True)
-        if hasattr(self.conv2, 'conv_offset'):       # deformable conv2: BN/ReLU follow as separate ops
-            out = torch.relu(self.norm2(self.conv2(out)))
+        if hasattr(self.conv2, 'conv_offset') and (self.norm2.training or not out.is_cuda or
+                                                   not getattr(self, 'fuse_dcn_bn', True) or
+                                                   type(self.conv2).__name__ != 'DeformConv2dPack'):
+            out = torch.relu(self.norm2(self.conv2(out)))      # deformable conv2 with live BN statistics / DCNv2
+        elif hasattr(self.conv2, 'conv_offset'):     # deformable conv2: folded BN + ReLU in its GEMM epilogue
+            w, b = frozen_bn_fold(self.conv2.weight, self.norm2)
+            out = self.conv2(out, relu=True, weight=w, bias=b)
         else:
             out = conv_bn(self.conv2, self.norm2, out, relu=True)
         identity = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)

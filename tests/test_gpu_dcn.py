@@ -79,3 +79,39 @@ def test_r101_dcn_backbone_block_matches_oracle():
     ref = D.bottleneck(sd, 'blk', x, 2, dcn=True)
     y = layer.to(dev)(x.to(dev).contiguous(memory_format=CL))
     torch.testing.assert_close(y.detach().cpu(), ref, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_dcn_bottleneck_folded_bn_relu_epilogue():
+    """Bottleneck with a deformable conv2: frozen BN + ReLU folded into the epilogue of the DCN GEMM against the
+    unfused relu(bn(dcn(x))) of the reference (backbones/resnet.py:278-291), forward and every gradient."""
+    import torch.nn as nn
+    from htd_amd.detector.resnet import Bottleneck
+    torch.manual_seed(2)
+    dev = torch.device('cuda:0')
+    blk = Bottleneck(64, 16, dcn=dict(type='DCN', deform_groups=1, fallback_on_stride=False)).to(dev)
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    blk.conv2.conv_offset.weight.data.normal_(0, 0.05)        # non-trivial offsets
+    blk.conv2.conv_offset.bias.data.normal_(0, 0.5)
+    blk.eval()
+    x = torch.randn(2, 64, 14, 18, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    res, g = [], None
+    for fused in (True, False):
+        blk.fuse_dcn_bn = fused
+        blk.zero_grad()
+        x.grad = None
+        y = blk(x)
+        g = torch.randn_like(y) if g is None else g
+        y.backward(g)
+        res.append((y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blk.named_parameters()}))
+    (y1, gx1, p1), (y2, gx2, p2) = res
+    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx1, gx2, rtol=1e-4, atol=1e-5)
+    assert set(p1) == set(p2)
+    for n in p2:
+        torch.testing.assert_close(p1[n], p2[n], rtol=1e-4, atol=1e-5 * max(1.0, float(p2[n].abs().max())), msg=n)
