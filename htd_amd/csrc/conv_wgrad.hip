@@ -467,7 +467,7 @@ Cfg choose(int Co, int Ntot, int64_t K)
     if (tiles * cap < 256)                                           // ... unless that leaves CUs idle (short reductions)
         cap = std::max(cap, std::min<int64_t>(htd::ceil_div(256, tiles), std::max<int64_t>(1, slices / 5)));
     want = std::min<int64_t>(want, cap);
-    c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 96));
+    c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 192));
     if (c.splits >= 6) c.splits = (c.splits + 7) / 8 * 8;            // multiples of 8: one split per XCD group
     return c;
 }
