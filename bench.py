@@ -77,8 +77,14 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP ops have no CPU path)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # HTD_REHEARSE_RCCL=1: initialise RCCL and run the bucketed gradient exchange even with ONE rank -- the only way
+    # to exercise the nccl-backend code path (side stream, hooks, packed log all-reduce) on a one-GPU box
+    rehearse = bool(int(os.environ.get('HTD_REHEARSE_RCCL', '0')))
+    if world > 1 or rehearse:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
     assert world == args.gpus or world == 1
 
@@ -107,7 +113,7 @@ def main():
         data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
 
     def sync():
-        if world > 1:
+        if world > 1 or rehearse:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,4 +181,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    finally:
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()

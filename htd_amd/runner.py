@@ -13,6 +13,7 @@ configs/_base_/schedules/schedule_1x.py:2-11), re-designed for one process per M
     htd_bbox_head.py:219) contribute zeros: the flat gradient buffer is zero-filled each step.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -96,7 +97,9 @@ class GradientExchange:
         self.flat = flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.enabled = self.world > 1
+        # a single-rank group still runs the exchange when HTD_REHEARSE_RCCL=1 (bench.py: one-GPU rehearsal of the
+        # nccl code path)
+        self.enabled = self.world > 1 or (dist.is_initialized() and os.environ.get('HTD_REHEARSE_RCCL') == '1')
         self.on_gpu = flat.grad.is_cuda
         self.stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self._pending = None
