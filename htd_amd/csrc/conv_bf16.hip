@@ -1,0 +1,236 @@
+// bf16 implicit-GEMM convolution forward on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+// groundwork for the bf16 configurations of BASELINE.json (configs[2], configs[3]); the fp32 kernels of conv_fwd.hip
+// carry the headline path.  Same decomposition as conv_igemm_kernel:
+//
+//   Y[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] + R[m][n] ),  m = (b, ho, wo), n = co, k = (kh, kw, ci)
+//
+// NHWC bf16 activations and KRSC bf16 weights are staged global -> registers -> LDS as 16-byte vectors (8 elements);
+// one LDS slice buffer of BK = 64 elements (the same 128 bytes per row as the fp32 kernel's BK = 32) plus register
+// prefetch.  A lane's MFMA operand is 8 consecutive k of its row (lane half h takes k = 8h..8h+7 of a 16-wide
+// step), i.e. exactly one ds_read_b128 -- no k permutation needed.  Accumulators leave through an fp32 LDS stage and
+// are rounded to bf16 (RNE) after bias / residual / ReLU.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+struct BfParams {
+    const unsigned short *x, *w, *residual;
+    const float *bias;
+    unsigned short *y;
+    int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo, relu;
+    int64_t M;
+    int mt, nt;
+};
+
+__device__ __forceinline__ uint4 keep16(bool ok, uint4 v)
+{
+    return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+}
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__device__ __forceinline__ unsigned short f2bf(float f)      // round to nearest even
+{
+    const unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);      // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// 128x128 tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA blocks; BK bf16 elements per slice
+template <int BK>
+__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BfParams p)
+{
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WGN = 2;
+    constexpr int LS = BK + 8;                                  // LDS row stride in elements (+16 B pad)
+    constexpr int VPR = BK / 8;                                 // 16-byte vectors per row slice
+    constexpr int RPP = 256 / VPR;                              // rows covered per pass
+    constexpr int PA = BM / RPP, PB = BN / RPP;
+    constexpr int MAIN_BYTES = (BM + BN) * LS * 2;
+    constexpr int EPI_STRIDE = BN + 4;
+    constexpr int EPI_BYTES = 64 * EPI_STRIDE * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+    unsigned short *lds = reinterpret_cast<unsigned short *>(smem);
+
+    const int nblk = p.mt * p.nt;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.nt, tile_n = bid % p.nt;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int vcol = tid % VPR, vrow = tid / VPR;
+
+    int a_hi0[PA], a_wi0[PA];
+    unsigned a_img[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int64_t m = m0 + vrow + i * RPP;
+        a_ok[i] = m < p.M;
+        const unsigned mm = a_ok[i] ? (unsigned)m : 0u;
+        const unsigned wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+        a_hi0[i] = (int)ho * p.stride - p.pad;
+        a_wi0[i] = (int)wo * p.stride - p.pad;
+        a_img[i] = b * (unsigned)(p.H * p.W);
+    }
+    const unsigned wrow = (unsigned)(p.kh * p.kw * p.Ci);
+    bool b_ok[PB];
+    unsigned b_off[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + vrow + i * RPP;
+        b_ok[i] = n < p.Co;
+        b_off[i] = (unsigned)(b_ok[i] ? n : 0) * wrow + vcol * 8;
+    }
+    const int total_slices = p.kh * p.kw * (p.Ci / BK);
+    int ld_ci0 = 0, ld_ky = 0, ld_kx = 0;
+    unsigned ld_woff = 0;
+    uint4 ra[PA], rb[PB];
+    unsigned ra_ok = 0u;
+    auto load_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int hi = a_hi0[i] + ld_ky * p.dil, wi = a_wi0[i] + ld_kx * p.dil;
+            const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned off = ok ? (a_img[i] + (unsigned)hi * (unsigned)p.W + (unsigned)wi) * (unsigned)p.Ci + ld_ci0 + vcol * 8 : 0u;
+            ra[i] = *reinterpret_cast<const uint4 *>(p.x + off);
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const uint4 *>(p.w + b_off[i] + ld_woff);
+        ld_woff += BK;
+        ld_ci0 += BK;
+        if (ld_ci0 == p.Ci) {
+            ld_ci0 = 0;
+            if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
+        }
+    };
+    auto store_slice = [&]() {
+        unsigned short *la = lds, *lb = lds + BM * LS;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<uint4 *>(la + (vrow + i * RPP) * LS + vcol * 8) = keep16((ra_ok >> i) & 1u, ra[i]);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            *reinterpret_cast<uint4 *>(lb + (vrow + i * RPP) * LS + vcol * 8) = keep16(b_ok[i], rb[i]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    load_slice();
+    store_slice();
+    __syncthreads();
+    for (int s = 0; s < total_slices; ++s) {
+        if (s + 1 < total_slices) load_slice();
+        const unsigned short *la = lds + (wm * TM * 32 + frow) * LS + fhalf * 8;
+        const unsigned short *lb = lds + (BM + wn * TN * 32 + frow) * LS + fhalf * 8;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(la + i * 32 * LS + kk * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8 *>(lb + j * 32 * LS + kk * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < total_slices) {
+            __syncthreads();
+            store_slice();
+        }
+        __syncthreads();
+    }
+
+    // epilogue through an fp32 LDS stage: full output rows, 4 channels (8 bytes of bf16) per lane
+    float *stage = reinterpret_cast<float *>(smem);
+    constexpr int V = BN / 4, ROWS = 256 / V;                   // 32 quads per row, 8 rows per pass
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                stage[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
+            }
+        __syncthreads();
+        const int c4 = tid % V;
+        const int n = n0 + c4 * 4;
+#pragma unroll
+        for (int pass = 0; pass < 64 / ROWS; ++pass) {
+            const int row = tid / V + pass * ROWS;
+            const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+            if (m >= p.M || n >= p.Co) continue;
+            float4 v = *reinterpret_cast<const float4 *>(stage + row * EPI_STRIDE + c4 * 4);
+            const int64_t o = m * p.Co + n;
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (p.residual) {
+                const uint2 rv = *reinterpret_cast<const uint2 *>(p.residual + o);
+                v.x += bf2f((unsigned short)(rv.x & 0xffffu)); v.y += bf2f((unsigned short)(rv.x >> 16));
+                v.z += bf2f((unsigned short)(rv.y & 0xffffu)); v.w += bf2f((unsigned short)(rv.y >> 16));
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            uint2 ov;
+            ov.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+            ov.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+            *reinterpret_cast<uint2 *>(p.y + o) = ov;
+        }
+        if (i + 1 < TM) __syncthreads();
+    }
+}
+
+}  // namespace
+
+// x [B][H][W][Ci] bf16, w [Co][kh][kw][Ci] bf16, bias [Co] fp32 or NULL, residual [B][Ho][Wo][Co] bf16 or NULL,
+// y [B][Ho][Wo][Co] bf16.  Ci % 32 == 0, Co % 4 == 0.
+extern "C" int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, const void *residual, void *y, int B,
+                                   int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                                   void *stream)
+{
+    HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
+                "conv2d_fwd_bf16: bad sizes");
+    HTD_REQUIRE(Ci % 32 == 0 && Co % 4 == 0, "conv2d_fwd_bf16: needs Ci %% 32 == 0 and Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
+    HTD_REQUIRE(x && w && y, "conv2d_fwd_bf16: null pointer");
+    BfParams p{};
+    p.x = (const unsigned short *)x; p.w = (const unsigned short *)w; p.residual = (const unsigned short *)residual;
+    p.bias = bias; p.y = (unsigned short *)y;
+    p.B = B; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
+    p.relu = relu;
+    p.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_fwd_bf16: empty output");
+    p.M = (int64_t)B * p.Ho * p.Wo;
+    HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && (int64_t)Co * kh * kw * Ci < (1ll << 31) && p.M < (1ll << 31),
+                "conv2d_fwd_bf16: operand larger than 2^31 elements");
+    p.mt = (int)htd::ceil_div(p.M, 128);
+    p.nt = (int)htd::ceil_div(Co, 128);
+    const dim3 grid((unsigned)(p.mt * p.nt));
+    if (Ci % 64 == 0)
+        hipLaunchKernelGGL(conv_bf16_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_bf16_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return htd::check_launch("conv2d_fwd_bf16");
+}

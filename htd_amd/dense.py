@@ -356,6 +356,26 @@ class ResStageFunction(Function):
         return (g, None, None, None, *grads)
 
 
+def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
+    """Forward-only bf16 convolution (fp32 accumulate, htd_conv2d_fwd_bf16): x (B,Ci,H,W) and weight (Co,Ci,kh,kw)
+    bf16 channels_last, bias fp32, residual bf16 -> bf16.  Groundwork for the bf16 configurations; not yet wired into
+    the detector (no gradient kernels)."""
+    _need_gpu(x, 'conv2d_bf16')
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+        raise TypeError('conv2d_bf16: x and weight must be bfloat16')
+    x = x.contiguous(memory_format=CL)
+    weight = weight.contiguous(memory_format=CL)
+    B, Ci, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
+    y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.bfloat16, memory_format=CL)
+    b = bias.float().contiguous() if bias is not None else None
+    res = residual.to(torch.bfloat16).contiguous(memory_format=CL) if residual is not None else None
+    capi.call('htd_conv2d_fwd_bf16', _P(x), _P(weight), _P(b), _P(res), _P(y), B, H, W, Ci, Co, kh, kw, int(stride),
+              int(padding), int(dilation), int(bool(relu)), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
+    return y
+
+
 def _pad_channels(x, weight, mult=8):
     """Zero-pad the channel dimension of (x, weight) to a multiple of `mult` (3-channel stem input)."""
     Ci = x.size(1)

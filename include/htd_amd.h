@@ -263,6 +263,12 @@ int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, 
 int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, int W, int C, int k, int stride,
                        int pad, void *stream);
 
+/* bf16 forward convolution (fp32 accumulate) on v_mfma_f32_32x32x16_bf16: groundwork for the bf16 configurations
+ * (BASELINE configs[2], [3]); same semantics as htd_conv2d_fwd with x, w, residual, y in bf16 (NHWC / KRSC) and bias in
+ * fp32.  Ci % 32 == 0, Co % 4 == 0. */
+int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, const void *residual, void *y, int B, int H,
+                        int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
  * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):

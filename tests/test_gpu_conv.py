@@ -152,3 +152,35 @@ def test_fpn_fused_top_down_matches_interpolate_add():
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
     for n in p2:
         torch.testing.assert_close(p1[n], p2[n], rtol=1e-4, atol=1e-4 * float(p2[n].abs().max()), msg=n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Ci,H,W,Co,k,stride,pad,relu,with_res', [
+    (2, 64, 20, 28, 128, 3, 1, 1, True, False), (1, 256, 13, 17, 256, 1, 1, 0, False, True),
+    (2, 96, 15, 15, 72, 3, 2, 1, True, True), (1, 128, 9, 40, 300, 3, 1, 2, False, False)])
+def test_conv2d_bf16_forward(B, Ci, H, W, Co, k, stride, pad, relu, with_res):
+    """bf16 MFMA forward (fp32 accumulate) against an fp32 convolution of the same bf16-rounded operands: the only
+    differences are the summation order and the final rounding to bf16."""
+    from htd_amd import dense
+    torch.manual_seed(Ci + Co)
+    dev = torch.device('cuda:0')
+    dil = 2 if pad == 2 else 1
+    x = torch.randn(B, Ci, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    b = torch.randn(Co, device=dev)
+    y_ref = F.conv2d(x.float(), w.float(), b, stride, pad, dil)
+    res = torch.randn_like(y_ref).to(torch.bfloat16) if with_res else None
+    if with_res:
+        y_ref = y_ref + res.float()
+    if relu:
+        y_ref = y_ref.relu()
+    y = dense.conv2d_bf16(x, w, b, stride, pad, dil, relu, res)
+    assert y.dtype == torch.bfloat16 and y.shape == y_ref.shape
+    torch.testing.assert_close(y.float(), y_ref, rtol=1e-2, atol=2e-2)
+    # exactness on integer data: every product and partial sum is representable -> bit-equal to the fp32 result
+    xi = torch.randint(-2, 3, x.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wi = torch.randint(-1, 2, w.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    yi = dense.conv2d_bf16(xi, wi, None, stride, pad, dil)
+    ri = F.conv2d(xi.float(), wi.float(), None, stride, pad, dil)
+    assert torch.equal(yi.float(), ri.to(torch.bfloat16).float())
