@@ -234,3 +234,206 @@ extern "C" int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bi
         hipLaunchKernelGGL(conv_bf16_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return htd::check_launch("conv2d_fwd_bf16");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 weight gradient:  gw[co][tap][ci] (fp32) = sum over pixels k of gy[k][co] * x[k shifted by tap][ci]
+// GEMM M = Co, N = kh*kw*Ci, reduction K = B*Ho*Wo.  Both operands are K-major in memory ([pixel][channel]); they are
+// staged to LDS exactly as they lie -- [k][m] and [k][n] images, 16-byte coalesced writes -- and the MFMA operands
+// (8 consecutive k of one row) are gathered by the hardware transposing read ds_read_b64_tr_b16: per 16-lane group a
+// 4-row x 16-column block delivered column-major, two reads per 32x16 operand.  Rows are 320 bytes apart (256 + 64
+// pad): the four rows of a block then sit 16 banks apart and both groups of a 32-lane half read conflict-free.
+// Split-K over workgroups with fp32 partial tiles and a fixed-order second pass, like the fp32 kernel.
+namespace {
+
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+struct BfWgradParams {
+    const unsigned short *x, *gy;
+    float *out;
+    int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo;
+    int64_t K;
+    int Ntot, mt, nt, splits;
+    int64_t slices_per_split;
+};
+
+constexpr int WB_K = 64;                 // pixels per slice
+constexpr int WB_ROW = 160;              // LDS row stride in elements: 128 + 32 (= 320 bytes)
+
+__device__ __forceinline__ bf16x8 tr_operand(const unsigned short *img, int k0, int c0, int lane)
+{
+    // lane l: h = l>>5 takes k0 + 8h .. +7; its 16-lane group covers columns c0 + 16*((l>>4)&1) .. +15
+    const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned short *a = img + (k0 + 8 * h + q) * WB_ROW + c0 + 16 * g + 4 * pp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 4 * WB_ROW));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+__global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(BfWgradParams p)
+{
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WGN = 2;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * WB_K * WB_ROW];
+    unsigned short *la = lds, *lb = lds + WB_K * WB_ROW;
+    const int tiles = p.mt * p.nt;
+    const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+    const int tile_m = tile % p.mt, tile_n = tile / p.mt;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    // staging: 64 rows x 16 chunks of 8 elements per operand = 1024 vectors, 4 per thread
+    const int chunk = tid & 15, row0 = tid >> 4;                  // rows row0 + 16*i
+    const bool a_cok = m0 + chunk * 8 < p.Co;
+    const int nb = n0 + chunk * 8;
+    const bool b_cok = nb < p.Ntot;
+    const int tap = b_cok ? nb / p.Ci : 0;
+    const int b_ci = b_cok ? nb - tap * p.Ci : 0;
+    const int b_dy = (tap / p.kw) * p.dil - p.pad, b_dx = (tap % p.kw) * p.dil - p.pad;
+    const int64_t total_slices = (p.K + WB_K - 1) / WB_K;
+    const int64_t s_begin = (int64_t)split * p.slices_per_split;
+    const int64_t s_end = min(total_slices, s_begin + p.slices_per_split);
+
+    uint4 ra[4], rb[4];
+    unsigned ok_a = 0u, ok_b = 0u;
+    auto load_slice = [&](int64_t s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned k = (unsigned)(s * WB_K) + row0 + 16 * i;
+            const bool kin = k < (unsigned)p.K;
+            const bool oa = a_cok && kin;
+            ra[i] = *reinterpret_cast<const uint4 *>(p.gy + (oa ? k * (unsigned)p.Co + m0 + chunk * 8 : 0u));
+            ok_a = oa ? (ok_a | (1u << i)) : (ok_a & ~(1u << i));
+            const unsigned kk = kin ? k : 0u;
+            const unsigned wo = kk % (unsigned)p.Wo, t = kk / (unsigned)p.Wo;
+            const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+            const int hi = (int)ho * p.stride + b_dy, wi = (int)wo * p.stride + b_dx;
+            const bool ob = b_cok && kin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned off = ((b * (unsigned)p.H + (unsigned)hi) * (unsigned)p.W + (unsigned)wi) * (unsigned)p.Ci + b_ci;
+            rb[i] = *reinterpret_cast<const uint4 *>(p.x + (ob ? off : 0u));
+            ok_b = ob ? (ok_b | (1u << i)) : (ok_b & ~(1u << i));
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4 *>(la + (row0 + 16 * i) * WB_ROW + chunk * 8) = keep16((ok_a >> i) & 1u, ra[i]);
+            *reinterpret_cast<uint4 *>(lb + (row0 + 16 * i) * WB_ROW + chunk * 8) = keep16((ok_b >> i) & 1u, rb[i]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_slice(s_begin);
+        store_slice();
+    }
+    __syncthreads();
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) load_slice(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < WB_K / 16; ++kk) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = tr_operand(la, kk * 16, wm * 64 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = tr_operand(lb, kk * 16, wn * 64 + j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < s_end) {
+            __syncthreads();
+            store_slice();
+        }
+        __syncthreads();
+    }
+
+    float *out = p.out + (int64_t)split * p.Co * p.Ntot;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fcol;
+            if (n >= p.Ntot) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
+                                                                 int64_t n4, int64_t n, int splits)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4 *>(ws + (int64_t)k * n + i * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i * 4) = s;
+    }
+}
+
+int bf16_wgrad_splits(int Co, int Ntot, int64_t K)
+{
+    const int64_t tiles = htd::ceil_div(Co, 128) * htd::ceil_div(Ntot, 128);
+    const int64_t slices = htd::ceil_div(K, WB_K);
+    int64_t want = htd::ceil_div(2304, tiles);
+    want = std::min<int64_t>(want, std::max<int64_t>(1, slices / 8));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, 128));
+}
+
+}  // namespace
+
+extern "C" int64_t htd_conv2d_wgrad_bf16_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+                                                         int pad, int dil)
+{
+    const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    return (int64_t)bf16_wgrad_splits(Co, kh * kw * Ci, (int64_t)B * Ho * Wo) * Co * kh * kw * Ci * 4 + 256;
+}
+
+// x [B][H][W][Ci] bf16, gy [B][Ho][Wo][Co] bf16 -> gw [Co][kh][kw][Ci] fp32.  Ci % 8 == 0, Co % 8 == 0.
+extern "C" int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *gw, int B, int H, int W, int Ci, int Co,
+                                          int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream)
+{
+    HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
+                "conv2d_bwd_weight_bf16: bad sizes");
+    HTD_REQUIRE(Ci % 8 == 0 && Co % 8 == 0, "conv2d_bwd_weight_bf16: Ci and Co must be multiples of 8");
+    HTD_REQUIRE(x && gy && gw && workspace, "conv2d_bwd_weight_bf16: null pointer");
+    BfWgradParams p{};
+    p.x = (const unsigned short *)x; p.gy = (const unsigned short *)gy;
+    p.B = B; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
+    p.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
+    p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_bwd_weight_bf16: empty output");
+    p.K = (int64_t)B * p.Ho * p.Wo;
+    HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.K * Co < (1ll << 31), "conv2d_bwd_weight_bf16: operand too large");
+    p.Ntot = kh * kw * Ci;
+    p.mt = (int)htd::ceil_div(Co, 128);
+    p.nt = (int)htd::ceil_div(p.Ntot, 128);
+    p.splits = bf16_wgrad_splits(Co, p.Ntot, p.K);
+    p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, WB_K), p.splits);
+    p.out = p.splits == 1 ? gw : (float *)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)(p.mt * p.nt * p.splits)), dim3(256), 0, s, p);
+    if (p.splits > 1) {
+        const int64_t n = (int64_t)Co * p.Ntot;
+        const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n / 4, 256), 2048);
+        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)workspace, gw, n / 4,
+                           n, p.splits);
+    }
+    return htd::check_launch("conv2d_bwd_weight_bf16");
+}

@@ -376,6 +376,67 @@ def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=Fals
     return y
 
 
+def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1):
+    """fp32 weight gradient of a convolution from bf16 activations x (B,Ci,H,W) and bf16 output gradient gy
+    (htd_conv2d_bwd_weight_bf16) -> (Co,Ci,kh,kw) fp32 channels_last."""
+    _need_gpu(x, 'conv2d_wgrad_bf16')
+    x = x.contiguous(memory_format=CL)
+    gy = gy.contiguous(memory_format=CL)
+    B, Ci, H, W = x.shape
+    Co, _, kh, kw = weight_shape
+    gw = torch.empty((Co, Ci, kh, kw), device=x.device, dtype=torch.float32, memory_format=CL)
+    nbytes = capi.lib().htd_conv2d_wgrad_bf16_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
+    ws = torch.empty(nbytes // 4 + 1, device=x.device, dtype=torch.float32)
+    capi.call('htd_conv2d_bwd_weight_bf16', _P(x), _P(gy), _P(gw), B, H, W, Ci, Co, kh, kw, int(stride), int(padding),
+              int(dilation), _P(ws), _S(), work=('flop', 2.0 * gy.numel() * kh * kw * Ci))
+    return gw
+
+
+class Conv2dBf16Function(Function):
+    """Mixed-precision convolution for the bf16 configurations: bf16 activations, fp32 master weight / bias.
+    forward  y = act(conv(x, bf16(w)) + b [+ residual])           htd_conv2d_fwd_bf16
+    backward gx = conv(gy, flip(bf16(w)))  (stride 1; strided layers fall back to the fp32 kernels)
+             gw = fp32 weight gradient from bf16 x, gy           htd_conv2d_bwd_weight_bf16
+    Gradients w.r.t. weight and bias come out in fp32, ready for the flat fp32 gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu):
+        wb = weight.to(torch.bfloat16).contiguous(memory_format=CL)
+        y = conv2d_bf16(x, wb, bias, stride, padding, dilation, relu, residual)
+        ctx.save_for_backward(x, wb, y if relu else None)
+        ctx.cfg = (stride, padding, dilation, bias is not None, residual is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, wb, y = ctx.saved_tensors
+        stride, padding, dilation, has_bias, has_res, wshape = ctx.cfg
+        g = g.contiguous(memory_format=CL)
+        if y is not None:
+            g = g * (y > 0).to(g.dtype)
+        need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+        gx = gw = gb = None
+        kh = wshape[2]
+        if need_x:
+            if stride == 1:
+                wT = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=CL)        # [ci][kh'][kw'][co]
+                gx = conv2d_bf16(g, wT, None, 1, dilation * (kh - 1) - padding, dilation)
+            else:
+                gx = _dgrad_raw(g.float().contiguous(memory_format=CL), wb.float().contiguous(memory_format=CL),
+                                x.shape, stride, padding, dilation).to(torch.bfloat16)
+        if need_w:
+            gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation)
+        if has_bias and need_b:
+            gb = g.float().sum((0, 2, 3))
+        return gx, gw, gb, (g if (has_res and need_r) else None), None, None, None, None
+
+
+def conv2d_bf16_autograd(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
+    """Differentiable bf16 convolution with fp32 master parameters (see Conv2dBf16Function)."""
+    return Conv2dBf16Function.apply(x, weight, bias, residual, int(stride), int(padding), int(dilation), bool(relu))
+
+
 def _pad_channels(x, weight, mult=8):
     """Zero-pad the channel dimension of (x, weight) to a multiple of `mult` (3-channel stem input)."""
     Ci = x.size(1)

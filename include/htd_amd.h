@@ -268,6 +268,13 @@ int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, 
  * fp32.  Ci % 32 == 0, Co % 4 == 0. */
 int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, const void *residual, void *y, int B, int H,
                         int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, void *stream);
+/* bf16 weight gradient: gw [Co][kh][kw][Ci] fp32 from x, gy in bf16 (NHWC); both K-major operands are consumed through
+ * the transposing LDS read ds_read_b64_tr_b16; deterministic split-K through `workspace`
+ * (htd_conv2d_wgrad_bf16_workspace_bytes).  Ci % 8 == 0, Co % 8 == 0. */
+int64_t htd_conv2d_wgrad_bf16_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                                              int dil);
+int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *gw, int B, int H, int W, int Ci, int Co, int kh,
+                               int kw, int stride, int pad, int dil, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv

@@ -184,3 +184,57 @@ def test_conv2d_bf16_forward(B, Ci, H, W, Co, k, stride, pad, relu, with_res):
     yi = dense.conv2d_bf16(xi, wi, None, stride, pad, dil)
     ri = F.conv2d(xi.float(), wi.float(), None, stride, pad, dil)
     assert torch.equal(yi.float(), ri.to(torch.bfloat16).float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Ci,H,W,Co,k,stride,pad', [(2, 64, 20, 28, 128, 3, 1, 1), (1, 256, 13, 17, 256, 1, 1, 0),
+                                                      (2, 96, 15, 15, 72, 3, 2, 1), (3, 40, 9, 11, 200, 3, 1, 2)])
+def test_conv2d_wgrad_bf16(B, Ci, H, W, Co, k, stride, pad):
+    """bf16 weight gradient (operands through the transposing LDS read) against autograd on the same bf16-rounded
+    operands in fp32, and bit-exactly on small-integer data (asymmetric: catches transposed or permuted operands)."""
+    from htd_amd import dense
+    torch.manual_seed(Ci * 3 + Co)
+    dev = torch.device('cuda:0')
+    dil = 2 if pad == 2 else 1
+    x = torch.randn(B, Ci, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(Co, Ci, k, k, device=dev, requires_grad=True)
+    y = F.conv2d(x.float(), w, None, stride, pad, dil)
+    gy = torch.randn_like(y).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ref, = torch.autograd.grad(y, w, gy.float())
+    got = dense.conv2d_wgrad_bf16(x, gy, w.shape, stride, pad, dil)
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    xi = torch.randint(-2, 3, x.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gi = torch.randint(-1, 2, gy.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    yi = F.conv2d(xi.float(), w, None, stride, pad, dil)
+    refi, = torch.autograd.grad(yi, w, gi.float())
+    assert torch.equal(dense.conv2d_wgrad_bf16(xi, gi, w.shape, stride, pad, dil), refi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Ci,Co,k,stride,pad,relu', [(64, 128, 3, 1, 1, True), (256, 64, 1, 1, 0, False),
+                                                     (96, 96, 3, 2, 1, True)])
+def test_conv2d_bf16_autograd_matches_fp32_autograd(Ci, Co, k, stride, pad, relu):
+    """Conv2dBf16Function (bf16 activations, fp32 master weights) against fp32 autograd on the bf16-rounded operands:
+    output, data gradient, fp32 weight and bias gradients, to bf16 accuracy."""
+    from htd_amd import dense
+    torch.manual_seed(Ci + 7 * Co)
+    dev = torch.device('cuda:0')
+    x = torch.randn(2, Ci, 18, 22, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Co, device=dev) * 0.1
+    xa, wa, ba = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y = dense.conv2d_bf16_autograd(xa, wa, ba, stride, pad, 1, relu)
+    xr = x.float().requires_grad_()
+    wr = w.to(torch.bfloat16).float().requires_grad_()
+    br = b.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, stride, pad)
+    yr = yr.relu() if relu else yr
+    g = torch.randn_like(yr).to(torch.bfloat16)
+    y.backward(g)
+    yr.backward(g.float())
+    tol = dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(y.float(), yr, **tol)
+    torch.testing.assert_close(xa.grad.float(), xr.grad, rtol=3e-2, atol=3e-2 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(wa.grad, wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max()))
+    torch.testing.assert_close(ba.grad, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
+    assert wa.grad.dtype == torch.float32 and xa.grad.dtype == torch.bfloat16
