@@ -34,6 +34,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4, help='images per GPU (BASELINE configs[1]: 4)')
     ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--bf16', action='store_true', help='bf16 backbone / FPN / RPN conv (BASELINE configs[2] precision)')
     ap.add_argument('--dcn', action='store_true', help='ResNet-DCN backbone (BASELINE configs[3] architecture, fp32 here)')
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1344)
@@ -107,7 +108,7 @@ def main():
                     return model.simple_test(d['img'], d['img_metas'])
         trainer = _Infer()
     else:
-        model = build_htd_detector(args.depth, dcn=args.dcn)  # init_weights() of every module, seed 0
+        model = build_htd_detector(args.depth, dcn=args.dcn, bf16=args.bf16)  # init_weights(), seed 0
         model = model.to(dev).train()
         trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
         data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
@@ -165,7 +166,7 @@ def main():
                    'images/sec (1333x800) HTD-R%d train step') % args.depth, 'value': round(value, 3),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': (f'HTD ResNet-{args.depth} FPN fp32 inference (simple_test, hard NMS), batch {args.batch}/GPU '
                                 f'@ {args.width - 11}x{args.height}, {args.proposals} proposals/img into the RoI head'
                                 if args.infer else

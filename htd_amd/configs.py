@@ -84,8 +84,14 @@ def htd_config(depth=50, dcn=False, soft_nms=None):
         total_epochs=12 if depth == 50 else 24)
 
 
-def build_htd_detector(depth=50, dcn=False, cfg=None):
+def build_htd_detector(depth=50, dcn=False, cfg=None, bf16=False):
+    """bf16=True: backbone stages, FPN and the RPN's shared conv run on the bf16 MFMA kernels (fp32 master weights, fp32
+    accumulate); the stem, the RoI head and all box / loss arithmetic stay fp32 (BASELINE configs[2] precision map)."""
     from . import detector  # noqa: F401  (registers the components)
     from .registry import build_detector
     cfg = htd_config(depth, dcn) if cfg is None else cfg
-    return build_detector(copy.deepcopy(cfg.model.to_dict()), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    model = build_detector(copy.deepcopy(cfg.model.to_dict()), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    if bf16:
+        import torch
+        model.backbone.compute_dtype = torch.bfloat16
+    return model

@@ -15,8 +15,12 @@ CL = torch.channels_last
 
 
 def dense_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False):
-    """y = act(conv2d(x, w) + bias + residual) on NHWC activations / KRSC weights."""
+    """y = act(conv2d(x, w) + bias + residual) on NHWC activations / KRSC weights.  bf16 activations take the
+    mixed-precision kernels (bf16 operands, fp32 accumulate, fp32 master parameters and parameter gradients)."""
     from .. import dense
+    if x.dtype == torch.bfloat16:
+        assert not residual_up, 'the bf16 kernels take same-size residuals only'
+        return dense.conv2d_bf16_autograd(x, weight, bias, stride, padding, dilation, relu, residual)
     return dense.conv2d(x, weight, bias, stride, padding, dilation, relu, residual, residual_up)
 
 

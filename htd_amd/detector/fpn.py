@@ -1,5 +1,6 @@
 """FPN neck (mmdet/models/necks/fpn.py:9-216): 1x1 laterals, nearest top-down add, 3x3 output convs,
 P6 = stride-2 subsample of P5.  The HTD configs use the plain variant (no extra convs, no norm)."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -41,7 +42,8 @@ class FPN(nn.Module):
 
     def _fused_top_down(self, inputs):
         """Plain lateral convs (no norm / activation) on GPU tensors, nearest up-sampling to the finer level's size."""
-        if not inputs[0].is_cuda or self.upsample_cfg.get('mode', 'nearest') != 'nearest' or \
+        if not inputs[0].is_cuda or inputs[0].dtype != torch.float32 or \
+                self.upsample_cfg.get('mode', 'nearest') != 'nearest' or \
                 self.out_channels % 4 != 0 or not getattr(self, 'fused_top_down', True):
             return False
         if 'scale_factor' in self.upsample_cfg:      # must land exactly on the finer level's size

@@ -122,8 +122,8 @@ class ResLayer(nn.Sequential):
         return True
 
     def forward(self, x):
-        if not x.is_cuda or not self._fusable():
-            return super().forward(x)
+        if not x.is_cuda or x.dtype != torch.float32 or not self._fusable():
+            return super().forward(x)           # CPU / bf16 activations / DCN blocks: block by block
         params = []
         for blk in self:
             for conv, bn in ((blk.conv1, blk.norm1), (blk.conv2, blk.norm2), (blk.conv3, blk.norm3)):
@@ -229,6 +229,8 @@ class ResNet(nn.Module):
             x = M.max_pool2d(x, mp.kernel_size, mp.stride, mp.padding)      # NHWC kernel of libhtd_amd.so
         else:
             x = mp(x)
+        if getattr(self, 'compute_dtype', torch.float32) == torch.bfloat16 and x.is_cuda:
+            x = x.to(torch.bfloat16)            # bf16 configurations: stages (and the neck) run on the bf16 kernels
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

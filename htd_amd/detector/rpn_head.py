@@ -87,6 +87,8 @@ class RPNHead(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward_single(self, x):
         x = self.rpn_conv(x, relu=True)
+        if x.dtype != torch.float32:             # bf16 pyramid: the 3- and 12-channel heads and all box math stay fp32
+            x = x.float()
         return self.rpn_cls(x), self.rpn_reg(x)
 
     def forward(self, feats):

@@ -151,6 +151,7 @@ class TwoStageDetector(BaseDetector):
                       proposals=None, **kwargs):
         x = self.extract_feat(img)
         losses = dict()
+        x32 = x if x[0].dtype == torch.float32 else tuple(f.float() for f in x)     # RoI head: fp32 (force_fp32 sites)
         if self.with_rpn:
             proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
             static = x[0].is_cuda and gt_masks is None and not kwargs and \
@@ -160,11 +161,11 @@ class TwoStageDetector(BaseDetector):
                                                                     proposal_cfg=proposal_cfg, padded=static)
             losses.update(rpn_losses)
             if static:       # fixed-shape RoI head: the whole train step runs without a host/device synchronisation
-                losses.update(self.roi_head.forward_train_static(x, img_metas, *proposal_list, gt_bboxes, gt_labels))
+                losses.update(self.roi_head.forward_train_static(x32, img_metas, *proposal_list, gt_bboxes, gt_labels))
                 return losses
         else:
             proposal_list = proposals
-        losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
+        losses.update(self.roi_head.forward_train(x32, img_metas, proposal_list, gt_bboxes, gt_labels,
                                                   gt_bboxes_ignore, gt_masks, **kwargs))
         return losses
 
@@ -172,7 +173,8 @@ class TwoStageDetector(BaseDetector):
         assert self.with_bbox, 'Bbox head must be implemented.'
         x = self.extract_feat(img)
         proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
-        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
+        x32 = x if x[0].dtype == torch.float32 else tuple(f.float() for f in x)
+        return self.roi_head.simple_test(x32, proposal_list, img_metas, rescale=rescale)
 
 
 @DETECTORS.register_module()

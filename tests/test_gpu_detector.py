@@ -361,3 +361,42 @@ def test_fused_rpn_loss_matches_tensor_formulation(det, golden):
     assert lt[1] > 0
     for a, b in zip(gf, gt_):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * max(1.0, float(b.abs().max())))
+
+
+def test_bf16_train_step_tracks_the_fp32_step(det, golden):
+    """BASELINE configs[2] precision map (bf16 backbone stages / FPN / RPN shared conv on the bf16 MFMA kernels, fp32
+    master weights, fp32 RoI head and losses) against the fp32 step on the same inputs and samples: losses within
+    bf16 accuracy, gradients of the same direction."""
+    from htd_amd.core import set_randperm
+    from htd_amd.core.bbox import set_sample_keys
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, gts, labels = inputs(g, dev)
+    coef = torch.tensor([12.9898, 78.233, 37.719, 93.989], device=dev)
+    det.train()
+    set_randperm(None)
+    set_sample_keys(lambda cand: torch.frac(torch.sin((cand.round() * coef).sum(-1)) * 43758.5453).abs())
+    out = {}
+    try:
+        for dt in (torch.float32, torch.bfloat16):
+            det.backbone.compute_dtype = dt
+            det.zero_grad()
+            losses = det(img=img, img_metas=metas, gt_bboxes=gts, gt_labels=labels)
+            loss, log_vars = det._parse_losses(losses)
+            loss.backward()
+            out[dt] = ({k: float(v) for k, v in log_vars.items()},
+                       {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None})
+    finally:
+        det.backbone.compute_dtype = torch.float32
+        set_sample_keys(None)
+        set_randperm(lambda n, device: torch.randperm(n).to(device))
+    (l32, g32), (l16, g16) = out[torch.float32], out[torch.bfloat16]
+    assert abs(l16['loss'] - l32['loss']) <= 5e-2 * abs(l32['loss']), (l16, l32)
+    for k in ('loss_rpn_cls', 'loss_global', 's0.loss_cls', 's1.loss_cls'):
+        assert abs(l16[k] - l32[k]) <= 6e-2 * max(abs(l32[k]), 0.05), (k, l16[k], l32[k])
+    for n in ('backbone.layer2.0.conv1.weight', 'backbone.layer3.1.conv2.weight', 'neck.fpn_convs.0.conv.weight',
+              'neck.lateral_convs.2.conv.weight', 'rpn_head.rpn_conv.weight'):
+        a, b = g16[n].flatten().double(), g32[n].flatten().double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.9, (n, cos)
+        assert g16[n].dtype == torch.float32
