@@ -14,12 +14,14 @@ def _small(cfg):
     return cfg
 
 
-def test_r101_dcn_train_step():
+@pytest.mark.parametrize('bf16', [False, True])
+def test_r101_dcn_train_step(bf16):
+    """BASELINE configs[3] architecture (R101-DCN), fp32 and with the bf16 precision map."""
     from htd_amd.configs import build_htd_detector, htd_config
     from htd_amd.runner import Trainer, synthetic_batch
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    model = build_htd_detector(cfg=_small(htd_config(101, dcn=True))).to(dev).train()
+    model = build_htd_detector(cfg=_small(htd_config(101, dcn=True)), bf16=bf16).to(dev).train()
     tr = Trainer(model, lr=0.01)
     data = synthetic_batch(2, 256, 320, 311, device=dev, seed=1)
     for _ in range(2):
