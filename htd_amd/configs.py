@@ -94,4 +94,6 @@ def build_htd_detector(depth=50, dcn=False, cfg=None, bf16=False):
     if bf16:
         import torch
         model.backbone.compute_dtype = torch.bfloat16
+        for head in model.roi_head.bbox_head:          # the 12544->1024->1024 FC stacks of both stages
+            head.compute_dtype = torch.bfloat16
     return model

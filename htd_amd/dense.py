@@ -414,7 +414,7 @@ class Conv2dBf16Function(Function):
         stride, padding, dilation, has_bias, has_res, wshape = ctx.cfg
         g = g.contiguous(memory_format=CL)
         if y is not None:
-            g = g * (y > 0).to(g.dtype)
+            g = torch.ops.aten.threshold_backward(g, y, 0)          # ReLU backward: one launch
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
         gx = gw = gb = None
         kh = wshape[2]
@@ -428,7 +428,7 @@ class Conv2dBf16Function(Function):
         if need_w:
             gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation)
         if has_bias and need_b:
-            gb = g.float().sum((0, 2, 3))
+            gb = torch.sum(g, dim=(0, 2, 3), dtype=torch.float32)       # fp32 accumulation, no fp32 copy of g
         return gx, gw, gb, (g if (has_res and need_r) else None), None, None, None, None
 
 
@@ -472,8 +472,11 @@ def linear(x, weight, bias=None, relu=False):
         K += pad
     x4 = x.contiguous().view(M, 1, 1, K).permute(0, 3, 1, 2)          # (M, K, 1, 1) channels_last view
     w4 = weight.contiguous().view(N, 1, 1, K).permute(0, 3, 1, 2)
-    y = Conv2dFunction.apply(x4, w4, bias, None, 1, 0, 1, relu)       # (M, N, 1, 1) channels_last
-    return y.permute(0, 2, 3, 1).reshape(M, N)
+    if x.dtype == torch.bfloat16 and K % 32 == 0 and N % 8 == 0:     # bf16 activations: mixed-precision kernels
+        y = Conv2dBf16Function.apply(x4, w4, bias, None, 1, 0, 1, relu)
+    else:
+        y = Conv2dFunction.apply(x4.float() if x.dtype != torch.float32 else x4, w4, bias, None, 1, 0, 1, relu)
+    return y.permute(0, 2, 3, 1).reshape(M, N)                         # (M, N, 1, 1) channels_last -> (M, N)
 
 
 class BatchedGemmNT(Function):

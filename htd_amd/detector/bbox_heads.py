@@ -63,12 +63,14 @@ class TileLinear(nn.Linear):
             self.weight.copy_(w2.view(self.out_features, *self.tile_shape))
 
 
-def fc_on_roi_tiles(x, fc, relu=True):
+def fc_on_roi_tiles(x, fc, relu=True, compute_dtype=None):
     """Linear over flattened (n,C,h,w) RoI features held NHWC.  The reference flattens in (c,h,w)
     order (convfc_bbox_head.py:147); here x is read in its physical (h,w,c) order and the weight is
     viewed in the matching order (free for a TileLinear, a permuted copy for a plain nn.Linear)."""
     n, C, h, w = x.shape
     xf = x.permute(0, 2, 3, 1).reshape(n, h * w * C)
+    if compute_dtype is not None and xf.dtype != compute_dtype:
+        xf = xf.to(compute_dtype)                 # bf16 configurations: the FC stack runs on the bf16 kernels
     if isinstance(fc, TileLinear):
         wt = fc.weight_hwc()
     else:
@@ -289,12 +291,12 @@ class ConvFCBBoxHead(BBoxHead):
                 from .. import mmcv_ops as M
                 x = M.global_avg_pool(x).flatten(1)
             elif len(fcs) > 0:
-                x, fcs = fc_on_roi_tiles(x, fcs[0]), fcs[1:]
+                x, fcs = fc_on_roi_tiles(x, fcs[0], compute_dtype=getattr(self, 'compute_dtype', None)), fcs[1:]
             else:
                 x = x.flatten(1)
         for fc in fcs:
             x = dense.linear(x, fc.weight, fc.bias, relu=True)
-        return x
+        return x.float() if x.dtype != torch.float32 else x       # classifier / regressor and the losses: fp32
 
     def forward(self, x):
         if self.num_shared_convs > 0 or self.num_shared_fcs > 0:

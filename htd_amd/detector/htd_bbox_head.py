@@ -81,10 +81,10 @@ class HTDBBoxHead(BBoxHead):
     def _cls_fcs(self, x):
         """fcs = Linear(12544,1024)+ReLU, Linear(1024,1024)+ReLU on NHWC RoI tiles."""
         lin = [m for m in self.fcs if isinstance(m, nn.Linear)]
-        x = fc_on_roi_tiles(x, lin[0], relu=True)
+        x = fc_on_roi_tiles(x, lin[0], relu=True, compute_dtype=getattr(self, 'compute_dtype', None))
         for fc in lin[1:]:
             x = dense.linear(x, fc.weight, fc.bias, relu=True)
-        return x
+        return x.float() if x.dtype != torch.float32 else x       # PGraph, classifier and losses: fp32
 
     def forward_reg(self, x_reg, enhanced_feat, pos_rois=None, global_feat=None):
         """Regression branch (htd_bbox_head.py:157-190): BA-enhanced positives -> 3 GN convs -> pool -> fc_reg."""

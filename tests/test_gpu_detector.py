@@ -380,6 +380,8 @@ def test_bf16_train_step_tracks_the_fp32_step(det, golden):
     try:
         for dt in (torch.float32, torch.bfloat16):
             det.backbone.compute_dtype = dt
+            for head in det.roi_head.bbox_head:                 # the FC stacks of both RoI stages as well
+                head.compute_dtype = None if dt == torch.float32 else dt
             det.zero_grad()
             losses = det(img=img, img_metas=metas, gt_bboxes=gts, gt_labels=labels)
             loss, log_vars = det._parse_losses(losses)
@@ -388,6 +390,8 @@ def test_bf16_train_step_tracks_the_fp32_step(det, golden):
                        {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None})
     finally:
         det.backbone.compute_dtype = torch.float32
+        for head in det.roi_head.bbox_head:
+            head.compute_dtype = None
         set_sample_keys(None)
         set_randperm(lambda n, device: torch.randperm(n).to(device))
     (l32, g32), (l16, g16) = out[torch.float32], out[torch.bfloat16]
@@ -395,7 +399,8 @@ def test_bf16_train_step_tracks_the_fp32_step(det, golden):
     for k in ('loss_rpn_cls', 'loss_global', 's0.loss_cls', 's1.loss_cls'):
         assert abs(l16[k] - l32[k]) <= 6e-2 * max(abs(l32[k]), 0.05), (k, l16[k], l32[k])
     for n in ('backbone.layer2.0.conv1.weight', 'backbone.layer3.1.conv2.weight', 'neck.fpn_convs.0.conv.weight',
-              'neck.lateral_convs.2.conv.weight', 'rpn_head.rpn_conv.weight'):
+              'neck.lateral_convs.2.conv.weight', 'rpn_head.rpn_conv.weight', 'roi_head.bbox_head.0.shared_fcs.1.weight',
+              'roi_head.bbox_head.1.fcs.0.weight'):
         a, b = g16[n].flatten().double(), g32[n].flatten().double()
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.9, (n, cos)
