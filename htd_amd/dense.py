@@ -428,7 +428,8 @@ class Conv2dBf16Function(Function):
         if need_w:
             gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation)
         if has_bias and need_b:
-            gb = torch.sum(g, dim=(0, 2, 3), dtype=torch.float32)       # fp32 accumulation, no fp32 copy of g
+            # column sums of the [pixels][Co] matrix (NHWC memory), fp32 accumulation, no fp32 copy of g
+            gb = torch.sum(g.permute(0, 2, 3, 1).reshape(-1, g.size(1)), dim=0, dtype=torch.float32)
         return gx, gw, gb, (g if (has_res and need_r) else None), None, None, None, None
 
 
