@@ -25,6 +25,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0             # HBM3E peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 matrix peak (2:1 sparsity figures are not used)
 
 
 def parse():
@@ -125,7 +126,8 @@ def main():
     # --profile-kernels (costs ~6 % of the step)
     everything = args.profile_kernels or args.profile_detail
     capi.profile_begin(detail=args.profile_detail, only=None if everything else (
-        'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_bwd_weight', 'htd_bgemm_nt'))
+        'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_bwd_weight', 'htd_bgemm_nt', 'htd_conv2d_fwd_bf16',
+        'htd_conv2d_bwd_weight_bf16'))
     t0 = time.perf_counter()
     for i in range(args.steps):
         # kernel events on every 4th step of the timed region (all steps with --profile-kernels): their queue
@@ -146,13 +148,13 @@ def main():
     value = args.batch * world * args.steps / elapsed
 
     from htd_amd import dense
-    roof = dense.roofline_report(prof, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS)
+    roof = dense.roofline_report(prof, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS)
     # HBM bytes per launch of the dominant kernel class come from separate rocprofv3 PMC passes (FETCH_SIZE,
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:
         tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
         cls = 'conv_wgrad' if 'wgrad' in roof['kernel'] else 'conv_igemm'
-        if roof and 'conv' in roof['kernel']:
+        if roof and 'conv' in roof['kernel'] and 'bf16' not in roof['kernel']:      # PMC passes were taken on the fp32 kernels
             roof['traffic'] = tr[cls]['hbm_bytes_per_launch_corrected']
             roof['traffic_unit'] = 'bytes/launch (rocprofv3 PMC, profiles/r01_hbm_traffic.json)'
     except Exception:
@@ -170,7 +172,7 @@ def main():
         'config': {'workload': (f'HTD ResNet-{args.depth} FPN fp32 inference (simple_test, hard NMS), batch {args.batch}/GPU '
                                 f'@ {args.width - 11}x{args.height}, {args.proposals} proposals/img into the RoI head'
                                 if args.infer else
-                                f'HTD ResNet-{args.depth}{"-DCN" if args.dcn else ""} FPN fp32 train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
+                                f'HTD ResNet-{args.depth}{"-DCN" if args.dcn else ""} FPN {"bf16 (backbone / FPN / RPN conv / RoI FC stacks; fp32 master weights, RoI ops, losses)" if args.bf16 else "fp32"} train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
                                 f'{args.width - 11}x{args.height} (padded {args.width}x{args.height}), '
                                 'random-init weights, 2000 RPN proposals/img, 512 RoIs/img/stage'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}'},

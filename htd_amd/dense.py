@@ -518,7 +518,7 @@ def bgemm_nt(a, b):
     return BatchedGemmNT.apply(a, b)
 
 
-def roofline_report(prof, peak_tflops, peak_gbs):
+def roofline_report(prof, peak_tflops, peak_gbs, peak_bf16_tflops=2500.0):
     """The `roofline` object of bench.py for the dominant hand-written kernel of the timed region:
     achieved = algorithmic work of its launches / their summed device time (live HIP-event timing)."""
     # forward and data-gradient calls run the same GPU kernel (conv_igemm_kernel): one class, as rocprofv3 sees it
@@ -539,6 +539,8 @@ def roofline_report(prof, peak_tflops, peak_gbs):
         return None
     name, calls, ms, kind, work, nbytes = best
     if kind == 'flop':
+        if 'bf16' in name:                       # bf16 matrix-core peak for the bf16 kernels
+            peak_tflops = peak_bf16_tflops
         achieved = work / (ms * 1e-3) / 1e12
         return dict(kernel=name, bound='mfma', achieved=round(achieved, 3), peak=peak_tflops, unit='TFLOP/s',
                     frac=round(achieved / peak_tflops, 4), traffic=None, launches=calls,
