@@ -14,7 +14,8 @@ ARCH = 'gfx950'
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
           '-fhip-fp32-correctly-rounded-divide-sqrt']
 # per-file extra flags: NMS keeps the CPU path's unfused arithmetic (bit-exact keep sets)
-EXTRA = {'nms.hip': ['-ffp-contract=off'], 'box_ops.hip': ['-ffp-contract=off']}
+EXTRA = {'nms.hip': ['-ffp-contract=off'], 'box_ops.hip': ['-ffp-contract=off'],
+         'image_pipeline.hip': ['-ffp-contract=off']}
 
 
 def sources():

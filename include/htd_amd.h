@@ -277,6 +277,25 @@ int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *gw, int B, 
                                int kw, int stride, int pad, int dil, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * On-device data pipeline of one batch of decoded 8-bit images: in ONE pass
+ *   Resize   mmcv.imrescale -> cv2.resize(INTER_LINEAR) on uint8 (datasets/pipelines/transforms.py:202-231): OpenCV's
+ *            fixed-point bilinear (11-bit weights; exact 2x downscale = 2x2 mean), sizes chosen by the host;
+ *   flip     mmcv.imflip (transforms.py:440-444): bit 0 horizontal, bit 1 vertical, both = diagonal;
+ *   Normalize mmcv.imnormalize (transforms.py:563-575): BGR->RGB if to_rgb, (x - mean) in fp32, * (1/(double)std);
+ *   Pad + collate  mmcv.impad_to_multiple (transforms.py:496-505) and mmcv.parallel.collate's pad to the batch
+ *            maximum: every pixel outside an image's dst_h x dst_w is pad_val.
+ *   src      packed HWC (3 channels) uint8 images, image b starts at byte src_off[b]  (device)
+ *   meta     48 B per image (device, 8 B aligned): int32 {src_h, src_w, dst_h, dst_w, flip, area2, 0, 0} then double
+ *            {scale_x, scale_y} = 1.0 / ((double)dst / src), the values cv2.resize builds its tables from; area2 = 1
+ *            iff src_h == 2*dst_h && src_w == 2*dst_w; the caller guarantees dst_h <= Hp, dst_w <= Wp and that
+ *            every image lies inside `src`
+ *   out      [B][Hp][Wp][3] fp32, written in full (= torch channels_last of (B,3,Hp,Wp))
+ * ---------------------------------------------------------------------------------- */
+int htd_image_batch_pipeline(const uint8_t *src, const int64_t *src_off, const int *meta, float *out, int B, int Hp,
+                             int Wp, float mean0, float mean1, float mean2, float std0, float std1, float std2,
+                             int to_rgb, float pad_val, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * SGD with momentum and weight decay on the flat parameter buffer (the update the mmcv
  * OptimizerHook performs after the DDP all-reduce; configs/_base_/schedules/schedule_1x.py:2):
  *   g = grad*grad_scale + wd*p ; m = momentum*m + g ; p -= lr*m.     lr is a device scalar
