@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--depth', type=int, default=50)
     ap.add_argument('--bf16', action='store_true', help='bf16 backbone / FPN / RPN conv (BASELINE configs[2] precision)')
     ap.add_argument('--dcn', action='store_true', help='ResNet-DCN backbone (BASELINE configs[3] architecture, fp32 here)')
+    ap.add_argument('--resnext', action='store_true', help='ResNeXt 64x4d backbone (htd_resnetx101_dcn_2x_mstrain.py with --depth 101 --dcn)')
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -109,7 +110,7 @@ def main():
                     return model.simple_test(d['img'], d['img_metas'])
         trainer = _Infer()
     else:
-        model = build_htd_detector(args.depth, dcn=args.dcn, bf16=args.bf16)  # init_weights(), seed 0
+        model = build_htd_detector(args.depth, dcn=args.dcn, bf16=args.bf16, resnext=args.resnext)  # init_weights(), seed 0
         model = model.to(dev).train()
         trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
         data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
@@ -172,7 +173,7 @@ def main():
         'config': {'workload': (f'HTD ResNet-{args.depth} FPN fp32 inference (simple_test, hard NMS), batch {args.batch}/GPU '
                                 f'@ {args.width - 11}x{args.height}, {args.proposals} proposals/img into the RoI head'
                                 if args.infer else
-                                f'HTD ResNet-{args.depth}{"-DCN" if args.dcn else ""} FPN {"bf16 (backbone / FPN / RPN conv / RoI FC stacks; fp32 master weights, RoI ops, losses)" if args.bf16 else "fp32"} train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
+                                f'HTD {"ResNeXt-64x4d" if args.resnext else "ResNet"}-{args.depth}{"-DCN" if args.dcn else ""} FPN {"bf16 (backbone / FPN / RPN conv / RoI FC stacks; fp32 master weights, RoI ops, losses)" if args.bf16 else "fp32"} train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
                                 f'{args.width - 11}x{args.height} (padded {args.width}x{args.height}), '
                                 'random-init weights, 2000 RPN proposals/img, 512 RoIs/img/stage'),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}'},

@@ -26,9 +26,11 @@ def _rcnn(thr):
                 pos_weight=-1, debug=False)
 
 
-def htd_model(depth=50, dcn=False):
+def htd_model(depth=50, dcn=False, resnext=False):
     backbone = dict(type='ResNet', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
                     norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch')
+    if resnext:                                    # htd_resnetx101_dcn_2x_mstrain.py:138-150 (64x4d)
+        backbone.update(type='ResNeXt', groups=64, base_width=4)
     if dcn:
         backbone.update(dcn=dict(type='DCN', deform_groups=1, fallback_on_stride=False),
                         stage_with_dcn=(False, True, True, True))
@@ -72,11 +74,11 @@ def htd_test_cfg(soft_nms=False):
                 rcnn=dict(score_thr=0.05, nms=nms, max_per_img=100))
 
 
-def htd_config(depth=50, dcn=False, soft_nms=None):
+def htd_config(depth=50, dcn=False, soft_nms=None, resnext=False):
     """-> ConfigDict(model=..., train_cfg=..., test_cfg=..., optimizer=..., lr_config=...)."""
     soft_nms = (depth == 101) if soft_nms is None else soft_nms        # htd_resnet101_2x.py:298
     return ConfigDict(
-        model=htd_model(depth, dcn), train_cfg=htd_train_cfg(), test_cfg=htd_test_cfg(soft_nms),
+        model=htd_model(depth, dcn, resnext), train_cfg=htd_train_cfg(), test_cfg=htd_test_cfg(soft_nms),
         optimizer=dict(type='SGD', lr=0.02 if depth == 50 else 0.015, momentum=0.9, weight_decay=0.0001),
         optimizer_config=dict(grad_clip=None),
         lr_config=dict(policy='step', warmup='linear', warmup_iters=500, warmup_ratio=0.001,
@@ -84,12 +86,12 @@ def htd_config(depth=50, dcn=False, soft_nms=None):
         total_epochs=12 if depth == 50 else 24)
 
 
-def build_htd_detector(depth=50, dcn=False, cfg=None, bf16=False):
+def build_htd_detector(depth=50, dcn=False, cfg=None, bf16=False, resnext=False):
     """bf16=True: backbone stages, FPN and the RPN's shared conv run on the bf16 MFMA kernels (fp32 master weights, fp32
     accumulate); the stem, the RoI head and all box / loss arithmetic stay fp32 (BASELINE configs[2] precision map)."""
     from . import detector  # noqa: F401  (registers the components)
     from .registry import build_detector
-    cfg = htd_config(depth, dcn) if cfg is None else cfg
+    cfg = htd_config(depth, dcn, resnext=resnext) if cfg is None else cfg
     model = build_detector(copy.deepcopy(cfg.model.to_dict()), train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
     if bf16:
         import torch

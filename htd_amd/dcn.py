@@ -22,7 +22,8 @@ _P, _S = capi.ptr, capi.current_stream_ptr
 
 class DeformConv2dFunction(Function):
     @staticmethod
-    def forward(ctx, x, offset, mask, weight, stride, padding, dilation, deform_groups, bias=None, relu=False):
+    def forward(ctx, x, offset, mask, weight, stride, padding, dilation, deform_groups, bias=None, relu=False,
+                groups=1):
         if not x.is_cuda:
             raise NotImplementedError('deform_conv2d: only GPU tensors are supported')
         if x.dim() != 4:
@@ -32,7 +33,9 @@ class DeformConv2dFunction(Function):
         mask = mask.contiguous(memory_format=CL) if mask is not None else None
         weight = weight.contiguous(memory_format=CL)
         B, C, H, W = x.shape
-        Co, _, kh, kw = weight.shape
+        Co, cg, kh, kw = weight.shape
+        if cg * groups != C or (groups > 1 and Co != C):
+            raise ValueError(f'deform_conv2d: weight {tuple(weight.shape)} does not fit {C} channels in {groups} groups')
         Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
         Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
         if offset.shape != (B, 2 * deform_groups * kh * kw, Ho, Wo):
@@ -41,19 +44,24 @@ class DeformConv2dFunction(Function):
         cols = torch.empty(M, K, device=x.device, dtype=x.dtype)
         capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
                   dilation, deform_groups, _S(), work=('byte', 4.0 * M * K * 2))
-        y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
         bias = bias.contiguous() if bias is not None else None
-        capi.call('htd_conv2d_fwd', _P(cols), _P(weight), _P(bias), None, 0, 0, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1,
-                  int(bool(relu)), None, _S(), work=('flop', 2.0 * M * K * Co))     # bias / ReLU in the GEMM epilogue
+        if groups > 1:                                # ResNeXt: grouped GEMM over the gathered columns
+            geom = (C, groups, kh, kw, stride, padding, dilation)
+            y = dense._gconv_fwd_raw(cols, dense._gconv_pack(weight, groups, False), bias, geom, relu, (B, H, W))
+        else:
+            y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
+            capi.call('htd_conv2d_fwd', _P(cols), _P(weight), _P(bias), None, 0, 0, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1,
+                      int(bool(relu)), None, _S(), work=('flop', 2.0 * M * K * Co))     # bias / ReLU in the GEMM epilogue
         ctx.save_for_backward(x, offset, mask, weight, y if relu else None)
-        ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo, bias is not None)
+        ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo, bias is not None, groups)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         x, offset, mask, weight, y = ctx.saved_tensors
-        stride, padding, dilation, dg, Ho, Wo, has_bias = ctx.cfg
+        stride, padding, dilation, dg, Ho, Wo, has_bias, groups = ctx.cfg
+        geom = (x.size(1), groups, weight.size(2), weight.size(3), stride, padding, dilation)
         B, C, H, W = x.shape
         Co, _, kh, kw = weight.shape
         M, K = B * Ho * Wo, kh * kw * C
@@ -64,11 +72,14 @@ class DeformConv2dFunction(Function):
         gx = goff = gmask = gw = gb = None
         want_b = has_bias and ctx.needs_input_grad[8]
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
-            wT = torch.empty(K * Co, device=gy.device, dtype=gy.dtype)
-            capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, 1, 1, K, _S())
-            gcol = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
-            capi.call('htd_conv2d_bwd_data', _P(gy), _P(wT), None, None, _P(gcol), 1, M, 1, K, Co, 1, 1, 1, 0, 1, None, _S(),
-                      work=('flop', 2.0 * M * K * Co))
+            if groups > 1:
+                gcol = dense._gconv_dgrad_raw(gy, dense._gconv_pack(weight, groups, True), geom, x.shape, cols=True)
+            else:
+                wT = torch.empty(K * Co, device=gy.device, dtype=gy.dtype)
+                capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, 1, 1, K, _S())
+                gcol = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
+                capi.call('htd_conv2d_bwd_data', _P(gy), _P(wT), None, None, _P(gcol), 1, M, 1, K, Co, 1, 1, 1, 0, 1, None,
+                          _S(), work=('flop', 2.0 * M * K * Co))
             if ctx.needs_input_grad[0]:
                 gx = torch.empty((B, C, H, W), device=gy.device, dtype=gy.dtype, memory_format=CL).zero_()
             goff = torch.empty_like(offset, memory_format=CL)
@@ -79,24 +90,26 @@ class DeformConv2dFunction(Function):
             cols = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
             capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
                       dilation, dg, _S())
-            gw = torch.empty((Co, C, kh, kw), device=gy.device, dtype=gy.dtype, memory_format=CL)
-            nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(1, M, 1, K, Co, 1, 1, 1, 0, 1)
-            ws = torch.empty(nbytes // 4 + 1, device=gy.device, dtype=gy.dtype)
-            gb = torch.empty(Co, device=gy.device, dtype=gy.dtype) if want_b else None
-            capi.call('htd_conv2d_bwd_weight', _P(cols), _P(gy), _P(gw), _P(gb), 1, M, 1, K, Co, 1, 1, 1, 0, 1, _P(ws),
-                      _S(), work=('flop', 2.0 * M * K * Co))
+            if groups > 1:
+                gw = dense._gconv_wgrad_raw(cols, gy, weight, geom, x.shape, cols=True)
+                gb = gy.sum((0, 2, 3)) if want_b else None
+            else:
+                gw = torch.empty((Co, C, kh, kw), device=gy.device, dtype=gy.dtype, memory_format=CL)
+                nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(1, M, 1, K, Co, 1, 1, 1, 0, 1)
+                ws = torch.empty(nbytes // 4 + 1, device=gy.device, dtype=gy.dtype)
+                gb = torch.empty(Co, device=gy.device, dtype=gy.dtype) if want_b else None
+                capi.call('htd_conv2d_bwd_weight', _P(cols), _P(gy), _P(gw), _P(gb), 1, M, 1, K, Co, 1, 1, 1, 0, 1, _P(ws),
+                          _S(), work=('flop', 2.0 * M * K * Co))
         elif want_b:
             gb = gy.sum((0, 2, 3))
-        return gx, goff, gmask, gw, None, None, None, None, gb, None
+        return gx, goff, gmask, gw, None, None, None, None, gb, None, None
 
 
 def deform_conv2d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deform_groups=1, mask=None,
                   bias=None, relu=False):
     """mmcv.ops.deform_conv2d; bias / relu (extensions): folded-BN bias and ReLU in the epilogue of the GEMM half."""
-    if groups != 1:
-        raise NotImplementedError('deform_conv2d: groups > 1 is outside the HTD path (ResNeXt is SURVEY 8f)')
     s, p, d = _pair(stride)[0], _pair(padding)[0], _pair(dilation)[0]
-    return DeformConv2dFunction.apply(x, offset, mask, weight, s, p, d, deform_groups, bias, relu)
+    return DeformConv2dFunction.apply(x, offset, mask, weight, s, p, d, deform_groups, bias, relu, int(groups))
 
 
 class DeformConv2d(nn.Module):

@@ -265,6 +265,93 @@ class Conv2dFunction(Function):
         return gx, gw, (gb if (has_bias and need_b) else None), gr, None, None, None, None, None
 
 
+# ---- grouped convolutions (ResNeXt conv2): slab-packed weights, csrc/gconv.hip ------------------------------------
+
+def _gconv_pack(weight, groups, transpose):
+    C, cg, kh, kw = weight.shape
+    n = capi.lib().htd_gconv2d_packed_floats(C, groups, kh, kw)
+    if n <= 0:
+        raise ValueError(f'grouped conv2d: {C} channels in {groups} groups is unsupported')
+    wp = torch.empty(n, device=weight.device, dtype=weight.dtype)
+    capi.call('htd_gconv2d_pack_weights', _P(weight), _P(wp), C, groups, kh, kw, int(transpose), _S())
+    return wp
+
+
+def _gconv_fwd_raw(x, wp, bias, geom, relu, cols_shape=None):
+    """x: image (B,C,H,W) channels_last, or the column buffer [M][taps][C] of a deformable conv (cols_shape=(B,H,W))."""
+    C, groups, kh, kw, stride, padding, dilation = geom
+    B, H, W = cols_shape if cols_shape is not None else (x.size(0), x.size(2), x.size(3))
+    Ho, Wo = _out_hw(H, W, kh, kw, stride, padding, dilation)
+    y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
+    capi.call('htd_gconv2d_fwd', _P(x), _P(wp), _P(bias), _P(y), B, H, W, C, groups, kh, kw, stride, padding, dilation,
+              int(bool(relu)), int(cols_shape is not None), _S(),
+              work=('flop', 2.0 * B * Ho * Wo * C * kh * kw * (C // groups), 4.0 * (x.numel() + y.numel())))
+    return y
+
+
+def _gconv_dgrad_raw(g, wpT, geom, x_shape, cols=False):
+    C, groups, kh, kw, stride, padding, dilation = geom
+    B, _, H, W = x_shape
+    M = g.size(0) * g.size(2) * g.size(3)
+    gx = torch.empty((M, kh * kw, C), device=g.device, dtype=g.dtype) if cols else \
+        torch.empty((B, C, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+    capi.call('htd_gconv2d_bwd_data', _P(g), _P(wpT), _P(gx), B, H, W, C, groups, kh, kw, stride, padding, dilation,
+              int(cols), _S(), work=('flop', 2.0 * M * C * kh * kw * (C // groups), 4.0 * (g.numel() + gx.numel())))
+    return gx
+
+
+def _gconv_wgrad_raw(x, g, weight, geom, x_shape, cols=False):
+    C, groups, kh, kw, stride, padding, dilation = geom
+    B, _, H, W = x_shape
+    gw = grad_out(weight)
+    nbytes = capi.lib().htd_gconv2d_wgrad_workspace_bytes(B, H, W, C, groups, kh, kw, stride, padding, dilation)
+    ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
+    M = g.size(0) * g.size(2) * g.size(3)
+    capi.call('htd_gconv2d_bwd_weight', _P(x), _P(g), _P(gw), B, H, W, C, groups, kh, kw, stride, padding, dilation,
+              int(cols), _P(ws), _S(), work=('flop', 2.0 * M * C * kh * kw * (C // groups), 4.0 * (x.numel() + g.numel())))
+    return gw
+
+
+class GroupedConv2dFunction(Function):
+    """y = act(conv2d(x, w, groups) + bias), in == out channels (the 3x3 of a ResNeXt bottleneck)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, groups, relu):
+        _need_gpu(x, 'grouped conv2d')
+        x = x.contiguous(memory_format=CL)
+        weight = weight.contiguous(memory_format=CL)
+        C, cg, kh, kw = weight.shape
+        if x.size(1) != C or cg * groups != C:
+            raise ValueError(f'grouped conv2d: input {tuple(x.shape)}, weight {tuple(weight.shape)}, groups {groups}')
+        if x.dtype != torch.float32:
+            raise TypeError('grouped conv2d runs in fp32')
+        geom = (C, groups, kh, kw, stride, padding, dilation)
+        b = bias.contiguous() if bias is not None else None
+        y = _gconv_fwd_raw(x, _gconv_pack(weight, groups, False), b, geom, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.geom, ctx.relu, ctx.bias_ref = geom, bool(relu), b
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        g = g.contiguous(memory_format=CL)
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        gb = None
+        if ctx.bias_ref is not None and need_b:
+            g, gb = _colsum_raw(g, y if ctx.relu else None, ctx.bias_ref)
+        elif ctx.relu:
+            g = _mask_raw(g, y)
+        gx = _gconv_dgrad_raw(g, _gconv_pack(weight, ctx.geom[1], True), ctx.geom, x.shape) if need_x else None
+        gw = _gconv_wgrad_raw(x, g, weight, ctx.geom, x.shape) if need_w else None
+        return gx, gw, gb, None, None, None, None, None
+
+
+def grouped_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, relu=False):
+    return GroupedConv2dFunction.apply(x, weight, bias, int(stride), int(padding), int(dilation), int(groups), bool(relu))
+
+
 class ResStageFunction(Function):
     """A run of bottleneck blocks (one ResLayer, resnet.py:95-300 / res_layer.py:5-102) with frozen-BN-folded
     weights as ONE autograd node.  Forward is the same four fused convolutions per block as the per-layer path.

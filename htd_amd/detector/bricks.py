@@ -31,7 +31,9 @@ class Conv2d(nn.Conv2d):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        assert self.groups == 1 and self.padding_mode == 'zeros'
+        assert self.padding_mode == 'zeros'
+        assert self.groups == 1 or (self.in_channels == self.out_channels and self.bias is None), \
+            'grouped convs: the in == out, bias-free 3x3 of the ResNeXt bottleneck'
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
 
     def _apply(self, fn, recurse=True):
@@ -42,6 +44,13 @@ class Conv2d(nn.Conv2d):
     def forward(self, x, relu=False, residual=None, weight=None, bias=None, residual_up=False):
         w = self.weight if weight is None else weight
         b = self.bias if bias is None else bias
+        if self.groups > 1:
+            from .. import dense
+            assert residual is None
+            dt = x.dtype                              # fp32 kernels: bf16 stages cast around the grouped 3x3
+            y = dense.grouped_conv2d(x.float() if dt != torch.float32 else x, w, b, self.stride[0], self.padding[0],
+                                     self.dilation[0], self.groups, relu)
+            return y.to(dt) if dt != torch.float32 else y
         return dense_conv2d(x, w, b, self.stride[0], self.padding[0], self.dilation[0], relu, residual, residual_up)
 
 

@@ -7,6 +7,8 @@ Execution differs from the reference: BatchNorm always runs with frozen statisti
 convolution: BN is folded into the conv weights/bias by differentiable tensor ops (bricks.frozen_bn_fold)
 and ReLU / the residual add live in the conv epilogue.  Activations stay NHWC end to end.
 """
+import math
+
 import torch
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
@@ -34,7 +36,8 @@ class Bottleneck(nn.Module):
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch', with_cp=False,
-                 conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None):
+                 conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None, groups=1, base_width=4,
+                 base_channels=64):
         super().__init__()
         assert style in ['pytorch', 'caffe']
         assert dcn is None or isinstance(dcn, dict)
@@ -43,24 +46,29 @@ class Bottleneck(nn.Module):
         self.style, self.with_cp, self.conv_cfg, self.norm_cfg = style, with_cp, conv_cfg, norm_cfg
         self.dcn, self.with_dcn = dcn, dcn is not None
         self.conv1_stride, self.conv2_stride = (1, stride) if style == 'pytorch' else (stride, 1)
-        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
-        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        # ResNeXt (backbones/resnext.py:33-38): the 3x3 runs `groups` groups of base_width * planes / base_channels
+        self.groups = groups
+        width = planes if groups == 1 else math.floor(planes * (base_width / base_channels)) * groups
+        self.width = width
+        gkw = dict(groups=groups) if groups != 1 else {}
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, width, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, width, postfix=2)
         self.norm3_name, norm3 = build_norm_layer(norm_cfg, planes * self.expansion, postfix=3)
-        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, kernel_size=1, stride=self.conv1_stride, bias=False)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, width, kernel_size=1, stride=self.conv1_stride, bias=False)
         self.add_module(self.norm1_name, norm1)
         fallback_on_stride = False
         if self.with_dcn:
             dcn = dict(dcn)
             fallback_on_stride = dcn.pop('fallback_on_stride', False)
         if not self.with_dcn or fallback_on_stride:
-            self.conv2 = build_conv_layer(conv_cfg, planes, planes, kernel_size=3, stride=self.conv2_stride,
-                                          padding=dilation, dilation=dilation, bias=False)
+            self.conv2 = build_conv_layer(conv_cfg, width, width, kernel_size=3, stride=self.conv2_stride,
+                                          padding=dilation, dilation=dilation, bias=False, **gkw)
         else:
             assert conv_cfg is None, 'conv_cfg must be None for DCN'
-            self.conv2 = build_conv_layer(dcn, planes, planes, kernel_size=3, stride=self.conv2_stride,
-                                          padding=dilation, dilation=dilation, bias=False)
+            self.conv2 = build_conv_layer(dcn, width, width, kernel_size=3, stride=self.conv2_stride,
+                                          padding=dilation, dilation=dilation, bias=False, **gkw)
         self.add_module(self.norm2_name, norm2)
-        self.conv3 = build_conv_layer(conv_cfg, planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.conv3 = build_conv_layer(conv_cfg, width, planes * self.expansion, kernel_size=1, bias=False)
         self.add_module(self.norm3_name, norm3)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
@@ -116,7 +124,7 @@ class ResLayer(nn.Sequential):
         """All blocks plain bottlenecks (no DCN), 'pytorch' style, BN on running statistics: the whole layer runs
         as one autograd node with the fused backward of dense.ResStageFunction."""
         for blk in self:
-            if not isinstance(blk, Bottleneck) or blk.with_dcn or blk.style != 'pytorch':
+            if not isinstance(blk, Bottleneck) or blk.with_dcn or blk.style != 'pytorch' or blk.groups != 1:
                 return False
             bns = [blk.norm1, blk.norm2, blk.norm3] + ([blk.downsample[1]] if blk.downsample is not None else [])
             if any(bn.training or not isinstance(bn, nn.BatchNorm2d) for bn in bns):
@@ -175,16 +183,19 @@ class ResNet(nn.Module):
         self.res_layers = []
         for i, num_blocks in enumerate(self.stage_blocks):
             planes = base_channels * 2**i
-            res_layer = ResLayer(block=self.block, inplanes=self.inplanes, planes=planes, num_blocks=num_blocks,
-                                 stride=strides[i], dilation=dilations[i], style=style, avg_down=avg_down,
-                                 with_cp=with_cp, conv_cfg=conv_cfg, norm_cfg=norm_cfg,
-                                 dcn=self.dcn if self.stage_with_dcn[i] else None)
+            res_layer = self.make_res_layer(block=self.block, inplanes=self.inplanes, planes=planes,
+                                            num_blocks=num_blocks, stride=strides[i], dilation=dilations[i],
+                                            style=style, avg_down=avg_down, with_cp=with_cp, conv_cfg=conv_cfg,
+                                            norm_cfg=norm_cfg, dcn=self.dcn if self.stage_with_dcn[i] else None)
             self.inplanes = planes * self.block.expansion
             name = f'layer{i + 1}'
             self.add_module(name, res_layer)
             self.res_layers.append(name)
         self._freeze_stages()
         self.feat_dim = self.block.expansion * base_channels * 2**(len(self.stage_blocks) - 1)
+
+    def make_res_layer(self, **kwargs):
+        return ResLayer(**kwargs)
 
     @property
     def norm1(self):
@@ -248,3 +259,16 @@ class ResNet(nn.Module):
                 if isinstance(m, _BatchNorm):
                     m.eval()
         return self
+
+
+@BACKBONES.register_module()
+class ResNeXt(ResNet):
+    """backbones/resnext.py:86-153: ResNet whose bottleneck 3x3 is grouped (X101-64x4d: groups=64, base_width=4).
+    The grouped 3x3 -- plain or deformable -- runs on the slab kernels of csrc/gconv.hip."""
+
+    def __init__(self, groups=1, base_width=4, **kwargs):
+        self.groups, self.base_width = groups, base_width
+        super().__init__(**kwargs)
+
+    def make_res_layer(self, **kwargs):
+        return ResLayer(groups=self.groups, base_width=self.base_width, base_channels=self.base_channels, **kwargs)

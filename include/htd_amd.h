@@ -277,6 +277,30 @@ int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *gw, int B, 
                                int kw, int stride, int pad, int dil, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Grouped convolutions of the ResNeXt bottlenecks: conv2 of backbones/resnext.py:33-84 is
+ * nn.Conv2d(width, width, 3, groups=64) -- ATen/MIOpen in the reference -- or, with dcn=..., the grouped
+ * deformable conv (deform_conv_ext with group=64, build/lib/mmdet/ops/dcn/deform_conv.py:51-58).
+ *   x  [B][H][W][C]   w  [C][kh][kw][C/groups] (grouped KRSC)   y [B][Ho][Wo][C]   (in == out channels)
+ *   C % 16 == 0; channels per group 4, 8, 16 or a multiple of 16; kh*kw <= 9.
+ * The kernels take the weights PACKED into 16x16 channel-slab tiles (block-diagonal across narrow groups):
+ * htd_gconv2d_pack_weights(w, wp, ..., transpose) with transpose = 0 for fwd, 1 for bwd_data;
+ * htd_gconv2d_packed_floats() floats each.
+ *   cols = 1: x (fwd, bwd_weight) / gx (bwd_data) is the gathered column buffer [M][kh*kw][C] of the deformable
+ *   conv (htd_deform_im2col) instead of an image; M = B*Ho*Wo.
+ * bwd_weight: deterministic split over pixels through `workspace` (htd_gconv2d_wgrad_workspace_bytes).
+ * ---------------------------------------------------------------------------------- */
+int64_t htd_gconv2d_packed_floats(int C, int groups, int kh, int kw);
+int htd_gconv2d_pack_weights(const float *w, float *wp, int C, int groups, int kh, int kw, int transpose, void *stream);
+int htd_gconv2d_fwd(const float *x, const float *wp, const float *bias, float *y, int B, int H, int W, int C, int groups,
+                    int kh, int kw, int stride, int pad, int dil, int relu, int cols, void *stream);
+int htd_gconv2d_bwd_data(const float *gy, const float *wpT, float *gx, int B, int H, int W, int C, int groups, int kh,
+                         int kw, int stride, int pad, int dil, int cols, void *stream);
+int64_t htd_gconv2d_wgrad_workspace_bytes(int B, int H, int W, int C, int groups, int kh, int kw, int stride, int pad,
+                                          int dil);
+int htd_gconv2d_bwd_weight(const float *x, const float *gy, float *gw, int B, int H, int W, int C, int groups, int kh,
+                           int kw, int stride, int pad, int dil, int cols, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * On-device data pipeline of one batch of decoded 8-bit images: in ONE pass
  *   Resize   mmcv.imrescale -> cv2.resize(INTER_LINEAR) on uint8 (datasets/pipelines/transforms.py:202-231): OpenCV's
  *            fixed-point bilinear (11-bit weights; exact 2x downscale = 2x2 mean), sizes chosen by the host;

@@ -51,17 +51,18 @@ def _bn_eval(sd, p, x, eps=1e-5):
                         False, 0., eps)
 
 
-def _conv2(sd, p, x, stride, dcn):
+def _conv2(sd, p, x, stride, dcn, groups=1):
     if dcn and (p + '.conv_offset.weight') in sd:
         off = F.conv2d(x, sd[p + '.conv_offset.weight'], sd[p + '.conv_offset.bias'], stride=stride, padding=1)
-        return ops.deform_conv2d_autograd(x, off, sd[p + '.weight'], stride=stride, padding=1)
-    return F.conv2d(x, sd[p + '.weight'], None, stride=stride, padding=1)
+        return ops.deform_conv2d_autograd(x, off, sd[p + '.weight'], stride=stride, padding=1, groups=groups)
+    return F.conv2d(x, sd[p + '.weight'], None, stride=stride, padding=1, groups=groups)
 
 
-def bottleneck(sd, p, x, stride, dcn=False):
-    """Bottleneck.forward, backbones/resnet.py:260-300 (style='pytorch': stride on conv2)."""
+def bottleneck(sd, p, x, stride, dcn=False, groups=1):
+    """Bottleneck.forward, backbones/resnet.py:260-300 (style='pytorch': stride on conv2); groups > 1: the ResNeXt
+    block of backbones/resnext.py:9-84 (same forward, grouped conv2)."""
     out = F.relu(_bn_eval(sd, p + '.bn1', F.conv2d(x, sd[p + '.conv1.weight'])))
-    out = F.relu(_bn_eval(sd, p + '.bn2', _conv2(sd, p + '.conv2', out, stride, dcn)))
+    out = F.relu(_bn_eval(sd, p + '.bn2', _conv2(sd, p + '.conv2', out, stride, dcn, groups)))
     out = _bn_eval(sd, p + '.bn3', F.conv2d(out, sd[p + '.conv3.weight']))
     idt = x
     if (p + '.downsample.0.weight') in sd:

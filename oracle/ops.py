@@ -193,9 +193,9 @@ def deform_conv2d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, 
     return out
 
 
-def deform_conv2d_autograd(x, offset, weight, stride=1, padding=0, dilation=1, mask=None):
-    """Differentiable pure-torch restatement of the same DCN (deform_groups=1,
-    groups=1), used to check gradients of the HIP kernels.  Bilinear sampling with
+def deform_conv2d_autograd(x, offset, weight, stride=1, padding=0, dilation=1, mask=None, groups=1):
+    """Differentiable pure-torch restatement of the same DCN (deform_groups=1; `groups` conv groups as in the
+    ResNeXt bottleneck), used to check gradients of the HIP kernels.  Bilinear sampling with
     zero padding, written with gather so autograd supplies d/dx, d/doffset, d/dw."""
     B, C, H, W = x.shape
     Co, _, kh, kw = weight.shape
@@ -226,4 +226,9 @@ def deform_conv2d_autograd(x, offset, weight, stride=1, padding=0, dilation=1, m
         tap(h0 + 1, w0, lh * (1 - lw)) + tap(h0 + 1, w0 + 1, lh * lw)
     if mask is not None:
         col = col * mask.view(B, 1, kh * kw, Ho, Wo)
-    return torch.einsum('bckhw,ock->bohw', col, weight.reshape(Co, C, kh * kw))
+    if groups == 1:
+        return torch.einsum('bckhw,ock->bohw', col, weight.reshape(Co, C, kh * kw))
+    cg, cog = C // groups, Co // groups
+    out = torch.einsum('bgckhw,gock->bgohw', col.reshape(B, groups, cg, kh * kw, Ho, Wo),
+                       weight.reshape(groups, cog, cg, kh * kw))
+    return out.reshape(B, Co, Ho, Wo)
