@@ -305,6 +305,39 @@ class DeltaXYWHBBoxCoder:
 
 
 # ------------------------------------------------------------------ transforms
+def bbox_flip(bboxes, img_shape, direction='horizontal'):
+    """core/bbox/transforms.py:6-31 (tensor form of RandomFlip.bbox_flip)."""
+    assert bboxes.shape[-1] % 4 == 0
+    if direction not in ('horizontal', 'vertical', 'diagonal'):
+        raise ValueError(f"Invalid flipping direction '{direction}'")
+    flipped = bboxes.clone()
+    if direction != 'vertical':
+        flipped[..., 0::4] = img_shape[1] - bboxes[..., 2::4]
+        flipped[..., 2::4] = img_shape[1] - bboxes[..., 0::4]
+    if direction != 'horizontal':
+        flipped[..., 1::4] = img_shape[0] - bboxes[..., 3::4]
+        flipped[..., 3::4] = img_shape[0] - bboxes[..., 1::4]
+    return flipped
+
+
+def _scale_tensor(scale_factor, like):
+    vals = [float(scale_factor)] if isinstance(scale_factor, (int, float)) else [float(v) for v in scale_factor]
+    return const_tensor(vals, like.device, like.dtype)
+
+
+def bbox_mapping(bboxes, img_shape, scale_factor, flip, flip_direction='horizontal'):
+    """Original image scale -> one test-time augmentation (core/bbox/transforms.py:34-43)."""
+    new_bboxes = bboxes * _scale_tensor(scale_factor, bboxes)
+    return bbox_flip(new_bboxes, img_shape, flip_direction) if flip else new_bboxes
+
+
+def bbox_mapping_back(bboxes, img_shape, scale_factor, flip, flip_direction='horizontal'):
+    """One test-time augmentation -> original image scale (core/bbox/transforms.py:46-55)."""
+    new_bboxes = bbox_flip(bboxes, img_shape, flip_direction) if flip else bboxes
+    new_bboxes = new_bboxes.view(-1, 4) / _scale_tensor(scale_factor, bboxes)
+    return new_bboxes.view(bboxes.shape)
+
+
 def bbox2roi(bbox_list):
     rois_list = []
     for img_id, bboxes in enumerate(bbox_list):

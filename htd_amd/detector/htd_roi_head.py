@@ -339,3 +339,33 @@ class HTDRoIHead(nn.Module):
     def simple_test(self, x, proposal_list, img_metas, rescale=False):
         det_bboxes, det_labels = self.simple_test_bboxes(x, proposal_list, img_metas, rescale)
         return [bbox2result(b, l, self.bbox_head[-1].num_classes) for b, l in zip(det_bboxes, det_labels)]
+
+    def aug_test(self, features, proposal_list, img_metas, rescale=False):
+        """roi_heads/htd_roi_head.py:388-433: the merged proposals of one image go through both stages on every
+        augmentation's pyramid; boxes are mapped back, averaged with the scores, and take ONE multi-class NMS.
+        Like the reference, the result is in the original image scale whatever `rescale` says."""
+        from ..core.bbox import bbox_mapping
+        from ..core.post_processing import merge_aug_bboxes, multiclass_nms
+        aug_bboxes, aug_scores = [], []
+        for x, img_meta in zip(features, img_metas):
+            m = img_meta[0]                                         # one image per batch in aug test
+            proposals = bbox_mapping(proposal_list[0][:, :4], m['img_shape'], m['scale_factor'], m['flip'],
+                                     m['flip_direction'])
+            global_feat = self.glbctx_head(x)[1] if self.with_global else None
+            rois = bbox2roi([proposals])
+            ms_scores = []
+            for i in range(self.num_stages):
+                res = self._bbox_forward(i, x, rois, global_feat)
+                ms_scores.append(res['cls_score'])
+                if i < self.num_stages - 1:
+                    label = res['cls_score'][:, :-1].argmax(dim=1)
+                    rois = self.bbox_head[i].regress_by_class(rois, label, res['bbox_pred'], m)
+            cls_score = sum(ms_scores) / float(len(ms_scores))
+            bboxes, scores = self.bbox_head[-1].get_bboxes(rois, cls_score, res['bbox_pred'], m['img_shape'],
+                                                           m['scale_factor'], rescale=False, cfg=None)
+            aug_bboxes.append(bboxes)
+            aug_scores.append(scores)
+        merged_bboxes, merged_scores = merge_aug_bboxes(aug_bboxes, aug_scores, img_metas, self.test_cfg)
+        det_bboxes, det_labels = multiclass_nms(merged_bboxes, merged_scores, self.test_cfg.score_thr, self.test_cfg.nms,
+                                                self.test_cfg.max_per_img)
+        return [bbox2result(det_bboxes, det_labels, self.bbox_head[-1].num_classes)]

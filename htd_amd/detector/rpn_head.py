@@ -105,6 +105,17 @@ class RPNHead(nn.Module):
     def simple_test_rpn(self, x, img_metas):
         return self.get_bboxes(*self(x), img_metas)
 
+    def aug_test_rpn(self, feats, img_metas):
+        """dense_heads/rpn_test_mixin.py:39-59: proposals of every augmentation, merged per image at original scale."""
+        from ..core.post_processing import merge_aug_proposals
+        samples_per_gpu = len(img_metas[0])
+        aug_proposals = [[] for _ in range(samples_per_gpu)]
+        for x, img_meta in zip(feats, img_metas):
+            for i, proposals in enumerate(self.simple_test_rpn(x, img_meta)):
+                aug_proposals[i].append(proposals)
+        aug_img_metas = [[img_metas[j][i] for j in range(len(img_metas))] for i in range(samples_per_gpu)]
+        return [merge_aug_proposals(p, m, self.test_cfg) for p, m in zip(aug_proposals, aug_img_metas)]
+
     # ------------------------------------------------------------------ targets + loss
     def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
         mlvl = self.anchor_generator.grid_anchors(featmap_sizes, device)

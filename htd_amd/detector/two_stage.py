@@ -44,7 +44,9 @@ class BaseDetector(nn.Module):
             if 'proposals' in kwargs:
                 kwargs['proposals'] = kwargs['proposals'][0]
             return self.simple_test(imgs[0], img_metas[0], **kwargs)
-        raise NotImplementedError('test-time augmentation (aug_test) is outside this path')
+        assert imgs[0].size(0) == 1, f'aug test does not support inference with batch size {imgs[0].size(0)}'
+        assert 'proposals' not in kwargs
+        return self.aug_test(imgs, img_metas, **kwargs)
 
     def forward(self, img, img_metas, return_loss=True, **kwargs):
         if return_loss:
@@ -146,6 +148,18 @@ class TwoStageDetector(BaseDetector):
     def extract_feat(self, img):
         x = self.backbone(img)
         return self.neck(x) if self.with_neck else x
+
+    def extract_feats(self, imgs):
+        """detectors/base.py:51-63: one feature pyramid per test-time augmentation."""
+        assert isinstance(imgs, list)
+        return [self.extract_feat(img) for img in imgs]
+
+    def aug_test(self, imgs, img_metas, rescale=False):
+        """detectors/two_stage.py:213-222: multi-scale / flip test-time augmentation of ONE image."""
+        x = self.extract_feats(imgs)
+        proposal_list = self.rpn_head.aug_test_rpn(x, img_metas)
+        x32 = [f if f[0].dtype == torch.float32 else tuple(t.float() for t in f) for f in x]
+        return self.roi_head.aug_test(x32, proposal_list, img_metas, rescale=rescale)
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
                       proposals=None, **kwargs):

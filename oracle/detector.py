@@ -485,6 +485,73 @@ def simple_test(sd, img, img_metas, cfg):
     return props, roi_head_simple_test(sd, x, props, img_metas, cfg)
 
 
+# ------------------------------------------------------------------ test-time augmentation
+def bbox_flip(bboxes, img_shape, direction='horizontal'):
+    """core/bbox/transforms.py:6-31."""
+    out = bboxes.clone()
+    if direction in ('horizontal', 'diagonal'):
+        out[..., 0::4] = img_shape[1] - bboxes[..., 2::4]
+        out[..., 2::4] = img_shape[1] - bboxes[..., 0::4]
+    if direction in ('vertical', 'diagonal'):
+        out[..., 1::4] = img_shape[0] - bboxes[..., 3::4]
+        out[..., 3::4] = img_shape[0] - bboxes[..., 1::4]
+    return out
+
+
+def bbox_mapping(bboxes, meta):
+    """core/bbox/transforms.py:34-43."""
+    out = bboxes * bboxes.new_tensor(meta['scale_factor'])
+    return bbox_flip(out, meta['img_shape'], meta['flip_direction']) if meta['flip'] else out
+
+
+def bbox_mapping_back(bboxes, meta):
+    """core/bbox/transforms.py:46-55."""
+    out = bbox_flip(bboxes, meta['img_shape'], meta['flip_direction']) if meta['flip'] else bboxes
+    return (out.view(-1, 4) / out.new_tensor(meta['scale_factor'])).view(bboxes.shape)
+
+
+def merge_aug_proposals(aug_proposals, metas, rcfg):
+    """core/post_processing/merge_augs.py:9-51."""
+    rec = []
+    for p, m in zip(aug_proposals, metas):
+        q = p.clone()
+        q[:, :4] = bbox_mapping_back(q[:, :4], m)
+        rec.append(q)
+    allp = torch.cat(rec, 0)
+    merged, _ = ops.nms(allp[:, :4].contiguous(), allp[:, -1].contiguous(), rcfg['nms_thr'])
+    order = merged[:, 4].sort(0, descending=True)[1]
+    return merged[order[:min(rcfg['max_num'], merged.shape[0])]]
+
+
+def aug_test(sd, imgs, img_metas, cfg):
+    """TwoStageDetector.aug_test (two_stage.py:213-222) = extract_feats + RPNTestMixin.aug_test_rpn
+    (rpn_test_mixin.py:39-59) + HTDRoIHead.aug_test (htd_roi_head.py:388-433), one image, bbox branch.
+    imgs: list (augmentations) of (1,3,H,W); img_metas: list of [meta].  -> (merged proposals, (dets, labels))."""
+    feats = [extract_feat(sd, im, cfg) for im in imgs]
+    aug_props = []
+    for x, metas in zip(feats, img_metas):
+        cls, reg = rpn_forward(sd, x)
+        aug_props.append(rpn_get_bboxes(cls, reg, metas, cfg['test_cfg']['rpn'], cfg, cfg['strides'])[0])
+    proposals = merge_aug_proposals(aug_props, [m[0] for m in img_metas], cfg['test_cfg']['rpn'])
+    aug_b, aug_s = [], []
+    for x, metas in zip(feats, img_metas):
+        m = metas[0]
+        rois = B.bbox2roi([bbox_mapping(proposals[:, :4], m)])
+        _, gfeat = sfa_forward(sd, x)
+        f0 = fuse_global(single_roi_extract(x[:4], rois, cfg['roi_strides']), gfeat, rois)
+        cls0, reg0 = shared2fc_forward(sd, f0)
+        rois = regress_by_class(rois, reg0, m, cfg['stds'][0])
+        bf = single_roi_extract(x[:4], rois, cfg['roi_strides'])
+        enh = ba_extract(sd, x[:4], rois, cfg['roi_strides'], cfg['edge'])
+        cls1, reg1 = htd_bbox_head_forward(sd, bf, bf, rois, enh, rois, gfeat, cfg['alpha'])
+        aug_s.append(F.softmax((cls0 + cls1) / 2.0, dim=1))
+        aug_b.append(bbox_mapping_back(B.delta2bbox(rois[:, 1:], reg1, (0., 0., 0., 0.), cfg['stds'][1],
+                                                    max_shape=m['img_shape']), m))
+    rc = cfg['test_cfg']['rcnn']
+    bboxes, scores = torch.stack(aug_b).mean(0), torch.stack(aug_s).mean(0)
+    return proposals, multiclass_nms(bboxes, scores, rc['score_thr'], rc['nms'], rc['max_per_img'])
+
+
 def state_shapes(depth=50, dcn=False, num_classes=80):
     """Key -> shape of every parameter/buffer, named as the reference's state_dict."""
     s = {}

@@ -144,3 +144,25 @@ def test_bad_arguments_are_reported():
     with pytest.raises(ValueError, match='null'):
         capi.call('htd_image_batch_pipeline', None, capi.ptr(x), capi.ptr(x), capi.ptr(x), 1, 4, 4, 0., 0., 0., 1., 1.,
                   1., 1, 0., capi.current_stream_ptr())
+
+
+def test_tta_pipeline_drives_aug_test():
+    """MultiScaleFlipAug (test_time_aug.py:8-121) -> collate -> forward_test -> aug_test on one image."""
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.pipelines import build_pipeline, collate
+    torch.manual_seed(0)
+    cfg = htd_config(50)
+    cfg.test_cfg.rpn.update(nms_pre=200, nms_post=100, max_num=100)
+    det = build_htd_detector(cfg=cfg).to('cuda:0').eval()
+    tta = build_pipeline([dict(type='LoadImageFromFile'),
+                          dict(type='MultiScaleFlipAug', img_scale=[(320, 256), (400, 300)], flip=True,
+                               transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'),
+                                           dict(type='Normalize', mean=MEAN, std=STD, to_rgb=True),
+                                           dict(type='Pad', size_divisor=32), dict(type='ImageToTensor', keys=['img']),
+                                           dict(type='Collect', keys=['img'])])])
+    data = collate([tta(dict(img=_img(240, 320, 4), img_info=dict(filename='t.jpg'), img_prefix=None))], 'cuda:0')
+    assert len(data['img']) == 4 and data['img'][0].shape == (1, 3, 256, 320) and data['img'][2].shape == (1, 3, 320, 416)
+    assert [m[0]['flip'] for m in data['img_metas']] == [False, True, False, True]
+    with torch.no_grad():
+        res = det.forward_test(data['img'], data['img_metas'])
+    assert len(res) == 1 and len(res[0]) == 80 and all(c.shape[1] == 5 for c in res[0])

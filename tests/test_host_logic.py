@@ -233,3 +233,30 @@ def test_checkpoint_wire_format_round_trip(tmp_path):
     got = {k: tuple(v.shape) for k, v in saved['state_dict'].items() if not k.endswith('num_batches_tracked')}
     assert got == {k: tuple(v.shape) for k, v in ref.items()}
     assert torch.equal(saved['state_dict']['roi_head.bbox_head.1.fcs.0.weight'], ref['roi_head.bbox_head.1.fcs.0.weight'])
+
+
+def test_bbox_mapping_round_trip_and_aug_merge():
+    """core/bbox/transforms.py:34-55 and merge_augs.py:54-81 (host tensors)."""
+    import numpy as np
+    import torch
+    from htd_amd.core.bbox import bbox_flip, bbox_mapping, bbox_mapping_back
+    from htd_amd.core.post_processing import merge_aug_bboxes, merge_aug_scores
+    from oracle import detector as D
+    boxes = torch.tensor([[10., 20., 50., 80.], [0., 0., 99., 59.]])
+    meta = dict(img_shape=(75, 125, 3), scale_factor=np.array([1.25] * 4, dtype=np.float32), flip=True,
+                flip_direction='horizontal')
+    fwd = bbox_mapping(boxes, meta['img_shape'], meta['scale_factor'], True, 'horizontal')
+    torch.testing.assert_close(fwd, torch.tensor([[62.5, 25., 112.5, 100.], [1.25, 0., 125., 73.75]]))
+    torch.testing.assert_close(fwd, D.bbox_mapping(boxes, meta))
+    torch.testing.assert_close(bbox_mapping_back(fwd, meta['img_shape'], meta['scale_factor'], True, 'horizontal'), boxes)
+    torch.testing.assert_close(bbox_flip(bbox_flip(boxes, (60, 100), 'diagonal'), (60, 100), 'diagonal'), boxes)
+    torch.testing.assert_close(bbox_flip(boxes, (60, 100), 'vertical')[0], torch.tensor([10., -20., 50., 40.]))
+    # class-wise boxes (n, 4*classes) of two augmentations average after mapping back
+    a = torch.tensor([[10., 10., 20., 20., 0., 0., 8., 8.]])
+    b = bbox_mapping(a.view(-1, 4), meta['img_shape'], meta['scale_factor'], True, 'horizontal').view(1, 8)
+    plain = dict(img_shape=(60, 100, 3), scale_factor=1.0, flip=False, flip_direction=None)
+    merged, scores = merge_aug_bboxes([a, b], [torch.tensor([[.2, .8, 0.]]), torch.tensor([[.4, .4, .2]])],
+                                      [[plain], [meta]], None)
+    torch.testing.assert_close(merged, a)
+    torch.testing.assert_close(scores, torch.tensor([[.3, .6, .1]]))
+    torch.testing.assert_close(merge_aug_scores([torch.ones(2), torch.zeros(2)]), torch.full((2,), .5))
