@@ -8,7 +8,9 @@ CL = torch.channels_last
 
 
 @pytest.mark.parametrize('B,C,H,W,Co,stride,with_mask', [(2, 32, 11, 13, 24, 1, False), (1, 64, 9, 10, 32, 2, False),
-                                                          (2, 16, 8, 8, 16, 1, True)])
+                                                          (2, 16, 8, 8, 16, 1, True),
+                                                          (2, 128, 19, 21, 24, 1, False),     # tiled col2im, 2 slices
+                                                          (1, 64, 17, 9, 16, 1, True), (2, 192, 13, 12, 8, 2, False)])
 def test_deform_conv_fwd_bwd(B, C, H, W, Co, stride, with_mask):
     from htd_amd.dcn import deform_conv2d
     from oracle import ops as O
