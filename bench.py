@@ -165,8 +165,9 @@ def main():
             rate = (work / (tot_ms * 1e-3) / 1e12) if (kind and tot_ms > 0) else 0.0
             print(f'# {name:64s} calls={n:5d} total={tot_ms:9.3f} ms  {kind or ""} {rate:8.2f} T/s', file=sys.stderr)
     out = {
-        'metric': ('images/sec (1333x800) HTD-R%d inference' if args.infer else
-                   'images/sec (1333x800) HTD-R%d train step') % args.depth, 'value': round(value, 3),
+        'metric': ('images/sec (1333x800) HTD-%s%d inference' if args.infer else
+                   'images/sec (1333x800) HTD-%s%d train step') % ('X' if args.resnext else 'R', args.depth),
+        'value': round(value, 3),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',

@@ -30,30 +30,6 @@ __device__ __forceinline__ int in_slab_of(const GGeo &g, int os, int is)
     return g.islabs == 1 ? os : (os / g.islabs) * g.islabs + is;
 }
 
-// Row (pixel index into the [rows][C] source) feeding output row m through `tap`, or -1.
-template <int MODE>
-__device__ __forceinline__ int64_t src_row(const GGeo &g, int64_t m, int b, int oy, int ox, int tap)
-{
-    if (MODE == G_COLS) return m * (g.kh * g.kw) + tap;
-    if (MODE == G_DGRAD_COLS) return m;
-    const int dy = tap / g.kw, dx = tap - dy * g.kw;
-    if (MODE == G_CONV) {
-        const int iy = oy * g.stride - g.pad + dy * g.dil, ix = ox * g.stride - g.pad + dx * g.dil;
-        if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return -1;
-        return ((int64_t)b * g.H + iy) * g.W + ix;
-    }
-    // G_DGRAD: (oy, ox) is the INPUT-space pixel; the output-space pixel that touched it through (dy, dx)
-    int ty = oy + g.pad - dy * g.dil, tx = ox + g.pad - dx * g.dil;
-    if (ty < 0 || tx < 0) return -1;
-    if (g.stride != 1) {
-        if (ty % g.stride || tx % g.stride) return -1;
-        ty /= g.stride;
-        tx /= g.stride;
-    }
-    if (ty >= g.Ho || tx >= g.Wo) return -1;
-    return ((int64_t)b * g.Ho + ty) * g.Wo + tx;
-}
-
 // ----------------------------------------------------------------------------------------------- weight packing
 // wp[((os*islabs + is)*taps + tap)*64 + l] (float4), l = n + 16 j, component s:
 //   forward  : w[out = 16 os + n][tap][in  = 16 in_slab + 4j + s]      (zero across groups)
@@ -77,7 +53,36 @@ __global__ void gconv_pack_kernel(const float *__restrict__ w, float *__restrict
 }
 
 // ----------------------------------------------------------------------------------------------- forward / dgrad
+// Element offset (into the [rows][C] source) of the pixel feeding an output pixel through tap (dy, dx), or -1.
+// `oy`, `ox`: the output pixel (G_CONV) or the input-space pixel (G_DGRAD); `pb` = image index.
 template <int MODE>
+__device__ __forceinline__ int64_t tap_offset(const GGeo &g, int64_t m, int pb, int oy, int ox, int dy, int dx, int tap,
+                                              int taps)
+{
+    if (MODE == G_COLS) return (m * taps + tap) * g.C;
+    if (MODE == G_DGRAD_COLS) return m * g.C;
+    if (MODE == G_CONV) {
+        const int iy = oy * g.stride - g.pad + dy * g.dil, ix = ox * g.stride - g.pad + dx * g.dil;
+        if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return -1;
+        return (((int64_t)pb * g.H + iy) * g.W + ix) * g.C;
+    }
+    int ty = oy + g.pad - dy * g.dil, tx = ox + g.pad - dx * g.dil;
+    if (ty < 0 || tx < 0) return -1;
+    if (g.stride == 2) {
+        if ((ty | tx) & 1) return -1;
+        ty >>= 1;
+        tx >>= 1;
+    } else if (g.stride != 1) {
+        if (ty % g.stride || tx % g.stride) return -1;
+        ty /= g.stride;
+        tx /= g.stride;
+    }
+    if (ty >= g.Ho || tx >= g.Wo) return -1;
+    return (((int64_t)pb * g.Ho + ty) * g.Wo + tx) * g.C;
+}
+
+// KW3: the kernel is 3 taps wide (every layer of the path), so (dy, dx) of an unrolled tap are constants.
+template <int MODE, bool KW3>
 __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ x, const f32x4 *__restrict__ wp,
                                                     const float *__restrict__ bias, float *__restrict__ y, GGeo g, int relu)
 {
@@ -97,28 +102,28 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ x,
         live[t] = m < g.M;
         pb[t] = py[t] = px[t] = 0;
         if (live[t] && (MODE == G_CONV || MODE == G_DGRAD)) {
-            const int w_ = (MODE == G_CONV) ? g.Wo : g.W, h_ = (MODE == G_CONV) ? g.Ho : g.H;
-            px[t] = (int)(m % w_);
-            const int64_t q = m / w_;
-            py[t] = (int)(q % h_);
+            const unsigned w_ = (MODE == G_CONV) ? g.Wo : g.W, h_ = (MODE == G_CONV) ? g.Ho : g.H;
+            const unsigned mu = (unsigned)m, q = mu / w_;              // M < 2^31 (checked by the launcher)
+            px[t] = (int)(mu - q * w_);
             pb[t] = (int)(q / h_);
+            py[t] = (int)(q - (unsigned)pb[t] * h_);
         }
     }
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int is = 0; is < g.islabs; ++is) {
-        const int ch = 16 * in_slab_of(g, os, is) + 4 * j;
+        const float *xs = x + 16 * in_slab_of(g, os, is) + 4 * j;
         const f32x4 *wq = wp + ((int64_t)(os * g.islabs + is) * taps) * 64 + lane;
-        for (int tap = (only_tap < 0 ? 0 : only_tap); tap < (only_tap < 0 ? taps : only_tap + 1); ++tap) {
+        auto one_tap = [&](int tap, int dy, int dx) {
             const f32x4 bw = wq[(int64_t)tap * 64];
             f32x4 a[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (live[t]) {
-                    const int64_t row = src_row<MODE>(g, m0 + t * 16 + r, pb[t], py[t], px[t], tap);
-                    if (row >= 0) a[t] = *reinterpret_cast<const f32x4 *>(x + row * g.C + ch);
+                    const int64_t off = tap_offset<MODE>(g, m0 + t * 16 + r, pb[t], py[t], px[t], dy, dx, tap, taps);
+                    if (off >= 0) a[t] = *reinterpret_cast<const f32x4 *>(xs + off);
                 }
             }
 #pragma unroll
@@ -128,6 +133,15 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ x,
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, bw.z, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, bw.w, acc[t], 0, 0, 0);
             }
+        };
+        if (MODE == G_DGRAD_COLS) {
+            one_tap(only_tap, 0, 0);
+        } else if (KW3) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+                if (tap < taps) one_tap(tap, tap / 3, tap % 3);
+        } else {
+            for (int tap = 0; tap < taps; ++tap) one_tap(tap, tap / g.kw, tap % g.kw);
         }
     }
     // D: lane holds rows 4j + i (pixels), column r (channel) of each 16x16 tile
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ x,
 // chunk's pixels, 4 pixels per MFMA: A[n][k] = gy[m+k][16 os + n], B[k][c] = x[src(m+k, tap)][16 in_slab + c].
 // Partial tiles go to ws[chunk][os*islabs + is][tap][n][c]; gconv_wgrad_reduce_kernel sums the chunks and drops the
 // cross-group zeros.
-template <int MODE>
+template <int MODE, bool KW3>
 __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                           float *__restrict__ ws, GGeo g, int64_t chunk_rows)
 {
@@ -170,29 +184,35 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float *__restric
     f32x4 acc[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int64_t m4 = begin; m4 < end; m4 += 4) {
-        const int64_t m = m4 + k;
+    // this lane's pixel m = begin + k, advanced by 4 per step; (b, oy, ox) follow incrementally
+    int b = 0, oy = 0, ox = 0;
+    if (MODE == G_CONV && begin + k < g.M) {
+        const unsigned mu = (unsigned)(begin + k), q = mu / (unsigned)g.Wo;
+        ox = (int)(mu - q * (unsigned)g.Wo);
+        b = (int)(q / (unsigned)g.Ho);
+        oy = (int)(q - (unsigned)b * (unsigned)g.Ho);
+    }
+    for (int64_t m = begin + k; m - k < end; m += 4) {
         const bool ok = m < end;
-        float a = 0.f;
-        int b = 0, oy = 0, ox = 0;
-        if (ok) {
-            a = gyp[m * g.C];
-            if (MODE == G_CONV) {
-                ox = (int)(m % g.Wo);
-                const int64_t q = m / g.Wo;
-                oy = (int)(q % g.Ho);
-                b = (int)(q / g.Ho);
+        const float a = ok ? gyp[m * g.C] : 0.f;
+        float v[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            v[t] = 0.f;
+            if (t < taps && ok) {
+                const int dy = KW3 ? t / 3 : t / g.kw, dx = KW3 ? t % 3 : t % g.kw;
+                const int64_t off = tap_offset<MODE>(g, m, b, oy, ox, dy, dx, t, taps);
+                if (off >= 0) v[t] = xp[off];
             }
         }
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            if (t < taps) {
-                float v = 0.f;
-                if (ok) {
-                    const int64_t row = src_row<MODE>(g, m, b, oy, ox, t);
-                    if (row >= 0) v = xp[row * g.C];
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[t], 0, 0, 0);
+        for (int t = 0; t < MAXT; ++t)
+            if (t < taps) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[t], acc[t], 0, 0, 0);
+        if (MODE == G_CONV) {
+            ox += 4;
+            while (ox >= g.Wo) {
+                ox -= g.Wo;
+                if (++oy == g.Ho) { oy = 0; ++b; }
             }
         }
     }
@@ -283,8 +303,13 @@ static int launch_gconv(const char *what, const float *x, const float *wp, const
     const int64_t blocks = htd::ceil_div(g.M, 64) * slab_blocks;
     HTD_REQUIRE(blocks < (1ll << 31), "%s: launch too large", what);
     const dim3 grid((unsigned)blocks, MODE == G_DGRAD_COLS ? (unsigned)(g.kh * g.kw) : 1u);
-    hipLaunchKernelGGL(gconv_kernel<MODE>, grid, dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<const f32x4 *>(wp),
-                       bias, y, g, relu);
+    HTD_REQUIRE(g.M < (1ll << 31) && (int64_t)g.B * g.H * g.W < (1ll << 31), "%s: more than 2^31 pixels", what);
+    if (g.kw == 3)
+        hipLaunchKernelGGL((gconv_kernel<MODE, true>), grid, dim3(256), 0, (hipStream_t)stream, x,
+                           reinterpret_cast<const f32x4 *>(wp), bias, y, g, relu);
+    else
+        hipLaunchKernelGGL((gconv_kernel<MODE, false>), grid, dim3(256), 0, (hipStream_t)stream, x,
+                           reinterpret_cast<const f32x4 *>(wp), bias, y, g, relu);
     return htd::check_launch(what);
 }
 
@@ -334,10 +359,15 @@ extern "C" int htd_gconv2d_bwd_weight(const float *x, const float *gy, float *gw
     const int pairs = (C / 16) * g.islabs;
     const dim3 grid((unsigned)htd::ceil_div(pairs, 4), (unsigned)chunks);
     float *ws = static_cast<float *>(workspace);
-    if (cols)
-        hipLaunchKernelGGL(gconv_wgrad_kernel<G_COLS>, grid, dim3(256), 0, (hipStream_t)stream, x, gy, ws, g, chunk_rows);
+    HTD_REQUIRE(g.M < (1ll << 31), "gconv2d_bwd_weight: more than 2^31 pixels");
+    if (cols && kw == 3)
+        hipLaunchKernelGGL((gconv_wgrad_kernel<G_COLS, true>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, ws, g, chunk_rows);
+    else if (cols)
+        hipLaunchKernelGGL((gconv_wgrad_kernel<G_COLS, false>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, ws, g, chunk_rows);
+    else if (kw == 3)
+        hipLaunchKernelGGL((gconv_wgrad_kernel<G_CONV, true>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, ws, g, chunk_rows);
     else
-        hipLaunchKernelGGL(gconv_wgrad_kernel<G_CONV>, grid, dim3(256), 0, (hipStream_t)stream, x, gy, ws, g, chunk_rows);
+        hipLaunchKernelGGL((gconv_wgrad_kernel<G_CONV, false>), grid, dim3(256), 0, (hipStream_t)stream, x, gy, ws, g, chunk_rows);
     if (int e = htd::check_launch("gconv2d_bwd_weight")) return e;
     const int64_t total = (int64_t)C * kh * kw * g.cg;
     const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 4096);
