@@ -12,6 +12,8 @@
 // four bilinear neighbours are four coalesced channel-vector reads (or four 256-byte atomic adds in col2im), and
 // the offset / mask gradients are wave reductions over channels.  Sampling rule = mmcv's deformable_im2col:
 // zero outside (-1, H) x (-1, W), per-corner zero padding.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -146,6 +148,209 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(DcnParams p, const f
     }
 }
 
+// Offset / mask gradients alone (no scatter): one wave per (pixel, tap), float4 per lane = 256 channels per pass,
+// one wave reduction at the end.  Streams gcol once; the four corner rows of x come from L2.
+__global__ __launch_bounds__(256) void deform_goffset_kernel(DcnParams p, const float *__restrict__ gcol,
+                                                             float *__restrict__ goffset, float *__restrict__ gmask)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int taps = p.kh * p.kw;
+    if (task >= p.M * taps) return;
+    int64_t m; int k, b, ho, wo;
+    decode(p, task, m, k, b, ho, wo);
+    const int ky = k / p.kw, kx = k % p.kw;
+    const float *img = p.x + (int64_t)b * p.H * p.W * p.C;
+    const float *gc = gcol + (m * taps + k) * p.C;
+    const float hs = (float)(ho * p.stride - p.pad + ky * p.dil) + p.offset[(m * taps + k) * 2];
+    const float ws = (float)(wo * p.stride - p.pad + kx * p.dil) + p.offset[(m * taps + k) * 2 + 1];
+    const Tap t = make_tap(hs, ws, p.H, p.W);
+    const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+    const float mk = p.mask ? p.mask[m * taps + k] : 1.f;
+    const float *r0 = img + ((int64_t)t.h_low * p.W + t.w_low) * p.C, *r1 = r0 + (int64_t)p.W * p.C;
+    float s_dy = 0.f, s_dx = 0.f, s_mk = 0.f;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = lane * 4; c < p.C; c += 256) {
+        const float4 gv = *reinterpret_cast<const float4 *>(gc + c);
+        const float4 v1 = t.ok1 ? *reinterpret_cast<const float4 *>(r0 + c) : z;
+        const float4 v2 = t.ok2 ? *reinterpret_cast<const float4 *>(r0 + p.C + c) : z;
+        const float4 v3 = t.ok3 ? *reinterpret_cast<const float4 *>(r1 + c) : z;
+        const float4 v4 = t.ok4 ? *reinterpret_cast<const float4 *>(r1 + p.C + c) : z;
+        auto acc = [&](float g, float a1, float a2, float a3, float a4) {
+            s_dy += g * mk * (hw * (a3 - a1) + t.lw * (a4 - a2));
+            s_dx += g * mk * (hh * (a2 - a1) + t.lh * (a4 - a3));
+            s_mk += g * (hh * hw * a1 + hh * t.lw * a2 + t.lh * hw * a3 + t.lh * t.lw * a4);
+        };
+        acc(gv.x, v1.x, v2.x, v3.x, v4.x);
+        acc(gv.y, v1.y, v2.y, v3.y, v4.y);
+        acc(gv.z, v1.z, v2.z, v3.z, v4.z);
+        acc(gv.w, v1.w, v2.w, v3.w, v4.w);
+    }
+    s_dy = htd::wave_sum(s_dy);
+    s_dx = htd::wave_sum(s_dx);
+    if (lane == 0 && goffset) {
+        goffset[(m * taps + k) * 2] = s_dy;
+        goffset[(m * taps + k) * 2 + 1] = s_dx;
+    }
+    if (gmask) {
+        s_mk = htd::wave_sum(s_mk);
+        if (lane == 0) gmask[m * taps + k] = s_mk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-owned col2im.  The direct kernel above issues four global float atomics per (pixel, tap, channel) and runs at
+// the chip's float-atomic rate (1.3 TB/s of added bytes); LDS float atomics are no way out (ds_add_f32 retires one
+// wave-instruction per ~165 cycles per CU).  Here a workgroup owns TILE x TILE output pixels and accumulates one
+// 64-channel slice at a time in an LDS window with PLAIN read-modify-writes, made race-free by ownership: every
+// window row belongs to one wave (row mod waves).  Once per workgroup the (pixel, tap) items are split into their top
+// and bottom bilinear halves and bucketed by the window row they hit; in the slice loop each wave walks only its own
+// bucket, so no two waves ever touch the same LDS word.  Halves that fall outside the window (offsets beyond the
+// margin) are kept in a common bucket and go to global memory with atomics, so every offset is handled.  The window
+// is flushed with one global atomic per touched (pixel, channel).  Offset / mask gradients come from a separate
+// streaming pass (deform_goffset_kernel: one wave reduction per (pixel, tap) over all channels, no atomics).
+struct HalfRec {          // one bilinear half (two corners of one row) of a (pixel, tap) item; 16 B
+    int dst;              // owned: float index of the left corner in the LDS window; common: pixel index in the image
+    int src;              // row of gcol: m * taps + k
+    float wa, wb;         // mask * row weight * column weight of the left / right corner (0 when outside the image)
+};
+
+constexpr int RW_WAVES = 8;
+
+__global__ __launch_bounds__(RW_WAVES * 64) void deform_col2im_rows_kernel(
+    DcnParams p, const float *__restrict__ gcol, float *__restrict__ gx, int tile, int tiles_x, int tiles_y, int WH,
+    int WW, int margin, int slices_per_block)
+{
+    extern __shared__ float win[];                                  // [WH*WW][64] | HalfRec[2*items] | counters
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int taps = p.kh * p.kw;
+    const int items = tile * tile * taps;
+    HalfRec *recs = reinterpret_cast<HalfRec *>(win + WH * WW * 64);
+    int *cnt = reinterpret_cast<int *>(recs + 2 * items);           // [RW_WAVES + 1] counts, then starts, then cursors
+    int *start = cnt + RW_WAVES + 1, *cursor = start + RW_WAVES + 2;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y_org = ty * tile * p.stride - p.pad - margin, x_org = tx * tile * p.stride - p.pad - margin;
+    float *gimg = gx + (int64_t)b * p.H * p.W * p.C;
+    const int slices = p.C >> 6;
+    const int s_begin = blockIdx.y * slices_per_block, s_end = min(slices, s_begin + slices_per_block);
+
+    // ---- once per workgroup: split the items into halves, bucket them by the wave that owns their window row
+    if (threadIdx.x <= RW_WAVES) cnt[threadIdx.x] = cursor[threadIdx.x] = 0;
+    __syncthreads();
+    for (int phase = 0; phase < 2; ++phase) {
+        for (int item = threadIdx.x; item < items; item += blockDim.x) {
+            const int pix = item / taps, k = item - pix * taps;
+            const int oy = ty * tile + pix / tile, ox = tx * tile + pix % tile;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            const int64_t m = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+            const int ky = k / p.kw, kx = k - ky * p.kw;
+            const float hs = (float)(oy * p.stride - p.pad + ky * p.dil) + p.offset[(m * taps + k) * 2];
+            const float ws = (float)(ox * p.stride - p.pad + kx * p.dil) + p.offset[(m * taps + k) * 2 + 1];
+            const Tap t = make_tap(hs, ws, p.H, p.W);
+            const float mk = p.mask ? p.mask[m * taps + k] : 1.f;
+            const int lx = t.w_low - x_org;
+            const bool cols_in = lx >= 0 && lx + 1 < WW;
+            for (int half = 0; half < 2; ++half) {
+                const bool oka = half ? t.ok3 : t.ok1, okb = half ? t.ok4 : t.ok2;
+                if (!oka && !okb) continue;
+                const int ly = t.h_low + half - y_org;
+                const bool owned = cols_in && ly >= 0 && ly < WH;
+                const int owner = owned ? ly % RW_WAVES : RW_WAVES;
+                if (phase == 0) {
+                    atomicAdd(&cnt[owner], 1);
+                } else {
+                    const int pos = start[owner] + atomicAdd(&cursor[owner], 1);
+                    const float wy = mk * (half ? t.lh : 1.f - t.lh);
+                    HalfRec r;
+                    r.dst = owned ? (ly * WW + lx) * 64 : (t.h_low + half) * p.W + t.w_low;
+                    r.src = (int)(m * taps + k);
+                    r.wa = oka ? wy * (1.f - t.lw) : 0.f;
+                    r.wb = okb ? wy * t.lw : 0.f;
+                    recs[pos] = r;
+                }
+            }
+        }
+        __syncthreads();
+        if (phase == 0) {
+            if (threadIdx.x == 0) {
+                int acc = 0;
+                for (int w = 0; w <= RW_WAVES; ++w) { start[w] = acc; acc += cnt[w]; }
+                start[RW_WAVES + 1] = acc;
+            }
+            __syncthreads();
+        }
+    }
+    const HalfRec *own = recs + start[wave];
+    const int n_own = cnt[wave];
+    const HalfRec *common = recs + start[RW_WAVES];
+    const int n_common = cnt[RW_WAVES];
+
+    constexpr int FLY = 4;
+    struct Batch { HalfRec r[FLY]; float gv[FLY]; };
+    for (int sl = s_begin; sl < s_end; ++sl) {
+        const float *gc = gcol + sl * 64 + lane;
+        for (int i = threadIdx.x; i < WH * WW * 16; i += blockDim.x)
+            reinterpret_cast<float4 *>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        // this wave's rows: plain LDS adds, the next batch's records and gradient columns fetched ahead
+        auto fetch = [&](const HalfRec *list, int n, int e0, int step, Batch &bt) {
+#pragma unroll
+            for (int f = 0; f < FLY; ++f) {
+                const int e = e0 + f * step;
+                bt.r[f].wa = bt.r[f].wb = 0.f;
+                bt.r[f].dst = bt.r[f].src = 0;
+                bt.gv[f] = 0.f;
+                if (e < n) {
+                    bt.r[f] = list[e];
+                    bt.gv[f] = gc[(int64_t)bt.r[f].src * p.C];
+                }
+            }
+        };
+        if (n_own > 0) {
+            Batch cur, nxt;
+            fetch(own, n_own, 0, 1, cur);
+            for (int e0 = 0; e0 < n_own; e0 += FLY) {
+                fetch(own, n_own, e0 + FLY, 1, nxt);
+#pragma unroll
+                for (int f = 0; f < FLY; ++f) {
+                    if (e0 + f >= n_own) continue;                  // (a padding slot must not touch another wave's row)
+                    float *q = win + cur.r[f].dst + lane;
+                    q[0] += cur.gv[f] * cur.r[f].wa;
+                    q[64] += cur.gv[f] * cur.r[f].wb;
+                }
+                cur = nxt;
+            }
+        }
+        // halves outside the window: global atomics, shared round-robin between the waves
+        for (int e0 = wave; e0 < n_common; e0 += FLY * RW_WAVES) {
+            Batch bt;
+            fetch(common, n_common, e0, RW_WAVES, bt);
+#pragma unroll
+            for (int f = 0; f < FLY; ++f) {
+                if (e0 + f * RW_WAVES >= n_common) continue;
+                float *q = gimg + (int64_t)bt.r[f].dst * p.C + sl * 64 + lane;
+                if (bt.r[f].wa != 0.f) atomicAdd(q, bt.gv[f] * bt.r[f].wa);
+                if (bt.r[f].wb != 0.f) atomicAdd(q + p.C, bt.gv[f] * bt.r[f].wb);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < WH * WW * 64; i += blockDim.x) {
+            const float v = win[i];
+            if (v != 0.f) {
+                const int pix = i >> 6, y = y_org + pix / WW, x = x_org + pix % WW;
+                // window cells outside the image only ever receive 0 * gradient; the bounds test keeps a NaN / Inf
+                // gradient from turning that into a write outside gx
+                if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                    atomicAdd(gimg + ((int64_t)y * p.W + x) * p.C + sl * 64 + (i & 63), v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 int fill(DcnParams &p, const float *x, const float *offset, const float *mask, int B, int H, int W, int C, int kh,
          int kw, int stride, int pad, int dil, int dg)
 {
@@ -196,6 +401,39 @@ extern "C" int htd_deform_col2im(const float *x, const float *offset, const floa
     if (st) return st;
     HTD_REQUIRE(gcolumns, "deform_col2im: null gradient columns");
     const int64_t tasks = p.M * kh * kw;
+    // row-owned LDS accumulation: needs gx, 64-channel slices inside one deformable group, a window within the LDS
+    // budget of two workgroups per CU, and 32-bit row / pixel indices
+    static const bool direct_only = getenv("HTD_DCN_DIRECT_COL2IM") != nullptr;
+    const int tile = stride == 1 ? 8 : 4, margin = 1;
+    const int WH = (tile - 1) * stride + (kh - 1) * dil + 2 + 2 * margin, WW = (tile - 1) * stride + (kw - 1) * dil + 2 + 2 * margin;
+    const int items = tile * tile * kh * kw;
+    const size_t lds = (size_t)WH * WW * 64 * sizeof(float) + (size_t)2 * items * sizeof(HalfRec) +
+                       (3 * (RW_WAVES + 2)) * sizeof(int);
+    if (!direct_only && gx && C % 64 == 0 && deform_groups == 1 && stride <= 2 && lds <= 80 * 1024 &&
+        p.M * kh * kw < (1ll << 31) && (int64_t)H * W < (1ll << 31)) {
+        const int tiles_x = (int)htd::ceil_div(p.Wo, tile), tiles_y = (int)htd::ceil_div(p.Ho, tile);
+        const int64_t nt = (int64_t)tiles_x * tiles_y * B;
+        HTD_REQUIRE(nt < (1ll << 31), "deform_col2im: too many tiles");
+        const int slices = C / 64;
+        int groups_y = (int)std::min<int64_t>(slices, std::max<int64_t>(1, htd::ceil_div(2048, nt)));   // >= 8 workgroups per CU
+        const int spb = (int)htd::ceil_div(slices, groups_y);
+        groups_y = (int)htd::ceil_div(slices, spb);
+        if (goffset || gmask) {         // offset / mask gradients: the direct kernel without its scatter (no atomics)
+            const int64_t blocks = htd::ceil_div(tasks, 4);
+            HTD_REQUIRE(blocks < (1ll << 31), "deform_col2im: too many tasks");
+            hipLaunchKernelGGL(deform_goffset_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, gcolumns,
+                               goffset, gmask);
+        }
+        static bool lds_opt_in = false;
+        if (!lds_opt_in) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deform_col2im_rows_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            lds_opt_in = true;
+        }
+        hipLaunchKernelGGL(deform_col2im_rows_kernel, dim3((unsigned)nt, (unsigned)groups_y), dim3(RW_WAVES * 64), lds,
+                           (hipStream_t)stream, p, gcolumns, gx, tile, tiles_x, tiles_y, WH, WW, margin, spb);
+        return htd::check_launch("deform_col2im(rows)");
+    }
     const int64_t blocks = htd::ceil_div(tasks, 4);
     HTD_REQUIRE(blocks < (1ll << 31), "deform_col2im: too many tasks");
     hipLaunchKernelGGL(deform_col2im_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, gcolumns, gx,

@@ -6,6 +6,7 @@ build/lib/mmdet/ops/dcn/deform_conv.py:257-300,385-…).  GPU only: the referenc
 (deform_conv.py:45-46 raises NotImplementedError).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -18,6 +19,7 @@ from .registry import CONV_LAYERS
 
 CL = torch.channels_last
 _P, _S = capi.ptr, capi.current_stream_ptr
+KEEP_COLUMNS = os.environ.get('HTD_DCN_KEEP_COLUMNS', '1') != '0'     # 0: re-sample in backward (saves memory)
 
 
 class DeformConv2dFunction(Function):
@@ -52,14 +54,17 @@ class DeformConv2dFunction(Function):
             y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
             capi.call('htd_conv2d_fwd', _P(cols), _P(weight), _P(bias), None, 0, 0, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1,
                       int(bool(relu)), None, _S(), work=('flop', 2.0 * M * K * Co))     # bias / ReLU in the GEMM epilogue
-        ctx.save_for_backward(x, offset, mask, weight, y if relu else None)
+        # the gathered columns are kept for the weight gradient (9x the input: ~5 GB over the 30 layers of R101-DCN at
+        # B = 4, ~20 GB for X101 -- nothing against 288 GB of HBM, and it saves re-sampling every layer in backward)
+        keep_cols = ctx.needs_input_grad[3] and KEEP_COLUMNS
+        ctx.save_for_backward(x, offset, mask, weight, y if relu else None, cols if keep_cols else None)
         ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo, bias is not None, groups)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, offset, mask, weight, y = ctx.saved_tensors
+        x, offset, mask, weight, y, cols = ctx.saved_tensors
         stride, padding, dilation, dg, Ho, Wo, has_bias, groups = ctx.cfg
         geom = (x.size(1), groups, weight.size(2), weight.size(3), stride, padding, dilation)
         B, C, H, W = x.shape
@@ -87,9 +92,10 @@ class DeformConv2dFunction(Function):
             capi.call('htd_deform_col2im', _P(x), _P(offset), _P(mask), _P(gcol), _P(gx), _P(goff), _P(gmask), B, H, W,
                       C, kh, kw, stride, padding, dilation, dg, _S())
         if ctx.needs_input_grad[3]:
-            cols = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
-            capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
-                      dilation, dg, _S())
+            if cols is None:
+                cols = torch.empty(M, K, device=gy.device, dtype=gy.dtype)
+                capi.call('htd_deform_im2col', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride,
+                          padding, dilation, dg, _S())
             if groups > 1:
                 gw = dense._gconv_wgrad_raw(cols, gy, weight, geom, x.shape, cols=True)
                 gb = gy.sum((0, 2, 3)) if want_b else None

@@ -117,3 +117,44 @@ def test_dcn_bottleneck_folded_bn_relu_epilogue():
     assert set(p1) == set(p2)
     for n in p2:
         torch.testing.assert_close(p1[n], p2[n], rtol=1e-4, atol=1e-5 * max(1.0, float(p2[n].abs().max())), msg=n)
+
+
+def test_col2im_row_owned_kernel_matches_direct_kernel():
+    """htd_deform_col2im picks the row-owned LDS kernel for wide layers; the direct scatter kernel (taken when gx is
+    not requested... or for narrow layers) is the reference here: same gx within float summation order, identical
+    offset gradients, for small and for large offsets (beyond the LDS window margin), stride 1 and 2, and with
+    non-finite gradients staying inside the buffers."""
+    from htd_amd import capi
+    P, S = capi.ptr, capi.current_stream_ptr
+    dev = torch.device('cuda:0')
+    for (B, H, W, C, stride, std) in [(2, 37, 45, 128, 1, 0.4), (1, 40, 33, 64, 2, 0.4), (2, 21, 19, 192, 1, 4.0)]:
+        g = torch.Generator(device='cpu').manual_seed(H)
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        x = torch.randn(B, H, W, C, generator=g).to(dev)
+        off = (torch.randn(B, Ho, Wo, 18, generator=g) * std).to(dev)
+        gcol = torch.randn(B * Ho * Wo, 9, C, generator=g).to(dev)
+        # reference: scatter each 32-channel half separately (C/2 is not a multiple of 64 for C = 64, 192; for C = 128
+        # the halves are 64 wide, so use quarter slices there) -> the direct kernel
+        gx = torch.zeros_like(x)
+        goff = torch.empty_like(off)
+        capi.call('htd_deform_col2im', P(x), P(off), None, P(gcol), P(gx), P(goff), None, B, H, W, C, 3, 3, stride, 1, 1, 1, S())
+        ref_gx = torch.zeros_like(x)
+        ref_goff = torch.zeros_like(off)
+        w = 32
+        for c0 in range(0, C, w):
+            xs = x[..., c0:c0 + w].contiguous()
+            gs = gcol[..., c0:c0 + w].contiguous()
+            gxs = torch.zeros_like(xs)
+            gos = torch.empty_like(off)
+            capi.call('htd_deform_col2im', P(xs), P(off), None, P(gs), P(gxs), P(gos), None, B, H, W, w, 3, 3, stride, 1, 1,
+                      1, S())
+            ref_gx[..., c0:c0 + w] = gxs
+            ref_goff += gos
+        torch.testing.assert_close(gx, ref_gx, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(goff, ref_goff, rtol=1e-4, atol=1e-3)
+    # a NaN gradient stays a NaN in gx and nothing faults
+    gcol[(Ho // 2) * Wo + Wo // 2 - 3:(Ho // 2) * Wo + Wo // 2 + 3, :, 0] = float('nan')     # centre pixels, all taps
+    gx.zero_()
+    capi.call('htd_deform_col2im', P(x), P(off), None, P(gcol), P(gx), P(goff), None, B, H, W, C, 3, 3, stride, 1, 1, 1, S())
+    torch.cuda.synchronize()
+    assert torch.isnan(gx).any()

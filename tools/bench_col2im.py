@@ -19,8 +19,11 @@ goff = torch.empty_like(off)
 P, S = capi.ptr, capi.current_stream_ptr
 
 
+MODE = os.environ.get('C2I_MODE', 'all')
+
+
 def run():
-    capi.call('htd_deform_col2im', P(x), P(off), None, P(gcol), P(gx), P(goff), None, B, H, W, C, 3, 3, 1, 1, 1, 1, S())
+    capi.call('htd_deform_col2im', P(x), P(off), None, P(gcol), None if MODE == 'goff' else P(gx), None if MODE == 'gx' else P(goff), None, B, H, W, C, 3, 3, 1, 1, 1, 1, S())
 
 
 for _ in range(3):
@@ -33,5 +36,5 @@ for _ in range(10):
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b) / 10
-print(f'col2im B{B} {H}x{W} C{C} std {std} dbg={os.environ.get("HTD_C2I_DBG")} direct={os.environ.get("HTD_DCN_DIRECT_COL2IM")}: '
+print(f'col2im B{B} {H}x{W} C{C} std {std} mode={MODE} direct={os.environ.get("HTD_DCN_DIRECT_COL2IM")}: '
       f'{ms:.3f} ms  (gcol {gcol.numel() * 4 / 1e6:.0f} MB -> {gcol.numel() * 4 / ms / 1e6:.0f} GB/s)')
