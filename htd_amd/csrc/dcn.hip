@@ -18,8 +18,38 @@
 
 namespace {
 
+// Element types of x / columns / gradient columns: float, or bf16 carried as its 16-bit pattern (the bf16 mode of the
+// detector keeps activations in bf16; sampling arithmetic, offsets and every accumulation stay fp32).
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if (f != f) return 0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);                                // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float ld1(const float *p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t *p) { return bf2f(*p); }
+__device__ __forceinline__ float4 ld4v(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld4v(const bf16_t *p)
+{
+    const uint2 r = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4v(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void st4v(bf16_t *p, float4 v)
+{
+    uint2 r;
+    r.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    r.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2 *>(p) = r;
+}
+
 struct DcnParams {
-    const float *x, *offset, *mask;
+    const void *x;
+    const float *offset, *mask;
     int B, H, W, C, kh, kw, stride, pad, dil, dg, Ho, Wo;
     int64_t M;
 };
@@ -59,7 +89,8 @@ __device__ __forceinline__ void decode(const DcnParams &p, int64_t task, int64_t
     b = (int)(t / p.Ho);
 }
 
-__global__ __launch_bounds__(256) void deform_im2col_kernel(DcnParams p, float *__restrict__ col)
+template <typename T>
+__global__ __launch_bounds__(256) void deform_im2col_kernel(DcnParams p, T *__restrict__ col)
 {
     const int lane = threadIdx.x & 63;
     const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -69,8 +100,8 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(DcnParams p, float *
     decode(p, task, m, k, b, ho, wo);
     const int ky = k / p.kw, kx = k % p.kw;
     const int cpg = p.C / p.dg;
-    const float *img = p.x + (int64_t)b * p.H * p.W * p.C;
-    float *out = col + (m * taps + k) * p.C;
+    const T *img = static_cast<const T *>(p.x) + (int64_t)b * p.H * p.W * p.C;
+    T *out = col + (m * taps + k) * p.C;
     for (int c = lane * 4; c < p.C; c += 256) {
         const int g = c / cpg;
         const int64_t ob = m * (int64_t)(p.dg * taps * 2) + (int64_t)(g * taps + k) * 2;
@@ -81,7 +112,7 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(DcnParams p, float *
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         auto acc = [&](bool ok, int y, int x, float wgt) {
             if (!ok) return;
-            const float4 s = *reinterpret_cast<const float4 *>(img + ((int64_t)y * p.W + x) * p.C + c);
+            const float4 s = ld4v(img + ((int64_t)y * p.W + x) * p.C + c);
             v.x += wgt * s.x; v.y += wgt * s.y; v.z += wgt * s.z; v.w += wgt * s.w;
         };
         acc(t.ok1, t.h_low, t.w_low, hh * hw);
@@ -92,12 +123,13 @@ __global__ __launch_bounds__(256) void deform_im2col_kernel(DcnParams p, float *
             const float mk = p.mask[m * (int64_t)(p.dg * taps) + g * taps + k];
             v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
         }
-        *reinterpret_cast<float4 *>(out + c) = v;
+        st4v(out + c, v);
     }
 }
 
 // gx must be zero-initialised; goffset [M][dg*taps*2], gmask [M][dg*taps] are written in full.
-__global__ __launch_bounds__(256) void deform_col2im_kernel(DcnParams p, const float *__restrict__ gcol,
+template <typename T>
+__global__ __launch_bounds__(256) void deform_col2im_kernel(DcnParams p, const T *__restrict__ gcol,
                                                             float *__restrict__ gx, float *__restrict__ goffset,
                                                             float *__restrict__ gmask)
 {
@@ -109,9 +141,9 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(DcnParams p, const f
     decode(p, task, m, k, b, ho, wo);
     const int ky = k / p.kw, kx = k % p.kw;
     const int cpg = p.C / p.dg;
-    const float *img = p.x + (int64_t)b * p.H * p.W * p.C;
+    const T *img = static_cast<const T *>(p.x) + (int64_t)b * p.H * p.W * p.C;
     float *gimg = gx ? gx + (int64_t)b * p.H * p.W * p.C : nullptr;
-    const float *gc = gcol + (m * taps + k) * p.C;
+    const T *gc = gcol + (m * taps + k) * p.C;
     for (int g = 0; g < p.dg; ++g) {
         const int64_t ob = m * (int64_t)(p.dg * taps * 2) + (int64_t)(g * taps + k) * 2;
         const float hs = (float)(ho * p.stride - p.pad + ky * p.dil) + p.offset[ob];
@@ -121,11 +153,11 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(DcnParams p, const f
         const float mk = p.mask ? p.mask[m * (int64_t)(p.dg * taps) + g * taps + k] : 1.f;
         float s_dy = 0.f, s_dx = 0.f, s_mk = 0.f;
         for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
-            const float gv = gc[c];
-            const float v1 = t.ok1 ? img[((int64_t)t.h_low * p.W + t.w_low) * p.C + c] : 0.f;
-            const float v2 = t.ok2 ? img[((int64_t)t.h_low * p.W + t.w_low + 1) * p.C + c] : 0.f;
-            const float v3 = t.ok3 ? img[((int64_t)(t.h_low + 1) * p.W + t.w_low) * p.C + c] : 0.f;
-            const float v4 = t.ok4 ? img[((int64_t)(t.h_low + 1) * p.W + t.w_low + 1) * p.C + c] : 0.f;
+            const float gv = ld1(gc + c);
+            const float v1 = t.ok1 ? ld1(img + ((int64_t)t.h_low * p.W + t.w_low) * p.C + c) : 0.f;
+            const float v2 = t.ok2 ? ld1(img + ((int64_t)t.h_low * p.W + t.w_low + 1) * p.C + c) : 0.f;
+            const float v3 = t.ok3 ? ld1(img + ((int64_t)(t.h_low + 1) * p.W + t.w_low) * p.C + c) : 0.f;
+            const float v4 = t.ok4 ? ld1(img + ((int64_t)(t.h_low + 1) * p.W + t.w_low + 1) * p.C + c) : 0.f;
             // d(val)/dh = hw*(v3-v1) + lw*(v4-v2) ; d(val)/dw = hh*(v2-v1) + lh*(v4-v3)
             s_dy += gv * mk * (hw * (v3 - v1) + t.lw * (v4 - v2));
             s_dx += gv * mk * (hh * (v2 - v1) + t.lh * (v4 - v3));
@@ -150,7 +182,8 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(DcnParams p, const f
 
 // Offset / mask gradients alone (no scatter): one wave per (pixel, tap), float4 per lane = 256 channels per pass,
 // one wave reduction at the end.  Streams gcol once; the four corner rows of x come from L2.
-__global__ __launch_bounds__(256) void deform_goffset_kernel(DcnParams p, const float *__restrict__ gcol,
+template <typename T>
+__global__ __launch_bounds__(256) void deform_goffset_kernel(DcnParams p, const T *__restrict__ gcol,
                                                              float *__restrict__ goffset, float *__restrict__ gmask)
 {
     const int lane = threadIdx.x & 63;
@@ -160,22 +193,22 @@ __global__ __launch_bounds__(256) void deform_goffset_kernel(DcnParams p, const 
     int64_t m; int k, b, ho, wo;
     decode(p, task, m, k, b, ho, wo);
     const int ky = k / p.kw, kx = k % p.kw;
-    const float *img = p.x + (int64_t)b * p.H * p.W * p.C;
-    const float *gc = gcol + (m * taps + k) * p.C;
+    const T *img = static_cast<const T *>(p.x) + (int64_t)b * p.H * p.W * p.C;
+    const T *gc = gcol + (m * taps + k) * p.C;
     const float hs = (float)(ho * p.stride - p.pad + ky * p.dil) + p.offset[(m * taps + k) * 2];
     const float ws = (float)(wo * p.stride - p.pad + kx * p.dil) + p.offset[(m * taps + k) * 2 + 1];
     const Tap t = make_tap(hs, ws, p.H, p.W);
     const float hh = 1.f - t.lh, hw = 1.f - t.lw;
     const float mk = p.mask ? p.mask[m * taps + k] : 1.f;
-    const float *r0 = img + ((int64_t)t.h_low * p.W + t.w_low) * p.C, *r1 = r0 + (int64_t)p.W * p.C;
+    const T *r0 = img + ((int64_t)t.h_low * p.W + t.w_low) * p.C, *r1 = r0 + (int64_t)p.W * p.C;
     float s_dy = 0.f, s_dx = 0.f, s_mk = 0.f;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int c = lane * 4; c < p.C; c += 256) {
-        const float4 gv = *reinterpret_cast<const float4 *>(gc + c);
-        const float4 v1 = t.ok1 ? *reinterpret_cast<const float4 *>(r0 + c) : z;
-        const float4 v2 = t.ok2 ? *reinterpret_cast<const float4 *>(r0 + p.C + c) : z;
-        const float4 v3 = t.ok3 ? *reinterpret_cast<const float4 *>(r1 + c) : z;
-        const float4 v4 = t.ok4 ? *reinterpret_cast<const float4 *>(r1 + p.C + c) : z;
+        const float4 gv = ld4v(gc + c);
+        const float4 v1 = t.ok1 ? ld4v(r0 + c) : z;
+        const float4 v2 = t.ok2 ? ld4v(r0 + p.C + c) : z;
+        const float4 v3 = t.ok3 ? ld4v(r1 + c) : z;
+        const float4 v4 = t.ok4 ? ld4v(r1 + p.C + c) : z;
         auto acc = [&](float g, float a1, float a2, float a3, float a4) {
             s_dy += g * mk * (hw * (a3 - a1) + t.lw * (a4 - a2));
             s_dx += g * mk * (hh * (a2 - a1) + t.lh * (a4 - a3));
@@ -217,8 +250,9 @@ struct HalfRec {          // one bilinear half (two corners of one row) of a (pi
 
 constexpr int RW_WAVES = 8;
 
+template <typename T>
 __global__ __launch_bounds__(RW_WAVES * 64) void deform_col2im_rows_kernel(
-    DcnParams p, const float *__restrict__ gcol, float *__restrict__ gx, int tile, int tiles_x, int tiles_y, int WH,
+    DcnParams p, const T *__restrict__ gcol, float *__restrict__ gx, int tile, int tiles_x, int tiles_y, int WH,
     int WW, int margin, int slices_per_block)
 {
     extern __shared__ float win[];                                  // [WH*WW][64] | HalfRec[2*items] | counters
@@ -291,7 +325,7 @@ __global__ __launch_bounds__(RW_WAVES * 64) void deform_col2im_rows_kernel(
     constexpr int FLY = 4;
     struct Batch { HalfRec r[FLY]; float gv[FLY]; };
     for (int sl = s_begin; sl < s_end; ++sl) {
-        const float *gc = gcol + sl * 64 + lane;
+        const T *gc = gcol + sl * 64 + lane;
         for (int i = threadIdx.x; i < WH * WW * 16; i += blockDim.x)
             reinterpret_cast<float4 *>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
@@ -305,7 +339,7 @@ __global__ __launch_bounds__(RW_WAVES * 64) void deform_col2im_rows_kernel(
                 bt.gv[f] = 0.f;
                 if (e < n) {
                     bt.r[f] = list[e];
-                    bt.gv[f] = gc[(int64_t)bt.r[f].src * p.C];
+                    bt.gv[f] = ld1(gc + (int64_t)bt.r[f].src * p.C);
                 }
             }
         };
@@ -351,7 +385,7 @@ __global__ __launch_bounds__(RW_WAVES * 64) void deform_col2im_rows_kernel(
     }
 }
 
-int fill(DcnParams &p, const float *x, const float *offset, const float *mask, int B, int H, int W, int C, int kh,
+int fill(DcnParams &p, const void *x, const float *offset, const float *mask, int B, int H, int W, int C, int kh,
          int kw, int stride, int pad, int dil, int dg)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0 && dg > 0,
@@ -377,9 +411,9 @@ extern "C" int64_t htd_deform_columns_bytes(int B, int H, int W, int C, int kh, 
     return (int64_t)B * Ho * Wo * kh * kw * C * 4;
 }
 
-extern "C" int htd_deform_im2col(const float *x, const float *offset, const float *mask, float *columns, int B, int H,
-                                 int W, int C, int kh, int kw, int stride, int pad, int dil, int deform_groups,
-                                 void *stream)
+template <typename T>
+static int launch_im2col(const void *x, const float *offset, const float *mask, T *columns, int B, int H, int W, int C,
+                         int kh, int kw, int stride, int pad, int dil, int deform_groups, void *stream)
 {
     DcnParams p{};
     const int st = fill(p, x, offset, mask, B, H, W, C, kh, kw, stride, pad, dil, deform_groups);
@@ -388,19 +422,22 @@ extern "C" int htd_deform_im2col(const float *x, const float *offset, const floa
     const int64_t tasks = p.M * kh * kw;
     const int64_t blocks = htd::ceil_div(tasks, 4);
     HTD_REQUIRE(blocks < (1ll << 31), "deform_im2col: too many tasks");
-    hipLaunchKernelGGL(deform_im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, columns);
+    hipLaunchKernelGGL(deform_im2col_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, columns);
     return htd::check_launch("deform_im2col");
 }
 
-extern "C" int htd_deform_col2im(const float *x, const float *offset, const float *mask, const float *gcolumns,
-                                 float *gx, float *goffset, float *gmask, int B, int H, int W, int C, int kh, int kw,
-                                 int stride, int pad, int dil, int deform_groups, void *stream)
+template <typename T>
+static int launch_col2im(const void *x, const float *offset, const float *mask, const T *gcolumns, float *gx,
+                         float *goffset, float *gmask, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                         int dil, int deform_groups, void *stream)
 {
     DcnParams p{};
     const int st = fill(p, x, offset, mask, B, H, W, C, kh, kw, stride, pad, dil, deform_groups);
     if (st) return st;
     HTD_REQUIRE(gcolumns, "deform_col2im: null gradient columns");
     const int64_t tasks = p.M * kh * kw;
+    const int64_t blocks = htd::ceil_div(tasks, 4);
+    HTD_REQUIRE(blocks < (1ll << 31), "deform_col2im: too many tasks");
     // row-owned LDS accumulation: needs gx, 64-channel slices inside one deformable group, a window within the LDS
     // budget of two workgroups per CU, and 32-bit row / pixel indices
     static const bool direct_only = getenv("HTD_DCN_DIRECT_COL2IM") != nullptr;
@@ -418,25 +455,51 @@ extern "C" int htd_deform_col2im(const float *x, const float *offset, const floa
         int groups_y = (int)std::min<int64_t>(slices, std::max<int64_t>(1, htd::ceil_div(2048, nt)));   // >= 8 workgroups per CU
         const int spb = (int)htd::ceil_div(slices, groups_y);
         groups_y = (int)htd::ceil_div(slices, spb);
-        if (goffset || gmask) {         // offset / mask gradients: the direct kernel without its scatter (no atomics)
-            const int64_t blocks = htd::ceil_div(tasks, 4);
-            HTD_REQUIRE(blocks < (1ll << 31), "deform_col2im: too many tasks");
-            hipLaunchKernelGGL(deform_goffset_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, gcolumns,
-                               goffset, gmask);
-        }
+        if (goffset || gmask)           // offset / mask gradients: their own streaming pass (no atomics)
+            hipLaunchKernelGGL(deform_goffset_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p,
+                               gcolumns, goffset, gmask);
         static bool lds_opt_in = false;
         if (!lds_opt_in) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deform_col2im_rows_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(deform_col2im_rows_kernel<T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             lds_opt_in = true;
         }
-        hipLaunchKernelGGL(deform_col2im_rows_kernel, dim3((unsigned)nt, (unsigned)groups_y), dim3(RW_WAVES * 64), lds,
+        hipLaunchKernelGGL(deform_col2im_rows_kernel<T>, dim3((unsigned)nt, (unsigned)groups_y), dim3(RW_WAVES * 64), lds,
                            (hipStream_t)stream, p, gcolumns, gx, tile, tiles_x, tiles_y, WH, WW, margin, spb);
         return htd::check_launch("deform_col2im(rows)");
     }
-    const int64_t blocks = htd::ceil_div(tasks, 4);
-    HTD_REQUIRE(blocks < (1ll << 31), "deform_col2im: too many tasks");
-    hipLaunchKernelGGL(deform_col2im_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, gcolumns, gx,
+    hipLaunchKernelGGL(deform_col2im_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, gcolumns, gx,
                        goffset, gmask);
     return htd::check_launch("deform_col2im");
+}
+
+extern "C" int htd_deform_im2col(const float *x, const float *offset, const float *mask, float *columns, int B, int H,
+                                 int W, int C, int kh, int kw, int stride, int pad, int dil, int deform_groups,
+                                 void *stream)
+{
+    return launch_im2col<float>(x, offset, mask, columns, B, H, W, C, kh, kw, stride, pad, dil, deform_groups, stream);
+}
+
+extern "C" int htd_deform_col2im(const float *x, const float *offset, const float *mask, const float *gcolumns,
+                                 float *gx, float *goffset, float *gmask, int B, int H, int W, int C, int kh, int kw,
+                                 int stride, int pad, int dil, int deform_groups, void *stream)
+{
+    return launch_col2im<float>(x, offset, mask, gcolumns, gx, goffset, gmask, B, H, W, C, kh, kw, stride, pad, dil,
+                                deform_groups, stream);
+}
+
+extern "C" int htd_deform_im2col_bf16(const void *x, const float *offset, const float *mask, void *columns, int B, int H,
+                                      int W, int C, int kh, int kw, int stride, int pad, int dil, int deform_groups,
+                                      void *stream)
+{
+    return launch_im2col<bf16_t>(x, offset, mask, static_cast<bf16_t *>(columns), B, H, W, C, kh, kw, stride, pad, dil,
+                                 deform_groups, stream);
+}
+
+extern "C" int htd_deform_col2im_bf16(const void *x, const float *offset, const float *mask, const void *gcolumns,
+                                      float *gx, float *goffset, float *gmask, int B, int H, int W, int C, int kh, int kw,
+                                      int stride, int pad, int dil, int deform_groups, void *stream)
+{
+    return launch_col2im<bf16_t>(x, offset, mask, static_cast<const bf16_t *>(gcolumns), gx, goffset, gmask, B, H, W, C, kh,
+                                 kw, stride, pad, dil, deform_groups, stream);
 }

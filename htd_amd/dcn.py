@@ -111,10 +111,80 @@ class DeformConv2dFunction(Function):
         return gx, goff, gmask, gw, None, None, None, None, gb, None, None
 
 
+class DeformConv2dBf16Function(Function):
+    """Mixed-precision deformable convolution (bf16 mode, BASELINE configs[3]): bf16 activations / columns / gradient
+    columns, fp32 offsets, fp32 master weight and bias.  The three GEMM halves run on the bf16 MFMA kernels
+    (htd_conv2d_fwd_bf16 as a 1x1 over the column matrix, htd_conv2d_bwd_weight_bf16), sampling and scatter on the bf16
+    forms of the im2col / col2im kernels; all accumulation is fp32."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, stride, padding, dilation, deform_groups, bias, relu):
+        BF = torch.bfloat16
+        x = x.contiguous(memory_format=CL)
+        offset = offset.float().contiguous(memory_format=CL)
+        mask = mask.float().contiguous(memory_format=CL) if mask is not None else None
+        B, C, H, W = x.shape
+        Co, _, kh, kw = weight.shape
+        Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+        if offset.shape != (B, 2 * deform_groups * kh * kw, Ho, Wo):
+            raise ValueError(f'offset shape {tuple(offset.shape)} does not match output {(B, Ho, Wo)}')
+        M, K = B * Ho * Wo, kh * kw * C
+        cols = torch.empty(M, K, device=x.device, dtype=BF)
+        capi.call('htd_deform_im2col_bf16', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride, padding,
+                  dilation, deform_groups, _S(), work=('byte', 2.0 * M * K * 2))
+        wb = weight.to(BF).contiguous(memory_format=CL)                 # [Co][kh][kw][C] = [Co][K]
+        bias = bias.float().contiguous() if bias is not None else None
+        y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=BF, memory_format=CL)
+        capi.call('htd_conv2d_fwd_bf16', _P(cols), _P(wb), _P(bias), None, _P(y), 1, M, 1, K, Co, 1, 1, 1, 0, 1,
+                  int(bool(relu)), _S(), work=('flop', 2.0 * M * K * Co))
+        ctx.save_for_backward(x, offset, mask, wb, y if relu else None, cols if ctx.needs_input_grad[3] else None)
+        ctx.cfg = (stride, padding, dilation, deform_groups, Ho, Wo, bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        BF = torch.bfloat16
+        x, offset, mask, wb, y, cols = ctx.saved_tensors
+        stride, padding, dilation, dg, Ho, Wo, has_bias, wshape = ctx.cfg
+        B, C, H, W = x.shape
+        Co, _, kh, kw = wshape
+        M, K = B * Ho * Wo, kh * kw * C
+        gy = gy.to(BF).contiguous(memory_format=CL)
+        if y is not None:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        gx = goff = gmask = gw = gb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or (mask is not None and ctx.needs_input_grad[2]):
+            wT = wb.permute(0, 2, 3, 1).reshape(Co, K).t().contiguous()   # [K = (tap, c)][Co]: gcol = gy @ W, 1x1 over M
+            gcol = torch.empty(M, K, device=gy.device, dtype=BF)
+            capi.call('htd_conv2d_fwd_bf16', _P(gy), _P(wT), None, None, _P(gcol), 1, M, 1, Co, K, 1, 1, 1, 0, 1, 0, _S(),
+                      work=('flop', 2.0 * M * K * Co))
+            gx32 = torch.empty((B, C, H, W), device=gy.device, dtype=torch.float32, memory_format=CL).zero_() \
+                if ctx.needs_input_grad[0] else None
+            goff = torch.empty_like(offset, memory_format=CL)
+            gmask = torch.empty_like(mask, memory_format=CL) if mask is not None else None
+            capi.call('htd_deform_col2im_bf16', _P(x), _P(offset), _P(mask), _P(gcol), _P(gx32), _P(goff), _P(gmask), B, H,
+                      W, C, kh, kw, stride, padding, dilation, dg, _S())
+            gx = gx32.to(BF) if gx32 is not None else None
+        if ctx.needs_input_grad[3]:
+            if cols is None:
+                cols = torch.empty(M, K, device=gy.device, dtype=BF)
+                capi.call('htd_deform_im2col_bf16', _P(x), _P(offset), _P(mask), _P(cols), B, H, W, C, kh, kw, stride,
+                          padding, dilation, dg, _S())
+            gw = dense.conv2d_wgrad_bf16(cols.view(1, M, 1, K).permute(0, 3, 1, 2), gy.permute(0, 2, 3, 1).reshape(
+                1, M, 1, Co).permute(0, 3, 1, 2), (Co, K, 1, 1)).reshape(Co, kh, kw, C).permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[8]:
+            gb = torch.sum(gy.permute(0, 2, 3, 1).reshape(-1, Co), dim=0, dtype=torch.float32)
+        return gx, goff, gmask, gw, None, None, None, None, gb, None
+
+
 def deform_conv2d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deform_groups=1, mask=None,
                   bias=None, relu=False):
     """mmcv.ops.deform_conv2d; bias / relu (extensions): folded-BN bias and ReLU in the epilogue of the GEMM half."""
     s, p, d = _pair(stride)[0], _pair(padding)[0], _pair(dilation)[0]
+    if x.dtype == torch.bfloat16 and groups == 1 and x.size(1) % 32 == 0 and weight.size(0) % 32 == 0:
+        return DeformConv2dBf16Function.apply(x, offset, mask, weight, s, p, d, deform_groups, bias, relu)
     return DeformConv2dFunction.apply(x, offset, mask, weight, s, p, d, deform_groups, bias, relu, int(groups))
 
 
@@ -167,7 +237,7 @@ class DeformConv2dPack(DeformConv2d):
     def forward(self, x, relu=False, weight=None, bias=None):
         """weight / bias / relu: the frozen-BN-folded pair and the activation that follow this layer in a bottleneck
         (the offsets are always predicted from the layer's own parameters)."""
-        offset = self.conv_offset(x)
+        offset = self.conv_offset(x.float() if x.dtype != torch.float32 else x)      # offsets are always fp32
         return deform_conv2d(x, offset, self.weight if weight is None else weight, self.stride, self.padding,
                              self.dilation, self.groups, self.deform_groups, bias=bias, relu=relu)
 

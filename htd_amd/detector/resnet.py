@@ -93,9 +93,12 @@ class Bottleneck(nn.Module):
             out = torch.relu(self.norm2(self.conv2(out)))      # deformable conv2 with live BN statistics / DCNv2
         elif hasattr(self.conv2, 'conv_offset'):     # deformable conv2: folded BN + ReLU in its GEMM epilogue
             w, b = frozen_bn_fold(self.conv2.weight, self.norm2)
-            dt = out.dtype                           # the deformable sampling kernels are fp32: bf16 stages cast around
-            out = self.conv2(out.float() if dt != torch.float32 else out, relu=True, weight=w, bias=b)
-            out = out.to(dt) if dt != torch.float32 else out
+            dt = out.dtype
+            if dt == torch.bfloat16 and self.groups == 1:            # bf16 mode: bf16 sampling / GEMM kernels
+                out = self.conv2(out, relu=True, weight=w, bias=b)
+            else:                                    # fp32, or the grouped (ResNeXt) form whose kernels are fp32
+                out = self.conv2(out.float() if dt != torch.float32 else out, relu=True, weight=w, bias=b)
+                out = out.to(dt) if dt != torch.float32 else out
         else:
             out = conv_bn(self.conv2, self.norm2, out, relu=True)
         identity = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)

@@ -181,6 +181,13 @@ int htd_deform_im2col(const float *x, const float *offset, const float *mask, fl
 int htd_deform_col2im(const float *x, const float *offset, const float *mask, const float *gcolumns,
                       float *gx, float *goffset, float *gmask, int B, int H, int W, int C, int kh,
                       int kw, int stride, int pad, int dil, int deform_groups, void *stream);
+/* bf16 forms for the mixed-precision mode (BASELINE configs[3]): x, columns and gradient columns in bf16; offsets,
+ * masks, every interpolation and accumulation, gx / goffset / gmask in fp32. */
+int htd_deform_im2col_bf16(const void *x, const float *offset, const float *mask, void *columns, int B, int H, int W,
+                           int C, int kh, int kw, int stride, int pad, int dil, int deform_groups, void *stream);
+int htd_deform_col2im_bf16(const void *x, const float *offset, const float *mask, const void *gcolumns, float *gx,
+                           float *goffset, float *gmask, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                           int dil, int deform_groups, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * SFA global pooling (GlobalContextHead.forward global_context_head.py:386,

@@ -158,3 +158,42 @@ def test_col2im_row_owned_kernel_matches_direct_kernel():
     capi.call('htd_deform_col2im', P(x), P(off), None, P(gcol), P(gx), P(goff), None, B, H, W, C, 3, 3, stride, 1, 1, 1, S())
     torch.cuda.synchronize()
     assert torch.isnan(gx).any()
+
+
+@pytest.mark.parametrize('B,C,H,W,Co,stride', [(2, 64, 13, 15, 64, 1), (1, 128, 10, 12, 96, 2)])
+def test_deform_conv_bf16_tracks_fp32(B, C, H, W, Co, stride):
+    """bf16 mode of the deformable conv (bf16 columns / GEMMs, fp32 offsets and accumulation) against the fp32 kernels
+    on the same bf16-rounded operands: relative L2 error of the output <= 0.5 %, of the gradients <= 1-2 %."""
+    from htd_amd.dcn import deform_conv2d
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(C + H)
+    BF = torch.bfloat16
+    x = torch.randn(B, C, H, W, generator=g).to(BF).float()
+    w = (torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5).to(BF).float()
+    bias = torch.randn(Co, generator=g) * 0.1
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    off = torch.randn(B, 18, Ho, Wo, generator=g) * 1.2
+    go = torch.randn(B, Co, Ho, Wo, generator=g).to(BF).float()
+    names = ['y', 'gx', 'goffset', 'gw', 'gbias']
+    for relu in (False, True):
+        outs = []
+        for dt in (torch.float32, BF):
+            xd = x.to(dev).to(dt).contiguous(memory_format=CL).requires_grad_()
+            od = off.to(dev).contiguous(memory_format=CL).requires_grad_()
+            wd = w.to(dev).contiguous(memory_format=CL).requires_grad_()
+            bd = bias.to(dev).requires_grad_()
+            y = deform_conv2d(xd, od, wd, stride, 1, 1, bias=bd, relu=relu)
+            assert y.dtype == dt
+            y.backward(go.to(dev).to(dt))
+            outs.append([t.detach().float() for t in (y, xd.grad, od.grad, wd.grad, bd.grad)])
+        for n, a, b in zip(names, *outs):
+            # relative L2 error.  With the ReLU a mask bit can flip where y is within rounding of 0, which moves single
+            # gradient elements (and the short sums behind gbias) by a whole contribution: without it every gradient
+            # is held tightly, with it the output is, and the gradients by direction
+            if relu and n != 'y':
+                cos = float((a * b).sum() / (a.norm() * b.norm()))
+                assert cos >= 0.99, (n, cos)
+                continue
+            err = float((a - b).norm() / a.norm())
+            tol = {'y': 5e-3, 'gx': 1.5e-2, 'goffset': 2e-2, 'gw': 1e-2, 'gbias': 5e-3}[n]
+            assert err <= tol, (n, relu, err)
