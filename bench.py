@@ -38,6 +38,8 @@ def parse():
     ap.add_argument('--bf16', action='store_true', help='bf16 backbone / FPN / RPN conv (BASELINE configs[2] precision)')
     ap.add_argument('--dcn', action='store_true', help='ResNet-DCN backbone (BASELINE configs[3] architecture, fp32 here)')
     ap.add_argument('--resnext', action='store_true', help='ResNeXt 64x4d backbone (htd_resnetx101_dcn_2x_mstrain.py with --depth 101 --dcn)')
+    ap.add_argument('--pipeline', action='store_true', help='feed the step from uint8 images resident in HBM through the fused on-device '
+                    'data pipeline (Resize 1333x800 keep-ratio / RandomFlip / Normalize / Pad 32) inside the timed region')
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1344)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -72,6 +74,34 @@ def cpu_baseline(depth, H, W):
                        f'R{depth}, fp32, {dt:.1f} s wall')
 
 
+def pipeline_batch(batch, dev, rank):
+    """600x1000 uint8 images (-> 800x1333, padded 800x1344: the shape of the default workload) planned by the reference's
+    train pipeline, uploaded once; feed() runs the fused kernel on the resident bytes."""
+    import numpy as np
+    from htd_amd.pipelines import DeviceBatchStager, build_pipeline, collate
+    norm = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+    pipe = build_pipeline([dict(type='LoadImageFromFile'), dict(type='LoadAnnotations', with_bbox=True),
+                           dict(type='Resize', img_scale=(1333, 800), keep_ratio=True),
+                           dict(type='RandomFlip', flip_ratio=0.5), dict(type='Normalize', **norm),
+                           dict(type='Pad', size_divisor=32), dict(type='DefaultFormatBundle'),
+                           dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels'])])
+    rng = np.random.RandomState(rank)
+    np.random.seed(rank)
+    samples = []
+    for i in range(batch):
+        k = rng.randint(1, 10)
+        cx, cy, bw, bh = rng.rand(k, 4).T
+        boxes = np.stack([(cx - bw / 2).clip(0, 1) * 1000, (cy - bh / 2).clip(0, 1) * 600, (cx + bw / 2).clip(0, 1) * 1000,
+                          (cy + bh / 2).clip(0, 1) * 600], 1).astype(np.float32)
+        samples.append(pipe(dict(img=rng.randint(0, 256, (600, 1000, 3)).astype(np.uint8), img_prefix=None, bbox_fields=[],
+                                 img_info=dict(filename=f'{i}.jpg'),
+                                 ann_info=dict(bboxes=boxes, labels=rng.randint(0, 80, k).astype(np.int64)))))
+    data = collate(samples, dev)
+    stager = DeviceBatchStager(dev)
+    resident, plan = stager.upload([s['img'] for s in samples])
+    return data, lambda: stager.run(resident, plan)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -99,9 +129,9 @@ def main():
     torch.manual_seed(0)
     if args.infer:
         from htd_amd.configs import htd_config
-        cfg = htd_config(args.depth, soft_nms=False)        # configs[4]: hard NMS, 512 proposals into the RoI head
+        cfg = htd_config(args.depth, dcn=args.dcn, soft_nms=False, resnext=args.resnext)   # configs[4]: hard NMS, 512 proposals
         cfg.test_cfg.rpn.update(nms_post=args.proposals, max_num=args.proposals)
-        model = build_htd_detector(cfg=cfg).to(dev).eval()
+        model = build_htd_detector(cfg=cfg, bf16=args.bf16).to(dev).eval()
         data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
 
         class _Infer:                                       # same .train_step() shape as Trainer for the loop below
@@ -114,6 +144,14 @@ def main():
         model = model.to(dev).train()
         trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
         data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
+        if args.pipeline:
+            data, feed = pipeline_batch(args.batch, dev, rank)
+            step_plain = trainer.train_step
+
+            def step_with_pipeline(d):                      # one launch of htd_image_batch_pipeline per step
+                d['img'] = feed()
+                return step_plain(d)
+            trainer.train_step = step_with_pipeline
 
     def sync():
         if world > 1 or rehearse:
@@ -170,8 +208,9 @@ def main():
         'value': round(value, 3),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if args.bf16 else 'f32', 'data': 'synthetic',
-        'config': {'workload': (f'HTD ResNet-{args.depth} FPN fp32 inference (simple_test, hard NMS), batch {args.batch}/GPU '
+        'dtype': 'bf16' if args.bf16 else 'f32',
+        'data': 'synthetic uint8 images through the on-device data pipeline' if args.pipeline else 'synthetic',
+        'config': {'workload': (f'HTD {"ResNeXt-64x4d" if args.resnext else "ResNet"}-{args.depth}{"-DCN" if args.dcn else ""} FPN {"bf16 (backbone / FPN / RPN conv / RoI FC stacks)" if args.bf16 else "fp32"} inference (simple_test, hard NMS), batch {args.batch}/GPU '
                                 f'@ {args.width - 11}x{args.height}, {args.proposals} proposals/img into the RoI head'
                                 if args.infer else
                                 f'HTD {"ResNeXt-64x4d" if args.resnext else "ResNet"}-{args.depth}{"-DCN" if args.dcn else ""} FPN {"bf16 (backbone / FPN / RPN conv / RoI FC stacks; fp32 master weights, RoI ops, losses)" if args.bf16 else "fp32"} train step fwd+bwd+SGD, batch {args.batch}/GPU @ '
