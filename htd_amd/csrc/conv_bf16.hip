@@ -19,7 +19,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 struct BfParams {
-    const unsigned short *x, *w, *residual;
+    const unsigned short *x, *w, *residual, *mask;
     const float *bias;
     unsigned short *y;
     int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo, relu;
@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BfParams p)
                 v.z += bf2f((unsigned short)(rv.y & 0xffffu)); v.w += bf2f((unsigned short)(rv.y >> 16));
             }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.mask) {                       // ReLU backward of the layer that produced this map: keep where it was > 0
+                const uint2 mv = *reinterpret_cast<const uint2 *>(p.mask + o);
+                if (!(bf2f((unsigned short)(mv.x & 0xffffu)) > 0.f)) v.x = 0.f;
+                if (!(bf2f((unsigned short)(mv.x >> 16)) > 0.f)) v.y = 0.f;
+                if (!(bf2f((unsigned short)(mv.y & 0xffffu)) > 0.f)) v.z = 0.f;
+                if (!(bf2f((unsigned short)(mv.y >> 16)) > 0.f)) v.w = 0.f;
+            }
             uint2 ov;
             ov.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
             ov.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
@@ -205,26 +212,27 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BfParams p)
 }  // namespace
 
 // x [B][H][W][Ci] bf16, w [Co][kh][kw][Ci] bf16, bias [Co] fp32 or NULL, residual [B][Ho][Wo][Co] bf16 or NULL,
-// y [B][Ho][Wo][Co] bf16.  Ci % 32 == 0, Co % 4 == 0.
-extern "C" int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, const void *residual, void *y, int B,
-                                   int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
-                                   void *stream)
+// mask [B][Ho][Wo][Co] bf16 or NULL, y [B][Ho][Wo][Co] bf16.  Ci % 32 == 0, Co % 4 == 0.
+static int launch_conv_bf16(const char *what, const void *x, const void *w, const float *bias, const void *residual,
+                            const void *mask, void *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+                            int pad, int dil, int relu, void *stream)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
-                "conv2d_fwd_bf16: bad sizes");
-    HTD_REQUIRE(Ci % 32 == 0 && Co % 4 == 0, "conv2d_fwd_bf16: needs Ci %% 32 == 0 and Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
-    HTD_REQUIRE(x && w && y, "conv2d_fwd_bf16: null pointer");
+                "%s: bad sizes", what);
+    HTD_REQUIRE(Ci % 32 == 0 && Co % 4 == 0, "%s: needs Ci %% 32 == 0 and Co %% 4 == 0 (Ci=%d Co=%d)", what, Ci, Co);
+    HTD_REQUIRE(x && w && y, "%s: null pointer", what);
     BfParams p{};
     p.x = (const unsigned short *)x; p.w = (const unsigned short *)w; p.residual = (const unsigned short *)residual;
+    p.mask = (const unsigned short *)mask;
     p.bias = bias; p.y = (unsigned short *)y;
     p.B = B; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
     p.relu = relu;
     p.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
-    HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_fwd_bf16: empty output");
+    HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "%s: empty output", what);
     p.M = (int64_t)B * p.Ho * p.Wo;
     HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && (int64_t)Co * kh * kw * Ci < (1ll << 31) && p.M < (1ll << 31),
-                "conv2d_fwd_bf16: operand larger than 2^31 elements");
+                "%s: operand larger than 2^31 elements", what);
     p.mt = (int)htd::ceil_div(p.M, 128);
     p.nt = (int)htd::ceil_div(Co, 128);
     const dim3 grid((unsigned)(p.mt * p.nt));
@@ -232,7 +240,140 @@ extern "C" int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bi
         hipLaunchKernelGGL(conv_bf16_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(conv_bf16_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    return htd::check_launch("conv2d_fwd_bf16");
+    return htd::check_launch(what);
+}
+
+extern "C" int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, const void *residual, void *y, int B,
+                                   int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                                   void *stream)
+{
+    return launch_conv_bf16("conv2d_fwd_bf16", x, w, bias, residual, nullptr, y, B, H, W, Ci, Co, kh, kw, stride, pad, dil,
+                            relu, stream);
+}
+
+// The data-gradient form: gx = (conv(gy, wT) + accum) * (mask_src > 0), all maps bf16; (H, W) are gy's, the conv is
+// stride 1 with the transposed / tap-flipped weights (htd_weights_prep_bf16) and padding dil*(k-1) - pad of the layer.
+extern "C" int htd_conv2d_dgrad_bf16(const void *gy, const void *wT, const void *mask_src, const void *accum, void *gx,
+                                     int B, int H, int W, int Ci, int Co, int kh, int kw, int pad, int dil, void *stream)
+{
+    return launch_conv_bf16("conv2d_dgrad_bf16", gy, wT, nullptr, accum, mask_src, gx, B, H, W, Ci, Co, kh, kw, 1, pad, dil, 0,
+                            stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Parameter preparation for one layer, one launch: fp32 master / BN-folded weights w [Co][kh][kw][Ci] ->
+//   wb [Co][kh][kw][Ci] bf16 (forward operand) and wT [Ci][kh][kw][Co] bf16 with the taps flipped (data-gradient operand)
+namespace {
+__global__ void weights_prep_bf16_kernel(const float *__restrict__ w, unsigned short *__restrict__ wb,
+                                         unsigned short *__restrict__ wT, int Co, int taps, int Ci, int64_t total)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned short v = f2bf(w[i]);
+        if (wb) wb[i] = v;
+        if (wT) {
+            const int ci = (int)(i % Ci);
+            const int64_t r = i / Ci;
+            const int t = (int)(r % taps), co = (int)(r / taps);
+            wT[((int64_t)ci * taps + (taps - 1 - t)) * Co + co] = v;
+        }
+    }
+}
+
+// column sums of a bf16 matrix g [rows][C] in fp32, two deterministic stages
+__global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned short *__restrict__ g,
+                                                                  float *__restrict__ partial, int64_t rows, int C,
+                                                                  int64_t rows_per_block)
+{
+    __shared__ float4 red[256];
+    const int V = C / 4;                                            // column quads
+    const int lanes = V < 256 ? V : 256;                            // threads across columns
+    const int rlanes = 256 / lanes;                                 // threads across rows
+    const int cq = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int q0 = 0; q0 < V; q0 += lanes) {                         // uniform trip count: barriers inside
+        const int q = q0 + cq;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < rlanes && q < V) {
+            const unsigned short *gp = g + q * 4;
+            int64_t r = r0 + rl;
+            for (; r + 3 * rlanes < r1; r += 4 * rlanes) {          // four rows in flight
+                uint2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint2 *>(gp + (r + u * rlanes) * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s.x += bf2f((unsigned short)(v[u].x & 0xffffu)); s.y += bf2f((unsigned short)(v[u].x >> 16));
+                    s.z += bf2f((unsigned short)(v[u].y & 0xffffu)); s.w += bf2f((unsigned short)(v[u].y >> 16));
+                }
+            }
+            for (; r < r1; r += rlanes) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(gp + r * C);
+                s.x += bf2f((unsigned short)(v.x & 0xffffu)); s.y += bf2f((unsigned short)(v.x >> 16));
+                s.z += bf2f((unsigned short)(v.y & 0xffffu)); s.w += bf2f((unsigned short)(v.y >> 16));
+            }
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0 && q < V) {
+            for (int k = 1; k < rlanes; ++k) {
+                const float4 o = red[k * lanes + cq];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            *reinterpret_cast<float4 *>(partial + (int64_t)blockIdx.x * C + q * 4) = s;
+        }
+        __syncthreads();
+    }
+}
+
+// out[c] = sum over the partial rows; a block takes 32 columns x 8 row lanes
+__global__ __launch_bounds__(256) void colsum_bf16_final_kernel(const float *__restrict__ partial, float *__restrict__ out,
+                                                                int blocks, int C)
+{
+    __shared__ float red[256];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    float s = 0.f;
+    if (col < C)
+        for (int b = rl; b < blocks; b += 8) s += partial[(int64_t)b * C + col];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s += red[k * 32 + (threadIdx.x & 31)];
+        out[col] = s;
+    }
+}
+}  // namespace
+
+extern "C" int htd_weights_prep_bf16(const float *w, void *wb, void *wT, int Co, int kh, int kw, int Ci, void *stream)
+{
+    HTD_REQUIRE(w && (wb || wT), "weights_prep_bf16: null pointer");
+    HTD_REQUIRE(Co > 0 && kh > 0 && kw > 0 && Ci > 0, "weights_prep_bf16: bad sizes");
+    const int64_t total = (int64_t)Co * kh * kw * Ci;
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 2048);
+    hipLaunchKernelGGL(weights_prep_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)wb,
+                       (unsigned short *)wT, Co, kh * kw, Ci, total);
+    return htd::check_launch("weights_prep_bf16");
+}
+
+extern "C" int64_t htd_colsum_bf16_workspace_bytes(int64_t rows, int C)
+{
+    if (rows <= 0 || C <= 0) return -1;
+    const int64_t blocks = std::min<int64_t>(1024, htd::ceil_div(rows, 128));
+    return blocks * C * (int64_t)sizeof(float);
+}
+
+extern "C" int htd_colsum_bf16(const void *g, float *out, int64_t rows, int C, void *workspace, void *stream)
+{
+    HTD_REQUIRE(g && out && workspace, "colsum_bf16: null pointer");
+    HTD_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, "colsum_bf16: bad sizes (rows=%lld C=%d)", (long long)rows, C);
+    const int64_t blocks = std::min<int64_t>(1024, htd::ceil_div(rows, 128));
+    const int64_t rpb = htd::ceil_div(rows, blocks);
+    hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)g, (float *)workspace, rows, C, rpb);
+    if (int e = htd::check_launch("colsum_bf16")) return e;
+    hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3((unsigned)htd::ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, out, (int)blocks, C);
+    return htd::check_launch("colsum_bf16(final)");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

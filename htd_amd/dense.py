@@ -479,6 +479,54 @@ def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1):
     return gw
 
 
+# ---- bf16 raw launches ------------------------------------------------------------------------------------------
+BF16 = torch.bfloat16
+
+
+def _prep_bf16(weight, want_wT=True):
+    """fp32 (folded) weight (Co,Ci,kh,kw) channels_last -> (wb, wT): bf16 forward operand and the transposed,
+    tap-flipped data-gradient operand, one launch."""
+    weight = weight.contiguous(memory_format=CL)
+    Co, Ci, kh, kw = weight.shape
+    wb = torch.empty((Co, Ci, kh, kw), device=weight.device, dtype=BF16, memory_format=CL)
+    wT = torch.empty((Ci, Co, kh, kw), device=weight.device, dtype=BF16, memory_format=CL) if want_wT else None
+    capi.call('htd_weights_prep_bf16', _P(weight), _P(wb), _P(wT), Co, kh, kw, Ci, _S())
+    return wb, wT
+
+
+def _dgrad_bf16_raw(g, wT, kh, pad, dil, mask_src=None, accum=None):
+    """gx = (conv(g, wT) + accum) * (mask_src > 0) for a stride-1 layer with padding `pad`; all maps bf16."""
+    B, Co, H, W = g.shape
+    Ci = wT.size(0)
+    p = dil * (kh - 1) - pad
+    Ho, Wo = _out_hw(H, W, kh, kh, 1, p, dil)
+    gx = torch.empty((B, Ci, Ho, Wo), device=g.device, dtype=BF16, memory_format=CL)
+    capi.call('htd_conv2d_dgrad_bf16', _P(g), _P(wT), _P(mask_src), _P(accum), _P(gx), B, H, W, Co, Ci, kh, kh, p, dil,
+              _S(), work=('flop', 2.0 * B * Ho * Wo * Ci * kh * kh * Co))
+    return gx
+
+
+def _colsum_bf16_raw(g, out=None):
+    """fp32 column sums of the bf16 gradient map g (B,C,H,W) channels_last -> (C,)."""
+    B, C, H, W = g.shape
+    rows = B * H * W
+    out = torch.empty(C, device=g.device, dtype=torch.float32) if out is None else out
+    nbytes = capi.lib().htd_colsum_bf16_workspace_bytes(rows, C)
+    ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=torch.float32)
+    capi.call('htd_colsum_bf16', _P(g), _P(out), rows, C, _P(ws), _S())
+    return out
+
+
+def _dgrad_bf16_any(g, wT, w32, x_shape, kh, stride, pad, dil, mask_src=None, accum=None):
+    """Data gradient in bf16; strided layers (three per backbone) fall back to the fp32 kernel."""
+    if stride == 1:
+        return _dgrad_bf16_raw(g, wT, kh, pad, dil, mask_src, accum)
+    gx = _dgrad_raw(g.float().contiguous(memory_format=CL), w32, x_shape, stride, pad, dil,
+                    mask_src=mask_src.float() if mask_src is not None else None,
+                    accum=accum.float() if accum is not None else None)
+    return gx.to(BF16)
+
+
 class Conv2dBf16Function(Function):
     """Mixed-precision convolution for the bf16 configurations: bf16 activations, fp32 master weight / bias.
     forward  y = act(conv(x, bf16(w)) + b [+ residual])           htd_conv2d_fwd_bf16
@@ -488,17 +536,18 @@ class Conv2dBf16Function(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu):
-        wb = weight.to(torch.bfloat16).contiguous(memory_format=CL)
+        need_wT = ctx.needs_input_grad[0] and stride == 1
+        wb, wT = _prep_bf16(weight, need_wT)
         y = conv2d_bf16(x, wb, bias, stride, padding, dilation, relu, residual)
-        ctx.save_for_backward(x, wb, y if relu else None)
-        ctx.cfg = (stride, padding, dilation, bias is not None, residual is not None, tuple(weight.shape))
+        ctx.save_for_backward(x, wT if need_wT else wb, y if relu else None)
+        ctx.cfg = (stride, padding, dilation, bias is not None, residual is not None, tuple(weight.shape), need_wT)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        x, wb, y = ctx.saved_tensors
-        stride, padding, dilation, has_bias, has_res, wshape = ctx.cfg
+        x, wsaved, y = ctx.saved_tensors
+        stride, padding, dilation, has_bias, has_res, wshape, have_wT = ctx.cfg
         g = g.contiguous(memory_format=CL)
         if y is not None:
             g = torch.ops.aten.threshold_backward(g, y, 0)          # ReLU backward: one launch
@@ -506,18 +555,105 @@ class Conv2dBf16Function(Function):
         gx = gw = gb = None
         kh = wshape[2]
         if need_x:
-            if stride == 1:
-                wT = wb.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=CL)        # [ci][kh'][kw'][co]
-                gx = conv2d_bf16(g, wT, None, 1, dilation * (kh - 1) - padding, dilation)
+            if have_wT:
+                gx = _dgrad_bf16_raw(g, wsaved, kh, padding, dilation)
             else:
-                gx = _dgrad_raw(g.float().contiguous(memory_format=CL), wb.float().contiguous(memory_format=CL),
+                gx = _dgrad_raw(g.float().contiguous(memory_format=CL), wsaved.float().contiguous(memory_format=CL),
                                 x.shape, stride, padding, dilation).to(torch.bfloat16)
         if need_w:
             gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation)
         if has_bias and need_b:
-            # column sums of the [pixels][Co] matrix (NHWC memory), fp32 accumulation, no fp32 copy of g
-            gb = torch.sum(g.permute(0, 2, 3, 1).reshape(-1, g.size(1)), dim=0, dtype=torch.float32)
+            gb = _colsum_bf16_raw(g) if g.size(1) % 4 == 0 else \
+                torch.sum(g.permute(0, 2, 3, 1).reshape(-1, g.size(1)), dim=0, dtype=torch.float32)
         return gx, gw, gb, (g if (has_res and need_r) else None), None, None, None, None
+
+
+class ResStageBf16Function(Function):
+    """ResStageFunction for bf16 activations (fp32 BN-folded master parameters): one autograd node per ResLayer.
+    Per layer and step one launch prepares both bf16 weight operands; in backward the ReLU masks and the identity-branch
+    sum live in the data-gradient epilogues (htd_conv2d_dgrad_bf16), bias gradients are one column-sum launch each.
+    Strided data gradients (the first block of layers 2-4) fall back to the fp32 kernel."""
+
+    @staticmethod
+    def forward(ctx, x, strides, dilation, has_ds, *params):
+        _need_gpu(x, 'res_stage_bf16')
+        x = x.contiguous(memory_format=CL)
+        params = [t.contiguous(memory_format=CL) if t.dim() == 4 else t.contiguous() for t in params]
+        saved, wTs, k = [], [], 0
+        bwd = any(ctx.needs_input_grad)           # inference: forward operands only
+        for stride, ds in zip(strides, has_ds):
+            w1, b1, w2, b2, w3, b3 = params[k:k + 6]
+            k += 6
+            (wb1, wT1), (wb2, wT2), (wb3, wT3) = _prep_bf16(w1, bwd), _prep_bf16(w2, bwd and stride == 1), _prep_bf16(w3, bwd)
+            h1 = conv2d_bf16(x, wb1, b1, 1, 0, 1, True)
+            h2 = conv2d_bf16(h1, wb2, b2, stride, dilation, dilation, True)
+            wTd = None
+            if ds:
+                wd, bd = params[k:k + 2]
+                k += 2
+                wbd, wTd = _prep_bf16(wd, bwd and stride == 1)
+                idn = conv2d_bf16(x, wbd, bd, stride, 0, 1, False)
+            else:
+                idn = x
+            out = conv2d_bf16(h2, wb3, b3, 1, 0, 1, True, idn)
+            saved += [x, h1, h2, out]
+            wTs += [wT1, wT2, wT3, wTd]
+            x = out
+        ctx.save_for_backward(*saved, *params)
+        ctx.wTs = wTs                      # bf16 operands of this step (never exposed to autograd)
+        ctx.cfg = (strides, dilation, has_ds)
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        strides, dilation, has_ds = ctx.cfg
+        nb = len(strides)
+        saved, params = ctx.saved_tensors[:4 * nb], ctx.saved_tensors[4 * nb:]
+        wTs = ctx.wTs
+        offs, k = [], 0
+        for ds in has_ds:
+            offs.append(k)
+            k += 8 if ds else 6
+        need = ctx.needs_input_grad
+        grads = [None] * len(params)
+        g = g.to(BF16).contiguous(memory_format=CL)
+        premasked = False
+        for i in range(nb - 1, -1, -1):
+            x, h1, h2, out = saved[4 * i:4 * i + 4]
+            wT1, wT2, wT3, wTd = wTs[4 * i:4 * i + 4]
+            k, stride, ds = offs[i], strides[i], has_ds[i]
+            w1, b1, w2, b2, w3, b3 = params[k:k + 6]
+            pneed = need[4 + k:4 + k + (8 if ds else 6)]
+            first = i == 0
+            need_x = need[0] if first else True
+            gm3 = g if premasked else torch.ops.aten.threshold_backward(g, out, 0)
+            if pneed[4]:
+                grads[k + 4] = conv2d_wgrad_bf16(h2, gm3, w3.shape, 1, 0, 1)
+            gb3 = _colsum_bf16_raw(gm3) if (pneed[5] or (ds and pneed[7])) else None
+            grads[k + 5] = gb3 if pneed[5] else None
+            gm2 = _dgrad_bf16_raw(gm3, wT3, 1, 0, 1, mask_src=h2)
+            if pneed[2]:
+                grads[k + 2] = conv2d_wgrad_bf16(h1, gm2, w2.shape, stride, dilation, dilation)
+            grads[k + 3] = _colsum_bf16_raw(gm2) if pneed[3] else None
+            gm1 = _dgrad_bf16_any(gm2, wT2, w2, h1.shape, 3, stride, dilation, dilation, mask_src=h1)
+            if pneed[0]:
+                grads[k] = conv2d_wgrad_bf16(x, gm1, w1.shape, 1, 0, 1)
+            grads[k + 1] = _colsum_bf16_raw(gm1) if pneed[1] else None
+            acc = gm3
+            if ds:
+                wd = params[k + 6]
+                if pneed[6]:
+                    grads[k + 6] = conv2d_wgrad_bf16(x, gm3, wd.shape, stride, 0, 1)
+                grads[k + 7] = gb3 if pneed[7] else None
+                acc = _dgrad_bf16_any(gm3, wTd, wd, x.shape, 1, stride, 0, 1) if need_x else None
+            if need_x:
+                g = _dgrad_bf16_raw(gm1, wT1, 1, 0, 1, mask_src=None if first else x, accum=acc)
+                premasked = not first
+            else:
+                g = None
+        ctx.wTs = None
+        return (g, None, None, None, *grads)
 
 
 def conv2d_bf16_autograd(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):

@@ -8,17 +8,19 @@ convolution: BN is folded into the conv weights/bias by differentiable tensor op
 and ReLU / the residual add live in the conv epilogue.  Activations stay NHWC end to end.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from .. import mmcv_ops as M
-from ..dense import ResStageFunction
+from ..dense import ResStageBf16Function, ResStageFunction
 from ..registry import BACKBONES
 from .bricks import build_conv_layer, build_norm_layer, constant_init, frozen_bn_fold, kaiming_init
 
 CL = torch.channels_last
+FUSE_BF16_STAGE = os.environ.get('HTD_BF16_STAGE', '1') != '0'
 
 
 def conv_bn(conv, bn, x, relu=False, residual=None):
@@ -135,16 +137,18 @@ class ResLayer(nn.Sequential):
         return True
 
     def forward(self, x):
-        if not x.is_cuda or x.dtype != torch.float32 or not self._fusable():
-            return super().forward(x)           # CPU / bf16 activations / DCN blocks: block by block
+        if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or not self._fusable() or \
+                (x.dtype == torch.bfloat16 and not FUSE_BF16_STAGE):
+            return super().forward(x)           # CPU / DCN or grouped blocks: block by block
         params = []
         for blk in self:
             for conv, bn in ((blk.conv1, blk.norm1), (blk.conv2, blk.norm2), (blk.conv3, blk.norm3)):
                 params += frozen_bn_fold(conv.weight, bn)
             if blk.downsample is not None:
                 params += frozen_bn_fold(blk.downsample[0].weight, blk.downsample[1])
-        return ResStageFunction.apply(x, tuple(blk.conv2_stride for blk in self), self[0].dilation,
-                                      tuple(blk.downsample is not None for blk in self), *params)
+        fn = ResStageFunction if x.dtype == torch.float32 else ResStageBf16Function
+        return fn.apply(x, tuple(blk.conv2_stride for blk in self), self[0].dilation,
+                        tuple(blk.downsample is not None for blk in self), *params)
 
 
 @BACKBONES.register_module()

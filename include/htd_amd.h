@@ -275,6 +275,19 @@ int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, 
  * fp32.  Ci % 32 == 0, Co % 4 == 0. */
 int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, const void *residual, void *y, int B, int H,
                         int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, void *stream);
+/* The data-gradient form of the bf16 convolution: gx = (conv(gy, wT) + accum) * (mask_src > 0), every map bf16;
+ * (H, W) are gy's; stride-1 layers only; wT = the transposed, tap-flipped weights [Ci'][kh][kw][Co'] of
+ * htd_weights_prep_bf16 (Ci = channels of gy, Co = channels of gx); pad = dil*(k-1) - layer padding.  mask_src (the
+ * saved input activation: ReLU backward of its producer) and accum (the gradient arriving over the identity branch)
+ * may be NULL. */
+int htd_conv2d_dgrad_bf16(const void *gy, const void *wT, const void *mask_src, const void *accum, void *gx, int B, int H,
+                          int W, int Ci, int Co, int kh, int kw, int pad, int dil, void *stream);
+/* One launch per layer and step: fp32 (BN-folded) weights w [Co][kh][kw][Ci] -> wb (bf16, same layout) and
+ * wT [Ci][kh][kw][Co] (bf16, taps flipped); either output may be NULL. */
+int htd_weights_prep_bf16(const float *w, void *wb, void *wT, int Co, int kh, int kw, int Ci, void *stream);
+/* fp32 column sums of a bf16 matrix g [rows][C] (bias gradients), deterministic two-stage; C % 4 == 0. */
+int64_t htd_colsum_bf16_workspace_bytes(int64_t rows, int C);
+int htd_colsum_bf16(const void *g, float *out, int64_t rows, int C, void *workspace, void *stream);
 /* bf16 weight gradient: gw [Co][kh][kw][Ci] fp32 from x, gy in bf16 (NHWC); both K-major operands are consumed through
  * the transposing LDS read ds_read_b64_tr_b16; deterministic split-K through `workspace`
  * (htd_conv2d_wgrad_bf16_workspace_bytes).  Ci % 8 == 0, Co % 8 == 0. */
