@@ -542,9 +542,10 @@ extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float
 
 namespace {
 __global__ __launch_bounds__(256) void flip_weights_kernel(const float *__restrict__ w, float *__restrict__ wT, int Co,
-                                                           int taps, int Ci)
+                                                           int taps, int Ci, int Cop)
 {
-    // w[co][t][ci] -> wT[ci][taps-1-t][co]; 32x32 LDS transpose per (t, co-tile, ci-tile)
+    // w[co][t][ci] -> wT[ci][taps-1-t][co], rows of wT padded with zeros to Cop >= Co; 32x32 LDS transpose per
+    // (t, co-tile, ci-tile)
     __shared__ float tile[32][33];
     const int t = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -555,7 +556,17 @@ __global__ __launch_bounds__(256) void flip_weights_kernel(const float *__restri
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int ci = ci0 + r, co = co0 + tx;
-        if (ci < Ci && co < Co) wT[((int64_t)ci * taps + (taps - 1 - t)) * Co + co] = tile[tx][r];
+        if (ci < Ci && co < Cop) wT[((int64_t)ci * taps + (taps - 1 - t)) * Cop + co] = tile[tx][r];
+    }
+}
+
+// y[row][0..Cp) = x[row][0..C) followed by zeros (the reduction channels of a skinny head's data gradient)
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t total,
+                                                           int C, int Cp)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        y[i] = c < C ? x[(i / Cp) * C + c] : 0.f;
     }
 }
 }  // namespace
@@ -564,6 +575,24 @@ extern "C" int htd_conv2d_flip_weights(const float *w, float *wT, int Co, int kh
 {
     HTD_REQUIRE(w && wT && Co > 0 && Ci > 0 && kh > 0 && kw > 0, "flip_weights: bad arguments");
     dim3 grid((unsigned)htd::ceil_div(Ci, 32), (unsigned)htd::ceil_div(Co, 32), (unsigned)(kh * kw));
-    hipLaunchKernelGGL(flip_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wT, Co, kh * kw, Ci);
+    hipLaunchKernelGGL(flip_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wT, Co, kh * kw, Ci, Co);
     return htd::check_launch("flip_weights");
+}
+
+extern "C" int htd_conv2d_flip_weights_padded(const float *w, float *wT, int Co, int Co_padded, int kh, int kw, int Ci,
+                                              void *stream)
+{
+    HTD_REQUIRE(w && wT && Co > 0 && Co_padded >= Co && Ci > 0 && kh > 0 && kw > 0, "flip_weights_padded: bad arguments");
+    dim3 grid((unsigned)htd::ceil_div(Ci, 32), (unsigned)htd::ceil_div(Co_padded, 32), (unsigned)(kh * kw));
+    hipLaunchKernelGGL(flip_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wT, Co, kh * kw, Ci, Co_padded);
+    return htd::check_launch("flip_weights_padded");
+}
+
+extern "C" int htd_pad_channels(const float *x, float *y, int64_t rows, int C, int C_padded, void *stream)
+{
+    HTD_REQUIRE(x && y && rows > 0 && C > 0 && C_padded >= C, "pad_channels: bad arguments");
+    const int64_t total = rows * C_padded;
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 8192);
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, total, C, C_padded);
+    return htd::check_launch("pad_channels");
 }

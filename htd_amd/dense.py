@@ -164,16 +164,19 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
     B, Ci, H, W = x_shape
     Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
-    gd, wd, Cod = g, weight, Co
-    if Co % 8 != 0:      # skinny heads (RPN cls+reg, Co=15): pad the reduction channels with zeros
-        padc = (-Co) % 8
-        gd = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
-        wd = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, padc)).contiguous(memory_format=CL)
-        Cod = Co + padc
     if B == 0:
         return torch.empty((0, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+    gd, Cod = g, Co
+    if Co % 8 != 0:      # skinny heads (RPN cls+reg Co=15, fc_cls 81, fc_reg 4): zero-pad the reduction channels
+        Cod = Co + (-Co) % 8
+        gd = torch.empty((B, Cod, Ho, Wo), device=g.device, dtype=g.dtype, memory_format=CL)
+        if gd.numel():
+            capi.call('htd_pad_channels', _P(g), _P(gd), B * Ho * Wo, Co, Cod, _S())
     wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
-    capi.call('htd_conv2d_flip_weights', _P(wd), _P(wT), Cod, kh, kw, Ci, _S())
+    if Cod != Co:
+        capi.call('htd_conv2d_flip_weights_padded', _P(weight), _P(wT), Co, Cod, kh, kw, Ci, _S())
+    else:
+        capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, kh, kw, Ci, _S())
     gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
     capi.call('htd_conv2d_bwd_data', _P(gd), _P(wT), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci, Cod, kh, kw, stride,
               padding, dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(),

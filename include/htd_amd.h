@@ -147,6 +147,11 @@ int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const floa
  * (torch.mm calls of htd_bbox_head.py:210,213,214,216 batched over all (image, level) groups). */
 int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int M, int N, int K, void *stream);
 int htd_conv2d_flip_weights(const float *w, float *wT, int Co, int kh, int kw, int Ci, void *stream);
+/* Skinny heads (RPN 3+12 channels, fc_cls 81, fc_reg 4): the data gradient reduces over Co, which the MFMA kernel wants
+ * as a multiple of 8.  One launch each instead of ATen pad / copy chains: wT rows zero-padded to Co_padded, and
+ * y [rows][C_padded] = x [rows][C] followed by zeros for the gradient map. */
+int htd_conv2d_flip_weights_padded(const float *w, float *wT, int Co, int Co_padded, int kh, int kw, int Ci, void *stream);
+int htd_pad_channels(const float *x, float *y, int64_t rows, int C, int C_padded, void *stream);
 /* gx = relu_mask(dgrad(gy) + accum): accum (may be NULL, stride 1 only) is another gradient of the same tensor (the
  * identity branch of a residual block, basic_block/bottleneck `out += identity` resnet.py:278-282), mask_src (may be
  * NULL) the activation whose ReLU produced the conv input (gx is zeroed where mask_src <= 0). */
