@@ -98,4 +98,6 @@ def build_htd_detector(depth=50, dcn=False, cfg=None, bf16=False, resnext=False)
         model.backbone.compute_dtype = torch.bfloat16
         for head in model.roi_head.bbox_head:          # the 12544->1024->1024 FC stacks of both stages
             head.compute_dtype = torch.bfloat16
+            for m in getattr(head, 'convs', []):       # and the 3x3 stack of the regression branch (GroupNorm stays fp32)
+                m.compute_dtype = torch.bfloat16
     return model

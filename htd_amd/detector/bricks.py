@@ -218,9 +218,18 @@ class ConvModule(nn.Module):
             constant_init(self.norm, 1, bias=0)
 
     def forward(self, x):
+        # compute_dtype = torch.bfloat16 (set by configs.build_htd_detector(bf16=True)): the convolution runs on the bf16
+        # MFMA kernels, the normalisation and everything downstream stay fp32
+        low = getattr(self, 'compute_dtype', None) == torch.bfloat16 and x.is_cuda and x.dtype == torch.float32 and \
+            self.conv.in_channels % 32 == 0 and self.conv.out_channels % 8 == 0 and self.conv.groups == 1
+        if low:
+            x = x.to(torch.bfloat16)
         if not self.with_norm:
-            return self.conv(x, relu=self.with_activation)
+            y = self.conv(x, relu=self.with_activation)
+            return y.float() if low else y
         x = self.conv(x)
+        if low:
+            x = x.float()
         norm = self.norm
         if isinstance(norm, nn.GroupNorm):
             return M.group_norm_relu(x, norm.weight, norm.bias, norm.num_groups, norm.eps, self.with_activation)
