@@ -264,18 +264,29 @@ extern "C" int htd_conv2d_dgrad_bf16(const void *gy, const void *wT, const void 
 // Parameter preparation for one layer, one launch: fp32 master / BN-folded weights w [Co][kh][kw][Ci] ->
 //   wb [Co][kh][kw][Ci] bf16 (forward operand) and wT [Ci][kh][kw][Co] bf16 with the taps flipped (data-gradient operand)
 namespace {
-__global__ void weights_prep_bf16_kernel(const float *__restrict__ w, unsigned short *__restrict__ wb,
-                                         unsigned short *__restrict__ wT, int Co, int taps, int Ci, int64_t total)
+__global__ __launch_bounds__(256) void weights_prep_bf16_kernel(const float *__restrict__ w, unsigned short *__restrict__ wb,
+                                                                unsigned short *__restrict__ wT, int Co, int taps, int Ci)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned short v = f2bf(w[i]);
-        if (wb) wb[i] = v;
-        if (wT) {
-            const int ci = (int)(i % Ci);
-            const int64_t r = i / Ci;
-            const int t = (int)(r % taps), co = (int)(r / taps);
-            wT[((int64_t)ci * taps + (taps - 1 - t)) * Co + co] = v;
+    // w[co][t][ci] -> wb (same order) and wT[ci][taps-1-t][co]; one 32x32 (co, ci) tile of tap t per workgroup, transposed
+    // through LDS so that both outputs are written along their fastest dimension
+    __shared__ unsigned short tile[32][34];
+    const int t = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        unsigned short v = 0;
+        if (co < Co && ci < Ci) {
+            const int64_t i = ((int64_t)co * taps + t) * Ci + ci;
+            v = f2bf(w[i]);
+            if (wb) wb[i] = v;
         }
+        tile[r][tx] = v;
+    }
+    if (!wT) return;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Ci && co < Co) wT[((int64_t)ci * taps + (taps - 1 - t)) * Co + co] = tile[tx][r];
     }
 }
 
@@ -348,10 +359,10 @@ extern "C" int htd_weights_prep_bf16(const float *w, void *wb, void *wT, int Co,
 {
     HTD_REQUIRE(w && (wb || wT), "weights_prep_bf16: null pointer");
     HTD_REQUIRE(Co > 0 && kh > 0 && kw > 0 && Ci > 0, "weights_prep_bf16: bad sizes");
-    const int64_t total = (int64_t)Co * kh * kw * Ci;
-    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 2048);
-    hipLaunchKernelGGL(weights_prep_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)wb,
-                       (unsigned short *)wT, Co, kh * kw, Ci, total);
+    const dim3 grid((unsigned)htd::ceil_div(Ci, 32), (unsigned)htd::ceil_div(Co, 32), (unsigned)(kh * kw));
+    HTD_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "weights_prep_bf16: too many tiles");
+    hipLaunchKernelGGL(weights_prep_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)wb,
+                       (unsigned short *)wT, Co, kh * kw, Ci);
     return htd::check_launch("weights_prep_bf16");
 }
 
