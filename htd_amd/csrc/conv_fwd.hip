@@ -22,6 +22,8 @@
 // s*s dense sub-problems, one per output parity class, through an explicit tap table).
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -56,6 +58,11 @@ struct ConvParams {
     int splits;         // split-K: gridDim.y workgroups share one output tile, partials go to `partial`
     int slices_per_split;
     float *partial;     // [splits][M][Co] raw accumulators when splits > 1
+    // balanced tail (splits == 1 only): tiles [0, tail_first) are computed whole; the last few tiles -- the ones that
+    // would leave some CUs one tile more than the others -- are cut into tail_splits K ranges each, so that the
+    // remainder is spread over the whole chip.  Their partial tiles go to partial[(tile - tail_first) * tail_splits +
+    // split][BM][BN]; conv_tail_epilogue_kernel sums them and applies the epilogue.
+    int tail_first, tail_splits, tail_sps;
 };
 
 // BK: floats of K per slice; WGM x WGN: wave grid of the block; TM x TN: 32x32 MFMA blocks per wave
@@ -84,8 +91,20 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
     // the N tiles of an M tile adjacent: the A rows of an M tile are fetched into that XCD's L2 once for all its
     // N tiles, neighbouring M tiles share their halo rows, and the (small) weight panel stays L2-resident.
     const int nblk = p.mt * p.nt;
-    int bid = blockIdx.x;
-    {
+    int bid = blockIdx.x, tail_split = -1;
+    if (p.tail_splits > 0) {
+        // per XCD (workgroups congruent mod 8, dispatched in increasing id): first its run of whole tiles, then its share
+        // of the tail units; tail_first is a multiple of 8
+        const int xcd = bid % 8, idx = bid / 8, dp = p.tail_first / 8;
+        if (idx < dp) {
+            bid = xcd * dp + idx;
+        } else {
+            const int units = (nblk - p.tail_first) * p.tail_splits, q = units / 8, r = units % 8;
+            const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (idx - dp);
+            bid = p.tail_first + w / p.tail_splits;
+            tail_split = w % p.tail_splits;
+        }
+    } else {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -130,8 +149,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
 
     const int slices_per_tap = p.Ci / BK;
     const int total_slices = (TAPS ? p.ntaps : p.kh * p.kw) * slices_per_tap;
-    const int s_begin = blockIdx.y * p.slices_per_split;
-    const int num_slices = min(total_slices, s_begin + p.slices_per_split);
+    const int s_begin = tail_split >= 0 ? tail_split * p.tail_sps : blockIdx.y * p.slices_per_split;
+    const int num_slices = min(total_slices, s_begin + (tail_split >= 0 ? p.tail_sps : p.slices_per_split));
 
     // state of the NEXT slice to stage (advanced incrementally: no divisions inside the K loop)
     int ld_ci0, ld_ky, ld_kx;
@@ -263,6 +282,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
                 o = (((int64_t)b * p.oH + p.o_h0 + p.o_step * (int)ho) * p.oW + p.o_w0 + p.o_step * (int)wo) * p.Co + n;
             } else
                 o = m * p.Co + n;
+            if (tail_split >= 0) {       // tail unit: raw partial tile, dense [BM][BN]
+                const int lrow = ((row >> 5) * TM + i) * 32 + (row & 31);
+                float *dst = p.partial + ((int64_t)(bid - p.tail_first) * p.tail_splits + tail_split) * (T::BM * T::BN) +
+                             lrow * T::BN + c4 * 4;
+                *reinterpret_cast<float4 *>(dst) = v;
+                continue;
+            }
             if (p.splits > 1) {          // raw partial sums; bias / residual / activation happen in the reduce pass
                 float *dst = p.partial + (int64_t)blockIdx.y * p.M * p.Co + o;
                 if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
@@ -340,6 +366,38 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvParams p)
     }
 }
 
+// sums the partial tiles of the balanced tail and applies the epilogue; one thread per output element of a tail tile
+__global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvParams p, int BM, int BN)
+{
+    const int64_t per_tile = (int64_t)BM * BN, total = (int64_t)(p.mt * p.nt - p.tail_first) * per_tile;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(e / per_tile), within = (int)(e - (int64_t)t * per_tile);
+        const int tile = p.tail_first + t, tile_m = tile / p.nt, tile_n = tile % p.nt;
+        const int64_t m = (int64_t)tile_m * BM + within / BN;
+        const int n = tile_n * BN + within % BN;
+        if (m >= p.M || n >= p.Co) continue;
+        const float *src = p.partial + (int64_t)t * p.tail_splits * per_tile + within;
+        float v = 0.f;
+        for (int k = 0; k < p.tail_splits; ++k) v += src[(int64_t)k * per_tile];
+        const int64_t o = m * p.Co + n;
+        if (p.bias) v += p.bias[n];
+        if (p.residual) {
+            int64_t ro = o;
+            if (p.res_H > 0) {
+                const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, tt = mm / (unsigned)p.Wo;
+                const unsigned ho = tt % (unsigned)p.Ho, b = tt / (unsigned)p.Ho;
+                const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
+            }
+            v += p.residual[ro];
+        }
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
+        p.y[o] = v;
+    }
+}
+
 template <int WGM, int WGN, int TM, int TN>
 void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
 {
@@ -369,17 +427,46 @@ int plan_splits(int64_t M, int Co, int Ci, int taps)
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, 16));
 }
 
-int launch_conv(ConvParams p, hipStream_t s, void *workspace)
+// tile follows the output-channel count and the amount of work: 128x128 (2x2 waves of 64x64) for big
+// problems, 128x64 / 128x32 (4x1 waves) for narrow outputs, 64x64 (2x2 waves of 32x32) when the problem has
+// too few big tiles to balance 256 CUs
+void choose_tile(int64_t M, int Co, int &bm, int &bn)
 {
-    // tile follows the output-channel count and the amount of work: 128x128 (2x2 waves of 64x64) for big
-    // problems, 128x64 / 128x32 (4x1 waves) for narrow outputs, 64x64 (2x2 waves of 32x32) when the problem has
-    // too few big tiles to balance 256 CUs
-    int bm = 128;
-    int bn = p.Co <= 32 ? 32 : ((p.Co <= 64 || (p.Co % 128 != 0 && p.Co % 128 <= 64 && p.Co < 256)) ? 64 : 128);
+    bm = 128;
+    bn = Co <= 32 ? 32 : ((Co <= 64 || (Co % 128 != 0 && Co % 128 <= 64 && Co < 256)) ? 64 : 128);
     // thresholds swept on the HTD-R50 layer set (768..5000 / 600..6000): below ~8 big tiles per CU the finer tiles'
     // better balance across 256 CUs outweighs their extra L2 traffic
-    if (bn == 128 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 128) < 2200) bn = 64;
-    if (bn == 64 && p.Co >= 64 && htd::ceil_div(p.M, 128) * htd::ceil_div(p.Co, 64) < 4400 && p.M >= 2048) bm = 64;
+    if (bn == 128 && htd::ceil_div(M, 128) * htd::ceil_div(Co, 128) < 2200) bn = 64;
+    if (bn == 64 && Co >= 64 && htd::ceil_div(M, 128) * htd::ceil_div(Co, 64) < 4400 && M >= 2048) bm = 64;
+}
+
+// Balanced tail: with t tiles on 256 CUs and t / 256 small, the CUs that receive ceil(t / 256) tiles set the run time.
+// Keep floor(t / 256) * 256 tiles whole and cut the remaining ones into K ranges, about 256 units in all.
+// -> number of whole tiles (0: no tail), splits and slices per split of the tail tiles
+static const bool g_no_tail = getenv("HTD_CONV_NO_TAIL") != nullptr;
+int plan_tail(int64_t M, int Co, int Ci, int taps, int bm, int bn, int &tail_splits, int &tail_sps)
+{
+    tail_splits = tail_sps = 0;
+    if (g_no_tail || (Co & 3)) return 0;
+    const int bk = Ci % 32 == 0 ? 32 : (Ci % 16 == 0 ? 16 : 8);
+    const int total_slices = taps * (Ci / bk);
+    const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
+    const int64_t rem = tiles % 256, whole = tiles - rem;
+    // measured on the HTD layer set: pays at 3..6 whole tiles per CU (M = 16 800 layers: +10 %); with fewer the CUs are not
+    // saturated and an extra resident tile costs little, with more the dispatcher's own balancing already hides it
+    if (tiles < 256 * 3 || tiles >= 256 * 7 || rem == 0 || rem > 128 || total_slices < 8) return 0;
+    int want = (int)std::min<int64_t>(16, std::max<int64_t>(2, (256 + rem / 2) / rem));
+    want = std::min(want, total_slices / 4);
+    if (want < 2) return 0;
+    tail_sps = (int)htd::ceil_div(total_slices, want);
+    tail_splits = (int)htd::ceil_div(total_slices, tail_sps);
+    return (int)whole;
+}
+
+int launch_conv(ConvParams p, hipStream_t s, void *workspace)
+{
+    int bm, bn;
+    choose_tile(p.M, p.Co, bm, bn);
     p.mt = (int)htd::ceil_div(p.M, bm);
     p.nt = (int)htd::ceil_div(p.Co, bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;
@@ -393,14 +480,27 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     p.slices_per_split = (int)htd::ceil_div(total_slices, p.splits);
     p.splits = (int)htd::ceil_div(total_slices, p.slices_per_split);
     p.partial = (float *)workspace;
+    unsigned launch_blocks = (unsigned)blocks;
+    p.tail_first = p.tail_splits = p.tail_sps = 0;
+    if (workspace && p.ntaps == 0 && p.splits == 1 && p.w_bstride == 0) {
+        const int whole = plan_tail(p.M, p.Co, p.Ci, p.kh * p.kw, bm, bn, p.tail_splits, p.tail_sps);
+        if (p.tail_splits > 0) {
+            p.tail_first = whole;
+            launch_blocks = (unsigned)(whole + (blocks - whole) * p.tail_splits);
+        }
+    }
     if (bm == 64)
-        launch_cfg<2, 2, 1, 1>(p, (unsigned)blocks, s);
+        launch_cfg<2, 2, 1, 1>(p, launch_blocks, s);
     else if (bn == 32)
-        launch_cfg<4, 1, 1, 1>(p, (unsigned)blocks, s);
+        launch_cfg<4, 1, 1, 1>(p, launch_blocks, s);
     else if (bn == 64)
-        launch_cfg<4, 1, 1, 2>(p, (unsigned)blocks, s);
+        launch_cfg<4, 1, 1, 2>(p, launch_blocks, s);
     else
-        launch_cfg<2, 2, 2, 2>(p, (unsigned)blocks, s);
+        launch_cfg<2, 2, 2, 2>(p, launch_blocks, s);
+    if (p.tail_splits > 0) {
+        const int64_t elems = (blocks - p.tail_first) * (int64_t)bm * bn;
+        hipLaunchKernelGGL(conv_tail_epilogue_kernel, dim3((unsigned)htd::ceil_div(elems, 256)), dim3(256), 0, s, p, bm, bn);
+    }
     if (p.splits > 1) {
         const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(p.M * p.Co, 256), 4096);
         hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(rb), dim3(256), 0, s, p);
@@ -443,7 +543,13 @@ extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias,
 extern "C" int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw)
 {
     const int splits = plan_splits(M, Co, Ci, kh * kw);
-    return splits > 1 ? (int64_t)splits * M * Co * 4 : 0;
+    if (splits > 1) return (int64_t)splits * M * Co * 4;
+    int bm, bn, ts, tsps;
+    choose_tile(M, Co, bm, bn);
+    const int whole = plan_tail(M, Co, Ci, kh * kw, bm, bn, ts, tsps);
+    if (ts == 0) return 0;
+    const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
+    return (tiles - whole) * ts * (int64_t)bm * bn * 4;
 }
 
 // Batched NT GEMM on the same kernel: c[g] = a[g] @ b[g]^T, a [G][M][K], b [G][N][K], c [G][M][N].

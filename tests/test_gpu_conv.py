@@ -19,6 +19,11 @@ CASES = [
     (3, 576, 7, 7, 576, 3, 1, 1, 1),
     (1, 16, 9, 9, 40, 3, 1, 2, 2),
     (1, 24, 5, 6, 8, 3, 1, 1, 1),
+    # 265 / 300 / 1058 tiles: a few tiles more than a multiple of 256 -> the balanced tail (whole tiles + K-split remainder)
+    (1, 32, 130, 130, 64, 3, 1, 1, 1),
+    (2, 64, 98, 98, 64, 1, 1, 0, 1),
+    (1, 64, 130, 130, 256, 1, 1, 0, 1),
+    (1, 32, 130, 130, 256, 3, 1, 1, 1),
 ]
 
 
@@ -289,3 +294,22 @@ def test_colsum_bf16_and_weight_prep(rows, C):
         wb, wT = dense._prep_bf16(w)
         assert torch.equal(wb, w.to(torch.bfloat16))
         assert torch.equal(wT, w.to(torch.bfloat16).flip(2, 3).permute(1, 0, 2, 3))
+
+
+@pytest.mark.gpu
+def test_balanced_tail_epilogue_mask_and_accum():
+    """A layer size that takes the balanced-tail path (1060 tiles of 64x64: 1024 whole + 36 cut along K): the data
+    gradient with the ReLU mask and the identity-branch sum in its epilogue equals mask * (plain data gradient + accum)."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    g = torch.randn(1, 256, 130, 130, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 64, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    shape = (1, 64, 130, 130)
+    mask_src = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    accum = torch.randn(shape, device=dev).contiguous(memory_format=torch.channels_last)
+    plain = dense._dgrad_raw(g, w, shape, 1, 1, 1)
+    fused = dense._dgrad_raw(g, w, shape, 1, 1, 1, mask_src=mask_src, accum=accum)
+    torch.testing.assert_close(fused, (plain + accum) * (mask_src > 0), rtol=1e-5, atol=1e-5)
+    ref = torch.nn.functional.conv_transpose2d(g.double(), w.double(), None, 1, 1)
+    torch.testing.assert_close(plain.double(), ref, rtol=1e-4, atol=1e-3)
