@@ -166,7 +166,7 @@ def main():
     everything = args.profile_kernels or args.profile_detail
     capi.profile_begin(detail=args.profile_detail, only=None if everything else (
         'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_bwd_weight', 'htd_bgemm_nt', 'htd_conv2d_fwd_bf16',
-        'htd_conv2d_bwd_weight_bf16'))
+        'htd_conv2d_dgrad_bf16', 'htd_conv2d_bwd_weight_bf16'))
     t0 = time.perf_counter()
     for i in range(args.steps):
         # kernel events on every 4th step of the timed region (all steps with --profile-kernels): their queue

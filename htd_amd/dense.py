@@ -753,6 +753,10 @@ def roofline_report(prof, peak_tflops, peak_gbs, peak_bf16_tflops=2500.0):
     if parts:
         prof['conv_igemm_kernel (htd_conv2d_fwd + htd_conv2d_bwd_data)'] = (
             sum(p[0] for p in parts), sum(p[1] for p in parts), 'flop', sum(p[3] for p in parts), sum(p[4] for p in parts))
+    parts = [prof.pop(k) for k in ('htd_conv2d_fwd_bf16', 'htd_conv2d_dgrad_bf16') if k in prof]
+    if parts:                                        # same for the bf16 kernel
+        prof['conv_bf16_kernel (htd_conv2d_fwd_bf16 + htd_conv2d_dgrad_bf16)'] = (
+            sum(p[0] for p in parts), sum(p[1] for p in parts), 'flop', sum(p[3] for p in parts), sum(p[4] for p in parts))
     if 'htd_conv2d_bwd_weight' in prof:
         prof['conv_wgrad_kernel + splitk_reduce_kernel (htd_conv2d_bwd_weight)'] = prof.pop('htd_conv2d_bwd_weight')
     best = None
