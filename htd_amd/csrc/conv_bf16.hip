@@ -11,6 +11,8 @@
 // are rounded to bf16 (RNE) after bias / residual / ReLU.
 #include <algorithm>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -41,11 +43,14 @@ __device__ __forceinline__ unsigned short f2bf(float f)      // round to nearest
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// 128x128 tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA blocks; BK bf16 elements per slice
-template <int BK>
-__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(BfParams p)
+// 4 waves (2x2), each wave TM x TN MFMA blocks of 32x32: 128x128 tiles (TM = TN = 2) for layers that fill the chip,
+// 64x64 tiles (TM = TN = 1) for the small ones -- with one 128x128 workgroup per CU there is a single wave per SIMD and
+// the global->LDS staging latency of every K slice is exposed; four small workgroups per CU hide it.
+// BK bf16 elements per slice.
+template <int BK, int TM, int TN>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 5)) void conv_bf16_kernel(BfParams p)
 {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WGN = 2;
+    constexpr int WGN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32;
     constexpr int LS = BK + 8;                                  // LDS row stride in elements (+16 B pad)
     constexpr int VPR = BK / 8;                                 // 16-byte vectors per row slice
     constexpr int RPP = 256 / VPR;                              // rows covered per pass
@@ -233,13 +238,27 @@ static int launch_conv_bf16(const char *what, const void *x, const void *w, cons
     p.M = (int64_t)B * p.Ho * p.Wo;
     HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && (int64_t)Co * kh * kw * Ci < (1ll << 31) && p.M < (1ll << 31),
                 "%s: operand larger than 2^31 elements", what);
-    p.mt = (int)htd::ceil_div(p.M, 128);
-    p.nt = (int)htd::ceil_div(Co, 128);
+    // 64x64 tiles: below three 128x128 tiles per CU, and for 1x1 layers (a handful of K slices per tile: the wave count,
+    // not the tile's arithmetic intensity, decides) up to ~20 per CU.  Measured on the R101 layer set at B = 4:
+    // 1x1 256->1024 at 50x84 209 -> 296 TFLOP/s, 1x1 128->512 at 100x168 154 -> 199, 3x3 256 at 50x84 408 -> 427, while
+    // 3x3 256 at 100x168 (1050 big tiles) drops 688 -> 584 with the small tile and keeps the big one.
+    static const int small_below = getenv("HTD_BF16_SMALL_TILES") ? atoi(getenv("HTD_BF16_SMALL_TILES")) : 768;
+    static const int small_1x1_below = getenv("HTD_BF16_SMALL_TILES_1X1") ? atoi(getenv("HTD_BF16_SMALL_TILES_1X1")) : 5000;
+    const int64_t big_tiles = htd::ceil_div(p.M, 128) * htd::ceil_div(Co, 128);
+    const bool small = big_tiles < small_below || (kh * kw == 1 && big_tiles < small_1x1_below);
+    const int bt = small ? 64 : 128;
+    p.mt = (int)htd::ceil_div(p.M, bt);
+    p.nt = (int)htd::ceil_div(Co, bt);
     const dim3 grid((unsigned)(p.mt * p.nt));
-    if (Ci % 64 == 0)
-        hipLaunchKernelGGL(conv_bf16_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (small) {
+        if (Ci % 64 == 0)
+            hipLaunchKernelGGL((conv_bf16_kernel<64, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((conv_bf16_kernel<32, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else if (Ci % 64 == 0)
+        hipLaunchKernelGGL((conv_bf16_kernel<64, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(conv_bf16_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_bf16_kernel<32, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
     return htd::check_launch(what);
 }
 
