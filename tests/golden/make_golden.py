@@ -593,6 +593,58 @@ def gen_detector():
     npz('detector', **out)
 
 
+def aug_inputs():
+    """One image under two test-time augmentations (scale 1.0 unflipped, scale 1.25 flipped): the recipe shared by
+    this generator, tests/test_oracle_golden.py and tests/test_gpu_detector.py."""
+    rs = np.random.RandomState(5)
+    imgs, metas = [], []
+    for (H, W), (h, w), sf, flip in [((160, 224), (150, 210), 1.0, False), ((192, 256), (188, 256), 1.25, True)]:
+        im = ((rs.rand(1, 3, H, W) - 0.5) * 4).astype(np.float32)
+        im[:, :, h:] = 0
+        im[:, :, :, w:] = 0
+        imgs.append(im)
+        metas.append([dict(img_shape=(h, w, 3), pad_shape=(H, W, 3), ori_shape=(150, 210, 3),
+                           scale_factor=np.array([sf] * 4, dtype=np.float32), flip=flip,
+                           flip_direction='horizontal' if flip else None)])
+    return imgs, metas
+
+
+def gen_aug_test():
+    """The reference's own test-time-augmentation path -- TwoStageDetector.aug_test -> RPNTestMixin.aug_test_rpn ->
+    merge_aug_proposals, HTDRoIHead.aug_test -> merge_aug_bboxes -> multiclass_nms -- on the seeded detector."""
+    for m in ('mmdet.models.losses', 'mmdet.models.backbones.resnet', 'mmdet.models.necks.fpn',
+              'mmdet.models.dense_heads.anchor_head', 'mmdet.models.dense_heads.rpn_test_mixin',
+              'mmdet.models.dense_heads.rpn_head',
+              'mmdet.models.roi_heads.base_roi_head', 'mmdet.models.roi_heads.bbox_heads.bbox_head',
+              'mmdet.models.roi_heads.bbox_heads.convfc_bbox_head',
+              'mmdet.models.roi_heads.bbox_heads.global_context_head',
+              'mmdet.models.roi_heads.bbox_heads.htd_bbox_head',
+              'mmdet.models.roi_heads.roi_extractors.single_level_roi_extractor',
+              'mmdet.models.roi_heads.roi_extractors.adaptative_roi_extractor',
+              'mmdet.models.roi_heads.htd_roi_head', 'mmdet.models.detectors.base',
+              'mmdet.models.detectors.two_stage', 'mmdet.models.detectors.faster_rcnn'):
+        ref(m)
+    builder = ref('mmdet.models.builder')
+    cfg = load_cfg('configs/htd/htd_resnet50_1x.py')
+    model_cfg, train_cfg, test_cfg = small_model_cfg(cfg)
+    torch.manual_seed(0)
+    det = builder.build_detector(model_cfg, train_cfg=train_cfg, test_cfg=test_cfg)
+    det.init_weights(None)
+    load_seeded_(det, 'det.')
+    det.eval()
+    imgs, metas = aug_inputs()
+    imgs = [torch.from_numpy(i) for i in imgs]
+    with torch.no_grad():
+        feats = det.extract_feats(imgs)
+        props = det.rpn_head.aug_test_rpn(feats, metas)
+        res = det.aug_test(imgs, metas)
+    assert len(props) == 1 and len(res) == 1
+    dets = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, dtype=np.float32)], 1)
+                           for c, r in enumerate(res[0])], 0)
+    npz('aug_test', proposals=props[0].numpy(), dets=dets)
+    print('aug_test: proposals', tuple(props[0].shape), 'detections', dets.shape)
+
+
 def main():
     torch.set_num_threads(8)
     install_mmcv_standin()
@@ -604,6 +656,8 @@ def main():
         gen_heads()
     if 'detector' in which:
         gen_detector()
+    if 'aug' in which:
+        gen_aug_test()
 
 
 if __name__ == '__main__':

@@ -89,3 +89,31 @@ def demo_inputs(B, H, W, rng, num_classes=80):
     return imgs, gts, labels
 
 
+
+
+def aug_inputs():
+    """One image under two test-time augmentations (scale 1.0 unflipped, scale 1.25 flipped); same recipe as
+    tests/golden/make_golden.py::aug_inputs, which fed the reference's aug_test for tests/golden/aug_test.npz."""
+    rs = np.random.RandomState(5)
+    imgs, metas = [], []
+    for (H, W), (h, w), sf, flip in [((160, 224), (150, 210), 1.0, False), ((192, 256), (188, 256), 1.25, True)]:
+        im = ((rs.rand(1, 3, H, W) - 0.5) * 4).astype(np.float32)
+        im[:, :, h:] = 0
+        im[:, :, :, w:] = 0
+        imgs.append(im)
+        metas.append([dict(img_shape=(h, w, 3), pad_shape=(H, W, 3), ori_shape=(150, 210, 3),
+                           scale_factor=np.array([sf] * 4, dtype=np.float32), flip=flip,
+                           flip_direction='horizontal' if flip else None)])
+    return imgs, metas
+
+
+def match_detections(mine, ref, tol=1e-2):
+    """One-to-one matching of (k, 6) [x1, y1, x2, y2, score, class] rows: detections with (nearly) equal scores may
+    swap ranks, so rows are matched instead of compared in order."""
+    assert mine.shape == ref.shape, (mine.shape, ref.shape)
+    used = np.zeros(len(mine), dtype=bool)
+    for r in ref:
+        d = np.abs(mine[:, :5] - r[:5]).max(1) + 1e3 * (mine[:, 5] != r[5]) + 1e3 * used
+        j = int(d.argmin())
+        assert d[j] <= tol + 1e-3 * np.abs(r[:4]).max(), (r, mine[j], d[j])
+        used[j] = True

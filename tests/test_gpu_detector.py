@@ -407,26 +407,20 @@ def test_bf16_train_step_tracks_the_fp32_step(det, golden):
         assert g16[n].dtype == torch.float32
 
 
-def test_aug_test_matches_oracle(det):
+def test_aug_test_matches_reference_fixture(det, golden):
     """Multi-scale + flip test-time augmentation of one image (TwoStageDetector.aug_test -> RPN aug_test_rpn ->
-    HTDRoIHead.aug_test, htd_roi_head.py:388-433) against the oracle's restatement on the same seeded weights."""
+    HTDRoIHead.aug_test, htd_roi_head.py:388-433) against the outputs of the reference's own aug_test
+    (tests/golden/aug_test.npz) and against the oracle's restatement on the same seeded weights."""
+    from golden_util import aug_inputs, match_detections
     from oracle import detector as D
+    g = golden('aug_test')
     dev = torch.device('cuda:0')
     cfg = D.htd_config(50)
     cfg['test_cfg']['rpn'].update(nms_pre=100, nms_post=60, max_num=60)
     cfg['test_cfg']['rcnn']['score_thr'] = 0.001
     sd = seeded_state_dict(D.state_shapes(50), prefix='det.')
-    rs = np.random.RandomState(5)
-    shapes = [((160, 224), (150, 210), 1.0, False), ((192, 256), (188, 262 - 6), 1.25, True)]
-    imgs, metas = [], []
-    for (H, W), (h, w), sf, flip in shapes:
-        im = ((rs.rand(1, 3, H, W) - 0.5) * 4).astype(np.float32)
-        im[:, :, h:] = 0
-        im[:, :, :, w:] = 0
-        imgs.append(T(im))
-        metas.append([dict(img_shape=(h, w, 3), pad_shape=(H, W, 3), ori_shape=(150, 210, 3),
-                           scale_factor=np.array([sf] * 4, dtype=np.float32), flip=flip,
-                           flip_direction='horizontal' if flip else None)])
+    imgs, metas = aug_inputs()
+    imgs = [T(i) for i in imgs]
     with torch.no_grad():
         ref_props, (ref_d, ref_l) = D.aug_test(sd, imgs, metas, cfg)
     det.eval()
@@ -434,18 +428,13 @@ def test_aug_test_matches_oracle(det):
         feats = det.extract_feats([i.to(dev) for i in imgs])
         props = det.rpn_head.aug_test_rpn(feats, metas)
         res = det.forward_test([i.to(dev) for i in imgs], [[dict(m[0])] for m in metas])
-    assert len(props) == 1 and props[0].shape == ref_props.shape
+    assert len(props) == 1 and props[0].shape == ref_props.shape == g['proposals'].shape
+    np.testing.assert_allclose(props[0].cpu().numpy(), g['proposals'], rtol=1e-4, atol=2e-3)
     np.testing.assert_allclose(props[0].cpu().numpy(), ref_props.numpy(), rtol=1e-4, atol=2e-3)
     assert len(res) == 1 and len(res[0]) == 80
     mine = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, dtype=np.float32)], 1)
                            for c, r in enumerate(res[0])], 0)
-    ref = torch.cat([ref_d, ref_l[:, None].float()], 1).numpy()
-    assert mine.shape == ref.shape
-    used = np.zeros(len(mine), dtype=bool)
-    for r in ref:
-        d = np.abs(mine[:, :5] - r[:5]).max(1) + 1e3 * (mine[:, 5] != r[5]) + 1e3 * used
-        j = int(d.argmin())
-        assert d[j] <= 1e-2 + 1e-3 * np.abs(r[:4]).max(), (r, mine[j], d[j])
-        used[j] = True
+    match_detections(mine, g['dets'])
+    match_detections(mine, torch.cat([ref_d, ref_l[:, None].float()], 1).numpy())
     with pytest.raises(AssertionError, match='batch size'):
         det.forward_test([torch.zeros(2, 3, 64, 64, device=dev)] * 2, [[{}, {}], [{}, {}]])

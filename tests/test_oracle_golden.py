@@ -217,3 +217,18 @@ def test_detector_train_and_test(golden):
         assert mine.shape == refs.shape
         np.testing.assert_array_equal(mine[:, 5], refs[:, 5])
         np.testing.assert_allclose(mine[:, :5], refs[:, :5], rtol=1e-3, atol=1e-2)
+
+
+def test_aug_test_matches_reference_fixture(golden):
+    """Test-time augmentation (two_stage.py:213-222, rpn_test_mixin.py:39-59, htd_roi_head.py:388-433, merge_augs.py):
+    the oracle's restatement against the outputs of the reference's own aug_test (tests/golden/aug_test.npz)."""
+    from golden_util import aug_inputs, match_detections
+    g = golden('aug_test')
+    cfg = small_cfg()
+    sd = seeded_state_dict(D.state_shapes(50), prefix='det.')
+    imgs, metas = aug_inputs()
+    with torch.no_grad():
+        props, (dets, labels) = D.aug_test(sd, [T(i) for i in imgs], metas, cfg)
+    assert props.shape == g['proposals'].shape
+    np.testing.assert_allclose(props.numpy(), g['proposals'], rtol=1e-4, atol=1e-3)
+    match_detections(torch.cat([dets, labels[:, None].float()], 1).numpy(), g['dets'])
