@@ -593,6 +593,30 @@ def gen_detector():
     npz('detector', **out)
 
 
+def gen_resnext():
+    """A ResNeXt stage of the reference (backbones/resnext.py Bottleneck + utils/res_layer.py ResLayer; groups = 8,
+    base_width = 4, two blocks, stride 2) on seeded weights: output and gradient digests."""
+    ref('mmdet.models.backbones.resnet')
+    rx = ref('mmdet.models.backbones.resnext')
+    ResLayer = ref('mmdet.models.utils.res_layer').ResLayer
+    torch.manual_seed(0)
+    layer = ResLayer(block=rx.Bottleneck, inplanes=64, planes=64, num_blocks=2, stride=2, groups=8, base_width=4,
+                     base_channels=64, norm_cfg=dict(type='BN', requires_grad=True))
+    load_seeded_(layer, 'xblk.')
+    layer.eval()
+    x = torch.randn(2, 64, 12, 14, generator=torch.Generator().manual_seed(1)).requires_grad_()
+    y = layer(x)
+    go = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(go)
+    out = dict(y=y.detach().numpy())
+    put_digest(out, 'gx', x.grad)
+    for k, p_ in layer.named_parameters():
+        put_digest(out, 'grad.' + k, p_.grad)
+    out['conv2_shape'] = np.array(layer[0].conv2.weight.shape)
+    npz('resnext_stage', **out)
+    print('resnext_stage: y', tuple(y.shape), 'conv2', tuple(layer[0].conv2.weight.shape))
+
+
 def aug_inputs():
     """One image under two test-time augmentations (scale 1.0 unflipped, scale 1.25 flipped): the recipe shared by
     this generator, tests/test_oracle_golden.py and tests/test_gpu_detector.py."""
@@ -658,6 +682,8 @@ def main():
         gen_detector()
     if 'aug' in which:
         gen_aug_test()
+    if 'resnext' in which:
+        gen_resnext()
 
 
 if __name__ == '__main__':

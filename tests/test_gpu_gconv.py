@@ -85,6 +85,15 @@ def test_resnext_stage_matches_oracle(dcn):
         want = sd['blk' + k].grad
         scale = max(1.0, float(want.abs().max()))
         torch.testing.assert_close(p.grad.cpu().contiguous(), want, rtol=1e-3, atol=2e-4 * scale, msg=k)
+    if not dcn:      # the plain stage also against the reference's own module (tests/golden/resnext_stage.npz)
+        import numpy as np
+        from golden_util import digest
+        g = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'resnext_stage.npz'))
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g['y'], rtol=1e-3, atol=1e-4)
+        for key, t in [('gx', xd.grad)] + [('grad.' + k, p.grad) for k, p in layer.named_parameters()]:
+            sums, sample = digest(t.detach().cpu().contiguous())
+            refs = g[key + '.sample']
+            np.testing.assert_allclose(sample, refs, rtol=2e-3, atol=5e-4 * max(1.0, np.abs(refs).max()), err_msg=key)
 
 
 def test_resnext101_dcn_detector_train_step():

@@ -232,3 +232,30 @@ def test_aug_test_matches_reference_fixture(golden):
     assert props.shape == g['proposals'].shape
     np.testing.assert_allclose(props.numpy(), g['proposals'], rtol=1e-4, atol=1e-3)
     match_detections(torch.cat([dets, labels[:, None].float()], 1).numpy(), g['dets'])
+
+
+def test_resnext_stage_matches_reference_fixture(golden):
+    """ResNeXt bottlenecks (backbones/resnext.py:9-84; groups = 8, base_width = 4, stride-2 stage of two blocks): the
+    oracle's bottleneck(groups=...) against the reference's own module outputs and gradients."""
+    g = golden('resnext_stage')
+    shapes = {}
+    w = 32
+    for b, cin in ((0, 64), (1, 256)):
+        shapes.update({f'{b}.conv1.weight': (w, cin, 1, 1), f'{b}.conv2.weight': (w, 4, 3, 3),
+                       f'{b}.conv3.weight': (256, w, 1, 1)})
+        for n, c in (('bn1', w), ('bn2', w), ('bn3', 256)):
+            for k in ('weight', 'bias', 'running_mean', 'running_var'):
+                shapes[f'{b}.{n}.{k}'] = (c,)
+    shapes['0.downsample.0.weight'] = (256, 64, 1, 1)
+    for k in ('weight', 'bias', 'running_mean', 'running_var'):
+        shapes[f'0.downsample.1.{k}'] = (256,)
+    assert tuple(g['conv2_shape']) == shapes['0.conv2.weight']
+    sd = {'blk' + k: v.requires_grad_('running' not in k)
+          for k, v in seeded_state_dict(shapes, prefix='xblk.').items()}
+    x = torch.randn(2, 64, 12, 14, generator=torch.Generator().manual_seed(1)).requires_grad_()
+    y = D.bottleneck(sd, 'blk1', D.bottleneck(sd, 'blk0', x, 2, groups=8), 1, groups=8)
+    torch.testing.assert_close(y.detach(), T(g['y']), rtol=1e-4, atol=1e-5)
+    y.backward(torch.randn(y.shape, generator=torch.Generator().manual_seed(2)))
+    check_digest(g, 'gx', x.grad)
+    for k in [f[5:-5] for f in g.files if f.startswith('grad.') and f.endswith('.sums')]:
+        check_digest(g, 'grad.' + k, sd['blk' + k].grad)
