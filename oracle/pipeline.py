@@ -12,10 +12,11 @@ immediately before the hot path.  numpy restatement of
     INTER_RESIZE_COEF_BITS = 11 bits, horizontal pass to int32, vertical pass
     ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2, and the exact-2x-downscale shortcut to INTER_AREA.
 
-PARITY UNPINNED for the cv2-backed steps (resize, normalize arithmetic): neither mmcv nor OpenCV is importable in this
-image and the reference's tests hold no golden pixels for them, so this restatement is checked only against
-hand-derived cases (tests/test_pipeline_oracle.py).  flip / pad / collate / bbox arithmetic are plain numpy
-definitions and are exact.
+PARITY UNPINNED for the PIXELS of the cv2-backed steps (resize, normalize arithmetic): neither mmcv nor OpenCV is
+importable in this image and the reference's tests hold no golden pixels for them, so this restatement is checked only
+against hand-derived cases (tests/test_pipeline_oracle.py).  Everything else -- scale selection, output sizes, scale
+factors, flips, box arithmetic, padding, test-time-augmentation planning -- is pinned by tests/golden/pipeline.npz,
+produced by the reference's own transform classes running over this module's image functions (make_golden.py pipeline).
 """
 import numpy as np
 

@@ -617,6 +617,90 @@ def gen_resnext():
     print('resnext_stage: y', tuple(y.shape), 'conv2', tuple(layer[0].conv2.weight.shape))
 
 
+def pipeline_samples():
+    """Decoded-image stand-ins + annotations shared by the generator and the tests (seeded)."""
+    out = []
+    for s, (h, w) in enumerate([(120, 160), (200, 150), (97, 333), (64, 64)]):
+        rs = np.random.RandomState(s)
+        xy = rs.uniform(0, [w - 8, h - 8], (5, 2))
+        boxes = np.concatenate([xy, xy + rs.uniform(4, 60, (5, 2))], 1).astype(np.float32)
+        img = np.random.RandomState(100 + s).randint(0, 256, (h, w, 3)).astype(np.uint8)
+        out.append((img, boxes, rs.randint(0, 80, 5).astype(np.int64)))
+    return out
+
+
+def gen_pipeline():
+    """The reference's own transform classes (datasets/pipelines/transforms.py Resize / RandomFlip / Normalize / Pad,
+    formating.py, test_time_aug.py, compose.py) on seeded samples.  The mmcv image functions they call (imrescale,
+    imflip, imnormalize, impad_to_multiple: cv2-backed, cv2 is not installed) are served by oracle/pipeline.py, so
+    this fixture pins the box / meta / random-number logic to the reference and the pixels to that restatement."""
+    from oracle import pipeline as OP
+    mmcv = sys.modules['mmcv']
+    mmcv.is_list_of = lambda seq, t: isinstance(seq, list) and all(isinstance(x, t) for x in seq)
+    mmcv.is_str = lambda x: isinstance(x, str)
+
+    def imrescale(img, scale, return_scale=False, interpolation='bilinear', backend=None):
+        out, f = OP.imrescale(img, scale)
+        return (out, f) if return_scale else out
+
+    def imresize(img, size, return_scale=False, interpolation='bilinear', out=None, backend=None):
+        h, w = img.shape[:2]
+        r = OP.imresize_bilinear_u8(img, size)
+        return (r, size[0] / w, size[1] / h) if return_scale else r
+    mmcv.imrescale, mmcv.imresize = imrescale, imresize
+    mmcv.imflip = lambda img, direction='horizontal': OP.imflip(img, direction)
+    mmcv.imnormalize = lambda img, mean, std, to_rgb=True: OP.imnormalize(img, mean, std, to_rgb)
+    mmcv.impad_to_multiple = lambda img, divisor, pad_val=0: OP.impad_to_multiple(img, divisor, pad_val)
+    core = sys.modules['mmdet.core']
+    core.PolygonMasks = type('PolygonMasks', (), {})
+    ev = types.ModuleType('mmdet.core.evaluation')
+    ev.__path__ = [os.path.join(REF, 'mmdet/core/evaluation')]
+    sys.modules['mmdet.core.evaluation'] = ev
+    ds = types.ModuleType('mmdet.datasets')
+    ds.__path__ = [os.path.join(REF, 'mmdet/datasets')]
+    sys.modules['mmdet.datasets'] = ds
+    pl = types.ModuleType('mmdet.datasets.pipelines')
+    pl.__path__ = [os.path.join(REF, 'mmdet/datasets/pipelines')]
+    sys.modules['mmdet.datasets.pipelines'] = pl
+    tr = ref('mmdet.datasets.pipelines.transforms')
+    tta = ref('mmdet.datasets.pipelines.test_time_aug')
+    comp = ref('mmdet.datasets.pipelines.compose')
+    norm = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+    pipe = comp.Compose([tr.Resize(img_scale=(1333, 800), keep_ratio=True), tr.RandomFlip(flip_ratio=0.5),
+                         tr.Normalize(**norm), tr.Pad(size_divisor=32)])
+    ms = comp.Compose([tr.Resize(img_scale=[(1600, 400), (1600, 1400)], multiscale_mode='range', keep_ratio=True),
+                       tr.RandomFlip(flip_ratio=0.5)])
+    out = {}
+    np.random.seed(7)
+    for i, (img, boxes, labels) in enumerate(pipeline_samples()):
+        r = pipe(dict(img=img, img_shape=img.shape, ori_shape=img.shape, img_fields=['img'], gt_bboxes=boxes.copy(),
+                      bbox_fields=['gt_bboxes'], mask_fields=[], seg_fields=[]))
+        out[f's{i}.img_shape'] = np.array(r['img_shape'])
+        out[f's{i}.pad_shape'] = np.array(r['pad_shape'])
+        out[f's{i}.scale_factor'] = r['scale_factor']
+        out[f's{i}.flip'] = np.array(int(bool(r['flip'])))
+        out[f's{i}.gt_bboxes'] = r['gt_bboxes']
+        put_digest(out, f's{i}.img', torch.from_numpy(np.ascontiguousarray(r['img'])))
+    np.random.seed(3)
+    for i, (img, boxes, labels) in enumerate(pipeline_samples()[:2]):
+        r = ms(dict(img=img, img_shape=img.shape, ori_shape=img.shape, img_fields=['img'], gt_bboxes=boxes.copy(),
+                    bbox_fields=['gt_bboxes'], mask_fields=[], seg_fields=[]))
+        out[f'm{i}.img_shape'] = np.array(r['img_shape'])
+        out[f'm{i}.flip'] = np.array(int(bool(r['flip'])))
+        out[f'm{i}.gt_bboxes'] = r['gt_bboxes']
+    t = tta.MultiScaleFlipAug(transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'),
+                                          dict(type='Pad', size_divisor=32)],
+                              img_scale=[(1333, 800), (1000, 600)], flip=True)
+    img = pipeline_samples()[0][0]
+    r = t(dict(img=img, img_shape=img.shape, ori_shape=img.shape, img_fields=['img'], bbox_fields=[], mask_fields=[],
+               seg_fields=[]))
+    out['tta.img_shapes'] = np.array([a for a in r['img_shape']])
+    out['tta.pad_shapes'] = np.array([a for a in r['pad_shape']])
+    out['tta.flips'] = np.array([int(bool(f)) for f in r['flip']])
+    npz('pipeline', **out)
+    print('pipeline: flips', [int(out[f's{i}.flip']) for i in range(4)], 'tta', out['tta.img_shapes'].tolist())
+
+
 def aug_inputs():
     """One image under two test-time augmentations (scale 1.0 unflipped, scale 1.25 flipped): the recipe shared by
     this generator, tests/test_oracle_golden.py and tests/test_gpu_detector.py."""
@@ -684,6 +768,8 @@ def main():
         gen_aug_test()
     if 'resnext' in which:
         gen_resnext()
+    if 'pipeline' in which:
+        gen_pipeline()
 
 
 if __name__ == '__main__':

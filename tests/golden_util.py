@@ -117,3 +117,15 @@ def match_detections(mine, ref, tol=1e-2):
         j = int(d.argmin())
         assert d[j] <= tol + 1e-3 * np.abs(r[:4]).max(), (r, mine[j], d[j])
         used[j] = True
+
+
+def pipeline_samples():
+    """Decoded-image stand-ins + annotations of tests/golden/pipeline.npz (same recipe as make_golden.py)."""
+    out = []
+    for s, (h, w) in enumerate([(120, 160), (200, 150), (97, 333), (64, 64)]):
+        rs = np.random.RandomState(s)
+        xy = rs.uniform(0, [w - 8, h - 8], (5, 2))
+        boxes = np.concatenate([xy, xy + rs.uniform(4, 60, (5, 2))], 1).astype(np.float32)
+        img = np.random.RandomState(100 + s).randint(0, 256, (h, w, 3)).astype(np.uint8)
+        out.append((img, boxes, rs.randint(0, 80, 5).astype(np.int64)))
+    return out

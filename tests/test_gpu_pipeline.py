@@ -166,3 +166,29 @@ def test_tta_pipeline_drives_aug_test():
     with torch.no_grad():
         res = det.forward_test(data['img'], data['img_metas'])
     assert len(res) == 1 and len(res[0]) == 80 and all(c.shape[1] == 5 for c in res[0])
+
+
+def test_device_batch_matches_reference_class_fixture():
+    """tests/golden/pipeline.npz (the reference's own transform classes over oracle/pipeline.py's image functions): the
+    collated device batch reproduces the stored pixel digest of every sample bit for bit."""
+    import os
+    from golden_util import digest, pipeline_samples
+    from htd_amd.pipelines import build_pipeline, collate
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pipeline.npz'))
+    pipe = build_pipeline([dict(type='LoadImageFromFile'), dict(type='LoadAnnotations', with_bbox=True),
+                           dict(type='Resize', img_scale=(1333, 800), keep_ratio=True),
+                           dict(type='RandomFlip', flip_ratio=0.5), dict(type='Normalize', mean=MEAN, std=STD, to_rgb=True),
+                           dict(type='Pad', size_divisor=32), dict(type='DefaultFormatBundle'),
+                           dict(type='Collect', keys=['img', 'gt_bboxes', 'gt_labels'])])
+    np.random.seed(7)
+    samples = [pipe(dict(img=img, img_info=dict(filename=f'{i}.jpg'), img_prefix=None, bbox_fields=[],
+                         ann_info=dict(bboxes=boxes, labels=labels)))
+               for i, (img, boxes, labels) in enumerate(pipeline_samples())]
+    batch = collate(samples, 'cuda:0')['img'].cpu()
+    for i, s in enumerate(samples):
+        ph, pw = s['img_metas']['pad_shape'][:2]
+        assert (ph, pw) == tuple(g[f's{i}.pad_shape'][:2])
+        hwc = batch[i, :, :ph, :pw].permute(1, 2, 0).contiguous()
+        _, sample = digest(hwc)
+        np.testing.assert_array_equal(sample, g[f's{i}.img.sample'])
+        np.testing.assert_array_equal(s['gt_bboxes'].numpy(), g[f's{i}.gt_bboxes'])

@@ -157,3 +157,51 @@ def test_out_of_order_pipelines_are_refused():
         bad(dict(img=_img(10, 10), img_info=dict(filename='x'), img_prefix=None))
     with pytest.raises(TypeError):
         build_pipeline([dict(type='LoadImageFromFile')])(dict(img=np.zeros((4, 4, 3), np.float32), img_info={}))
+
+
+def _ref_cfg(scale=(1333, 800), **kw):
+    return [dict(type='LoadImageFromFile'), dict(type='LoadAnnotations', with_bbox=True),
+            dict(type='Resize', img_scale=scale, keep_ratio=True, **kw), dict(type='RandomFlip', flip_ratio=0.5),
+            dict(type='Normalize', mean=MEAN, std=STD, to_rgb=True), dict(type='Pad', size_divisor=32)]
+
+
+def _ref_input(img, boxes, labels, i):
+    return dict(img=img, img_info=dict(filename=f'{i}.jpg'), img_prefix=None, bbox_fields=[],
+                ann_info=dict(bboxes=boxes, labels=labels))
+
+
+def test_planners_match_the_reference_transform_classes(golden):
+    """tests/golden/pipeline.npz was produced by the reference's own Resize / RandomFlip / Normalize / Pad /
+    MultiScaleFlipAug classes (make_golden.py pipeline; their mmcv image calls served by oracle/pipeline.py): same
+    random draws, shapes, scale factors, flips and boxes from the planners here, and the oracle's per-image pipeline
+    reproduces the stored pixel digests."""
+    from golden_util import digest, pipeline_samples
+    from htd_amd.pipelines import build_pipeline
+    g = golden('pipeline')
+    pipe = build_pipeline(_ref_cfg())
+    np.random.seed(7)
+    for i, (img, boxes, labels) in enumerate(pipeline_samples()):
+        r = pipe(_ref_input(img, boxes, labels, i))
+        assert tuple(r['img_shape']) == tuple(g[f's{i}.img_shape'])
+        assert tuple(r['pad_shape']) == tuple(g[f's{i}.pad_shape'])
+        np.testing.assert_array_equal(r['scale_factor'], g[f's{i}.scale_factor'])
+        assert int(bool(r['flip'])) == int(g[f's{i}.flip'])
+        np.testing.assert_array_equal(r['gt_bboxes'], g[f's{i}.gt_bboxes'])
+        ref = P.pipeline_sample(img, (1333, 800), r['flip_direction'] if r['flip'] else None, MEAN, STD, True, 32)
+        sums, sample = digest(torch.from_numpy(np.ascontiguousarray(ref['img'])))
+        np.testing.assert_array_equal(sample, g[f's{i}.img.sample'])
+    ms = build_pipeline(_ref_cfg(scale=[(1600, 400), (1600, 1400)], multiscale_mode='range')[:4])
+    np.random.seed(3)
+    for i, (img, boxes, labels) in enumerate(pipeline_samples()[:2]):
+        r = ms(_ref_input(img, boxes, labels, i))
+        assert tuple(r['img_shape']) == tuple(g[f'm{i}.img_shape'])
+        assert int(bool(r['flip'])) == int(g[f'm{i}.flip'])
+        np.testing.assert_array_equal(r['gt_bboxes'], g[f'm{i}.gt_bboxes'])
+    tta = build_pipeline([dict(type='LoadImageFromFile'),
+                          dict(type='MultiScaleFlipAug', img_scale=[(1333, 800), (1000, 600)], flip=True,
+                               transforms=[dict(type='Resize', keep_ratio=True), dict(type='RandomFlip'),
+                                           dict(type='Pad', size_divisor=32)])])
+    r = tta(dict(img=pipeline_samples()[0][0], img_info=dict(filename='a.jpg'), img_prefix=None))
+    np.testing.assert_array_equal(np.array(r['img_shape']), g['tta.img_shapes'])
+    np.testing.assert_array_equal(np.array(r['pad_shape']), g['tta.pad_shapes'])
+    assert [int(bool(f)) for f in r['flip']] == g['tta.flips'].tolist()
