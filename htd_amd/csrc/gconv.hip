@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ x,
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slabs = g.C >> 4, slab_blocks = (slabs + 3) >> 2;
-    const int os = (int)(blockIdx.x % slab_blocks) * 4 + wave;         // 4 adjacent slabs per block: 256 B per pixel
+    const int os0 = (int)(blockIdx.x % slab_blocks) * 4;               // 4 adjacent slabs per block: 256 B per pixel
+    const int os = os0 + wave;
     const int64_t m0 = (int64_t)(blockIdx.x / slab_blocks) * 64;
-    if (os >= slabs) return;
+    const bool active = os < slabs;                                    // (a block's last waves idle when C % 64 != 0)
     const int r = lane & 15, j = lane >> 4;
     const int taps = g.kh * g.kw;
     const int only_tap = (MODE == G_DGRAD_COLS) ? (int)blockIdx.y : -1;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ x,
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int is = 0; is < g.islabs; ++is) {
+    for (int is = 0; active && is < g.islabs; ++is) {
         const float *xs = x + 16 * in_slab_of(g, os, is) + 4 * j;
         const f32x4 *wq = wp + ((int64_t)(os * g.islabs + is) * taps) * 64 + lane;
         auto one_tap = [&](int tap, int dy, int dx) {
@@ -144,19 +145,31 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ x,
             for (int tap = 0; tap < taps; ++tap) one_tap(tap, tap / g.kw, tap % g.kw);
         }
     }
-    // D: lane holds rows 4j + i (pixels), column r (channel) of each 16x16 tile
-    const int co = 16 * os + r;
-    const float bv = bias ? bias[co] : 0.f;
+    // D: lane holds rows 4j + i (pixels), column r (channel) of each 16x16 tile.  The block's 64 pixels x 64 channels go
+    // through LDS so that a store instruction writes 16 B per lane along whole 256 B pixel rows (straight from the
+    // accumulators it would be 4 B per lane in 64 B pieces)
+    __shared__ float stage[64][68];
+    if (active) {
+        const float bv = bias ? bias[16 * os + r] : 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + t * 16 + 4 * j + i;
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[t][i] + bv;
+                if (relu) v = fmaxf(v, 0.f);
+                stage[t * 16 + 4 * j + i][wave * 16 + r] = v;
+            }
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 15, ch = os0 * 16 + q * 4;
+    if (ch < g.C) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int pl = (threadIdx.x >> 4) + pass * 16;
+            const int64_t m = m0 + pl;
             if (m >= g.M) continue;
-            float v = acc[t][i] + bv;
-            if (relu) v = fmaxf(v, 0.f);
             const int64_t orow = (MODE == G_DGRAD_COLS) ? m * taps + only_tap : m;
-            y[orow * g.C + co] = v;
+            *reinterpret_cast<f32x4 *>(y + orow * g.C + ch) = *reinterpret_cast<const f32x4 *>(&stage[pl][q * 4]);
         }
     }
 }
