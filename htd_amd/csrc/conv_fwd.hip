@@ -63,6 +63,10 @@ struct ConvParams {
     // remainder is spread over the whole chip.  Their partial tiles go to partial[(tile - tail_first) * tail_splits +
     // split][BM][BN]; conv_tail_epilogue_kernel sums them and applies the epilogue.
     int tail_first, tail_splits, tail_sps;
+    // K order of the slices: 0 = tap-major (all channels of a tap, then the next tap), 1 = channel-major (the kh*kw taps of
+    // one BK-channel slice back to back: a tile re-reads its own footprint from L1/L2 instead of streaming the whole
+    // input once per tap through an L2 that the concurrent tiles of the XCD overflow)
+    int cmajor;
 };
 
 // BK: floats of K per slice; WGM x WGN: wave grid of the block; TM x TN: 32x32 MFMA blocks per wave
@@ -154,13 +158,21 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
 
     // state of the NEXT slice to stage (advanced incrementally: no divisions inside the K loop)
     int ld_ci0, ld_ky, ld_kx;
-    {
+    unsigned ld_woff;                                   // k offset inside a weight row
+    const bool cmajor = !TAPS && p.cmajor;
+    if (cmajor) {
+        const int ntap = p.kh * p.kw, cs = s_begin / ntap, tap = s_begin - cs * ntap;
+        ld_ci0 = cs * BK;
+        ld_ky = tap / p.kw;
+        ld_kx = tap - ld_ky * p.kw;
+        ld_woff = (unsigned)(tap * p.Ci + ld_ci0);
+    } else {
         const int tap = s_begin / slices_per_tap;
         ld_ci0 = (s_begin - tap * slices_per_tap) * BK;
         ld_ky = TAPS ? tap : tap / p.kw;
         ld_kx = TAPS ? 0 : tap - ld_ky * p.kw;
+        ld_woff = (unsigned)s_begin * BK;               // tap-major: slices are contiguous in k
     }
-    unsigned ld_woff = (unsigned)s_begin * BK;          // k offset inside a weight row: slices are contiguous in k
 
     float4 ra[T::PASSES_A], rb[T::PASSES_B];
     unsigned ra_ok = 0u;                              // bit i: pass i of the staged A slice is in range
@@ -184,12 +196,24 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
         const unsigned woff = TAPS ? (unsigned)(p.tap_w[ld_ky] * p.Ci + ld_ci0) : ld_woff;
 #pragma unroll
         for (int i = 0; i < T::PASSES_B; ++i) rb[i] = *reinterpret_cast<const float4 *>(wbase + b_off[i] + woff);
-        ld_woff += BK;
-        ld_ci0 += BK;
-        if (ld_ci0 == p.Ci) {
-            ld_ci0 = 0;
-            if (TAPS) ++ld_ky;
-            else if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
+        if (cmajor) {
+            ld_woff += (unsigned)p.Ci;
+            if (++ld_kx == p.kw) {
+                ld_kx = 0;
+                if (++ld_ky == p.kh) {
+                    ld_ky = 0;
+                    ld_ci0 += BK;
+                    ld_woff = (unsigned)ld_ci0;
+                }
+            }
+        } else {
+            ld_woff += BK;
+            ld_ci0 += BK;
+            if (ld_ci0 == p.Ci) {
+                ld_ci0 = 0;
+                if (TAPS) ++ld_ky;
+                else if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
+            }
         }
     };
     auto store_slice = [&](int buf) {
@@ -480,6 +504,8 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     p.slices_per_split = (int)htd::ceil_div(total_slices, p.splits);
     p.splits = (int)htd::ceil_div(total_slices, p.slices_per_split);
     p.partial = (float *)workspace;
+    static const int cmajor_env = getenv("HTD_CONV_CMAJOR") ? atoi(getenv("HTD_CONV_CMAJOR")) : 1;
+    p.cmajor = (p.ntaps == 0 && p.kh * p.kw > 1) ? cmajor_env : 0;
     unsigned launch_blocks = (unsigned)blocks;
     p.tail_first = p.tail_splits = p.tail_sps = 0;
     if (workspace && p.ntaps == 0 && p.splits == 1 && p.w_bstride == 0) {

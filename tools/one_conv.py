@@ -1,0 +1,19 @@
+"""Run one forward convolution shape a few times (for rocprofv3 --pmc passes).  usage: one_conv.py Ci H W Co k [B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from htd_amd import dense  # noqa: E402
+
+Ci, H, W, Co, k = [int(v) for v in sys.argv[1:6]]
+B = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+dev = torch.device('cuda:0')
+CL = torch.channels_last
+x = torch.randn(B, Ci, H, W, device=dev).contiguous(memory_format=CL)
+w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05).contiguous(memory_format=CL)
+for _ in range(5):
+    y = dense._fwd_raw(x, w, None, None, 1, k // 2, 1, True)
+torch.cuda.synchronize()
+print('algorithmic MB', (x.numel() + w.numel() + y.numel()) * 4 / 1e6)
