@@ -27,6 +27,7 @@ struct BfParams {
     int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo, relu;
     int64_t M;
     int mt, nt;
+    int cmajor;             // K order: 1 = channel-major (taps of a channel slice back to back), 0 = tap-major
 };
 
 __device__ __forceinline__ uint4 keep16(bool ok, uint4 v)
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 5)) void conv_bf16_kernel(
         b_off[i] = (unsigned)(b_ok[i] ? n : 0) * wrow + vcol * 8;
     }
     const int total_slices = p.kh * p.kw * (p.Ci / BK);
+    // K order: the kh*kw taps of one BK-channel slice back to back (see conv_fwd.hip: a tile re-reads its own footprint
+    // from L1/L2 instead of streaming the input once per tap through an L2 that the XCD's resident tiles overflow)
     int ld_ci0 = 0, ld_ky = 0, ld_kx = 0;
     unsigned ld_woff = 0;
     uint4 ra[PA], rb[PB];
@@ -113,11 +116,23 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 5)) void conv_bf16_kernel(
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const uint4 *>(p.w + b_off[i] + ld_woff);
-        ld_woff += BK;
-        ld_ci0 += BK;
-        if (ld_ci0 == p.Ci) {
-            ld_ci0 = 0;
-            if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
+        if (p.cmajor) {
+            ld_woff += (unsigned)p.Ci;
+            if (++ld_kx == p.kw) {
+                ld_kx = 0;
+                if (++ld_ky == p.kh) {
+                    ld_ky = 0;
+                    ld_ci0 += BK;
+                    ld_woff = (unsigned)ld_ci0;
+                }
+            }
+        } else {
+            ld_woff += BK;
+            ld_ci0 += BK;
+            if (ld_ci0 == p.Ci) {
+                ld_ci0 = 0;
+                if (++ld_kx == p.kw) { ld_kx = 0; ++ld_ky; }
+            }
         }
     };
     auto store_slice = [&]() {
@@ -242,6 +257,10 @@ static int launch_conv_bf16(const char *what, const void *x, const void *w, cons
     // not the tile's arithmetic intensity, decides) up to ~20 per CU.  Measured on the R101 layer set at B = 4:
     // 1x1 256->1024 at 50x84 209 -> 296 TFLOP/s, 1x1 128->512 at 100x168 154 -> 199, 3x3 256 at 50x84 408 -> 427, while
     // 3x3 256 at 100x168 (1050 big tiles) drops 688 -> 584 with the small tile and keeps the big one.
+    // measured: the fp32 kernel's L2 miss traffic drops 4x with the channel-major order at equal speed; here it costs
+    // 3-5 % on the large layers (703 -> 670 TFLOP/s at 200x336), so tap-major stays the default (HTD_BF16_CMAJOR=1 flips it)
+    static const int cmajor_env = getenv("HTD_BF16_CMAJOR") ? atoi(getenv("HTD_BF16_CMAJOR")) : 0;
+    p.cmajor = kh * kw > 1 ? cmajor_env : 0;
     static const int small_below = getenv("HTD_BF16_SMALL_TILES") ? atoi(getenv("HTD_BF16_SMALL_TILES")) : 768;
     static const int small_1x1_below = getenv("HTD_BF16_SMALL_TILES_1X1") ? atoi(getenv("HTD_BF16_SMALL_TILES_1X1")) : 5000;
     const int64_t big_tiles = htd::ceil_div(p.M, 128) * htd::ceil_div(Co, 128);
