@@ -3,7 +3,11 @@
 SGD update) on synthetic 1333x800 COCO-shaped batches, fp32, B=4 per MI355X (BASELINE.json configs[1]).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 started plainly: this process touches no GPU, starts `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` as a CHILD (one rank per GPU over RCCL, the
+launch of tools/dist_train.sh:7-9) and exits with its code.  Started under torch.distributed.run already (WORLD_SIZE
+in the environment) it is a rank; WORLD_SIZE != --gpus is an error, never a silent one-GPU run.
 
 Prints ONE JSON line on rank 0 (see the driver contract): whole-job images/sec, plus
   roofline     -- the dominant hand-written kernel of the step, timed live with device events on the stream
@@ -48,7 +52,29 @@ def parse():
     ap.add_argument('--proposals', type=int, default=512)
     ap.add_argument('--profile-kernels', action='store_true', help='print the per-kernel-class time table')
     ap.add_argument('--profile-detail', action='store_true', help='per-layer-shape time table (implies the above)')
+    ap.add_argument('--trained-like', action='store_true', help='force 128 stage-2 positives per image (what a trained '
+                    'detector yields) so the HTD regression branch (1.24 GFLOP per positive RoI) is inside the timed region; '
+                    'random-init weights give ~6 per image')
+    ap.add_argument('--dry-launch', action='store_true', help='launcher rehearsal on CPU: ranks rendezvous over gloo, take the '
+                    'barrier + MAX-over-ranks timing path and print the JSON line without touching a GPU (tests)')
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child job and return its exit code.  Nothing in
+    this process has initialised the GPU at this point (importing torch does not), and it never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                  # a free rendezvous port on the loopback interface
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    print(f'# bench.py: starting {args.gpus} ranks: {" ".join(cmd)}', file=sys.stderr)
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(depth, H, W):
@@ -102,11 +128,42 @@ def pipeline_batch(batch, dev, rank):
     return data, lambda: stager.run(resident, plan)
 
 
+def dry_launch(args, world, rank):
+    """The rank protocol of the real run without a GPU: gloo rendezvous, barrier, timed region, MAX over ranks, rank 0
+    prints the line.  n_gpus is the world size the process group reports, not the flag."""
+    if world > 1:
+        dist.init_process_group('gloo')
+    seen = dist.get_world_size() if dist.is_initialized() else 1
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if dist.is_initialized():
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher rehearsal (no GPU work)', 'value': 0.0, 'unit': 'images/sec', 'n_gpus': seen,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed * 1e3, 3),
+                          'config': {'workload': 'dry launch', 'global_batch': args.batch * seen, 'parallelism': f'dp{seen}'}}))
+
+
 def main():
     args = parse()
+    launched = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a '
+                         f'{args.gpus}-GPU number from {world} rank(s)')
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP ops have no CPU path)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -119,7 +176,9 @@ def main():
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
-    assert world == args.gpus or world == 1
+    n_ranks = dist.get_world_size() if dist.is_initialized() else 1      # what RCCL actually sees
+    if n_ranks != args.gpus and not rehearse:
+        raise SystemExit(f'bench.py: process group has {n_ranks} ranks, --gpus says {args.gpus}')
 
     from htd_amd import capi
     from htd_amd.configs import build_htd_detector
@@ -184,6 +243,7 @@ def main():
     if rank != 0:
         return
     ms = elapsed / args.steps * 1e3
+    world = n_ranks
     value = args.batch * world * args.steps / elapsed
 
     from htd_amd import dense

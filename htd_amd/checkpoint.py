@@ -9,7 +9,8 @@ exactly that, so the authors' released `.pth` files and torchvision ResNet weigh
   * convolution weights live in KRSC (channels_last) memory and the first RoI-head FC in (out,h,w,C) order --
     `load_state_dict` / `state_dict` convert through strides and TileLinear's hooks, the files keep logical shapes;
   * frozen BatchNorm statistics are ordinary buffers (the fold into the convolution happens at run time).
-Only local files: there is no network on this path (`torchvision://`, `open-mmlab://`, `http(s)://` raise).
+Only local files: there is no network on this path.  `torchvision://` / `open-mmlab://` names (the reference configs'
+`pretrained`) resolve to files in $HTD_PRETRAINED_DIR, `http(s)://` raises.
 """
 import os
 import time
@@ -21,9 +22,29 @@ _REMOTE = ('modelzoo://', 'torchvision://', 'open-mmlab://', 'openmmlab://', 'mm
 
 
 def _strip_prefix(state_dict, prefix='module.'):
-    if state_dict and all(k.startswith(prefix) for k in state_dict):
+    """mmcv 1.2.1 decides on the FIRST key (`if list(state_dict.keys())[0].startswith('module.')`) and then cuts
+    len(prefix) characters off every key."""
+    keys = list(state_dict.keys())
+    if keys and keys[0].startswith(prefix):
         return OrderedDict((k[len(prefix):], v) for k, v in state_dict.items())
     return state_dict
+
+
+def _resolve(filename):
+    """Local path for a checkpoint name.  `torchvision://resnet50`, `open-mmlab://...` (what the reference configs
+    put in `pretrained`, configs/htd/htd_resnet50_1x.py:7) are looked up as <name>.pth / <name>-*.pth in the directory
+    $HTD_PRETRAINED_DIR -- there is no network on this path, so the files have to be placed there."""
+    if filename.startswith(_REMOTE):
+        scheme, name = filename.split('://', 1)
+        cache = os.environ.get('HTD_PRETRAINED_DIR')
+        if scheme in ('torchvision', 'open-mmlab', 'openmmlab', 'modelzoo', 'mmcls') and cache and os.path.isdir(cache):
+            base = name.replace('/', '_')
+            for f in sorted(os.listdir(cache)):
+                if f == base + '.pth' or (f.startswith(base + '-') and f.endswith('.pth')):
+                    return os.path.join(cache, f)
+        raise IOError(f'{filename}: remote checkpoints are not available here (no network); download the file and pass '
+                      f'its local path, or put it as {name.replace("/", "_")}.pth into the directory named by HTD_PRETRAINED_DIR')
+    return filename
 
 
 def load_state_dict(module, state_dict, strict=False, logger=None):
@@ -55,15 +76,25 @@ def load_state_dict(module, state_dict, strict=False, logger=None):
     return missing, unexpected, mismatched
 
 
-def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None):
+def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None, trusted=None):
     """Load `filename` (a local .pth in the reference format, or a bare state_dict) into `model`; returns the
-    checkpoint dict (with 'meta' when present), like mmcv.runner.load_checkpoint."""
-    if filename.startswith(_REMOTE):
-        raise IOError(f'{filename}: remote checkpoints are not available here (no network); download the file and '
-                      'pass its local path')
+    checkpoint dict (with 'meta' when present), like mmcv.runner.load_checkpoint.
+
+    Files are read with torch.load(weights_only=True): tensors, containers and plain scalars only -- enough for every
+    file this package writes and for torchvision / mmdet weight files.  A checkpoint that pickles other objects in its
+    'meta' needs trusted=True (or HTD_TRUST_CHECKPOINTS=1): unpickling runs code chosen by whoever wrote the file."""
+    filename = _resolve(filename)
     if not os.path.isfile(filename):
         raise IOError(f'{filename} is not a checkpoint file')
-    checkpoint = torch.load(filename, map_location=map_location, weights_only=False)
+    if trusted is None:
+        trusted = os.environ.get('HTD_TRUST_CHECKPOINTS') == '1'
+    try:
+        checkpoint = torch.load(filename, map_location=map_location, weights_only=True)
+    except Exception as e:                          # pickle.UnpicklingError and friends
+        if not trusted:
+            raise RuntimeError(f'{filename} holds pickled objects beyond tensors and plain containers ({e}); pass '
+                               'trusted=True / set HTD_TRUST_CHECKPOINTS=1 only for files from a source you trust') from e
+        checkpoint = torch.load(filename, map_location=map_location, weights_only=False)
     if isinstance(checkpoint, dict) and 'state_dict' in checkpoint:
         state_dict = checkpoint['state_dict']
     elif isinstance(checkpoint, dict) and 'model' in checkpoint and isinstance(checkpoint['model'], dict):
@@ -85,7 +116,9 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
     state = OrderedDict((k, v.detach().cpu().contiguous()) for k, v in model.state_dict().items())
     ckpt = dict(meta=meta, state_dict=state)
     if optimizer is not None:
-        ckpt['optimizer'] = optimizer.state_dict() if hasattr(optimizer, 'state_dict') else optimizer
+        opt = optimizer.state_dict() if hasattr(optimizer, 'state_dict') else optimizer
+        ckpt['optimizer'] = dict(opt, state={k: {n: (t.detach().cpu() if torch.is_tensor(t) else t) for n, t in st.items()}
+                                             for k, st in opt.get('state', {}).items()})
     os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
     torch.save(ckpt, filename)
     return filename

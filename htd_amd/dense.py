@@ -41,18 +41,37 @@ def _splitk_ws(M, Co, Cred, kh, kw, device):
 # per step).  A slice is handed out once per step; further gradients of the same parameter (shared RPN convs, the
 # stage-1 classifier reused by stage 2) use fresh tensors, autograd sums them, and FlatParams.collect() copies any
 # gradient that did not end up in its slice.
-_GRAD_SINK = {}
-_SINK_USED = set()
+# The registry is keyed by the parameter's address but every entry carries a weak reference to the Parameter and
+# belongs to one FlatParams (its own "used this step" set): several trainers can coexist, a dropped trainer's entries
+# disappear with it (FlatParams.close / __del__), and an entry whose parameter died or moved is never handed out to
+# a later tensor that happens to be allocated at the same address.
+_GRAD_SINK = {}                 # data_ptr -> (slice view, weakref to the Parameter, owner's used-set)
 
 
-def register_grad_sinks(mapping):
-    _GRAD_SINK.clear()
-    _GRAD_SINK.update(mapping)
-    _SINK_USED.clear()
+def register_grad_sinks(params, views, used):
+    """params[i]'s gradient slice is views[i]; `used` is the owner's per-step set.  -> the keys registered."""
+    import weakref
+    keys = []
+    for p, v in zip(params, views):
+        _GRAD_SINK[p.data_ptr()] = (v, weakref.ref(p), used)
+        keys.append(p.data_ptr())
+    used.clear()
+    return keys
 
 
-def reset_grad_sinks():
-    _SINK_USED.clear()
+def unregister_grad_sinks(keys, used):
+    for k in keys:
+        ent = _GRAD_SINK.get(k)
+        if ent is not None and ent[2] is used:
+            del _GRAD_SINK[k]
+
+
+def reset_grad_sinks(used=None):
+    if used is not None:
+        used.clear()
+    else:
+        for ent in _GRAD_SINK.values():
+            ent[2].clear()
     _SIDE_CONSUMED.clear()
 
 
@@ -64,16 +83,22 @@ def grad_out(like):
 def grad_out2(like):
     """-> (tensor, is_sink)."""
     key = like.data_ptr()
-    v = _GRAD_SINK.get(key)
-    if v is not None and key not in _SINK_USED and v.numel() == like.numel() and torch.is_grad_enabled() is False:
+    ent = _GRAD_SINK.get(key)
+    if ent is not None:
+        v, ref, used = ent
+        owner = ref()
+        if owner is None or owner.data_ptr() != key:          # the parameter is gone or was re-pointed: stale entry
+            del _GRAD_SINK[key]
+            ent = None
+    if ent is not None and key not in used and v.numel() == like.numel() and torch.is_grad_enabled() is False:
         if v.shape == like.shape and v.stride() == like.stride():
-            _SINK_USED.add(key)
+            used.add(key)
             return v.view_as(v), True
         if like.dim() == 4 and like.shape[2:] == (1, 1) and like.size(0) == v.size(0):
             if v.dim() == 4 and v.is_contiguous(memory_format=CL):       # TileLinear: (out,C,h,w) stored (out,h,w,C)
                 v = v.permute(0, 2, 3, 1).reshape(v.size(0), -1)
             if v.dim() == 2 and v.is_contiguous():
-                _SINK_USED.add(key)                   # Linear weight seen as a 1x1 conv (channels_last view)
+                used.add(key)                         # Linear weight seen as a 1x1 conv (channels_last view)
                 return v.view(v.size(0), 1, 1, v.size(1)).permute(0, 3, 1, 2), True
     if like.dim() == 4:
         return torch.empty(like.shape, device=like.device, dtype=like.dtype, memory_format=CL), False

@@ -59,7 +59,19 @@ class FlatParams:
                     self.bucket_of[m] = b
                 members, hi = [], lo
         self.grad_views = [self._view(self.grad, p, o) for p, o in zip(self.params, offs)]
-        dense.register_grad_sinks({p.data_ptr(): v for p, v in zip(self.params, self.grad_views)})
+        self._sink_used = set()
+        self._sink_keys = dense.register_grad_sinks(self.params, self.grad_views, self._sink_used)
+
+    def close(self):
+        """Withdraw this buffer's gradient sinks (also runs when the object is collected)."""
+        dense.unregister_grad_sinks(getattr(self, '_sink_keys', ()), getattr(self, '_sink_used', None))
+        self._sink_keys = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def _view(flat, p, off):
@@ -73,7 +85,7 @@ class FlatParams:
         """Zero the flat gradient buffer and detach .grad: the kernels that produce parameter gradients write them
         straight into their slice (dense.grad_out) and autograd adopts that tensor; collect() repairs the rest."""
         self.grad.zero_()
-        dense.reset_grad_sinks()
+        dense.reset_grad_sinks(self._sink_used)
         for p in self.params:
             p.grad = None
 
@@ -167,11 +179,28 @@ class GradientExchange:
 
 
 class WarmupStepLR:
-    """lr policy 'step' with linear warm-up (schedule_1x.py:5-10): warmup_iters=500, warmup_ratio=0.001."""
+    """lr policy 'step' with linear warm-up (schedule_1x.py:5-10): warmup_iters=500, warmup_ratio=0.001.
+    `iters_per_epoch` = len(dataset) / (world * samples_per_gpu) places the decay points; 7330 is COCO train2017
+    (117 266 images after filtering) at the reference's 8 x 2 images."""
 
     def __init__(self, base_lr, steps=(8, 11), gamma=0.1, warmup_iters=500, warmup_ratio=0.001, iters_per_epoch=7330):
-        self.base_lr, self.steps, self.gamma = base_lr, steps, gamma
+        self.base_lr, self.steps, self.gamma = base_lr, tuple(steps), gamma
         self.warmup_iters, self.warmup_ratio, self.iters_per_epoch = warmup_iters, warmup_ratio, iters_per_epoch
+
+    @classmethod
+    def from_cfg(cls, cfg, iters_per_epoch):
+        """From the reference's config keys: cfg.optimizer.lr, cfg.lr_config{policy, step, gamma, warmup, warmup_iters,
+        warmup_ratio} (configs/_base_/schedules/schedule_1x.py:2-10, configs/htd/htd_resnet101_2x.py:119-127: step
+        [16, 22] for the 2x configs).  iters_per_epoch must be given: it depends on the data set and the global batch."""
+        lc = cfg['lr_config']
+        if lc.get('policy', 'step') != 'step':
+            raise NotImplementedError(f"lr policy {lc.get('policy')!r}: the HTD configs use 'step'")
+        if lc.get('warmup', 'linear') not in ('linear', None):
+            raise NotImplementedError(f"warmup {lc.get('warmup')!r}: the HTD configs use 'linear'")
+        step = lc['step']
+        return cls(cfg['optimizer']['lr'], steps=[step] if isinstance(step, int) else list(step), gamma=lc.get('gamma', 0.1),
+                   warmup_iters=lc.get('warmup_iters', 0) if lc.get('warmup') else 0,
+                   warmup_ratio=lc.get('warmup_ratio', 0.1), iters_per_epoch=int(iters_per_epoch))
 
     def lr(self, it):
         epoch = it // self.iters_per_epoch
@@ -186,14 +215,119 @@ class Trainer:
     """train_step loop: zero_grad -> losses = model(**data) -> _parse_losses -> backward (+ overlapped gradient
     all-reduce) -> fused SGD update.  `data` = dict(img, img_metas, gt_bboxes, gt_labels)."""
 
-    def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, schedule=None, bucket_mb=64):
+    def __init__(self, model, lr=0.02, momentum=0.9, weight_decay=1e-4, schedule=None, bucket_mb=64, cfg=None,
+                 iters_per_epoch=None):
+        """cfg (+ iters_per_epoch): take lr / momentum / weight_decay / schedule from the reference's config keys
+        (cfg.optimizer, cfg.lr_config) instead of the keyword defaults."""
+        if cfg is not None:
+            opt = cfg['optimizer']
+            if opt.get('type', 'SGD') != 'SGD':
+                raise NotImplementedError(f"optimizer {opt.get('type')!r}: the HTD configs use SGD")
+            lr, momentum, weight_decay = opt['lr'], opt.get('momentum', 0.0), opt.get('weight_decay', 0.0)
+            if schedule is None:
+                if iters_per_epoch is None:
+                    raise ValueError('Trainer(cfg=...) needs iters_per_epoch = len(dataset) / (world * samples_per_gpu)')
+                schedule = WarmupStepLR.from_cfg(cfg, iters_per_epoch)
         self.model = model
         self.flat = FlatParams(model, bucket_mb)
         self.exchange = GradientExchange(self.flat)
         self.momentum, self.weight_decay = momentum, weight_decay
-        self.schedule = schedule or WarmupStepLR(lr)
+        self.schedule = schedule or WarmupStepLR(lr, iters_per_epoch=iters_per_epoch or 7330)
         self.lr_dev = torch.zeros(1, device=self.flat.flat.device)
         self.iter = 0
+        self.sync_from_rank0()
+
+    def sync_from_rank0(self):
+        """What DistributedDataParallel does at construction (apis/train.py:72-80): every rank starts from rank 0's
+        parameters and buffers.  Gradients are averaged, so ranks that start apart (different seed, a checkpoint
+        loaded on rank 0 only) would otherwise stay apart silently."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        dist.broadcast(self.flat.flat, src=0)
+        frozen = [p for p in self.model.parameters() if not p.requires_grad]
+        for t in frozen + list(self.model.buffers()):
+            if t.numel():
+                if t.is_contiguous():
+                    dist.broadcast(t.data, src=0)
+                else:                                       # channels_last conv weights: dense in memory, not "contiguous"
+                    buf = t.data.contiguous()
+                    dist.broadcast(buf, src=0)
+                    t.data.copy_(buf)
+        M.PARAM_EPOCH += 1                                  # folded-weight caches see new parameters
+
+    # ------------------------------------------------------------------ optimizer state / resume (apis/train.py:146-149)
+    @property
+    def epoch(self):
+        return self.iter // self.schedule.iters_per_epoch
+
+    def _numbering(self):
+        """Index of every trainable parameter in the optimizer's numbering.  mmcv's DefaultOptimizerConstructor hands
+        `model.parameters()` -- frozen ones included -- to torch.optim.SGD (apis/train.py:86), so the indices of a
+        reference checkpoint count ALL parameters in module order; frozen ones simply never get a state entry."""
+        pos = {id(p): i for i, p in enumerate(self.model.parameters())}
+        return [pos[id(p)] for p in self.flat.params], len(pos)
+
+    def state_dict(self):
+        """torch.optim.SGD-shaped state (what mmcv's CheckpointHook stores under 'optimizer'): momentum buffers are
+        per-parameter tensors in the parameter's logical shape, numbered like the reference's optimizer."""
+        idx, n_all = self._numbering()
+        state = {}
+        for i, p, o in zip(idx, self.flat.params, self.flat.offsets):
+            state[i] = {'momentum_buffer': FlatParams._view(self.flat.momentum, p, o).detach().clone().contiguous()}
+        group = dict(lr=self.schedule.lr(self.iter), momentum=self.momentum, dampening=0, weight_decay=self.weight_decay,
+                     nesterov=False, initial_lr=self.schedule.base_lr, params=list(range(n_all)))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        idx, n_all = self._numbering()
+        groups = sd.get('param_groups', [])
+        n = sum(len(g['params']) for g in groups)
+        if n == len(idx) and n != n_all:
+            idx = list(range(n))                            # a file that numbered the trainable parameters only
+        elif n != n_all:
+            raise ValueError(f'optimizer state numbers {n} parameters, the model has {n_all} ({len(idx)} trainable)')
+        if groups:
+            self.momentum = groups[0].get('momentum', self.momentum)
+            self.weight_decay = groups[0].get('weight_decay', self.weight_decay)
+        where = {i: k for k, i in enumerate(idx)}
+        self.flat.momentum.zero_()
+        for i, st in sd.get('state', {}).items():
+            buf = st.get('momentum_buffer')
+            if buf is None:
+                continue
+            if int(i) not in where:
+                raise ValueError(f'optimizer state entry {int(i)} belongs to a parameter that is frozen here')
+            k = where[int(i)]
+            p, o = self.flat.params[k], self.flat.offsets[k]
+            if tuple(buf.shape) != tuple(p.shape):
+                raise ValueError(f'momentum buffer {int(i)}: shape {tuple(buf.shape)} vs parameter {tuple(p.shape)}')
+            FlatParams._view(self.flat.momentum, p, o).copy_(buf)
+
+    def save_checkpoint(self, filename, meta=None):
+        """CheckpointHook's file: {'meta': {epoch, iter, ...}, 'state_dict', 'optimizer'}."""
+        from .checkpoint import save_checkpoint
+        meta = dict(meta or {})
+        meta.update(epoch=self.epoch, iter=self.iter)
+        return save_checkpoint(self.model, filename, optimizer=self.state_dict(), meta=meta)
+
+    def resume(self, filename, map_location='cpu'):
+        """runner.resume (apis/train.py:146-147): weights, optimizer state, epoch and iteration -- the LR schedule
+        continues where it stopped (no second warm-up)."""
+        from .checkpoint import load_checkpoint
+        ckpt = load_checkpoint(self.model, filename, map_location=map_location, strict=True)
+        if 'optimizer' in ckpt:
+            self.load_state_dict(ckpt['optimizer'])
+        meta = ckpt.get('meta', {})
+        self.iter = int(meta.get('iter', meta.get('epoch', 0) * self.schedule.iters_per_epoch))
+        M.PARAM_EPOCH += 1
+        return ckpt
+
+    def load_checkpoint(self, filename, map_location='cpu', strict=False):
+        """runner.load_checkpoint (cfg.load_from, apis/train.py:148-149): weights only, training starts at iteration 0."""
+        from .checkpoint import load_checkpoint
+        ckpt = load_checkpoint(self.model, filename, map_location=map_location, strict=strict)
+        M.PARAM_EPOCH += 1
+        return ckpt
 
     def train_step(self, data):
         self.flat.zero_grad()

@@ -260,3 +260,119 @@ def test_bbox_mapping_round_trip_and_aug_merge():
     torch.testing.assert_close(merged, a)
     torch.testing.assert_close(scores, torch.tensor([[.3, .6, .1]]))
     torch.testing.assert_close(merge_aug_scores([torch.ones(2), torch.zeros(2)]), torch.full((2,), .5))
+
+
+class _TinyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.frozen = torch.nn.Conv2d(3, 4, 3, padding=1)          # numbered by the reference's optimizer, never updated
+        for p in self.frozen.parameters():
+            p.requires_grad_(False)
+        self.conv = torch.nn.Conv2d(4, 6, 3, padding=1).to(memory_format=torch.channels_last)
+        self.fc = torch.nn.Linear(6, 2)
+
+    def train_step(self, data, optimizer):
+        y = self.conv(self.frozen(data)).mean((2, 3))
+        return dict(loss=self.fc(y).pow(2).mean())
+
+
+def test_trainer_state_dict_resume_continues_exactly(tmp_path):
+    """ADVICE r1 / apis/train.py:146-149: a checkpoint carries momentum and iteration, resume continues the warm-up /
+    step schedule where it stopped and reproduces the uninterrupted run bit for bit; the 'optimizer' entry has
+    torch.optim.SGD's shape with the reference's numbering (frozen parameters counted, without state)."""
+    from htd_amd.runner import Trainer, WarmupStepLR
+    sched = lambda: WarmupStepLR(0.1, steps=(1, ), warmup_iters=4, warmup_ratio=0.1, iters_per_epoch=3)
+    g = torch.Generator().manual_seed(0)
+    batches = [torch.randn(2, 3, 5, 5, generator=g) for _ in range(6)]
+    torch.manual_seed(1)
+    a = Trainer(_TinyNet(), schedule=sched())
+    for b in batches[:3]:
+        a.train_step(b)
+    a.save_checkpoint(str(tmp_path / 'epoch_1.pth'), meta=dict(CLASSES=('x', )))
+    for b in batches[3:]:
+        a.train_step(b)
+    ck = torch.load(tmp_path / 'epoch_1.pth', weights_only=True)
+    assert ck['meta']['iter'] == 3 and ck['meta']['epoch'] == 1
+    opt = ck['optimizer']
+    assert opt['param_groups'][0]['params'] == list(range(6)) and sorted(opt['state']) == [2, 3, 4, 5]
+    assert opt['state'][2]['momentum_buffer'].shape == (6, 4, 3, 3)
+    ref = torch.optim.SGD(_TinyNet().parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    ref.load_state_dict(opt)                                        # torch's own optimizer accepts the entry
+    torch.manual_seed(2)                                            # different init: everything must come from the file
+    b2 = Trainer(_TinyNet(), schedule=sched())
+    b2.resume(str(tmp_path / 'epoch_1.pth'))
+    assert b2.iter == 3 and b2.schedule.lr(b2.iter) == a.schedule.lr(3)
+    for b in batches[3:]:
+        b2.train_step(b)
+    assert torch.equal(a.flat.flat, b2.flat.flat) and torch.equal(a.flat.momentum, b2.flat.momentum)
+    # load_from semantics: weights only, iteration 0
+    c = Trainer(_TinyNet(), schedule=sched())
+    c.load_checkpoint(str(tmp_path / 'epoch_1.pth'))
+    assert c.iter == 0 and float(c.flat.momentum.abs().sum()) == 0.0
+    assert torch.equal(c.model.conv.weight, ck['state_dict']['conv.weight'])
+
+
+def test_lr_schedule_comes_from_the_config():
+    """R101 configs decay at epochs 16 / 22 of 24 (configs/htd/htd_resnet101_2x.py:119-127), R50 at 8 / 11."""
+    from htd_amd.configs import htd_config
+    from htd_amd.runner import Trainer, WarmupStepLR
+    s50 = WarmupStepLR.from_cfg(htd_config(50), iters_per_epoch=100)
+    s101 = WarmupStepLR.from_cfg(htd_config(101), iters_per_epoch=100)
+    assert s50.base_lr == 0.02 and s101.base_lr == 0.015
+    assert abs(s50.lr(0) - 0.02 * 0.001) < 1e-12 and abs(s50.lr(250) - 0.02 * (1 - 0.5 * 0.999)) < 1e-12
+    assert s50.lr(799) == 0.02 and abs(s50.lr(800) - 0.002) < 1e-12 and abs(s50.lr(1100) - 0.0002) < 1e-12
+    assert s101.lr(1599) == 0.015 and abs(s101.lr(1600) - 0.0015) < 1e-12 and abs(s101.lr(2200) - 0.00015) < 1e-12
+    with pytest.raises(ValueError):
+        Trainer(_TinyNet(), cfg=htd_config(101))                    # iters_per_epoch is not guessable
+    t = Trainer(_TinyNet(), cfg=htd_config(101), iters_per_epoch=50)
+    assert t.schedule.steps == (16, 22) and t.schedule.iters_per_epoch == 50 and t.weight_decay == 0.0001
+
+
+def test_checkpoint_loader_rules(tmp_path, monkeypatch):
+    """mmcv 1.2.1's prefix rule (first key decides), safe unpickling by default, pretrained:// names from a local dir."""
+    from htd_amd.checkpoint import load_checkpoint
+    net = torch.nn.Linear(3, 2)
+    sd = {'module.weight': torch.ones(2, 3), 'module.bias': torch.zeros(2)}
+    torch.save(dict(state_dict=sd), tmp_path / 'a.pth')
+    load_checkpoint(net, str(tmp_path / 'a.pth'), strict=True)
+    assert float(net.weight.detach().sum()) == 6.0
+
+    import pickle
+    with open(tmp_path / 'b.pth', 'wb') as f:                       # a pickled foreign object: needs explicit trust
+        pickle.dump(dict(state_dict={k: v.detach().numpy() for k, v in net.state_dict().items()},
+                         meta=dict(obj=pytest.approx(1.0))), f)
+    with pytest.raises(RuntimeError, match='trust'):
+        load_checkpoint(net, str(tmp_path / 'b.pth'))
+    (tmp_path / 'zoo').mkdir()
+    torch.save(net.state_dict(), tmp_path / 'zoo' / 'resnet50-19c8e357.pth')
+    monkeypatch.setenv('HTD_PRETRAINED_DIR', str(tmp_path / 'zoo'))
+    load_checkpoint(net, 'torchvision://resnet50', strict=True)
+    with pytest.raises(IOError):
+        load_checkpoint(net, 'torchvision://resnet101')
+
+
+def test_gradient_sinks_are_scoped_to_their_trainer():
+    """a second FlatParams must not disable the first one's sinks, and a dropped one must not leave entries
+    that a later tensor at the same address could pick up."""
+    import gc
+    from htd_amd import dense
+    from htd_amd.runner import FlatParams
+    n0 = len(dense._GRAD_SINK)
+    a, b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    fa, fb = FlatParams(a), FlatParams(b)
+    assert len(dense._GRAD_SINK) == n0 + 4
+    with torch.no_grad():
+        ga, used_a = dense.grad_out2(a.weight)
+        gb, used_b = dense.grad_out2(b.weight)
+    assert used_a and used_b and ga.data_ptr() == fa.grad_views[0].data_ptr() and gb.data_ptr() == fb.grad_views[0].data_ptr()
+    with torch.no_grad():
+        assert not dense.grad_out2(a.weight)[1]                     # handed out once per step
+    fa.zero_grad()
+    with torch.no_grad():
+        assert dense.grad_out2(a.weight)[1] and not dense.grad_out2(b.weight)[1]      # a's reset does not touch b's
+    key = a.weight.data_ptr()
+    del fa
+    gc.collect()
+    assert key not in dense._GRAD_SINK and len(dense._GRAD_SINK) == n0 + 2
+    fb.close()
+    assert len(dense._GRAD_SINK) == n0
