@@ -276,6 +276,8 @@ class RPNHead(nn.Module):
         featmap_sizes = [c.shape[-2:] for c in cls_scores]
         mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
         scores_l, deltas_l, anchors_l, seg_sizes = [], [], [], []
+        record = getattr(self, 'record_trail', False)       # tests: which candidates survive, in which order
+        flat_ids, level_off = [], 0
         for lvl in range(len(cls_scores)):
             s = cls_scores[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
             d = bbox_preds[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1, 4)
@@ -286,6 +288,9 @@ class RPNHead(nn.Module):
             deltas_l.append(torch.gather(d, 1, idx[..., None].expand(B, k, 4)))
             anchors_l.append(mlvl_anchors[lvl][idx])
             seg_sizes.append(k)
+            if record:
+                flat_ids.append(idx + level_off)
+                level_off += s.size(1)
         scores = torch.cat(scores_l, 1)                       # (B, K): level-major, descending inside a level
         K = scores.size(1)
         deltas = torch.cat(deltas_l, 1).reshape(B * K, 4)
@@ -329,6 +334,10 @@ class RPNHead(nn.Module):
         top, order = masked.sort(dim=1, descending=True, stable=True)
         n_keep = keep.sum(1).clamp(max=cfg.nms_post)
         order = order[:, :cfg.nms_post]
+        if record:
+            # rows of the level-concatenated candidate list in kept order (= `keep` of rpn_head.py:166-168) and the
+            # anchor each of them is (flat index over the levels); entries past n_keep[b] are meaningless
+            self._last_proposal_trail = (order, torch.gather(torch.cat(flat_ids, 1), 1, order), n_keep)
         boxes = torch.gather(proposals, 1, order[..., None].expand(-1, -1, 4))
         dets = torch.cat([boxes, top[:, :cfg.nms_post, None]], -1)
         if padded:

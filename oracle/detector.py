@@ -163,21 +163,27 @@ def rpn_loss(cls_scores, bbox_preds, gt_bboxes, img_metas, cfg, strides):
     return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
 
 
-def rpn_get_bboxes(cls_scores, bbox_preds, img_metas, pcfg, cfg, strides):
-    """AnchorHead.get_bboxes anchor_head.py:491-579 + RPNHead._get_bboxes_single rpn_head.py:78-168."""
+def rpn_get_bboxes(cls_scores, bbox_preds, img_metas, pcfg, cfg, strides, trace=None):
+    """AnchorHead.get_bboxes anchor_head.py:491-579 + RPNHead._get_bboxes_single rpn_head.py:78-168.
+    trace (list): per image (keep rows of the level-concatenated candidate list, flat anchor index of each kept box)."""
     sizes = [c.shape[-2:] for c in cls_scores]
+    level_off = [0]
+    for c in cls_scores:
+        level_off.append(level_off[-1] + int(c.shape[1] * c.shape[2] * c.shape[3]))
     mlvl_anchors = B.grid_anchors(sizes, strides, cfg['anchor_scales'], cfg['anchor_ratios'])
     results = []
     for img_id, meta in enumerate(img_metas):
-        scores_l, preds_l, anch_l, ids_l = [], [], [], []
+        scores_l, preds_l, anch_l, ids_l, flat_l = [], [], [], [], []
         for idx in range(len(cls_scores)):
             s = cls_scores[idx][img_id].detach().permute(1, 2, 0).reshape(-1).sigmoid()
             p = bbox_preds[idx][img_id].detach().permute(1, 2, 0).reshape(-1, 4)
             a = mlvl_anchors[idx]
+            topk = torch.arange(s.shape[0])
             if pcfg['nms_pre'] > 0 and s.shape[0] > pcfg['nms_pre']:
                 ranked, rank_inds = s.sort(descending=True, stable=True)
                 topk = rank_inds[:pcfg['nms_pre']]
                 s, p, a = ranked[:pcfg['nms_pre']], p[topk, :], a[topk, :]
+            flat_l.append(topk + level_off[idx])
             scores_l.append(s)
             preds_l.append(p)
             anch_l.append(a)
@@ -188,7 +194,10 @@ def rpn_get_bboxes(cls_scores, bbox_preds, img_metas, pcfg, cfg, strides):
             w, h = proposals[:, 2] - proposals[:, 0], proposals[:, 3] - proposals[:, 1]
             v = (w >= pcfg['min_bbox_size']) & (h >= pcfg['min_bbox_size'])
             proposals, scores, ids = proposals[v], scores[v], ids[v]
-        dets, _ = ops.batched_nms(proposals, scores, ids, dict(type='nms', iou_threshold=pcfg['nms_thr']))
+            flat_l = [torch.cat(flat_l)[v]]
+        dets, keep = ops.batched_nms(proposals, scores, ids, dict(type='nms', iou_threshold=pcfg['nms_thr']))
+        if trace is not None:
+            trace.append((keep[:pcfg['nms_post']], torch.cat(flat_l)[keep[:pcfg['nms_post']]]))
         results.append(dets[:pcfg['nms_post']])
     return results
 
@@ -429,7 +438,7 @@ def roi_head_forward_train(sd, x, img_metas, proposal_list, gt_bboxes, gt_labels
     return losses
 
 
-def roi_head_simple_test(sd, x, proposal_list, img_metas, cfg):
+def roi_head_simple_test(sd, x, proposal_list, img_metas, cfg, trace=None):
     """HTDRoIHead.simple_test, htd_roi_head.py:319-386 -> list (per image) of (dets (k,5), labels (k,))."""
     n_per = [len(p) for p in proposal_list]
     rois = B.bbox2roi(proposal_list)
@@ -441,6 +450,8 @@ def roi_head_simple_test(sd, x, proposal_list, img_metas, cfg):
     bbox_feats = single_roi_extract(x[:4], rois, cfg['roi_strides'])
     enhanced = ba_extract(sd, x[:4], rois, cfg['roi_strides'], cfg['edge'])
     cls1, reg1 = htd_bbox_head_forward(sd, bbox_feats, bbox_feats, rois, enhanced, rois, gfeat, cfg['alpha'])
+    if trace is not None:
+        trace.update(rois0=B.bbox2roi(proposal_list), cls0=cls0, reg0=reg0, rois1=rois, cls1=cls1, reg1=reg1)
     out = []
     rc = cfg['test_cfg']['rcnn']
     for r, c0, c1, p, m in zip(rois.split(n_per), cls0.split(n_per), cls1.split(n_per), reg1.split(n_per), img_metas):

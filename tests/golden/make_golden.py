@@ -554,6 +554,15 @@ def gen_detector():
                   scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(B)]
     gts = [np.minimum(g, np.array([W - 3, H, W - 3, H], dtype=np.float32)) for g in gts]
     img_t = torch.from_numpy(imgs)
+    # trail of the RoI head: what each stage was fed and what it answered (north_star: logits within 1e-4)
+    trail = {}
+    orig_bf = det.roi_head._bbox_forward
+
+    def rec_bf(stage, x, rois, *a, **k):
+        r = orig_bf(stage, x, rois, *a, **k)
+        trail[stage] = (rois.detach().clone(), r['cls_score'].detach().clone(), r['bbox_pred'].detach().clone())
+        return r
+    det.roi_head._bbox_forward = rec_bf
     torch.manual_seed(77)
     losses = det.forward_train(img_t, metas, [torch.from_numpy(g) for g in gts],
                                [torch.from_numpy(l) for l in labels])
@@ -571,6 +580,8 @@ def gen_detector():
         gr = sd[k].grad
         put_digest(grads, 'grad.' + k, gr if gr is not None else torch.zeros_like(sd[k]))
     out = dict(H=H, W=W, seed_sampler=77, img_w=W - 3)
+    for st in (0, 1):
+        out[f'train_s{st}_rois'], out[f'train_s{st}_cls'], out[f'train_s{st}_reg'] = trail[st]
     for i in range(B):
         out[f'gt{i}'] = gts[i]
         out[f'label{i}'] = labels[i]
@@ -579,10 +590,47 @@ def gen_detector():
     out.update(grads)
     # inference
     det.eval()
+    # trail of the proposal stage: the NMS call of every image (rpn_head.py:166-167) with its candidates and keep
+    rpn_mod = sys.modules['mmdet.models.dense_heads.rpn_head']
+    nms_calls = []
+    orig_nms = rpn_mod.batched_nms
+
+    def rec_nms(boxes, scores, ids, cfg):
+        dets, keep = orig_nms(boxes, scores, ids, cfg)
+        nms_calls.append((boxes.clone(), scores.clone(), ids.clone(), keep.clone()))
+        return dets, keep
+    rpn_mod.batched_nms = rec_nms
     with torch.no_grad():
         feats = det.extract_feat(img_t)
-        props = det.rpn_head.simple_test_rpn(feats, metas)
+        rpn_cls, rpn_reg = det.rpn_head(feats)
+        props = det.rpn_head.get_bboxes(rpn_cls, rpn_reg, metas)      # = simple_test_rpn (rpn_test_mixin.py:24-37)
         res = det.roi_head.simple_test(feats, props, metas, rescale=False)
+    rpn_mod.batched_nms = orig_nms
+    assert len(nms_calls) == B
+    for l in range(len(rpn_cls)):
+        out[f'rpn_cls{l}'] = rpn_cls[l]
+        out[f'rpn_reg{l}'] = rpn_reg[l]
+    level_off = np.cumsum([0] + [int(c.shape[1] * c.shape[2] * c.shape[3]) for c in rpn_cls])
+    for i in range(B):
+        boxes_i, scores_i, ids_i, keep_i = nms_calls[i]
+        # anchor identity of every candidate: the same sort the reference ran (rpn_head.py:135-137), per level
+        flat_ids = []
+        for l in range(len(rpn_cls)):
+            sc = rpn_cls[l][i].permute(1, 2, 0).reshape(-1).sigmoid()
+            if test_cfg.rpn.nms_pre > 0 and sc.shape[0] > test_cfg.rpn.nms_pre:
+                ranked, rank_inds = sc.sort(descending=True)
+                rank_inds, ranked = rank_inds[:test_cfg.rpn.nms_pre], ranked[:test_cfg.rpn.nms_pre]
+            else:
+                rank_inds, ranked = torch.arange(sc.shape[0]), sc
+            assert torch.equal(ranked, scores_i[ids_i == l])
+            flat_ids.append(rank_inds + int(level_off[l]))
+        flat_ids = torch.cat(flat_ids)
+        keep_i = keep_i[:test_cfg.rpn.nms_post]
+        out[f'test_keep{i}'] = keep_i                         # rows of the level-concatenated candidate list, kept order
+        out[f'test_prop_anchor{i}'] = flat_ids[keep_i]        # ... and which anchor of the image each of them is
+        assert torch.equal(boxes_i[keep_i], props[i][:, :4])
+    for st in (0, 1):
+        out[f'test_s{st}_rois'], out[f'test_s{st}_cls'], out[f'test_s{st}_reg'] = trail[st]
     for i in range(B):
         out[f'test_props{i}'] = props[i]
         out[f'test_dets{i}'] = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, dtype=np.float32)], 1)

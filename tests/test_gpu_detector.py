@@ -104,6 +104,75 @@ def test_inference_matches_reference_fixture(det, golden):
             used[j] = True
 
 
+def test_proposal_indices_and_stage_logits_match_reference_fixture(det, golden):
+    """north_star's parity clause at path level.  (1) Fed the RPN logits of the reference run (detector.npz), the
+    product's proposal stage -- per-level sort, decode, one batched NMS launch -- keeps the SAME candidates in the SAME
+    order: torch.equal on the keep rows and on the anchor identity of every proposal (rpn_head.py:122-168).  (2) Its
+    own RPN logits are within 1e-4 of the reference's.  (3) Fed the reference's stage inputs, both RoI stages (RoIAlign,
+    SFA fuse, FC stacks, BA, PGraph, regression branch) give cls / box logits within 1e-4."""
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, _, _ = inputs(g, dev)
+    det.eval()
+    rpn = det.rpn_head
+    cls = [T(g[f'rpn_cls{l}']).to(dev) for l in range(5)]
+    reg = [T(g[f'rpn_reg{l}']).to(dev) for l in range(5)]
+    rpn.record_trail = True
+    try:
+        with torch.no_grad():
+            props = rpn.get_bboxes(cls, reg, metas)
+        order, anchor_ids, n_keep = rpn._last_proposal_trail
+    finally:
+        rpn.record_trail = False
+    for i in range(2):
+        k = int(n_keep[i])
+        assert k == len(g[f'test_keep{i}'])
+        assert torch.equal(order[i, :k].cpu(), T(g[f'test_keep{i}']))
+        assert torch.equal(anchor_ids[i, :k].cpu(), T(g[f'test_prop_anchor{i}']))
+        # same logits, same candidates: boxes differ only by the device's exp / sigmoid rounding
+        np.testing.assert_allclose(props[i].cpu().numpy(), g[f'test_props{i}'], rtol=1e-5, atol=1e-4)
+    with torch.no_grad():
+        feats = det.extract_feat(img)
+        own_cls, own_reg = rpn(feats)
+        for l in range(5):
+            torch.testing.assert_close(own_cls[l].cpu(), T(g[f'rpn_cls{l}']), rtol=0, atol=1e-4)
+            torch.testing.assert_close(own_reg[l].cpu(), T(g[f'rpn_reg{l}']), rtol=0, atol=1e-4)
+        head = det.roi_head
+        gfeat = head.glbctx_head(feats)[1]
+        for st in (0, 1):
+            res = head._bbox_forward(st, feats, T(g[f'test_s{st}_rois']).to(dev), gfeat)
+            torch.testing.assert_close(res['cls_score'].cpu(), T(g[f'test_s{st}_cls']), rtol=0, atol=1e-4)
+            torch.testing.assert_close(res['bbox_pred'].cpu(), T(g[f'test_s{st}_reg']), rtol=0, atol=1e-4)
+
+
+def test_train_stage_logits_match_reference_fixture(det, golden):
+    """Training path, sampler replayed from the CPU generator: the rois each stage is fed and the logits it answers
+    with, against the reference run (train_s{0,1}_* of detector.npz), logits within 1e-4."""
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, gts, labels = inputs(g, dev)
+    det.train()
+    head = det.roi_head
+    trail = {}
+    orig = head._bbox_forward
+
+    def rec(stage, x, rois, *a, **k):
+        r = orig(stage, x, rois, *a, **k)
+        trail[stage] = (rois.detach().cpu(), r['cls_score'].detach().cpu(), r['bbox_pred'].detach().cpu())
+        return r
+    head._bbox_forward = rec
+    try:
+        torch.manual_seed(int(g['seed_sampler']))
+        det.forward_train(img, metas, gts, labels)
+    finally:
+        del head._bbox_forward
+    for st in (0, 1):
+        rois, cls, reg = trail[st]
+        torch.testing.assert_close(rois, T(g[f'train_s{st}_rois']), rtol=0, atol=1e-3)
+        torch.testing.assert_close(cls, T(g[f'train_s{st}_cls']), rtol=0, atol=1e-4)
+        torch.testing.assert_close(reg, T(g[f'train_s{st}_reg']), rtol=0, atol=1e-4)
+
+
 class ReplaySampler:
     """Stands in for RandomSampler.sample with the (pos, neg) index sets the oracle drew, so that the
     comparison below is between continuous quantities only: a one-ulp difference in a box coordinate can move

@@ -219,6 +219,46 @@ def test_detector_train_and_test(golden):
         np.testing.assert_allclose(mine[:, :5], refs[:, :5], rtol=1e-3, atol=1e-2)
 
 
+def test_detector_index_trail_and_stage_logits(golden):
+    """north_star's parity clause at path level, oracle side: fed the reference run's RPN logits, the proposal stage
+    keeps the SAME candidates in the SAME order (torch.equal on the keep rows and on the anchor identity of every
+    proposal, rpn_head.py:122-168); fed its stage inputs, both RoI stages answer with the reference's cls / box logits
+    within 1e-4 -- in the test path and in the training path (sampler replayed)."""
+    g = golden('detector')
+    cfg = small_cfg()
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+          for k, v in seeded_state_dict(D.state_shapes(50), prefix='det.').items()}
+    img, metas, gts, labels = detector_inputs(g)
+    cls = [T(g[f'rpn_cls{l}']) for l in range(5)]
+    reg = [T(g[f'rpn_reg{l}']) for l in range(5)]
+    trace = []
+    props = D.rpn_get_bboxes(cls, reg, metas, cfg['test_cfg']['rpn'], cfg, cfg['strides'], trace=trace)
+    for i in range(2):
+        keep, anchor_ids = trace[i]
+        assert torch.equal(keep, T(g[f'test_keep{i}']))
+        assert torch.equal(anchor_ids, T(g[f'test_prop_anchor{i}']))
+        assert torch.equal(props[i], T(g[f'test_props{i}']))                  # same arithmetic on the same logits: exact
+    with torch.no_grad():
+        x = D.extract_feat(sd, img, cfg)
+        own_cls, own_reg = D.rpn_forward(sd, x)
+        for l in range(5):                                                    # the oracle's own RPN logits
+            torch.testing.assert_close(own_cls[l], cls[l], rtol=0, atol=1e-4)
+            torch.testing.assert_close(own_reg[l], reg[l], rtol=0, atol=1e-4)
+        tr = {}
+        D.roi_head_simple_test(sd, x, [T(g[f'test_props{i}']) for i in range(2)], metas, cfg, trace=tr)
+    for st in (0, 1):
+        torch.testing.assert_close(tr[f'rois{st}'], T(g[f'test_s{st}_rois']), rtol=0, atol=1e-3)
+        torch.testing.assert_close(tr[f'cls{st}'], T(g[f'test_s{st}_cls']), rtol=0, atol=1e-4)
+        torch.testing.assert_close(tr[f'reg{st}'], T(g[f'test_s{st}_reg']), rtol=0, atol=1e-4)
+    torch.manual_seed(int(g['seed_sampler']))
+    tr = {}
+    D.forward_train(sd, img, metas, gts, labels, cfg, tr)
+    for st in (0, 1):
+        torch.testing.assert_close(tr[f'rois{st}'], T(g[f'train_s{st}_rois']), rtol=0, atol=1e-3)
+        torch.testing.assert_close(tr[f'cls{st}'].detach(), T(g[f'train_s{st}_cls']), rtol=0, atol=1e-4)
+        torch.testing.assert_close(tr[f'reg{st}'].detach(), T(g[f'train_s{st}_reg']), rtol=0, atol=1e-4)
+
+
 def test_aug_test_matches_reference_fixture(golden):
     """Test-time augmentation (two_stage.py:213-222, rpn_test_mixin.py:39-59, htd_roi_head.py:388-433, merge_augs.py):
     the oracle's restatement against the outputs of the reference's own aug_test (tests/golden/aug_test.npz)."""
