@@ -59,6 +59,8 @@ def lib():
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = L
+        from . import tuning
+        tuning.load(L)                      # tile table measured on MI355X (htd_amd/tuning/conv_tiles_gfx950.json)
     return _lib
 
 
@@ -131,6 +133,8 @@ def call(name, *args, work=None):
     key = name
     if _DETAIL:
         key = name + '(' + ','.join(str(a) for a in args if isinstance(a, int) and not isinstance(a, bool)) + ')'
+        # which pointer operands are present (residual / mask / accum select epilogue variants): 1 = given, 0 = NULL
+        key += '[' + ''.join('0' if a is None else '1' for a in args if a is None or isinstance(a, ctypes.c_void_p)) + ']'
     rec = _PROFILE.setdefault(key, dict(events=[], kind=None, work=0.0, bytes=0.0))
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

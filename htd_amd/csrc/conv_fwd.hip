@@ -21,6 +21,8 @@
 // (forward conv of gy with spatially flipped, channel-transposed weights; a stride-s data gradient is split into
 // s*s dense sub-problems, one per output parity class, through an explicit tap table).
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 
 #include <stdlib.h>
 
@@ -451,17 +453,107 @@ int plan_splits(int64_t M, int Co, int Ci, int taps)
     return (int)std::max<int64_t>(1, std::min<int64_t>(want, 16));
 }
 
-// tile follows the output-channel count and the amount of work: 128x128 (2x2 waves of 64x64) for big
-// problems, 128x64 / 128x32 (4x1 waves) for narrow outputs, 64x64 (2x2 waves of 32x32) when the problem has
-// too few big tiles to balance 256 CUs
-void choose_tile(int64_t M, int Co, int &bm, int &bn)
+// Tile configurations: id -> (BM, BN) and the wave grid / MFMA blocks per wave of the instantiation
+//   0  64x64   2x2 waves of 32x32        3  128x128  2x2 waves of 64x64
+//   1  128x32  4x1 waves of 32x32        4  128x64   2x2 waves of 64x32   (one A + ... fragment pair feeds 8 MFMAs)
+//   2  128x64  4x1 waves of 32x64        5  64x128   2x2 waves of 32x64
+struct TileCfg { int bm, bn; };
+constexpr TileCfg kTileCfg[] = {{64, 64}, {128, 32}, {128, 64}, {128, 128}, {128, 64}, {64, 128}};
+constexpr int kNumTileCfg = 6;
+
+// HTD_CONV_TUNE=1 makes the launcher re-read HTD_CONV_FORCE_TILE (a configuration id, -1 = automatic) on every call:
+// the knob of tools/sweep_conv_tiles.py.  Off (the default) nothing is read after the first call.
+static const bool g_tune = getenv("HTD_CONV_TUNE") != nullptr;
+int forced_tile()
 {
-    bm = 128;
-    bn = Co <= 32 ? 32 : ((Co <= 64 || (Co % 128 != 0 && Co % 128 <= 64 && Co < 256)) ? 64 : 128);
-    // thresholds swept on the HTD-R50 layer set (768..5000 / 600..6000): below ~8 big tiles per CU the finer tiles'
-    // better balance across 256 CUs outweighs their extra L2 traffic
-    if (bn == 128 && htd::ceil_div(M, 128) * htd::ceil_div(Co, 128) < 2200) bn = 64;
-    if (bn == 64 && Co >= 64 && htd::ceil_div(M, 128) * htd::ceil_div(Co, 64) < 4400 && M >= 2048) bm = 64;
+    if (!g_tune) return -1;
+    const char *e = getenv("HTD_CONV_FORCE_TILE");
+    const int v = e ? atoi(e) : -1;
+    return (v >= 0 && v < kNumTileCfg) ? v : -1;
+}
+
+// Tile choice.  Narrow outputs (Co <= 64) keep the 4x1-wave tiles.  Otherwise every candidate is scored by
+//     base(tile, K) * quantisation(tiles on 256 CUs) * useful fraction of the padded tiles
+// and the best one runs.  The numbers come from tools/sweep_conv_tiles.py on MI355X (B = 4 @ 800x1344 layer set):
+//   * long reductions (K >= 1024): 128x128 reaches ~122 TF/s, the two 128x64 / 64x128 forms ~120, 64x64 ~104 -- the
+//     smaller the tile the more L2 -> LDS traffic and barriers per FLOP;
+//   * short reductions (K <= 512, the 1x1 expansions): the 64 KB epilogue of a 128x128 tile is no longer hidden by
+//     other workgroups' main loops (84 vs 92 TF/s at K = 256), the small tiles lose nothing;
+//   * quantisation: t tiles on 256 CUs take ceil(t / 256) rounds unless the balanced tail (plan_tail, 3..7 rounds)
+//     spreads the remainder: M = 16 800 x Co = 256 is 264 tiles of 128x128 (63 TF/s) but 1 052 of 64x64 (104 TF/s),
+//     while M = 67 200 x Co = 128 is 1 050 tiles of 64x128 (100 TF/s) against 2 100 of 64x64 (81 TF/s).
+static float tile_score(int cfg, int64_t M, int Co, int K, int splits)
+{
+    const int bm = kTileCfg[cfg].bm, bn = kTileCfg[cfg].bn;
+    const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
+    const bool long_k = K >= 1024;
+    float base;
+    switch (cfg) {
+    case 3: base = long_k ? 1.00f : 0.90f; break;
+    case 4: base = long_k ? 0.98f : 0.97f; break;
+    case 5: base = long_k ? 0.98f : 0.98f; break;
+    default: base = long_k ? 0.86f : (K >= 512 ? 0.90f : 0.95f); break;
+    }
+    const float w = (float)(tiles * splits) / 256.f;        // split-K: every tile is `splits` workgroups
+    float quant;
+    if (w >= 7.f) quant = w / ceilf(w);
+    else if (w >= 3.f) quant = 0.97f;                         // balanced tail
+    else quant = w / ceilf(w);
+    const float useful = (float)((double)M * Co / ((double)tiles * bm * bn));
+    return base * quant * useful;
+}
+
+// Tuned tile table: (M, Co, Ci, taps, epilogue bits) -> configuration id, filled through htd_conv2d_tile_table_set by
+// htd_amd/tuning.py from the table tools/tune_conv_tiles.py measured INSIDE the train / inference step on MI355X (the
+// epilogue variant and the cache state the neighbouring kernels leave matter: stand-alone sweeps mis-rank the short-K
+// layers).  Problems that are not in the table fall back to the score below.
+struct TileKey {
+    int64_t M;
+    int Co, Ci, taps, epi;
+    bool operator==(const TileKey &o) const { return M == o.M && Co == o.Co && Ci == o.Ci && taps == o.taps && epi == o.epi; }
+};
+struct TileKeyHash {
+    size_t operator()(const TileKey &k) const
+    {
+        uint64_t h = (uint64_t)k.M * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)k.Co << 40) ^ ((uint64_t)k.Ci << 20) ^ ((uint64_t)k.taps << 4) ^ (uint64_t)k.epi;
+        h *= 0xBF58476D1CE4E5B9ull;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+std::mutex g_tile_mutex;
+std::unordered_map<TileKey, int, TileKeyHash> g_tile_table;
+
+int table_tile(int64_t M, int Co, int Ci, int taps, int epi)
+{
+    std::lock_guard<std::mutex> lock(g_tile_mutex);
+    if (g_tile_table.empty()) return -1;
+    const auto it = g_tile_table.find(TileKey{M, Co, Ci, taps, epi});
+    return it == g_tile_table.end() ? -1 : it->second;
+}
+
+// epi < 0: the problem cannot use the table (tap-table data gradients, batched GEMMs)
+int choose_tile(int64_t M, int Co, int Ci, int taps, int epi, int splits, int &bm, int &bn)
+{
+    const int K = taps * Ci;
+    int cfg = forced_tile();
+    if (cfg < 0 && epi >= 0) cfg = table_tile(M, Co, Ci, taps, epi);
+    if (cfg >= 0 && Co <= 64 && kTileCfg[cfg].bn > 64) cfg = -1;      // a table entry must still fit the kernel
+    if (cfg < 0) {
+        if (Co <= 32) cfg = 1;
+        else if (Co <= 64) cfg = (htd::ceil_div(M, 128) * htd::ceil_div(Co, 64) < 4400 && M >= 2048) ? 0 : 2;
+        else {
+            static const int cand[4] = {3, 4, 5, 0};
+            float best = -1.f;
+            for (int c : cand) {
+                const float sc = tile_score(c, M, Co, K, splits);
+                if (sc > best * 1.005f) { best = sc; cfg = c; }      // ties go to the earlier (larger) tile
+            }
+        }
+    }
+    bm = kTileCfg[cfg].bm;
+    bn = kTileCfg[cfg].bn;
+    return cfg;
 }
 
 // Balanced tail: with t tiles on 256 CUs and t / 256 small, the CUs that receive ceil(t / 256) tiles set the run time.
@@ -489,8 +581,14 @@ int plan_tail(int64_t M, int Co, int Ci, int taps, int bm, int bn, int &tail_spl
 
 int launch_conv(ConvParams p, hipStream_t s, void *workspace)
 {
+    const int bk = (p.Ci % 32 == 0 && p.ntaps == 0) ? 32 : (p.Ci % 16 == 0 ? 16 : 8);
+    const int total_slices = (p.ntaps > 0 ? p.ntaps : p.kh * p.kw) * (p.Ci / bk);
+    p.splits = (workspace && p.ntaps == 0) ? plan_splits(p.M, p.Co, p.Ci, p.kh * p.kw) : 1;
+    p.slices_per_split = (int)htd::ceil_div(total_slices, p.splits);
+    p.splits = (int)htd::ceil_div(total_slices, p.slices_per_split);
     int bm, bn;
-    choose_tile(p.M, p.Co, bm, bn);
+    const int epi = (p.ntaps > 0 || p.w_bstride > 0) ? -1 : ((p.residual ? 1 : 0) | (p.mask_src ? 2 : 0));
+    const int cfg = choose_tile(p.M, p.Co, p.Ci, p.ntaps > 0 ? p.ntaps : p.kh * p.kw, epi, p.splits, bm, bn);
     p.mt = (int)htd::ceil_div(p.M, bm);
     p.nt = (int)htd::ceil_div(p.Co, bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;
@@ -498,11 +596,6 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     HTD_REQUIRE((int64_t)p.B * p.Hx * p.Wx * p.Ci < (1ll << 31) && (int64_t)p.Co * p.kh * p.kw * p.Ci < (1ll << 31) &&
                     p.M < (1ll << 31),
                 "conv2d: operand larger than 2^31 elements (32-bit element offsets)");
-    const int bk = (p.Ci % 32 == 0 && p.ntaps == 0) ? 32 : (p.Ci % 16 == 0 ? 16 : 8);
-    const int total_slices = (p.ntaps > 0 ? p.ntaps : p.kh * p.kw) * (p.Ci / bk);
-    p.splits = (workspace && p.ntaps == 0) ? plan_splits(p.M, p.Co, p.Ci, p.kh * p.kw) : 1;
-    p.slices_per_split = (int)htd::ceil_div(total_slices, p.splits);
-    p.splits = (int)htd::ceil_div(total_slices, p.slices_per_split);
     p.partial = (float *)workspace;
     static const int cmajor_env = getenv("HTD_CONV_CMAJOR") ? atoi(getenv("HTD_CONV_CMAJOR")) : 1;
     p.cmajor = (p.ntaps == 0 && p.kh * p.kw > 1) ? cmajor_env : 0;
@@ -515,14 +608,14 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
             launch_blocks = (unsigned)(whole + (blocks - whole) * p.tail_splits);
         }
     }
-    if (bm == 64)
-        launch_cfg<2, 2, 1, 1>(p, launch_blocks, s);
-    else if (bn == 32)
-        launch_cfg<4, 1, 1, 1>(p, launch_blocks, s);
-    else if (bn == 64)
-        launch_cfg<4, 1, 1, 2>(p, launch_blocks, s);
-    else
-        launch_cfg<2, 2, 2, 2>(p, launch_blocks, s);
+    switch (cfg) {
+    case 0: launch_cfg<2, 2, 1, 1>(p, launch_blocks, s); break;
+    case 1: launch_cfg<4, 1, 1, 1>(p, launch_blocks, s); break;
+    case 2: launch_cfg<4, 1, 1, 2>(p, launch_blocks, s); break;
+    case 3: launch_cfg<2, 2, 2, 2>(p, launch_blocks, s); break;
+    case 4: launch_cfg<2, 2, 2, 1>(p, launch_blocks, s); break;
+    default: launch_cfg<2, 2, 1, 2>(p, launch_blocks, s); break;
+    }
     if (p.tail_splits > 0) {
         const int64_t elems = (blocks - p.tail_first) * (int64_t)bm * bn;
         hipLaunchKernelGGL(conv_tail_epilogue_kernel, dim3((unsigned)htd::ceil_div(elems, 256)), dim3(256), 0, s, p, bm, bn);
@@ -570,12 +663,42 @@ extern "C" int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh,
 {
     const int splits = plan_splits(M, Co, Ci, kh * kw);
     if (splits > 1) return (int64_t)splits * M * Co * 4;
-    int bm, bn, ts, tsps;
-    choose_tile(M, Co, bm, bn);
-    const int whole = plan_tail(M, Co, Ci, kh * kw, bm, bn, ts, tsps);
-    if (ts == 0) return 0;
-    const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
-    return (tiles - whole) * ts * (int64_t)bm * bn * 4;
+    int64_t need = 0;
+    for (int epi = 0; epi < 4; ++epi) {          // the caller does not say which epilogue the launch will have
+        int bm, bn, ts, tsps;
+        choose_tile(M, Co, Ci, kh * kw, epi, 1, bm, bn);
+        const int whole = plan_tail(M, Co, Ci, kh * kw, bm, bn, ts, tsps);
+        if (ts == 0) continue;
+        const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
+        need = std::max(need, (tiles - whole) * ts * (int64_t)bm * bn * 4);
+    }
+    return need;
+}
+
+// Tuned tile table (see choose_tile).  cfg: 0 64x64, 1 128x32, 2 128x64 (4x1 waves), 3 128x128, 4 128x64 (2x2 waves),
+// 5 64x128; cfg < 0 erases the entry.  epi: bit 0 = residual / accum operand present, bit 1 = mask_src present.
+extern "C" int htd_conv2d_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg)
+{
+    HTD_REQUIRE(M > 0 && Co > 0 && Ci > 0 && taps > 0 && epi >= 0 && epi < 4 && cfg < kNumTileCfg,
+                "tile_table_set: bad entry M=%lld Co=%d Ci=%d taps=%d epi=%d cfg=%d", (long long)M, Co, Ci, taps, epi, cfg);
+    std::lock_guard<std::mutex> lock(g_tile_mutex);
+    if (cfg < 0) g_tile_table.erase(TileKey{M, Co, Ci, taps, epi});
+    else g_tile_table[TileKey{M, Co, Ci, taps, epi}] = cfg;
+    return HTD_OK;
+}
+
+extern "C" int htd_conv2d_tile_table_clear()
+{
+    std::lock_guard<std::mutex> lock(g_tile_mutex);
+    g_tile_table.clear();
+    return HTD_OK;
+}
+
+// the configuration id a launch of this problem would use now (table, then score); splits as planned for it
+extern "C" int htd_conv2d_tile_query(int64_t M, int Co, int Ci, int taps, int epi)
+{
+    int bm, bn;
+    return choose_tile(M, Co, Ci, taps, epi, plan_splits(M, Co, Ci, taps), bm, bn);
 }
 
 // Batched NT GEMM on the same kernel: c[g] = a[g] @ b[g]^T, a [G][M][K], b [G][N][K], c [G][M][N].

@@ -139,6 +139,15 @@ int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att, const floa
  *            ReLU mask only.
  * ---------------------------------------------------------------------------------- */
 int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw);
+/* Tile table of conv_igemm_kernel (htd_conv2d_fwd / htd_conv2d_bwd_data): problem (M = B*Ho*Wo, Co, Ci, taps = kh*kw,
+ * epi: bit 0 residual / accum operand, bit 1 mask_src) -> tile configuration id (0 64x64, 1 128x32, 2 128x64 in 4x1
+ * waves, 3 128x128, 4 128x64 in 2x2 waves, 5 64x128; < 0 erases).  Replaces what cuDNN's / MIOpen's algorithm search
+ * does behind torch.backends.cudnn.benchmark for the reference (mmdet/apis/train.py: cudnn_benchmark of the configs):
+ * htd_amd/tuning.py loads the table measured on MI355X by tools/tune_conv_tiles.py; problems not in the table are
+ * scored by a model of tile efficiency x wave quantisation.  htd_conv2d_tile_query: the id a launch would use now. */
+int htd_conv2d_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg);
+int htd_conv2d_tile_table_clear(void);
+int htd_conv2d_tile_query(int64_t M, int Co, int Ci, int taps, int epi);
 int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, int res_h,
                    int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
                    int pad, int dil, int relu, void *workspace, void *stream);

@@ -1,0 +1,211 @@
+"""BASELINE.json configs[2], [3], [4] on a real MI355X, each against the CPU oracle at a size the oracle finishes:
+
+  configs[2]  HTD-R101 bf16 train step          (bf16 trunk / FC stacks, fp32 master weights, fp32 RoI ops and losses)
+  configs[3]  HTD-R101-DCN bf16 train step      (+ 30 deformable 3x3 layers on the bf16 kernels)
+  configs[4]  HTD-R101 inference, 512 proposals per image into the RoI head, hard NMS
+
+bf16 tolerance (stated, not a smoke bound).  A bf16 value carries 8 significand bits: rounding an activation or a
+weight perturbs it by at most 2^-9 relative (RMS 2^-9 / sqrt(3) ~ 1.1e-3).  The trunk rounds ~3 activations and ~3
+weight tensors per bottleneck over 33 bottlenecks plus the FPN, independent perturbations that add in quadrature:
+relative L2 error of a pyramid level ~ 1.1e-3 * sqrt(2 * 100) ~ 1.6e-2 worst case.  The bounds below are 2x what this
+model predicts and are checked as RELATIVE L2 ERRORS against the fp32 oracle run on the same fp32 master weights:
+    pyramid levels            <= 2e-2       losses (each)        <= 2e-2 relative (+1e-3 abs)
+    RPN logits                <= 2e-2       gradients (rel. L2)  <= 6e-2 trunk / 3e-2 heads
+The fp32 configuration of the same architectures is held to the fp32 bounds of tests/test_gpu_detector.py (1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import demo_inputs, load_seeded_, seeded_state_dict
+from test_gpu_detector import ReplaySampler, T
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _small(cfg_obj, ocfg):
+    cfg_obj.train_cfg.rpn_proposal.update(nms_pre=200, nms_post=100, max_num=100)
+    ocfg['train_cfg']['rpn_proposal'].update(nms_pre=200, nms_post=100, max_num=100)
+    for r in cfg_obj.train_cfg.rcnn:
+        r.sampler.num = 48
+    for r in ocfg['train_cfg']['rcnn']:
+        r['sampler']['num'] = 48
+
+
+@pytest.mark.parametrize('dcn', [False, True], ids=['configs2_r101_bf16', 'configs3_r101_dcn_bf16'])
+def test_r101_bf16_train_step_against_the_oracle(dcn):
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.core import set_randperm
+    from oracle import detector as D
+    dev = torch.device('cuda:0')
+    H, W, B = 128, 160, 2
+    imgs, gts, labels = demo_inputs(B, H, W, np.random.RandomState(11))
+    imgs = (imgs - 0.5) * 4
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3),
+                  scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(B)]
+    ocfg = D.htd_config(101, dcn)
+    cfg = htd_config(101, dcn=dcn)
+    _small(cfg, ocfg)
+    shapes = D.state_shapes(101, dcn)
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+          for k, v in seeded_state_dict(shapes, prefix='det.').items()}
+    if dcn:                                             # offsets of a trained layer: a pixel or so, not the zero init
+        with torch.no_grad():
+            for k, v in sd.items():
+                if 'conv_offset.weight' in k:
+                    v.mul_(1.5)
+    torch.manual_seed(21)
+    trace = {}
+    ref_losses = D.forward_train(sd, T(imgs), metas, [T(x) for x in gts], [T(x) for x in labels], ocfg, trace)
+    ref_loss, ref_log = D.parse_losses(ref_losses)
+    ref_loss.backward()
+
+    det = build_htd_detector(cfg=cfg, bf16=True)
+    load_seeded_(det, 'det.')
+    if dcn:
+        with torch.no_grad():
+            for k, p in det.named_parameters():
+                if 'conv_offset.weight' in k:
+                    p.mul_(1.5)
+    det = det.to(dev).train()
+    assert det.backbone.compute_dtype == torch.bfloat16
+    set_randperm(lambda n, device: torch.randperm(n).to(device))
+    try:
+        torch.manual_seed(21)
+        gts_d, labels_d = [T(x).to(dev) for x in gts], [T(x).to(dev) for x in labels]
+        x = det.extract_feat(T(imgs).to(dev))
+        errs = {f'P{i + 2}': rel_l2(a.float(), b) for i, (a, b) in enumerate(zip(x, trace['feats']))}
+        cls, reg = det.rpn_head(x)
+        errs['rpn_cls'] = max(rel_l2(a, b) for a, b in zip(cls, trace['rpn_cls']))
+        errs['rpn_reg'] = max(rel_l2(a, b) for a, b in zip(reg, trace['rpn_reg']))
+        # RPN losses end to end; RoI head on the oracle's proposals and sample picks (an IoU that sits on a threshold
+        # flips with any perturbation and reshuffles the random permutation: that is sampling, not arithmetic)
+        losses, _ = det.rpn_head.forward_train(x, metas, gts_d, proposal_cfg=det.train_cfg.rpn_proposal)
+        head = det.roi_head
+        saved = list(head.bbox_sampler)
+        try:
+            head.bbox_sampler = [ReplaySampler(saved[i], trace['samples'][i]) for i in range(2)]
+            x32 = tuple(f.float() for f in x)      # the RoI head reads the pyramid in fp32 (force_fp32 sites), as two_stage does
+            losses.update(head.forward_train(x32, metas, [p.to(dev) for p in trace['proposals']], gts_d, labels_d))
+        finally:
+            head.bbox_sampler = saved
+    finally:
+        set_randperm(None)
+    loss, log_vars = det._parse_losses(losses)
+    det.zero_grad()
+    loss.backward()
+    print('\nbf16 vs fp32 oracle (dcn=%s): relative L2 errors' % dcn, {k: round(v, 5) for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= 2e-2, (k, v)
+    for k, v in log_vars.items():
+        if 'acc' in k:
+            continue
+        print('  loss %-14s %.5f  oracle %.5f  rel %.2e' % (k, v, ref_log[k], abs(v - ref_log[k]) / max(abs(ref_log[k]), 1e-9)))
+        assert abs(v - ref_log[k]) <= 2e-2 * abs(ref_log[k]) + 1e-3, (k, v, ref_log[k])
+    params = dict(det.named_parameters())
+    trunk = ['backbone.layer2.0.conv1.weight', 'backbone.layer3.10.conv2.weight', 'backbone.layer4.2.conv3.weight',
+             'neck.lateral_convs.2.conv.weight', 'neck.fpn_convs.0.conv.weight', 'rpn_head.rpn_conv.weight']
+    heads = ['roi_head.bbox_head.0.shared_fcs.1.weight', 'roi_head.bbox_head.0.fc_cls.weight',
+             'roi_head.bbox_head.1.fcs.0.weight', 'roi_head.bbox_head.1.graph_lvl0_cls.weight',
+             'roi_head.bbox_head.1.convs.1.conv.weight', 'roi_head.bbox_roi_extractor.1.conv1.weight',
+             'roi_head.glbctx_head.convs.0.conv.weight']
+    if dcn:
+        trunk += ['backbone.layer3.5.conv2.conv_offset.weight']
+    for names, bound in ((trunk, 6e-2), (heads, 3e-2)):
+        for k in names:
+            a = params[k].grad.detach().cpu() if params[k].grad is not None else torch.zeros_like(params[k]).cpu()
+            b = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+            e = rel_l2(a.reshape(b.shape), b)
+            print('  grad %-48s rel L2 %.2e' % (k, e))
+            assert params[k].grad.dtype == torch.float32                 # fp32 master gradients
+            assert e <= bound, (k, e, bound)
+
+
+def test_r101_fp32_train_step_against_the_oracle():
+    """The same R101 step in fp32: the 1e-4-class bounds of the R50 fixtures hold for the deeper trunk too."""
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.core import set_randperm
+    from oracle import detector as D
+    dev = torch.device('cuda:0')
+    H, W, B = 128, 160, 2
+    imgs, gts, labels = demo_inputs(B, H, W, np.random.RandomState(11))
+    imgs = (imgs - 0.5) * 4
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3),
+                  scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(B)]
+    ocfg, cfg = D.htd_config(101), htd_config(101)
+    _small(cfg, ocfg)
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+          for k, v in seeded_state_dict(D.state_shapes(101), prefix='det.').items()}
+    torch.manual_seed(21)
+    ref_loss, ref_log = D.parse_losses(D.forward_train(sd, T(imgs), metas, [T(x) for x in gts], [T(x) for x in labels], ocfg))
+    det = load_seeded_(build_htd_detector(cfg=cfg), 'det.').to(dev).train()
+    set_randperm(lambda n, device: torch.randperm(n).to(device))
+    try:
+        torch.manual_seed(21)
+        losses = det.forward_train(T(imgs).to(dev), metas, [T(x).to(dev) for x in gts], [T(x).to(dev) for x in labels])
+    finally:
+        set_randperm(None)
+    _, log_vars = det._parse_losses(losses)
+    for k, v in log_vars.items():
+        np.testing.assert_allclose(v, ref_log[k], rtol=5e-4, atol=1e-4, err_msg=k)
+
+
+def test_r101_inference_512_proposals_against_the_oracle():
+    """configs[4] at a size the oracle finishes: HTD-R101 simple_test, ONE 256x320 image, nms_post = 512 proposals
+    into the RoI head (the oracle's regression branch alone is 0.63 TFLOP on the CPU), hard NMS.  Proposals, both
+    stages' logits on the oracle's rois, and the detections."""
+    from golden_util import match_detections
+    from htd_amd.configs import build_htd_detector, htd_config
+    from oracle import detector as D
+    dev = torch.device('cuda:0')
+    H, W = 256, 320
+    imgs, _, _ = demo_inputs(1, H, W, np.random.RandomState(4))
+    imgs = (imgs - 0.5) * 4
+    metas = [dict(img_shape=(H, W - 5, 3), pad_shape=(H, W, 3), ori_shape=(H, W - 5, 3),
+                  scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False)]
+    ocfg = D.htd_config(101)
+    ocfg['test_cfg']['rpn'].update(nms_pre=1000, nms_post=512, max_num=512)
+    ocfg['test_cfg']['rcnn']['score_thr'] = 0.002
+    cfg = htd_config(101, soft_nms=False)
+    cfg.test_cfg.rpn.update(nms_pre=1000, nms_post=512, max_num=512)
+    cfg.test_cfg.rcnn.score_thr = 0.002
+    sd = seeded_state_dict(D.state_shapes(101), prefix='det.')
+    with torch.no_grad():
+        x = D.extract_feat(sd, T(imgs), ocfg)
+        rcls, rreg = D.rpn_forward(sd, x)
+        trace = []
+        props = D.rpn_get_bboxes(rcls, rreg, metas, ocfg['test_cfg']['rpn'], ocfg, ocfg['strides'], trace=trace)
+        tr = {}
+        dets = D.roi_head_simple_test(sd, x, props, metas, ocfg, trace=tr)
+    assert props[0].shape == (512, 5)
+    det = load_seeded_(build_htd_detector(cfg=cfg), 'det.').to(dev).eval()
+    rpn = det.rpn_head
+    with torch.no_grad():
+        feats = det.extract_feat(T(imgs).to(dev))
+        # bit-exact index trail on the oracle's RPN logits (as in the R50 fixture test), 512 kept of ~4000 candidates
+        rpn.record_trail = True
+        try:
+            p_inj = rpn.get_bboxes([c.to(dev) for c in rcls], [r.to(dev) for r in rreg], metas)
+            order, anchor_ids, n_keep = rpn._last_proposal_trail
+        finally:
+            rpn.record_trail = False
+        assert int(n_keep[0]) == 512
+        assert torch.equal(order[0, :512].cpu(), trace[0][0]) and torch.equal(anchor_ids[0, :512].cpu(), trace[0][1])
+        np.testing.assert_allclose(p_inj[0].cpu().numpy(), props[0].numpy(), rtol=1e-5, atol=2e-4)
+        gfeat = det.roi_head.glbctx_head(feats)[1]
+        for st in (0, 1):
+            res = det.roi_head._bbox_forward(st, feats, tr[f'rois{st}'].to(dev), gfeat)
+            torch.testing.assert_close(res['cls_score'].cpu(), tr[f'cls{st}'], rtol=0, atol=1e-4)
+            torch.testing.assert_close(res['bbox_pred'].cpu(), tr[f'reg{st}'], rtol=0, atol=1e-4)
+        res = det.simple_test(T(imgs).to(dev), metas)
+    assert len(res) == 1 and len(res[0]) == 80
+    mine = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, dtype=np.float32)], 1) for c, r in enumerate(res[0])], 0)
+    d, l = dets[0]
+    ref = torch.cat([d, l[:, None].float()], 1).numpy()
+    assert len(ref) == 100                              # max_per_img reached: the cut is part of what is compared
+    match_detections(mine, ref, tol=2e-3)

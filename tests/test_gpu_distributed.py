@@ -106,3 +106,76 @@ def test_weight_gradient_stream_gives_identical_step():
     assert torch.isfinite(flats[0]).all()
     # float atomics of the RoIAlign backward make the gradients reproducible to rounding only
     torch.testing.assert_close(flats[0], flats[1], rtol=0, atol=1e-6)
+
+
+def _detector_worker(rank, world, port, q):
+    """Two ranks on the one GPU, gloo: the REAL detector -- gradient sinks writing into the flat buffer from kernels,
+    weight gradients on the side stream (OVERLAP_WGRAD), PyramidTaps, bucketed exchange from autograd hooks -- for two
+    steps on different data per rank; then, on every rank, the single-process result of averaging the two ranks'
+    gradients (semantics of DDP as configured at apis/train.py:72-80)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import copy
+    from htd_amd import dense
+    from htd_amd import mmcv_ops as M
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.core.bbox import set_sample_keys
+    from htd_amd.runner import FlatParams, Trainer, synthetic_batch
+    dev = torch.device('cuda:0')
+    dense.OVERLAP_WGRAD = True
+    cfg = htd_config(50)
+    cfg.train_cfg.rpn_proposal.update(nms_pre=300, nms_post=200, max_num=200)
+    for r in cfg.train_cfg.rcnn:
+        r.sampler.num = 64
+    coef = torch.tensor([12.9898, 78.233, 37.719, 93.989], device=dev)
+    set_sample_keys(lambda cand: torch.frac(torch.sin((cand * coef).sum(-1)) * 43758.5453).abs())   # sampling = f(boxes)
+    torch.manual_seed(1 + rank)                         # ranks build DIFFERENT weights: Trainer must broadcast rank 0's
+    model = build_htd_detector(cfg=cfg).to(dev).train()
+    tr = Trainer(model, lr=0.01, bucket_mb=8)
+    assert tr.exchange.enabled and len(tr.flat.buckets) > 4
+    start = tr.flat.flat.clone()
+    ref_model = copy.deepcopy(model)                    # after the broadcast: rank 0's weights on both ranks
+    datas = [synthetic_batch(2, 192, 256, 250, device=dev, seed=40 + r) for r in range(world)]
+    used_sinks = 0
+    for _ in range(2):
+        tr.train_step(datas[rank])
+        used_sinks = max(used_sinks, len(tr.flat._sink_used))
+    torch.cuda.synchronize()
+    got = tr.flat.flat.clone()
+    tr.flat.close()
+    # single-process reference: sum of the ranks' gradients, divided by world in the optimizer kernel
+    flat = FlatParams(ref_model, bucket_mb=8)
+    lr_dev = torch.zeros(1, device=dev)
+    for it in range(2):
+        total = torch.zeros_like(flat.grad)
+        for r in range(world):
+            flat.zero_grad()
+            ref_model.train_step(datas[r], None)['loss'].backward()
+            dense.join_side_stream()
+            flat.collect()
+            total += flat.grad
+        lr_dev.fill_(tr.schedule.lr(it))
+        M.sgd_momentum_step_(flat.flat, total, flat.momentum, lr_dev, tr.momentum, tr.weight_decay, grad_scale=1.0 / world)
+    torch.cuda.synchronize()
+    step_ref, step_got = flat.flat - start, got - start
+    scale = float(step_ref.abs().max())
+    err = float((step_got - step_ref).abs().max())
+    gathered = [torch.zeros_like(got.cpu()) for _ in range(world)]
+    dist.all_gather(gathered, got.cpu())
+    same = all(torch.equal(g, gathered[0]) for g in gathered)
+    q.put((rank, err <= 2e-3 * scale and scale > 0 and same and used_sinks > 100, err, scale, same, used_sinks))
+    set_sample_keys(None)
+    dist.destroy_process_group()
+
+
+def test_detector_world2_equals_averaged_gradients():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_detector_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res

@@ -110,3 +110,46 @@ def test_full_size_train_step_paths_agree_and_proposals_are_ordered():
     ref = _batched_max_iou_assign_tensor(a, anchors, inside, gts, gvalid)
     assert anchors.size(0) == 268569
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+def test_configs4_inference_batch64_properties_and_batch_invariance():
+    """BASELINE configs[4] at full size: HTD-R101 simple_test, B = 64 @ 800x1344, 512 proposals per image into the RoI
+    head (32 768 RoIs through RoIAlign x7, BA, PGraph, the 1.24 GFLOP/RoI regression branch), hard NMS.  Far beyond the
+    CPU oracle, so: output structure and ranges, and batch invariance -- an image's detections do not depend on the
+    batch it rides in (PGraph groups, SFA fuse and NMS segments are per image, htd_bbox_head.py:198-199)."""
+    import numpy as np
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.runner import synthetic_batch
+    dev = torch.device('cuda:0')
+    cfg = htd_config(101, soft_nms=False)
+    cfg.test_cfg.rpn.update(nms_post=512, max_num=512)
+    torch.manual_seed(0)
+    model = build_htd_detector(cfg=cfg).to(dev).eval()
+    B = 64
+    data = synthetic_batch(B, 800, 1344, 1333, device=dev, seed=5)
+    with torch.no_grad():
+        res = model.simple_test(data['img'], data['img_metas'])
+        feats = model.extract_feat(data['img'][:2])
+        props = model.rpn_head.simple_test_rpn(feats, data['img_metas'][:2])
+    assert all(p.shape == (512, 5) for p in props)                      # random-init RPN: the full 512 survive
+    assert len(res) == B and all(len(r) == 80 for r in res)
+    n_det = []
+    for r in res:
+        n = 0
+        for c in r:
+            assert c.dtype == np.float32 and c.ndim == 2 and c.shape[1] == 5 and np.isfinite(c).all()
+            if len(c):
+                assert (np.diff(c[:, 4]) <= 0).all()                    # descending score inside a class (bbox_nms.py:65-71)
+                assert (c[:, 4] > 0.05).all() and (c[:, 4] <= 1).all()  # score_thr
+                assert (c[:, 0] >= 0).all() and (c[:, 1] >= 0).all() and (c[:, 2] <= 1333).all() and (c[:, 3] <= 800).all()
+                assert (c[:, 2] >= c[:, 0]).all() and (c[:, 3] >= c[:, 1]).all()
+            n += len(c)
+        assert n <= 100                                                 # max_per_img
+        n_det.append(n)
+    assert sum(n_det) > 0
+    for i in (0, 37):                                                   # the same image alone
+        with torch.no_grad():
+            alone = model.simple_test(data['img'][i:i + 1].contiguous(memory_format=CL), data['img_metas'][i:i + 1])[0]
+        for c in range(80):
+            assert alone[c].shape == res[i][c].shape, (i, c)
+            np.testing.assert_allclose(alone[c], res[i][c], rtol=1e-4, atol=1e-3)

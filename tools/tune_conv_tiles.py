@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Measure the tile configuration of conv_igemm_kernel per convolution problem INSIDE the HTD step and write the table
+htd_amd/tuning/conv_tiles_gfx950.json (loaded by htd_amd/capi.py; include/htd_amd.h: htd_conv2d_tile_table_set).
+
+For every configuration id the whole step (train: fwd + bwd + SGD; --infer: simple_test) runs with that tile forced
+on every htd_conv2d_fwd / htd_conv2d_bwd_data launch (HTD_CONV_TUNE / HTD_CONV_FORCE_TILE), timed per call with device
+events; a problem gets a table entry when its best tile beats the launcher's own score-based choice by more than
+--margin.  Entries of earlier runs (other models / batch sizes) are kept.
+
+    python tools/tune_conv_tiles.py [--depth 101] [--dcn] [--trained-like] [--infer --batch 64] [--steps 3]
+"""
+import argparse
+import os
+import re
+import sys
+
+os.environ['HTD_CONV_TUNE'] = '1'
+os.environ['HTD_CONV_TABLE'] = '0'          # start from the heuristic; the table is applied by hand below
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+KEY = re.compile(r'^(htd_conv2d_fwd|htd_conv2d_bwd_data)\(([-\d,]+)\)\[([01]+)\]$')
+
+
+def signature(name, ints, mask):
+    """(M, Co, Ci, taps, epi) as conv_fwd.hip::launch_conv keys the launch, or None when the table does not apply."""
+    if name == 'htd_conv2d_fwd':
+        res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, dil, relu = ints
+        Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+        Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+        return (B * Ho * Wo, Co, Ci, kh * kw, int(mask[3] == '1'))
+    B, H, W, Ci, Co, kh, kw, stride, pad, dil = ints
+    if stride != 1:
+        return None                          # tap-table sub-problems: scored, not tabled
+    return (B * H * W, Ci, Co, kh * kw, int(mask[3] == '1') | (int(mask[2] == '1') << 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--dcn', action='store_true')
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--infer', action='store_true')
+    ap.add_argument('--proposals', type=int, default=512)
+    ap.add_argument('--trained-like', action='store_true')
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--margin', type=float, default=0.02)
+    ap.add_argument('--dry', action='store_true', help='measure and print, do not write the table')
+    ap.add_argument('--table', default=None, help='table file to merge into (default: the in-tree one)')
+    args = ap.parse_args()
+    import bench
+    from htd_amd import capi, tuning
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.runner import Trainer, synthetic_batch
+    dev = torch.device('cuda:0')
+    L = capi.lib()
+    torch.manual_seed(0)
+    data = synthetic_batch(args.batch, 800, 1344, 1333, device=dev, seed=0)
+    if args.infer:
+        cfg = htd_config(args.depth, dcn=args.dcn, soft_nms=False)
+        cfg.test_cfg.rpn.update(nms_post=args.proposals, max_num=args.proposals)
+        model = build_htd_detector(cfg=cfg).to(dev).eval()
+
+        def step():
+            with torch.no_grad():
+                model.simple_test(data['img'], data['img_metas'])
+    else:
+        model = build_htd_detector(args.depth, dcn=args.dcn).to(dev).train()
+        trainer = Trainer(model, lr=1e-4)
+        if args.trained_like:
+            bench.trained_like_proposals(model, data, args.batch)
+
+        def step():
+            trainer.train_step(data)
+
+    only = ('htd_conv2d_fwd', 'htd_conv2d_bwd_data')
+    times = {}                               # cfg -> {signature: [total_ms, calls]}
+    for cfg_id in (-1, 0, 2, 3, 4, 5):
+        os.environ['HTD_CONV_FORCE_TILE'] = str(cfg_id)
+        step()
+        capi.profile_begin(detail=True, only=only)
+        for _ in range(args.steps):
+            step()
+        per = {}
+        for key, (calls, ms, *_rest) in capi.profile_end().items():
+            m = KEY.match(key)
+            if not m:
+                continue
+            sig = signature(m.group(1), [int(v) for v in m.group(2).split(',')], m.group(3))
+            if sig is None:
+                continue
+            rec = per.setdefault(sig, [0.0, 0])
+            rec[0] += ms
+            rec[1] += calls
+        times[cfg_id] = per
+        print(f'# cfg {cfg_id:2d}: {sum(v[0] for v in per.values()) / args.steps:8.2f} ms of tabled conv time per step',
+              flush=True)
+    os.environ['HTD_CONV_FORCE_TILE'] = '-1'
+    path = args.table or tuning.TABLE
+    table = tuning.read_table(path if os.path.exists(path) else tuning.TABLE)
+    gained = 0.0
+    print(f'{"M":>8s} {"Co":>5s} {"Ci":>5s} taps epi | {"auto":>8s} ' + ' '.join(f'{"cfg" + str(c):>8s}' for c in (0, 2, 3, 4, 5)) +
+          ' | pick   us/call')
+    for sig in sorted(times[-1], key=lambda s_: -times[-1][s_][0]):
+        auto_ms, calls = times[-1][sig]
+        auto_cfg = L.htd_conv2d_tile_query(*sig)
+        cand = {}
+        for c in (0, 2, 3, 4, 5):
+            if sig[1] <= 64 and c in (3, 5):
+                continue                     # bn = 128 on a narrow output: never
+            if sig in times[c]:
+                cand[c] = times[c][sig][0]
+        best = min(cand, key=cand.get)
+        pick = best if cand[best] < auto_ms * (1.0 - args.margin) and best != auto_cfg else None
+        if pick is not None:
+            table[sig] = pick
+            gained += (auto_ms - cand[best]) / args.steps
+        elif sig in table:
+            del table[sig]                   # the score already picks (about) the best: no entry needed
+        print(f'{sig[0]:8d} {sig[1]:5d} {sig[2]:5d} {sig[3]:4d} {sig[4]:3d} | {auto_ms / calls * 1e3:8.1f} ' +
+              ' '.join(f'{cand[c] / calls * 1e3:8.1f}' if c in cand else f'{"-":>8s}' for c in (0, 2, 3, 4, 5)) +
+              f' | {("cfg" + str(pick)) if pick is not None else "auto=" + str(auto_cfg):7s} x{calls // args.steps}')
+    print(f'# expected gain over the score-based choice: {gained:.2f} ms per step; table now has {len(table)} entries')
+    if not args.dry:
+        tuning.write_table(table, meta=dict(device='MI355X (gfx950)', tool='tools/tune_conv_tiles.py',
+                                            note='tile id per (M,Co,Ci,taps,epi); see include/htd_amd.h'), path=path)
+
+
+if __name__ == '__main__':
+    main()
