@@ -123,6 +123,7 @@ def test_configs4_inference_batch64_properties_and_batch_invariance():
     dev = torch.device('cuda:0')
     cfg = htd_config(101, soft_nms=False)
     cfg.test_cfg.rpn.update(nms_post=512, max_num=512)
+    cfg.test_cfg.rcnn.score_thr = 0.0125        # random-init classifier: 81 near-uniform probabilities ~ 1/81 = 0.0123
     torch.manual_seed(0)
     model = build_htd_detector(cfg=cfg).to(dev).eval()
     B = 64
@@ -140,7 +141,7 @@ def test_configs4_inference_batch64_properties_and_batch_invariance():
             assert c.dtype == np.float32 and c.ndim == 2 and c.shape[1] == 5 and np.isfinite(c).all()
             if len(c):
                 assert (np.diff(c[:, 4]) <= 0).all()                    # descending score inside a class (bbox_nms.py:65-71)
-                assert (c[:, 4] > 0.05).all() and (c[:, 4] <= 1).all()  # score_thr
+                assert (c[:, 4] > 0.0125).all() and (c[:, 4] <= 1).all()  # score_thr
                 assert (c[:, 0] >= 0).all() and (c[:, 1] >= 0).all() and (c[:, 2] <= 1333).all() and (c[:, 3] <= 800).all()
                 assert (c[:, 2] >= c[:, 0]).all() and (c[:, 3] >= c[:, 1]).all()
             n += len(c)
