@@ -31,6 +31,35 @@
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// ---- fp32 on the bf16 matrix pipe (X3 kernels) -------------------------------------------------------------------
+// An fp32 value has a 24-bit significand; three bf16 numbers (8 significant bits each, the exponent range of fp32)
+// carry it:  a = a0 + a1 + a2 (+ <= 2^-27 |a|),  a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1), the two
+// differences being exact in fp32.  A product is then  a*b = sum_{i,j} a_i*b_j;  every a_i*b_j is exact in fp32 (8 x 8
+// bits) and the six terms with i + j <= 2 carry everything down to ~2^-24 |a*b| (the three dropped ones, a1*b2, a2*b1,
+// a2*b2, are <= 2^-25 |a*b| together).  v_mfma_f32_32x32x16_bf16 accumulates them in fp32 exactly like the fp32-input MFMA
+// accumulates its products, at 16x the per-instruction rate: six of them per 16 k cost 192 cycles against the 512 of
+// eight v_mfma_f32_32x32x2_f32 -- fp32 results (same rounding error class, tests/test_gpu_conv.py compares both forms with
+// an fp64 reference) at 2.67x the matrix throughput.  The split is done once per element while a K slice is written to
+// LDS (three 16-bit planes per operand row); the MFMA loop reads three fragments per operand block.
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// two floats -> three packed bf16 pairs (element 0 in the low half): one v_cvt_pk_bf16_f32 (round to nearest even) per
+// piece; the residuals a - a0 and a - a0 - a1 are exact in fp32, the last piece leaves <= 2^-27 |a|.  (An infinity turns
+// into a NaN on the way -- Inf - Inf -- which is what the sum of products it feeds would mostly become anyway.)
+__device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned &m, unsigned &l)
+{
+    union { bf16x2 v; unsigned u; } c;
+    c.v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    h = c.u;
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    c.v = __builtin_convertvector(f32x2{ra, rb}, bf16x2);
+    m = c.u;
+    c.v = __builtin_convertvector(f32x2{ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u)}, bf16x2);
+    l = c.u;
+}
 
 // value select (a ternary between two float4 lvalues would select between ADDRESSES and push both to scratch)
 __device__ __forceinline__ float4 keep4(bool ok, float4 v)
@@ -72,25 +101,29 @@ struct ConvParams {
 };
 
 // BK: floats of K per slice; WGM x WGN: wave grid of the block; TM x TN: 32x32 MFMA blocks per wave
-template <int BK, int WGM, int WGN, int TM, int TN>
+template <int BK, int WGM, int WGN, int TM, int TN, bool X3 = false>
 struct Tile {
     static constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     static constexpr int LDS_STRIDE = BK + 4;                 // floats
+    // X3: a row holds three bf16 planes of BK elements + 16 B pad: (3*BK + 8) half-words; 52 dwords at BK = 32, which
+    // puts the 16 rows of a ds_read_b128 group on 16 different 4-bank sets
+    static constexpr int ROW_HALFS = 3 * BK + 8;
     static constexpr int VEC_PER_ROW = BK / 4;                // float4 per row slice
     static constexpr int ROWS_PER_PASS = 256 / VEC_PER_ROW;   // rows covered by the 256 threads at once
     static constexpr int PASSES_A = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
     static constexpr int PASSES_B = (BN + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-    static constexpr int MAIN_FLOATS = (BM + BN) * LDS_STRIDE;       // ONE slice buffer + register prefetch
+    static constexpr int MAIN_FLOATS = X3 ? (BM + BN) * ROW_HALFS / 2 : (BM + BN) * LDS_STRIDE;   // ONE slice buffer + register prefetch
     static constexpr int EPI_STRIDE = BN + 4;
     static constexpr int EPI_ROWS = WGM * 32;                 // rows staged per epilogue round
     static constexpr int EPI_FLOATS = EPI_ROWS * EPI_STRIDE;
     static constexpr int LDS_FLOATS = MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS;
 };
 
-template <int BK, int WGM, int WGN, int TM, int TN, bool TAPS>
+template <int BK, int WGM, int WGN, int TM, int TN, bool TAPS, bool X3 = false>
 __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel(ConvParams p)
 {
-    using T = Tile<BK, WGM, WGN, TM, TN>;
+    static_assert(!X3 || BK % 16 == 0, "the bf16 MFMA takes 16 k per instruction");
+    using T = Tile<BK, WGM, WGN, TM, TN, X3>;
     __shared__ __attribute__((aligned(16))) float lds[T::LDS_FLOATS];
 
     // XCD-aware tile order: blocks that share an XCD (ids congruent mod 8) get one contiguous run of tiles with
@@ -219,6 +252,30 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
         }
     };
     auto store_slice = [&](int buf) {
+        if constexpr (X3) {
+            // float4 -> three planes of 4 bf16 (8 bytes each) at [row][plane][vcol * 4]
+            unsigned short *la = reinterpret_cast<unsigned short *>(lds);
+            unsigned short *lb = la + T::BM * T::ROW_HALFS;
+            auto put = [&](unsigned short *row, float4 v) {
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split3x2(v.x, v.y, h0, m0_, l0);
+                split3x2(v.z, v.w, h1, m1, l1);
+                *reinterpret_cast<uint2 *>(row + vcol * 4) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(row + BK + vcol * 4) = make_uint2(m0_, m1);
+                *reinterpret_cast<uint2 *>(row + 2 * BK + vcol * 4) = make_uint2(l0, l1);
+            };
+#pragma unroll
+            for (int i = 0; i < T::PASSES_A; ++i) {
+                const int r = vrow + i * T::ROWS_PER_PASS;
+                if (T::BM % T::ROWS_PER_PASS == 0 || r < T::BM) put(la + r * T::ROW_HALFS, keep4((ra_ok >> i) & 1u, ra[i]));
+            }
+#pragma unroll
+            for (int i = 0; i < T::PASSES_B; ++i) {
+                const int r = vrow + i * T::ROWS_PER_PASS;
+                if (T::BN % T::ROWS_PER_PASS == 0 || r < T::BN) put(lb + r * T::ROW_HALFS, keep4(b_ok[i], rb[i]));
+            }
+            return;
+        }
         float *la = lds;
         float *lb = lds + T::BM * T::LDS_STRIDE;
 #pragma unroll
@@ -251,10 +308,41 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
     __syncthreads();
     for (int s = s_begin; s < num_slices; ++s) {
         if (s + 1 < num_slices) load_slice();
+        if constexpr (X3) {
+            // lane (row frow, half fhalf) takes k = 16 kk + 8 fhalf .. + 7 of its row from each plane: one ds_read_b128
+            const unsigned short *lh = reinterpret_cast<const unsigned short *>(lds);
+            const unsigned short *la = lh + (wm * TM * 32 + frow) * T::ROW_HALFS + fhalf * 8;
+            const unsigned short *lb = lh + (T::BM + wn * TN * 32 + frow) * T::ROW_HALFS + fhalf * 8;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        fa[i][q] = *reinterpret_cast<const bf16x8 *>(la + i * 32 * T::ROW_HALFS + q * BK + kk * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + j * 32 * T::ROW_HALFS + q * BK + kk * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {      // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
         const float *la = lds + (wm * TM * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
         const float *lb = lds + (T::BM + wn * TN * 32 + frow) * T::LDS_STRIDE + fhalf * 4;
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
+        for (int kk = 0; kk < (X3 ? 0 : BK / 8); ++kk) {
             float4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4 *>(la + i * 32 * T::LDS_STRIDE + kk * 8);
@@ -424,20 +512,29 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvParams p, i
     }
 }
 
+// Arithmetic of the matrix products: 1 = fp32 through three-way bf16 splits on the bf16 matrix pipe (X3, above),
+// 0 = the fp32-input MFMA.  Both give fp32-accurate results; X3 is 2.67x the matrix throughput.  HTD_CONV_MATH / the
+// setter below choose; layers whose channel count is not a multiple of 16 (the 8-channel stem) always take 0.
+int g_conv_math = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
+
 template <int WGM, int WGN, int TM, int TN>
 void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
 {
     const dim3 grid(blocks, p.splits);
+    const bool x3 = g_conv_math == 1;
     if (p.ntaps > 0) {           // strided data gradient sub-problem: rare, one BK is enough
-        if (p.Ci % 16 == 0)
-            hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, true>), grid, dim3(256), 0, s, p);
-        else
+        if (p.Ci % 16 == 0) {
+            if (x3) hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, true, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, true>), grid, dim3(256), 0, s, p);
+        } else
             hipLaunchKernelGGL((conv_igemm_kernel<8, WGM, WGN, TM, TN, true>), grid, dim3(256), 0, s, p);
-    } else if (p.Ci % 32 == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<32, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
-    else if (p.Ci % 16 == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
-    else
+    } else if (p.Ci % 32 == 0) {
+        if (x3) hipLaunchKernelGGL((conv_igemm_kernel<32, WGM, WGN, TM, TN, false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<32, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
+    } else if (p.Ci % 16 == 0) {
+        if (x3) hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<16, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
+    } else
         hipLaunchKernelGGL((conv_igemm_kernel<8, WGM, WGN, TM, TN, false>), grid, dim3(256), 0, s, p);
 }
 
@@ -699,6 +796,14 @@ extern "C" int htd_conv2d_tile_query(int64_t M, int Co, int Ci, int taps, int ep
 {
     int bm, bn;
     return choose_tile(M, Co, Ci, taps, epi, plan_splits(M, Co, Ci, taps), bm, bn);
+}
+
+// 1: fp32 via three-way bf16 splits on the bf16 matrix pipe (default), 0: fp32-input MFMA.  Returns the previous mode.
+extern "C" int htd_conv2d_set_math(int mode)
+{
+    const int prev = g_conv_math;
+    if (mode == 0 || mode == 1) g_conv_math = mode;
+    return prev;
 }
 
 // Batched NT GEMM on the same kernel: c[g] = a[g] @ b[g]^T, a [G][M][K], b [G][N][K], c [G][M][N].

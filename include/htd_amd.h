@@ -145,6 +145,10 @@ int64_t htd_conv2d_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw);
  * does behind torch.backends.cudnn.benchmark for the reference (mmdet/apis/train.py: cudnn_benchmark of the configs):
  * htd_amd/tuning.py loads the table measured on MI355X by tools/tune_conv_tiles.py; problems not in the table are
  * scored by a model of tile efficiency x wave quantisation.  htd_conv2d_tile_query: the id a launch would use now. */
+/* Arithmetic of htd_conv2d_fwd / htd_conv2d_bwd_data / htd_bgemm_nt products: 1 (default) = fp32 through exact three-way
+ * bf16 splits of both operands, six v_mfma_f32_32x32x16_bf16 per 16 k with fp32 accumulation (error class of fp32);
+ * 0 = v_mfma_f32_32x32x2_f32.  Returns the previous mode (any other argument only queries). */
+int htd_conv2d_set_math(int mode);
 int htd_conv2d_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg);
 int htd_conv2d_tile_table_clear(void);
 int htd_conv2d_tile_query(int64_t M, int Co, int Ci, int taps, int epi);

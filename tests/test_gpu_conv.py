@@ -313,3 +313,42 @@ def test_balanced_tail_epilogue_mask_and_accum():
     torch.testing.assert_close(fused, (plain + accum) * (mask_src > 0), rtol=1e-5, atol=1e-5)
     ref = torch.nn.functional.conv_transpose2d(g.double(), w.double(), None, 1, 1)
     torch.testing.assert_close(plain.double(), ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('Ci,Co,k,H,W', [(256, 256, 3, 40, 56), (1024, 256, 1, 50, 84), (64, 256, 1, 60, 80), (48, 96, 3, 33, 47)])
+def test_split_bf16_products_are_fp32_accurate(Ci, Co, k, H, W):
+    """htd_conv2d_set_math(1): fp32 products through exact three-way bf16 splits (six bf16 MFMAs per 16 k, fp32
+    accumulation) against math 0 (the fp32-input MFMA) and an fp64 reference, on data with a wide dynamic range: the
+    split form must sit in the same error class as native fp32 -- its error against fp64 at most 1.5x the native
+    kernel's, both ~1e-7 relative to the accumulated magnitude -- for forward and data gradient."""
+    from htd_amd import capi, dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(Ci + k)
+    x = (torch.randn(2, Ci, H, W, generator=g) * torch.exp(torch.randn(2, Ci, H, W, generator=g) * 2)).to(dev)
+    w = (torch.randn(Co, Ci, k, k, generator=g) * torch.exp(torch.randn(Co, Ci, k, k, generator=g))).to(dev) / (Ci * k * k) ** 0.5
+    x = x.contiguous(memory_format=torch.channels_last)
+    w = w.contiguous(memory_format=torch.channels_last)
+    p = k // 2
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, p)
+    scale = torch.nn.functional.conv2d(x.double().abs(), w.double().abs(), None, 1, p)       # accumulated magnitude
+    gy = torch.randn(ref.shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 1, p)
+    gscale = torch.nn.grad.conv2d_input(x.shape, w.double().abs(), gy.double().abs(), 1, p)
+    L = capi.lib()
+    prev = L.htd_conv2d_set_math(-1)
+    err = {}
+    try:
+        for mode in (0, 1):
+            L.htd_conv2d_set_math(mode)
+            xr = x.clone().requires_grad_()
+            y = dense.conv2d(xr, w, None, 1, p, 1)
+            y.backward(gy)
+            err[mode] = (float(((y.detach().double() - ref).abs() / scale).max()),
+                         float(((xr.grad.double() - gref).abs() / gscale).max()))
+    finally:
+        L.htd_conv2d_set_math(prev)
+    K = Ci * k * k
+    for i, what in enumerate(('forward', 'data gradient')):
+        # both: fp32 rounding of a K-term accumulation, relative to the accumulated magnitude (measured 2e-7 .. 2e-6)
+        assert err[0][i] < 1.5e-7 * K ** 0.5 and err[1][i] < 1.5e-7 * K ** 0.5, (what, err, K)
+        assert err[1][i] <= 1.5 * err[0][i] + 2e-8, (what, err, K)
