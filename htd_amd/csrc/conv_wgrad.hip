@@ -286,6 +286,241 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(WgradParams p)
     }
 }
 
+// ---- fp32 through three-way bf16 splits on the bf16 matrix pipe (see conv_fwd.hip, "X3") ----------------------------
+// Same tiling, split-K and bias-gradient scheme as conv_wgrad_kernel<2,2,2,2,PIX,true>; what differs is the LDS image
+// and the MFMA loop.  Both operands are K-major in memory ([pixel][channel]).  Every staged float4 (four channels of one
+// pixel) is split into three bf16 pieces and written to three [k][m] plane images with 320-byte rows; the MFMA operands
+// (8 consecutive k of one channel) come out of the hardware transposing read ds_read_b64_tr_b16, two reads per
+// 32 x 16 fragment and plane, and six v_mfma_f32_32x32x16_bf16 per block and 16 k carry the fp32 product.
+using bf16x8w = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2w = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2w = __attribute__((ext_vector_type(2))) float;
+using s16x4w = __attribute__((ext_vector_type(4))) short;
+
+constexpr int X3_ROW = 160;                    // half-words per LDS row: 128 + 32 pad (rows 16 banks apart)
+constexpr int X3_PLANE = BKW * X3_ROW;         // half-words per plane image
+
+__device__ __forceinline__ void split3x2w(float a, float b, unsigned &h, unsigned &m, unsigned &l)
+{
+    union { bf16x2w v; unsigned u; } c;
+    c.v = __builtin_convertvector(f32x2w{a, b}, bf16x2w);
+    h = c.u;
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    c.v = __builtin_convertvector(f32x2w{ra, rb}, bf16x2w);
+    m = c.u;
+    c.v = __builtin_convertvector(f32x2w{ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u)}, bf16x2w);
+    l = c.u;
+}
+
+__device__ __forceinline__ bf16x8w tr_frag(const unsigned short *img, int k0, int c0, int lane)
+{
+    // lane l: h = l>>5 takes k0 + 8h .. +7; its 16-lane group covers columns c0 + 16*((l>>4)&1) .. +15
+    const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned short *a = img + (k0 + 8 * h + q) * X3_ROW + c0 + 16 * g + 4 * pp;
+    const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w *)a);
+    const s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w *)(a + 4 * X3_ROW));
+    union { struct { s16x4w a, b; } s; bf16x8w v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+template <int PIX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradParams p)
+{
+    constexpr int WGN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
+    constexpr int VA = BM / 4, VB = BN / 4, PA = BKW * VA / 256, PB = BKW * VB / 256;      // 4 float4 per thread and operand
+    __shared__ __attribute__((aligned(16))) unsigned short lds[6 * X3_PLANE];
+    unsigned short *la = lds, *lb = lds + 3 * X3_PLANE;
+
+    int tile, split;
+    {
+        const int tiles = p.mt * p.nt, L = blockIdx.x;
+        if (p.splits % 8 == 0) {
+            const int xcd = L % 8, idx = L / 8;
+            tile = idx % tiles;
+            split = (idx / tiles) * 8 + xcd;
+        } else {
+            tile = L % tiles;
+            split = L / tiles;
+        }
+    }
+    const int tile_m = tile % p.mt, tile_n = tile / p.mt;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    int a_row[PA], b_row[PB];
+    const int a_col = (tid % VA) * 4, b_col = (tid % VB) * 4;
+    const bool a_cok = m0 + a_col < p.Co;
+    const int nb = n0 + b_col;
+    const bool b_cok = nb < p.Ntot;
+    const int tap = b_cok ? nb / p.Ci : 0;
+    const int b_ci = b_cok ? nb - tap * p.Ci : 0;
+    const int b_dy = (tap / p.kw) * p.dil - p.pad, b_dx = (tap % p.kw) * p.dil - p.pad;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_row[i] = (tid + i * 256) / VA;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_row[i] = (tid + i * 256) / VB;
+
+    const int64_t total_slices = (p.K + BKW - 1) / BKW;
+    const int64_t s_begin = (int64_t)split * p.slices_per_split;
+    const int64_t s_end = min(total_slices, s_begin + p.slices_per_split);
+
+    unsigned a_k[PA], b_k[PB];
+    int b_b[PB], b_ho[PB], b_wo[PB];
+    auto decode = [&](int i) {
+        const unsigned kk = b_k[i] < (unsigned)p.K ? b_k[i] : 0u;
+        b_wo[i] = (int)(kk % (unsigned)p.Wo);
+        const unsigned t = kk / (unsigned)p.Wo;
+        b_ho[i] = (int)(t % (unsigned)p.Ho);
+        b_b[i] = (int)(t / (unsigned)p.Ho);
+    };
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_k[i] = (unsigned)(s_begin * BKW) + a_row[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        b_k[i] = (unsigned)(s_begin * BKW) + b_row[i];
+        if constexpr (PIX != PIX_POINTWISE) decode(i);
+    }
+
+    float4 ra[PA], rb[PB];
+    unsigned ra_ok = 0u, rb_ok = 0u;
+    auto load_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const bool ok = a_cok && a_k[i] < (unsigned)p.K;
+            ra[i] = *reinterpret_cast<const float4 *>(p.gy + (ok ? a_k[i] * (unsigned)p.Co + m0 + a_col : 0u));
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+            a_k[i] += BKW;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            bool ok = b_cok && b_k[i] < (unsigned)p.K;
+            unsigned off;
+            if constexpr (PIX == PIX_POINTWISE) {
+                off = b_k[i] * (unsigned)p.Ci + b_ci;
+            } else {
+                const int hi = b_ho[i] * p.stride + b_dy, wi = b_wo[i] * p.stride + b_dx;
+                ok = ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                off = (((unsigned)b_b[i] * p.H + hi) * p.W + wi) * (unsigned)p.Ci + b_ci;
+            }
+            rb[i] = *reinterpret_cast<const float4 *>(p.x + (ok ? off : 0u));
+            rb_ok = ok ? (rb_ok | (1u << i)) : (rb_ok & ~(1u << i));
+            b_k[i] += BKW;
+            if constexpr (PIX == PIX_WIDE) {
+                const int wo = b_wo[i] + BKW;
+                const bool c1 = wo >= p.Wo;
+                b_wo[i] = c1 ? wo - p.Wo : wo;
+                const int ho = b_ho[i] + (c1 ? 1 : 0);
+                const bool c2 = ho == p.Ho;
+                b_ho[i] = c2 ? 0 : ho;
+                b_b[i] += c2 ? 1 : 0;
+            } else if constexpr (PIX == PIX_GENERAL) {
+                decode(i);
+            }
+        }
+    };
+    const bool do_bias = p.bias_out != nullptr && tile_n == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto put = [&](unsigned short *img, int row, int col, float4 v) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3x2w(v.x, v.y, h0, m0_, l0);
+        split3x2w(v.z, v.w, h1, m1, l1);
+        unsigned short *d = img + row * X3_ROW + col;
+        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(d + X3_PLANE) = make_uint2(m0_, m1);
+        *reinterpret_cast<uint2 *>(d + 2 * X3_PLANE) = make_uint2(l0, l1);
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const float4 v = keep4((ra_ok >> i) & 1u, ra[i]);
+            put(la, a_row[i], a_col, v);
+            if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) put(lb, b_row[i], b_col, keep4((rb_ok >> i) & 1u, rb[i]));
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_slice();
+        store_slice();
+    }
+    __syncthreads();
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) load_slice();
+#pragma unroll
+        for (int kk = 0; kk < BKW / 16; ++kk) {
+            bf16x8w fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag(la + q * X3_PLANE, kk * 16, wm * 64 + i * 32, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fb[j][q] = tr_frag(lb + q * X3_PLANE, kk * 16, wn * 64 + j * 32, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {      // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (s + 1 < s_end) {
+            __syncthreads();
+            store_slice();
+        }
+        __syncthreads();
+    }
+
+    if (do_bias) {          // threads sharing a column quad (tid % VA) fold their row partials in a fixed order
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < VA) {
+            float4 t = red[tid];
+            for (int r = 1; r < 256 / VA; ++r) {
+                const float4 v = red[r * VA + tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            float *dst = p.bias_out + (int64_t)split * p.Co;
+            const int m = m0 + tid * 4;
+            if (m < p.Co) dst[m] = t.x;
+            if (m + 1 < p.Co) dst[m + 1] = t.y;
+            if (m + 2 < p.Co) dst[m + 2] = t.z;
+            if (m + 3 < p.Co) dst[m + 3] = t.w;
+        }
+    }
+    float *out = p.out + (int64_t)split * p.Co * p.Ntot;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fcol;
+            if (n >= p.Ntot) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[i][j][r];
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                             int64_t n, int splits, const float *__restrict__ ws2 = nullptr,
                                                             float *__restrict__ out2 = nullptr, int n2 = 0)
@@ -474,6 +709,8 @@ Cfg choose(int Co, int Ntot, int64_t K)
 
 }  // namespace
 
+int g_wgrad_math = -1;       // -1: HTD_CONV_MATH / default; set together with the forward mode by htd_conv2d_set_math
+
 extern "C" int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
                                                     int pad, int dil)
 {
@@ -513,7 +750,13 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     dim3 grid((unsigned)(c.mt * c.nt * c.splits));
     const int pix = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? PIX_POINTWISE : (p.Wo >= BKW ? PIX_WIDE : PIX_GENERAL);
     const bool covec = (Co & 3) == 0;
-    if (c.bm == 32)
+    static const int math_env = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
+    const bool x3 = (g_wgrad_math < 0 ? math_env : g_wgrad_math) == 1 && c.bm == 128 && covec && (Ci & 3) == 0;
+    if (x3) {
+        if (pix == PIX_POINTWISE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_POINTWISE>, grid, dim3(256), 0, s, p);
+        else if (pix == PIX_WIDE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_WIDE>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_GENERAL>, grid, dim3(256), 0, s, p);
+    } else if (c.bm == 32)
         launch_wgrad<1, 4, 1, 1>(pix, covec, grid, s, p);
     else
         launch_wgrad<2, 2, 2, 2>(pix, covec, grid, s, p);
