@@ -307,13 +307,24 @@ def main():
     value = args.batch * world * args.steps / elapsed
 
     from htd_amd import dense
-    roof = dense.roofline_report(prof, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS)
+    # fp32 convolutions run as six bf16 MFMA products per fp32 product (exact three-way bf16 splits of both operands,
+    # fp32 accumulation: conv_fwd.hip "X3"): the roof of that algorithm is the bf16 matrix peak / 6 in algorithmic fp32
+    # FLOP/s; with HTD_CONV_MATH=0 (fp32-input MFMA) it is the fp32 matrix peak
+    x3 = capi.lib().htd_conv2d_set_math(-1) == 1
+    roof = dense.roofline_report(prof, PEAK_BF16_MFMA_TFLOPS / 6.0 if x3 else PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS,
+                                 PEAK_BF16_MFMA_TFLOPS)
+    if roof and roof.get('bound') == 'mfma' and 'bf16' not in roof['kernel']:
+        roof['peak'] = round(roof['peak'], 1)
+        roof['math'] = ('fp32 = 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits, fp32 accumulate; peak = 2500 / 6 '
+                        'algorithmic TFLOP/s (the fp32-input MFMA peak, 157.3, is not the bound of this kernel)') if x3 else \
+            'v_mfma_f32_32x32x2_f32'
+        roof['issued_bf16_tflops'] = round(roof['achieved'] * 6.0, 1) if x3 else None
     # HBM bytes per launch of the dominant kernel class come from separate rocprofv3 PMC passes (FETCH_SIZE,
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:
         tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
         cls = 'conv_wgrad' if 'wgrad' in roof['kernel'] else 'conv_igemm'
-        if roof and 'conv' in roof['kernel'] and 'bf16' not in roof['kernel']:      # PMC passes were taken on the fp32 kernels
+        if roof and 'conv' in roof['kernel'] and 'bf16' not in roof['kernel'] and not x3:      # PMC passes were taken on the fp32-MFMA kernels
             roof['traffic'] = tr[cls]['hbm_bytes_per_launch_corrected']
             roof['traffic_unit'] = 'bytes/launch (rocprofv3 PMC, profiles/r01_hbm_traffic.json)'
     except Exception:
@@ -328,7 +339,7 @@ def main():
         'value': round(value, 3),
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if args.bf16 else 'f32',
+        'dtype': 'bf16' if args.bf16 else 'f32',        # tensors, accumulation and results fp32; see roofline.math for the products
         'data': 'synthetic uint8 images through the on-device data pipeline' if args.pipeline else 'synthetic',
         'config': {'workload': (f'HTD {"ResNeXt-64x4d" if args.resnext else "ResNet"}-{args.depth}{"-DCN" if args.dcn else ""} FPN {"bf16 (backbone / FPN / RPN conv / RoI FC stacks)" if args.bf16 else "fp32"} inference (simple_test, hard NMS), batch {args.batch}/GPU '
                                 f'@ {args.width - 11}x{args.height}, {args.proposals} proposals/img into the RoI head'

@@ -524,11 +524,11 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvParams p, i
     }
 }
 
+int g_conv_math = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
+
 // Arithmetic of the matrix products: 1 = fp32 through three-way bf16 splits on the bf16 matrix pipe (X3, above),
 // 0 = the fp32-input MFMA.  Both give fp32-accurate results; X3 is 2.67x the matrix throughput.  HTD_CONV_MATH / the
 // setter below choose; layers whose channel count is not a multiple of 16 (the 8-channel stem) always take 0.
-int g_conv_math = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
-
 template <int WGM, int WGN, int TM, int TN>
 void launch_cfg(const ConvParams &p, unsigned blocks, hipStream_t s)
 {
@@ -597,11 +597,23 @@ static float tile_score(int cfg, int64_t M, int Co, int K, int splits)
     const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
     const bool long_k = K >= 1024;
     float base;
-    switch (cfg) {
-    case 3: base = long_k ? 1.00f : 0.90f; break;
-    case 4: base = long_k ? 0.98f : 0.97f; break;
-    case 5: base = long_k ? 0.98f : 0.98f; break;
-    default: base = long_k ? 0.86f : (K >= 512 ? 0.90f : 0.95f); break;
+    if (g_conv_math == 1) {
+        // split-bf16 products: the MFMA phase of a slice is 2.7x shorter, so everything else -- L2 -> LDS traffic, the
+        // operand split, barriers -- weighs more and the big tile's 2x lower traffic per FLOP decides
+        // (P2 3x3: 183 / 155 / 161 / 131 TF/s for 128x128 / 128x64 / 64x128 / 64x64; K = 256: 128 / 116 / 122 / 109)
+        switch (cfg) {
+        case 3: base = 1.00f; break;
+        case 4: base = long_k ? 0.86f : 0.90f; break;
+        case 5: base = long_k ? 0.88f : 0.94f; break;
+        default: base = long_k ? 0.72f : 0.82f; break;
+        }
+    } else {
+        switch (cfg) {
+        case 3: base = long_k ? 1.00f : 0.90f; break;
+        case 4: base = long_k ? 0.98f : 0.97f; break;
+        case 5: base = long_k ? 0.98f : 0.98f; break;
+        default: base = long_k ? 0.86f : (K >= 512 ? 0.90f : 0.95f); break;
+        }
     }
     const float w = (float)(tiles * splits) / 256.f;        // split-K: every tile is `splits` workgroups
     float quant;
