@@ -98,7 +98,6 @@ struct ConvParams {
     // one BK-channel slice back to back: a tile re-reads its own footprint from L1/L2 instead of streaming the whole
     // input once per tap through an L2 that the concurrent tiles of the XCD overflow)
     int cmajor;
-    int dbg;            // experiments only (HTD_CONV_DBG): 1 = no operand split, 2 = no MFMAs, 4 = no LDS fragment reads
 };
 
 // BK: floats of K per slice; WGM x WGN: wave grid of the block; TM x TN: 32x32 MFMA blocks per wave
@@ -259,14 +258,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
             unsigned short *lb = la + T::BM * T::ROW_HALFS;
             auto put = [&](unsigned short *row, float4 v) {
                 unsigned h0, m0_, l0, h1, m1, l1;
-                if (p.dbg & 1) {
-                    h0 = __builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u);
-                    h1 = __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u);
-                    m0_ = l0 = m1 = l1 = 0u;
-                } else {
                 split3x2(v.x, v.y, h0, m0_, l0);
                 split3x2(v.z, v.w, h1, m1, l1);
-                }
                 *reinterpret_cast<uint2 *>(row + vcol * 4) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2 *>(row + BK + vcol * 4) = make_uint2(m0_, m1);
                 *reinterpret_cast<uint2 *>(row + 2 * BK + vcol * 4) = make_uint2(l0, l1);
@@ -308,10 +301,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fhalf = lane >> 5;
-    if (p.dbg >> 4) {        // experiment: stagger co-resident workgroups (bits 4..7: units of 256 cycles, bit 3: slot rule)
-        const int slot = (p.dbg & 8) ? (int)(blockIdx.x % 3) : (int)((blockIdx.x / 256) % 3);
-        for (int i = 0; i < slot * (p.dbg >> 4); ++i) __builtin_amdgcn_s_sleep(4);
-    }
     if (s_begin < num_slices) {
         load_slice();
         store_slice(0);
@@ -337,7 +326,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
 #pragma unroll
                     for (int q = 0; q < 3; ++q)
                         fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + j * 32 * T::ROW_HALFS + q * BK + kk * 16);
-                if (p.dbg & 2) continue;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -720,7 +708,6 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
     p.partial = (float *)workspace;
     static const int cmajor_env = getenv("HTD_CONV_CMAJOR") ? atoi(getenv("HTD_CONV_CMAJOR")) : 1;
     p.cmajor = (p.ntaps == 0 && p.kh * p.kw > 1) ? cmajor_env : 0;
-    p.dbg = getenv("HTD_CONV_DBG") ? atoi(getenv("HTD_CONV_DBG")) : 0;
     unsigned launch_blocks = (unsigned)blocks;
     p.tail_first = p.tail_splits = p.tail_sps = 0;
     if (workspace && p.ntaps == 0 && p.splits == 1 && p.w_bstride == 0) {
