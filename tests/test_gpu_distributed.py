@@ -163,7 +163,8 @@ def _detector_worker(rank, world, port, q):
     gathered = [torch.zeros_like(got.cpu()) for _ in range(world)]
     dist.all_gather(gathered, got.cpu())
     same = all(torch.equal(g, gathered[0]) for g in gathered)
-    q.put((rank, err <= 2e-3 * scale and scale > 0 and same and used_sinks > 100, err, scale, same, used_sinks))
+    # float atomics (RoIAlign backward) and summation order differ between the two runs: 5e-3 of the largest update
+    q.put((rank, err <= 5e-3 * scale and scale > 0 and same and used_sinks > 100, err, scale, same, used_sinks))
     set_sample_keys(None)
     dist.destroy_process_group()
 
