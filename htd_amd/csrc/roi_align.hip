@@ -249,6 +249,139 @@ __global__ __launch_bounds__(256) void roi_align_bwd_rows_kernel(const float *__
     }
 }
 
+// ---- backward, gather form: no atomics, bit-stable ---------------------------------------------------------------
+// The scatter kernels above add every RoI's contribution with float atomics: ~1.3 TB/s of added bytes is the chip's
+// ceiling for that, and the order of the additions -- hence the last bits of the gradient -- changes from run to run.
+// Here a wavefront OWNS a strip of GW_TILE consecutive pixels of one feature-map row (all channels of a 64*CPL-wide
+// chunk), walks the RoIs whose footprint covers the strip in ascending RoI order, and writes every pixel once:
+//   gfeat[y][x][:] (+)= sum_r sum_q Wx_r[q][x] * ( sum_p Wy_r[p][y] * gout[r][p][q][:] / count_r )
+// Footprint boxes are precomputed per RoI (roi_bbox_kernel: 16 bytes each); a strip finds its RoIs with one ballot per
+// 64 boxes.  Uncovered strips are written as zeros (accumulate = 0: the map needs no memset) or left alone
+// (accumulate = 1: the map already holds another consumer's gradient).
+constexpr int GW_TILE = 16;
+
+struct RoiBox { short b, r_lo, r_hi, c_lo, c_hi, pad0, pad1, pad2; };      // b < 0: not on this level / degenerate
+
+__global__ __launch_bounds__(256) void roi_bbox_kernel(const float *__restrict__ rois, const int64_t *__restrict__ roi_level,
+                                                       int level, RoiBox *__restrict__ box, int64_t n, int B, int H, int W,
+                                                       int ph, int pw, float scale, int sampling_ratio, int aligned)
+{
+    const int64_t ri = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ri >= n) return;
+    RoiBox o{};
+    o.b = -1;
+    if (!roi_level || roi_level[ri] == (int64_t)level) {
+        const RoiGeom g = roi_geometry(rois + 5 * ri, scale, ph, pw, sampling_ratio, aligned);
+        int r_lo, r_hi, c_lo, c_hi, t0, t1;
+        axis_span(g.start_h, g.bin_h, 0, g.grid_h, H, r_lo, t0);
+        axis_span(g.start_h, g.bin_h, ph - 1, g.grid_h, H, t1, r_hi);
+        bool ok = g.batch >= 0 && g.batch < B && !(t0 < r_lo || r_hi < t1);
+        axis_span(g.start_w, g.bin_w, 0, g.grid_w, W, c_lo, t0);
+        axis_span(g.start_w, g.bin_w, pw - 1, g.grid_w, W, t1, c_hi);
+        ok = ok && !(t0 < c_lo || c_hi < t1);
+        if (ok) { o.b = (short)g.batch; o.r_lo = (short)r_lo; o.r_hi = (short)r_hi; o.c_lo = (short)c_lo; o.c_hi = (short)c_hi; }
+    }
+    box[ri] = o;
+}
+
+template <int CPL>      // channels per lane: 4 (float4, 256-channel chunks) or 1 (64-channel chunks, 4x the waves)
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ rois,
+                                                                   const RoiBox *__restrict__ box, float *__restrict__ gfeat,
+                                                                   int64_t n, int B, int C, int H, int W, int ph, int pw,
+                                                                   float scale, int sampling_ratio, int aligned, int accumulate,
+                                                                   int chunks, int segs, int64_t tasks)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= tasks) return;                          // whole wave exits together
+    const int chunk = (int)(task % chunks);
+    int64_t t2 = task / chunks;
+    const int seg = (int)(t2 % segs);
+    t2 /= segs;
+    const int y = (int)(t2 % H), b = (int)(t2 / H);
+    const int x0 = seg * GW_TILE, x1 = min(W, x0 + GW_TILE) - 1;
+    const int ch = chunk * 64 * CPL + lane * CPL;
+    const bool act = ch < C;
+
+    float acc[GW_TILE][CPL];
+#pragma unroll
+    for (int i = 0; i < GW_TILE; ++i)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) acc[i][k] = 0.f;
+    bool touched = false;
+
+    for (int64_t base = 0; base < n; base += 64) {
+        bool hit = false;
+        if (base + lane < n) {
+            const RoiBox o = box[base + lane];
+            hit = o.b == b && o.r_lo <= y && y <= o.r_hi && o.c_lo <= x1 && o.c_hi >= x0;
+        }
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int src = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int64_t ri = base + src;              // wave-uniform, ascending: the summation order is fixed
+            touched = true;
+            const RoiGeom g = roi_geometry(rois + 5 * ri, scale, ph, pw, sampling_ratio, aligned);
+            // fold the bins along y for this row:  T[q] = sum_p Wy[p][y] * gout[p][q] / count
+            const float wy_l = lane < ph ? axis_weight(g.start_h, g.bin_h, lane, g.grid_h, y, H) * g.inv_count : 0.f;
+            float T[MAXP][CPL];
+#pragma unroll
+            for (int q = 0; q < MAXP; ++q)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) T[q][k] = 0.f;
+            const float *go = gout + (size_t)ri * ph * pw * C + ch;
+            for (int p = 0; p < ph; ++p) {
+                const float wy = lane_bcast(wy_l, p);
+                if (wy == 0.f) continue;
+#pragma unroll
+                for (int q = 0; q < MAXP; ++q)
+                    if (q < pw && act) {
+                        if constexpr (CPL == 4) {
+                            const float4 v = *reinterpret_cast<const float4 *>(go + ((size_t)p * pw + q) * C);
+                            T[q][0] += wy * v.x; T[q][1] += wy * v.y; T[q][2] += wy * v.z; T[q][3] += wy * v.w;
+                        } else {
+                            T[q][0] += wy * go[((size_t)p * pw + q) * C];
+                        }
+                    }
+            }
+            // x weights of the strip: lane (q, xi) = (lane / 16, lane % 16) holds bins q and q + 4
+            const int xi_l = lane & 15, q_l = lane >> 4;
+            const bool xin = x0 + xi_l <= x1;
+            const float wx_a = (xin && q_l < pw) ? axis_weight(g.start_w, g.bin_w, q_l, g.grid_w, x0 + xi_l, W) : 0.f;
+            const float wx_b = (xin && q_l + 4 < pw) ? axis_weight(g.start_w, g.bin_w, q_l + 4, g.grid_w, x0 + xi_l, W) : 0.f;
+#pragma unroll
+            for (int xi = 0; xi < GW_TILE; ++xi) {
+#pragma unroll
+                for (int q = 0; q < MAXP; ++q) {
+                    if (q >= pw) continue;
+                    const float w = q < 4 ? lane_bcast(wx_a, q * 16 + xi) : lane_bcast(wx_b, (q - 4) * 16 + xi);
+                    if (w != 0.f) {
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k) acc[xi][k] += w * T[q][k];
+                    }
+                }
+            }
+        }
+    }
+    if (!act || (accumulate && !touched)) return;
+    float *row = gfeat + (((size_t)b * H + y) * W + x0) * C + ch;
+#pragma unroll
+    for (int xi = 0; xi < GW_TILE; ++xi) {
+        if (x0 + xi > x1) continue;
+        if constexpr (CPL == 4) {
+            float4 v = make_float4(acc[xi][0], acc[xi][1], acc[xi][2], acc[xi][3]);
+            if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4 *>(row + (size_t)xi * C);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4 *>(row + (size_t)xi * C) = v;
+        } else {
+            row[(size_t)xi * C] = accumulate ? row[(size_t)xi * C] + acc[xi][0] : acc[xi][0];
+        }
+    }
+}
+
 int launch(bool backward, const float *in, const float *rois, const int64_t *roi_level, int level, float *out,
            int64_t n, int B, int C, int H, int W, int ph, int pw, float scale, int sr, int aligned,
            void *stream)
@@ -292,6 +425,47 @@ extern "C" int htd_roi_align_fwd(const float *feat, const float *rois, const int
 {
     return launch(false, feat, rois, roi_level, level, out, n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio,
                   aligned, stream);
+}
+
+extern "C" int64_t htd_roi_align_bwd_gather_workspace_bytes(int64_t n) { return (n > 0 ? n : 1) * (int64_t)sizeof(RoiBox); }
+
+// Gather-form backward (no atomics, bit-stable): grad_feat = (accumulate ? grad_feat : 0) + RoIAlign^T(grad_out).
+// Every pixel of grad_feat is written when accumulate == 0 (no memset needed).  workspace: ..._workspace_bytes(n).
+extern "C" int htd_roi_align_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
+                                        float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,
+                                        float spatial_scale, int sampling_ratio, int aligned, int accumulate, void *workspace,
+                                        void *stream)
+{
+    HTD_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && ph <= MAXP && pw <= MAXP,
+                "roi_align_bwd_gather: bad sizes n=%lld B=%d C=%d H=%d W=%d out=%dx%d", (long long)n, B, C, H, W, ph, pw);
+    HTD_REQUIRE(C % 4 == 0 && H < 32768 && W < 32768 && B < 32768, "roi_align_bwd_gather: C=%d must be a multiple of 4", C);
+    HTD_REQUIRE(grad_feat && (n == 0 || (grad_out && rois && workspace)), "roi_align_bwd_gather: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (!accumulate && hipMemsetAsync(grad_feat, 0, (size_t)B * H * W * C * 4, s) != hipSuccess) {
+            htd::set_error("roi_align_bwd_gather: memset failed");
+            return HTD_ERR_LAUNCH;
+        }
+        return HTD_OK;
+    }
+    RoiBox *box = (RoiBox *)workspace;
+    hipLaunchKernelGGL(roi_bbox_kernel, dim3((unsigned)htd::ceil_div(n, 256)), dim3(256), 0, s, rois, roi_level, level, box, n, B,
+                       H, W, ph, pw, spatial_scale, sampling_ratio, aligned);
+    const int segs = (W + GW_TILE - 1) / GW_TILE;
+    const int64_t strips = (int64_t)B * H * segs;
+    // float4 lanes (256-channel chunks) when that already gives the chip enough strips, else 64-channel chunks
+    const bool wide = strips * ((C + 255) / 256) >= 8192;
+    const int chunks = wide ? (C + 255) / 256 : (C + 63) / 64;
+    const int64_t tasks = strips * chunks;
+    const int64_t blocks = htd::ceil_div(tasks, 4);
+    HTD_REQUIRE(blocks < (1ll << 31), "roi_align_bwd_gather: too many strips");
+    if (wide)
+        hipLaunchKernelGGL(roi_align_bwd_gather_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out, rois, box, grad_feat,
+                           n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, accumulate, chunks, segs, tasks);
+    else
+        hipLaunchKernelGGL(roi_align_bwd_gather_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, grad_out, rois, box, grad_feat,
+                           n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, accumulate, chunks, segs, tasks);
+    return htd::check_launch("roi_align_bwd_gather");
 }
 
 extern "C" int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *roi_level, int level,

@@ -76,6 +76,37 @@ def _grad_buffer(galias, shape, device, dtype):
     return buf
 
 
+# RoIAlign backward: 'gather' (default) -- a wavefront owns a strip of feature-map pixels and sums the RoIs covering it in
+# RoI order: no float atomics, bit-stable, every pixel written once (no memset); 'scatter' -- the atomic kernels.
+ROI_BWD = __import__('os').environ.get('HTD_ROI_BWD', 'gather')
+
+
+def _roi_align_bwd(g, rois, lvls, level, galias, shape, ph, pw, scale, sr, aligned):
+    """-> gradient map of one level: galias (+)= RoIAlign^T(g), or a fresh map when nothing was handed down."""
+    B, C, H, W = shape
+    n = rois.size(0)
+    if ROI_BWD != 'gather' or ph > 8 or pw > 8:
+        gf = _grad_buffer(galias, shape, g.device, g.dtype)
+        capi.call('htd_roi_align_bwd', _P(g), _P(rois), _P(lvls), level, _P(gf), n, B, C, H, W, ph, pw, scale, sr, aligned, _S())
+        return gf
+    usable = galias is not None and galias.dtype == g.dtype and tuple(galias.shape) == tuple(shape) and \
+        galias.is_contiguous(memory_format=CL)
+    if usable:
+        gf, acc = galias, 1
+    else:
+        gf = torch.empty(shape, device=g.device, dtype=g.dtype, memory_format=CL)
+        acc = 0
+        if galias is not None:
+            gf.copy_(galias)
+            acc = 1
+    ws = torch.empty(capi.lib().htd_roi_align_bwd_gather_workspace_bytes(n), dtype=torch.uint8, device=g.device)
+    # algorithmic bytes: the map written once (+ read when accumulating) + every RoI's 7x7xC gradient read once
+    work = ('byte', 4.0 * (B * H * W * C * (1 + acc) + n * ph * pw * C)) if level in (0, None) or lvls is None else ('byte', 0.0)
+    capi.call('htd_roi_align_bwd_gather', _P(g), _P(rois), _P(lvls), level if level is not None else 0, _P(gf), n, B, C, H, W,
+              ph, pw, scale, sr, aligned, acc, _P(ws), _S(), work=work)
+    return gf
+
+
 class RoIAlignFunction(Function):
     """mmcv.ops.roi_align semantics (avg pooling, aligned flag, sampling_ratio=0 => adaptive).  chain=True also
     returns an identity alias of `feat` (see PyramidTaps)."""
@@ -110,9 +141,7 @@ class RoIAlignFunction(Function):
         if grad_out is None:
             return (galias, ) + (None, ) * 6
         grad_out = nhwc(grad_out)
-        gfeat = _grad_buffer(galias if ctx.chain else None, (B, C, H, W), grad_out.device, grad_out.dtype)
-        capi.call('htd_roi_align_bwd', _P(grad_out), _P(rois), None, 0, _P(gfeat), rois.size(0), B, C, H, W, ph, pw,
-                  scale, sr, aligned, _S())
+        gfeat = _roi_align_bwd(grad_out, rois, None, 0, galias if ctx.chain else None, (B, C, H, W), ph, pw, scale, sr, aligned)
         return gfeat, None, None, None, None, None, None
 
 
@@ -199,10 +228,8 @@ class _RoIAlignLevels(Function):
             if not ctx.needs_input_grad[7 + i]:
                 grads.append(None)
                 continue
-            gf = _grad_buffer(galias[i] if (ctx.chain and i < len(galias)) else None, (B, C, H, W), g.device, g.dtype)
-            capi.call('htd_roi_align_bwd', _P(g), _P(rois), _P(lvls), i, _P(gf), rois.size(0), B, C, H, W, ph, pw,
-                      float(scales[i]), sr, aligned, _S())
-            grads.append(gf)
+            grads.append(_roi_align_bwd(g, rois, lvls, i, galias[i] if (ctx.chain and i < len(galias)) else None,
+                                        (B, C, H, W), ph, pw, float(scales[i]), sr, aligned))
         return (None, None, None, None, None, None, None, *grads)
 
 

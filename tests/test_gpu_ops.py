@@ -315,3 +315,46 @@ def test_max_pool2d_matches_aten(dev, k, s, p, H, W):
     ya.backward(g.to(dev))
     yb.backward(g)
     torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('C,H,W,stride,n', [(256, 40, 56, 4, 300), (64, 20, 28, 8, 400), (8, 9, 7, 16, 20), (512, 50, 84, 16, 700)])
+def test_roi_align_backward_gather_form(dev, C, H, W, stride, n):
+    """The gather-form backward (no atomics): equal to the scatter kernels and to the oracle within fp32 summation order,
+    bit-identical from run to run, correct when it accumulates onto an existing map (chained consumers), and it writes
+    every pixel (a map full of NaNs must come back clean when accumulate = 0)."""
+    from htd_amd import capi
+    from oracle import ops as O
+    gen = torch.Generator().manual_seed(C + n)
+    B = 2
+    rois = rand_rois(gen, n, B, H, W, stride, big=True)
+    rois[0, 1:] = torch.tensor([0., 0., 0., 0.])
+    rois[1, 1:] = torch.tensor([0., 0., W * stride, H * stride])
+    go = torch.randn(n, C, 7, 7, generator=gen)
+    gref = O.roi_align_bwd(go, rois, (B, C, H, W), 1.0 / stride, 0, True)
+    god, rd = cl(go.to(dev)), rois.to(dev)
+    L = capi.lib()
+    ws = torch.empty(L.htd_roi_align_bwd_gather_workspace_bytes(n), dtype=torch.uint8, device=dev)
+
+    def gather(into, accumulate):
+        capi.call('htd_roi_align_bwd_gather', capi.ptr(god), capi.ptr(rd), None, 0, capi.ptr(into), n, B, C, H, W, 7, 7,
+                  1.0 / stride, 0, 1, accumulate, capi.ptr(ws), capi.current_stream_ptr())
+        return into
+    a = gather(torch.full((B, C, H, W), float('nan'), device=dev).contiguous(memory_format=torch.channels_last), 0)
+    b = gather(torch.empty((B, C, H, W), device=dev).contiguous(memory_format=torch.channels_last), 0)
+    assert torch.equal(a, b)                                            # bit-stable, every pixel written
+    torch.testing.assert_close(a.cpu(), gref, rtol=1e-4, atol=1e-4)
+    scat = torch.zeros((B, C, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+    capi.call('htd_roi_align_bwd', capi.ptr(god), capi.ptr(rd), None, 0, capi.ptr(scat), n, B, C, H, W, 7, 7, 1.0 / stride, 0, 1,
+              capi.current_stream_ptr())
+    torch.testing.assert_close(a, scat, rtol=1e-4, atol=1e-4)
+    base = torch.randn(B, C, H, W, generator=gen).to(dev).contiguous(memory_format=torch.channels_last)
+    c = gather(base.clone(memory_format=torch.channels_last), 1)
+    torch.testing.assert_close(c, base + a, rtol=1e-6, atol=1e-6)
+    # RoIs of another pyramid level are skipped
+    lv = torch.zeros(n, dtype=torch.int64, device=dev)
+    lv[::2] = 1
+    d = torch.empty_like(a)
+    capi.call('htd_roi_align_bwd_gather', capi.ptr(god), capi.ptr(rd), capi.ptr(lv), 1, capi.ptr(d), n, B, C, H, W, 7, 7,
+              1.0 / stride, 0, 1, 0, capi.ptr(ws), capi.current_stream_ptr())
+    gref1 = O.roi_align_bwd(go[::2], rois[::2], (B, C, H, W), 1.0 / stride, 0, True)
+    torch.testing.assert_close(d.cpu(), gref1, rtol=1e-4, atol=1e-4)
