@@ -10,8 +10,42 @@ result is scattered back -- a fixed, small number of launches with a single host
 """
 import torch
 
-from .. import dense
+from .. import capi, dense
 from ..core.misc import const_tensor
+
+_P, _S = capi.ptr, capi.current_stream_ptr
+FUSED_MAX_NPAD = 1024          # one wavefront holds a row of the (n, n) matrices in registers
+
+
+def local_adjacency(bx, counts):
+    """bx (G, npad, 4) group-padded boxes, counts (G,) -> A_local = D^-1/2 M D^-1/2 (G, npad, npad), M = (IoU with unit
+    diagonal) > 0 (htd_bbox_head.py:207-210): one launch, no gradient (a function of the boxes only)."""
+    G, npad = bx.shape[:2]
+    A = torch.empty(G, npad, npad, device=bx.device, dtype=torch.float32)
+    capi.call('htd_pgraph_adjacency', _P(bx.contiguous()), _P(counts), _P(A), G, npad, _S())
+    return A
+
+
+class _GlobalSoftmax(torch.autograd.Function):
+    """A_glob = softmax_row((1 - M) * sim) over each group's valid columns (:211,214-215), M read as A_local > 0."""
+
+    @staticmethod
+    def forward(ctx, sim, A_local, counts):
+        G, npad = sim.shape[:2]
+        sim = sim.contiguous()
+        A = torch.empty_like(sim)
+        capi.call('htd_pgraph_softmax_fwd', _P(sim), _P(A_local), _P(counts), _P(A), G, npad, _S())
+        ctx.save_for_backward(A, A_local, counts)
+        return A
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gA):
+        A, A_local, counts = ctx.saved_tensors
+        G, npad = A.shape[:2]
+        gsim = torch.empty_like(A)
+        capi.call('htd_pgraph_softmax_bwd', _P(gA.contiguous()), _P(A), _P(A_local), _P(counts), _P(gsim), G, npad, _S())
+        return gsim, None, None
 
 
 def group_layout(rois, target_lvls, num_levels, num_imgs=None, roi_valid=None):
@@ -66,25 +100,31 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, ro
     S8 = (sam.size(1) + 7) // 8 * 8
     sg = torch.nn.functional.pad(torch.index_select(sam, 0, flat_rows).view(G, npad, -1) * vf, (0, S8 - sam.size(1)))
     bx = torch.index_select(rois, 0, flat_rows).view(G, npad, -1)[..., 1:5]
-    # pairwise IoU inside each group (bbox_overlaps with its eps=1e-6 union floor), unit diagonal
-    lt = torch.max(bx[:, :, None, :2], bx[:, None, :, :2])
-    rb = torch.min(bx[:, :, None, 2:], bx[:, None, :, 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[..., 0] * wh[..., 1]
-    area = (bx[..., 2] - bx[..., 0]) * (bx[..., 3] - bx[..., 1])
-    union = torch.max(area[:, :, None] + area[:, None, :] - inter, const_tensor([1e-6], inter.device, inter.dtype))
-    eye = torch.eye(npad, device=x.device, dtype=torch.bool)[None]
-    pair = valid[:, :, None] & valid[:, None, :]
-    Mloc = (((inter / union > 0) | eye) & pair).to(x.dtype)                 # (G, npad, npad), symmetric
-    dinv = Mloc.sum(-1).clamp(min=1.0).pow(-0.5)                            # padded rows: avoid 0^-1/2
-    A_local = dinv[:, :, None] * Mloc * dinv[:, None, :]
-    # mixed^T[f][i] = sum_j x^T[f][j] * A_local[i][j]   (A_local @ x, kept transposed: it is the NT operand below)
-    mixedT = dense.bgemm_nt(xg.transpose(1, 2).contiguous(), A_local)       # (G, F, npad)
-    sim = dense.bgemm_nt(sg, sg)                                            # (G, npad, npad)
-    logits = (1.0 - Mloc) * sim
-    logits = torch.where(pair, logits, logits.new_full((1, ), float('-inf')))   # padded columns carry no mass
-    logits = torch.where(valid[:, :, None], logits, torch.zeros_like(logits))   # padded rows: finite, unused
-    A_glob = torch.softmax(logits, dim=-1) * vf
+    counts = counts.contiguous()
+    if npad <= FUSED_MAX_NPAD:
+        # IoU -> mask -> degree -> normalisation in one kernel; (1 - M) * sim -> row soft-max in another
+        A_local = local_adjacency(bx, counts)
+        # mixed^T[f][i] = sum_j x^T[f][j] * A_local[i][j]   (A_local @ x, kept transposed: it is the NT operand below)
+        mixedT = dense.bgemm_nt(xg.transpose(1, 2).contiguous(), A_local)   # (G, F, npad)
+        A_glob = _GlobalSoftmax.apply(dense.bgemm_nt(sg, sg), A_local, counts)
+    else:       # groups beyond 1024 RoIs (no HTD config gets there): the same arithmetic as tensor expressions
+        lt = torch.max(bx[:, :, None, :2], bx[:, None, :, :2])
+        rb = torch.min(bx[:, :, None, 2:], bx[:, None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        area = (bx[..., 2] - bx[..., 0]) * (bx[..., 3] - bx[..., 1])
+        union = torch.max(area[:, :, None] + area[:, None, :] - inter, const_tensor([1e-6], inter.device, inter.dtype))
+        eye = torch.eye(npad, device=x.device, dtype=torch.bool)[None]
+        pair = valid[:, :, None] & valid[:, None, :]
+        Mloc = (((inter / union > 0) | eye) & pair).to(x.dtype)             # (G, npad, npad), symmetric
+        dinv = Mloc.sum(-1).clamp(min=1.0).pow(-0.5)                        # padded rows: avoid 0^-1/2
+        A_local = dinv[:, :, None] * Mloc * dinv[:, None, :]
+        mixedT = dense.bgemm_nt(xg.transpose(1, 2).contiguous(), A_local)
+        sim = dense.bgemm_nt(sg, sg)                                        # (G, npad, npad)
+        logits = (1.0 - Mloc) * sim
+        logits = torch.where(pair, logits, logits.new_full((1, ), float('-inf')))   # padded columns carry no mass
+        logits = torch.where(valid[:, :, None], logits, torch.zeros_like(logits))   # padded rows: finite, unused
+        A_glob = torch.softmax(logits, dim=-1) * vf
     agg = dense.bgemm_nt(A_glob, mixedT).view(B, L, npad, Fdim)             # A_glob @ mixed
     outs = []
     for i, layer in enumerate(graph_layers):

@@ -534,3 +534,41 @@ def test_aug_test_matches_reference_fixture(det, golden):
     match_detections(mine, torch.cat([ref_d, ref_l[:, None].float()], 1).numpy())
     with pytest.raises(AssertionError, match='batch size'):
         det.forward_test([torch.zeros(2, 3, 64, 64, device=dev)] * 2, [[{}, {}], [{}, {}]])
+
+
+def test_fused_pgraph_kernels_match_the_tensor_formulation():
+    """htd_pgraph_adjacency (IoU -> mask -> degree -> A_local) and htd_pgraph_softmax_fwd / _bwd ((1 - M) * sim -> row
+    soft-max and its gradient) against the same arithmetic written with tensor expressions: refined features and the
+    gradients w.r.t. x and sam, groups of very different sizes, an empty group, unused slots (roi_valid)."""
+    from htd_amd.detector import pgraph as PG
+    from htd_amd.detector.roi_extractors import map_roi_levels
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    N, F_, S = 700, 1024, 1025
+    size = torch.exp(torch.rand(N, generator=g) * 3.5 + 2.5)
+    cx, cy = torch.rand(N, generator=g) * 600, torch.rand(N, generator=g) * 400
+    img = torch.sort(torch.randint(0, 3, (N, ), generator=g).float())[0]
+    rois = torch.stack([img, cx - size / 2, cy - size / 2, cx + size / 2, cy + size / 2], 1).to(dev)
+    rois[5] = rois[4]                                     # a duplicate box (IoU 1)
+    lv = map_roi_levels(rois, 4)
+    valid = (torch.rand(N, generator=g) > 0.1).to(dev)
+    layers = [torch.nn.Linear(F_, F_).to(dev) for _ in range(4)]
+    x0 = torch.randn(N, F_, generator=g).to(dev) * 0.3
+    s0 = torch.randn(N, S, generator=g).to(dev) * 0.1
+    go = torch.randn(N, F_, generator=g).to(dev)
+    per_img = tuple(int((img == b).sum()) for b in range(3))
+    out = {}
+    saved = PG.FUSED_MAX_NPAD
+    try:
+        for fused in (True, False):
+            PG.FUSED_MAX_NPAD = saved if fused else 0
+            x, s = x0.clone().requires_grad_(), s0.clone().requires_grad_()
+            r = PG.pgraph_refine(x, s, rois, lv, layers, per_img, valid)
+            r.backward(go)
+            out[fused] = (r.detach(), x.grad, s.grad)
+    finally:
+        PG.FUSED_MAX_NPAD = saved
+    for a, b, name in zip(out[True], out[False], ('refined', 'grad x', 'grad sam')):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1.0), (name, float((a - b).abs().max()), scale)
+    assert float(out[True][0][~valid].abs().max()) == 0.0          # unused slots stay zero
