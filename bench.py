@@ -322,11 +322,12 @@ def main():
     # HBM bytes per launch of the dominant kernel class come from separate rocprofv3 PMC passes (FETCH_SIZE,
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:
-        tr = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['kernels']
+        name = 'r02_hbm_traffic.json' if x3 else 'r01_hbm_traffic.json'     # passes taken on the kernels of that arithmetic
+        tr = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
         cls = 'conv_wgrad' if 'wgrad' in roof['kernel'] else 'conv_igemm'
-        if roof and 'conv' in roof['kernel'] and 'bf16' not in roof['kernel'] and not x3:      # PMC passes were taken on the fp32-MFMA kernels
+        if roof and 'conv' in roof['kernel'] and 'bf16' not in roof['kernel'] and args.depth == 50 and not args.infer:
             roof['traffic'] = tr[cls]['hbm_bytes_per_launch_corrected']
-            roof['traffic_unit'] = 'bytes/launch (rocprofv3 PMC, profiles/r01_hbm_traffic.json)'
+            roof['traffic_unit'] = f'bytes/launch (rocprofv3 PMC passes of this command, profiles/{name})'
     except Exception:
         pass
     if args.profile_kernels or args.profile_detail:

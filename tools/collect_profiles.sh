@@ -1,0 +1,38 @@
+#!/bin/bash
+# Evidence runs of a round (MI355X box, through gpurun): bench lines, rocprofv3 kernel stats and PMC passes.
+# usage: bash tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>/*
+set -o pipefail
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+[ -z "$R" ] && R=$(pwd)
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py"
+echo "== bench lines"
+$B --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+HTD_CONV_MATH=0 $B --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_fp32mfma.json 2>/dev/null
+$B --steps 20 --warmup 5 --no-cpu-baseline --trained-like > $OUT/bench_trained_like.json 2>/dev/null
+$B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 > $OUT/bench_r101.json 2>/dev/null
+$B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 --bf16 > $OUT/bench_r101_bf16.json 2>/dev/null
+$B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 --dcn > $OUT/bench_r101_dcn.json 2>/dev/null
+$B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 --dcn --bf16 > $OUT/bench_r101_dcn_bf16.json 2>/dev/null
+$B --steps 5 --warmup 2 --infer --depth 101 --batch 64 > $OUT/bench_infer_r101_b64.json 2>/dev/null
+$B --steps 5 --warmup 2 --infer --depth 101 --batch 64 --bf16 > $OUT/bench_infer_r101_b64_bf16.json 2>/dev/null
+echo "== kernel stats"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/a -o a -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_train.log 2>&1
+head -61 /tmp/p_$TAG/a/*kernel_stats.csv > $OUT/kernel_stats_top60.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/b -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --depth 101 --bf16 > $OUT/prof_bf16.log 2>&1
+head -61 /tmp/p_$TAG/b/*kernel_stats.csv > $OUT/kernel_stats_r101_bf16_top60.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/c -o c -- python3 $R/bench.py --steps 3 --warmup 1 --infer --depth 101 --batch 64 > $OUT/prof_infer.log 2>&1
+head -61 /tmp/p_$TAG/c/*kernel_stats.csv > $OUT/kernel_stats_infer_r101_b64_top60.csv
+echo "== PMC passes (each alone)"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_$TAG/f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_$TAG/w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 $R/tools/pmc_traffic.py /tmp/p_$TAG/f/*counter_collection.csv /tmp/p_$TAG/w/*counter_collection.csv $OUT/hbm_traffic.json > /dev/null
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d /tmp/p_$TAG/m -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python3 $R/tools/pmc_mfma.py /tmp/p_$TAG/m/*counter_collection.csv $OUT/mfma_busy.json > /dev/null
+echo "== RoIAlign"
+python3 $R/tools/bench_roi_align.py 2048 4 > $OUT/roi_align_2048.log 2>&1
+python3 $R/tools/bench_roi_align.py 32768 4 > $OUT/roi_align_32768.log 2>&1
+ls -la $OUT
