@@ -42,8 +42,13 @@ class TileLinear(nn.Linear):
         assert w.is_contiguous(memory_format=torch.channels_last)
         return w.permute(0, 2, 3, 1).reshape(w.size(0), -1)
 
-    def forward(self, x):            # reference-order 2-D input (tests / tools): logical matrix
-        return F.linear(x, self.weight.reshape(self.out_features, -1), self.bias)
+    def forward(self, x):
+        """Reference-order 2-D input (n, C*h*w): the logical matrix on the MFMA GEMM (the heads themselves go through
+        fc_on_roi_tiles and never re-order the activations).  GPU only, like every operator of this package."""
+        if not x.is_cuda:
+            raise NotImplementedError('TileLinear: only GPU tensors are supported (libhtd_amd.so has no CPU path)')
+        from .. import dense
+        return dense.linear(x, self.weight.reshape(self.out_features, -1).contiguous(), self.bias)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)
