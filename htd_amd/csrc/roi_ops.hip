@@ -360,6 +360,95 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(const float *__restric
     }
 }
 
+// ---- all frozen-BN folds (and the data-gradient weight images) of a ResNet stage in ONE launch ----------------------
+// A stage of R101 has up to 70 conv + BN pairs; folded one by one that is a 5-microsecond launch per pair and pass, and
+// every data gradient re-flips its weights (htd_conv2d_flip_weights) on top.  Here a device table describes the layers
+// (pointers, shapes, prefix sums of their 32 x 32 tiles / of their rows) and a workgroup looks its layer up.
+struct FoldDesc {
+    const float *w, *gamma, *beta, *mean, *var;
+    float *wf, *bf, *wT;            // wT (may be NULL): [ci][taps-1-t][co], the flipped / transposed image for dgrad
+    int Co, Ci, taps, tile0;        // tile0: first tile of this layer in the launch
+};
+struct FoldBwdDesc {
+    const float *w, *gamma, *mean, *var, *gwf, *gbf;
+    float *gw, *ggamma, *gbeta;
+    int Co, K, row0, pad;
+};
+
+template <typename D, typename F>
+__device__ __forceinline__ int find_layer(const D *d, int n, int idx, F first)
+{
+    int lo = 0, hi = n - 1;                 // last layer whose first index is <= idx
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first(d[mid]) <= idx) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void bn_fold_many_fwd_kernel(const FoldDesc *__restrict__ descs, int n, float eps)
+{
+    __shared__ float tile[32][33];
+    const int l = find_layer(descs, n, (int)blockIdx.x, [](const FoldDesc &x) { return x.tile0; });
+    const FoldDesc d = descs[l];
+    const int nco = (d.Co + 31) / 32, nci = (d.Ci + 31) / 32;
+    int idx = (int)blockIdx.x - d.tile0;
+    const int ci_t = idx % nci;
+    idx /= nci;
+    const int co_t = idx % nco, t = idx / nco;
+    const int co0 = co_t * 32, ci0 = ci_t * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        float v = 0.f;
+        if (co < d.Co && ci < d.Ci) {
+            const float s = d.gamma[co] * rsqrtf(d.var[co] + eps);
+            const int64_t i = ((int64_t)co * d.taps + t) * d.Ci + ci;
+            v = d.w[i] * s;
+            d.wf[i] = v;
+        }
+        tile[r][tx] = v;
+    }
+    if (t == 0 && ci_t == 0 && ty == 0 && co0 + tx < d.Co) {
+        const int co = co0 + tx;
+        const float s = d.gamma[co] * rsqrtf(d.var[co] + eps);
+        d.bf[co] = d.beta[co] - d.mean[co] * s;
+    }
+    if (!d.wT) return;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < d.Ci && co < d.Co) d.wT[((int64_t)ci * d.taps + (d.taps - 1 - t)) * d.Co + co] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_fold_many_bwd_kernel(const FoldBwdDesc *__restrict__ descs, int n, float eps)
+{
+    const int l = find_layer(descs, n, (int)blockIdx.x, [](const FoldBwdDesc &x) { return x.row0; });
+    const FoldBwdDesc d = descs[l];
+    const int co = (int)blockIdx.x - d.row0, K = d.K;
+    const float rs = rsqrtf(d.var[co] + eps);
+    const float s = d.gamma[co] * rs;
+    const float *wr = d.w + (int64_t)co * K, *gr = d.gwf + (int64_t)co * K;
+    float *go = d.gw + (int64_t)co * K;
+    float dot = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const float4 v = ld4(wr + k), g = ld4(gr + k);
+        dot += v.x * g.x + v.y * g.y + v.z * g.z + v.w * g.w;
+        st4(go + k, make_float4(g.x * s, g.y * s, g.z * s, g.w * s));
+    }
+    __shared__ float red[4];
+    dot = htd::wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const float gb = d.gbf[co];
+        d.gbeta[co] = gb;
+        d.ggamma[co] = (tot - d.mean[co] * gb) * rs;
+    }
+}
+
 inline unsigned grid_for(int64_t work, int block = 256, int cap = 4096)
 {
     int64_t b = htd::ceil_div(work, block);
@@ -504,6 +593,28 @@ extern "C" int htd_bn_fold_fwd(const float *w, const float *gamma, const float *
     hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((unsigned)Co), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, mean,
                        var, eps, w_folded, b_folded, K);
     return htd::check_launch("bn_fold_fwd");
+}
+
+// desc: device array of n_layers FoldDesc { const float *w, *gamma, *beta, *mean, *var; float *wf, *bf, *wT; int Co, Ci,
+// taps, tile0; } (80 bytes each); total_tiles = sum over layers of taps * ceil(Co/32) * ceil(Ci/32).
+extern "C" int htd_bn_fold_many_fwd(const void *desc, int n_layers, int total_tiles, float eps, void *stream)
+{
+    static_assert(sizeof(FoldDesc) == 80, "FoldDesc layout is part of the ABI");
+    HTD_REQUIRE(desc && n_layers > 0 && total_tiles > 0, "bn_fold_many_fwd: bad arguments");
+    hipLaunchKernelGGL(bn_fold_many_fwd_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const FoldDesc *)desc, n_layers, eps);
+    return htd::check_launch("bn_fold_many_fwd");
+}
+
+// desc: device array of n_layers FoldBwdDesc { const float *w, *gamma, *mean, *var, *gwf, *gbf; float *gw, *ggamma,
+// *gbeta; int Co, K, row0, pad; } (88 bytes each); total_rows = sum of Co; K % 4 == 0.
+extern "C" int htd_bn_fold_many_bwd(const void *desc, int n_layers, int total_rows, float eps, void *stream)
+{
+    static_assert(sizeof(FoldBwdDesc) == 88, "FoldBwdDesc layout is part of the ABI");
+    HTD_REQUIRE(desc && n_layers > 0 && total_rows > 0, "bn_fold_many_bwd: bad arguments");
+    hipLaunchKernelGGL(bn_fold_many_bwd_kernel, dim3((unsigned)total_rows), dim3(256), 0, (hipStream_t)stream,
+                       (const FoldBwdDesc *)desc, n_layers, eps);
+    return htd::check_launch("bn_fold_many_bwd");
 }
 
 extern "C" int htd_bn_fold_bwd(const float *w, const float *gamma, const float *mean, const float *var, float eps,

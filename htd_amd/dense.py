@@ -132,6 +132,20 @@ def mark_side_consumed(t):
     _SIDE_CONSUMED.add(t.data_ptr())
 
 
+# Flipped / transposed weight images produced ahead of time (bricks._BNFoldMany writes them with the folds of a whole
+# stage): offered under the folded weight's address during the forward pass, taken -- and removed -- by the autograd
+# node that will run the data gradient (ResStageFunction.forward), which keeps them with its saved tensors.
+_FLIPPED = {}
+
+
+def offer_flipped(weight, wT):
+    _FLIPPED[weight.data_ptr()] = wT
+
+
+def take_flipped(weight):
+    return _FLIPPED.pop(weight.data_ptr(), None)
+
+
 def join_side_stream():
     """Main stream waits for everything queued on the weight-gradient stream (call after backward)."""
     if _SIDE:
@@ -184,8 +198,9 @@ def _mask_raw(g, y):
     return gm
 
 
-def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, accum=None):
-    """Data gradient of conv2d(x, weight) for gy = g, optionally + accum and masked by (mask_src > 0)."""
+def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, accum=None, wT=None):
+    """Data gradient of conv2d(x, weight) for gy = g, optionally + accum and masked by (mask_src > 0).
+    wT: the flipped / transposed image of `weight` when somebody made it already (htd_bn_fold_many_fwd)."""
     B, Ci, H, W = x_shape
     Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
@@ -197,11 +212,12 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
         gd = torch.empty((B, Cod, Ho, Wo), device=g.device, dtype=g.dtype, memory_format=CL)
         if gd.numel():
             capi.call('htd_pad_channels', _P(g), _P(gd), B * Ho * Wo, Co, Cod, _S())
-    wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
-    if Cod != Co:
-        capi.call('htd_conv2d_flip_weights_padded', _P(weight), _P(wT), Co, Cod, kh, kw, Ci, _S())
-    else:
-        capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, kh, kw, Ci, _S())
+    if wT is None or Cod != Co:
+        wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
+        if Cod != Co:
+            capi.call('htd_conv2d_flip_weights_padded', _P(weight), _P(wT), Co, Cod, kh, kw, Ci, _S())
+        else:
+            capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, kh, kw, Ci, _S())
     gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
     capi.call('htd_conv2d_bwd_data', _P(gd), _P(wT), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci, Cod, kh, kw, stride,
               padding, dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(),
@@ -412,6 +428,7 @@ class ResStageFunction(Function):
             x = out
         ctx.save_for_backward(*saved, *params)
         ctx.cfg = (strides, dilation, has_ds)
+        ctx.flipped = [take_flipped(t) if t.dim() == 4 else None for t in params]      # same indexing as params
         return x
 
     @staticmethod
@@ -420,6 +437,7 @@ class ResStageFunction(Function):
         strides, dilation, has_ds = ctx.cfg
         nb = len(strides)
         saved, params = ctx.saved_tensors[:4 * nb], ctx.saved_tensors[4 * nb:]
+        flipped = ctx.flipped
         offs, k = [], 0
         for ds in has_ds:
             offs.append(k)
@@ -444,13 +462,13 @@ class ResStageFunction(Function):
             elif pneed[5] or (ds and pneed[7]):
                 gb3 = _colsum_raw(gm3)[1]
             grads[k + 5] = gb3 if pneed[5] else None
-            gm2 = _dgrad_raw(gm3, w3, h2.shape, 1, 0, 1, mask_src=h2)
+            gm2 = _dgrad_raw(gm3, w3, h2.shape, 1, 0, 1, mask_src=h2, wT=flipped[k + 4])
             if pneed[2]:
                 grads[k + 2], gb2 = _wgrad_raw(h1, gm2, w2, stride, dilation, dilation, True if pneed[3] else None)
             else:
                 gb2 = _colsum_raw(gm2)[1] if pneed[3] else None
             grads[k + 3] = gb2 if pneed[3] else None
-            gm1 = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1)
+            gm1 = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1, wT=flipped[k + 2])
             if pneed[0]:
                 grads[k], gb1 = _wgrad_raw(x, gm1, w1, 1, 0, 1, True if pneed[1] else None)
             else:
@@ -462,9 +480,9 @@ class ResStageFunction(Function):
                 if pneed[6]:
                     grads[k + 6] = _wgrad_raw(x, gm3, wd, stride, 0, 1)[0]
                 grads[k + 7] = gb3 if pneed[7] else None
-                acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1) if need_x else None
+                acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1, wT=flipped[k + 6]) if need_x else None
             if need_x:
-                g = _dgrad_raw(gm1, w1, x.shape, 1, 0, 1, mask_src=None if first else x, accum=acc)
+                g = _dgrad_raw(gm1, w1, x.shape, 1, 0, 1, mask_src=None if first else x, accum=acc, wT=flipped[k])
                 premasked = not first
             else:
                 g = None

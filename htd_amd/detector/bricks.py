@@ -134,6 +134,117 @@ class _BNFold(torch.autograd.Function):
         return outs + (None, None, None)
 
 
+class _BNFoldMany(torch.autograd.Function):
+    """frozen_bn_fold of EVERY conv + BN pair of a ResNet stage: one launch forward (htd_bn_fold_many_fwd, which also
+    writes the flipped / transposed images the data gradients take), one backward (htd_bn_fold_many_bwd), instead of
+    one ~5-microsecond launch per pair and pass plus one weight flip per data gradient (R50: 52 + 42 + 52 launches per
+    step).  Inputs per pair: w, gamma, beta, mean, var; outputs per pair: w', b'."""
+
+    @staticmethod
+    def forward(ctx, eps, want_flips, *tensors):
+        import numpy as np
+        from .. import capi, dense
+        n = len(tensors) // 5
+        dev = tensors[0].device
+        ws = [tensors[5 * i].contiguous(memory_format=CL) for i in range(n)]
+        sizes = [(w.size(0), w.size(1), w.size(2) * w.size(3)) for w in ws]            # Co, Ci, taps
+        total = sum(2 * w.numel() + w.size(0) for w in ws) if want_flips else sum(w.numel() + w.size(0) for w in ws)
+        flat = torch.empty(total, device=dev, dtype=torch.float32)
+        desc = np.zeros((n, 10), dtype=np.int64)
+        outs, flips, off, tile0 = [], [], 0, 0
+        for i, (w, (Co, Ci, taps)) in enumerate(zip(ws, sizes)):
+            wf = flat[off:off + w.numel()].view(Co, w.size(2), w.size(3), Ci).permute(0, 3, 1, 2)      # KRSC memory
+            off += w.numel()
+            bf = flat[off:off + Co]
+            off += Co
+            wT = None
+            if want_flips:
+                wT = flat[off:off + w.numel()]
+                off += w.numel()
+            g, b, m, v = tensors[5 * i + 1:5 * i + 5]
+            desc[i, :8] = (w.data_ptr(), g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), wf.data_ptr(), bf.data_ptr(),
+                           wT.data_ptr() if wT is not None else 0)
+            desc[i, 8] = Co | (Ci << 32)                     # two int32 per int64 slot (little endian): Co, Ci
+            desc[i, 9] = taps | (tile0 << 32)                # taps, tile0
+            tile0 += taps * ((Co + 31) // 32) * ((Ci + 31) // 32)
+            outs += [wf, bf]
+            flips.append(wT)
+        table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+        capi.call('htd_bn_fold_many_fwd', capi.ptr(table), n, tile0, float(eps), capi.current_stream_ptr())
+        for wf, wT in zip(outs[0::2], flips):
+            dense.mark_side_consumed(wf)
+            if wT is not None:
+                dense.offer_flipped(wf, wT)              # picked up by ResStageFunction.forward, see dense.py
+        ctx.save_for_backward(*[t for i in range(n) for t in (ws[i], tensors[5 * i + 1], tensors[5 * i + 3], tensors[5 * i + 4])])
+        ctx.beta_refs = [tensors[5 * i + 2] for i in range(n)]
+        ctx.eps, ctx.n = float(eps), n
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        import numpy as np
+        from .. import capi, dense
+        n, saved = ctx.n, ctx.saved_tensors
+        dev = saved[0].device
+
+        def launch():
+            desc = np.zeros((n, 11), dtype=np.int64)
+            outs, row0, all_sinks, keep = [], 0, True, []
+            for i in range(n):
+                w, gamma, mean, var = saved[4 * i:4 * i + 4]
+                Co, K = w.size(0), w.numel() // w.size(0)
+                gwf, gbf = grads[2 * i], grads[2 * i + 1]
+                gwf = torch.zeros_like(w, memory_format=CL) if gwf is None else gwf.contiguous(memory_format=CL)
+                gbf = torch.zeros(Co, device=dev) if gbf is None else gbf.contiguous()
+                keep += [gwf, gbf]
+                (gw, s1), (gg, s2), (gb, s3) = dense.grad_out2(w), dense.grad_out2(gamma), dense.grad_out2(ctx.beta_refs[i])
+                all_sinks = all_sinks and s1 and s2 and s3
+                desc[i, :9] = (w.data_ptr(), gamma.data_ptr(), mean.data_ptr(), var.data_ptr(), gwf.data_ptr(), gbf.data_ptr(),
+                               gw.data_ptr(), gg.data_ptr(), gb.data_ptr())
+                desc[i, 9] = Co | (K << 32)
+                desc[i, 10] = row0
+                row0 += Co
+                outs.append((gw, gg, gb))
+            table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+            capi.call('htd_bn_fold_many_bwd', capi.ptr(table), n, row0, ctx.eps, capi.current_stream_ptr())
+            return outs, all_sinks, keep
+        if not dense.OVERLAP_WGRAD or (capi.profiling() and not dense._OVERLAP_IN_PROFILE):
+            outs = launch()[0]
+        else:       # the weight gradients were produced on the side stream (dense.py)
+            main, side = torch.cuda.current_stream(), dense.side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                outs, all_sinks, keep = launch()
+            for t in keep:
+                t.record_stream(side)
+            if not all_sinks:
+                for trio in outs:
+                    for t in trio:
+                        t.record_stream(main)
+                main.wait_stream(side)
+        res = [None, None]
+        for gw, gg, gb in outs:
+            res += [gw, gg, gb, None, None]
+        return tuple(res)
+
+
+def frozen_bn_fold_many(pairs, want_flips=True):
+    """[(conv_weight, bn), ...] -> [w'_0, b'_0, w'_1, b'_1, ...]: every fold of a stage in one launch (training, fp32
+    weights with K % 4 == 0 on the GPU); otherwise pair by pair."""
+    ok = torch.is_grad_enabled() and all(w.is_cuda and w.dtype == torch.float32 and (w.numel() // w.size(0)) % 4 == 0 and
+                                          not bn.training for w, bn in pairs)
+    if not ok or len({bn.eps for _, bn in pairs}) != 1:
+        out = []
+        for w, bn in pairs:
+            out += frozen_bn_fold(w, bn)
+        return out
+    args = []
+    for w, bn in pairs:
+        args += [w, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    return list(_BNFoldMany.apply(pairs[0][1].eps, bool(want_flips), *args))
+
+
 def frozen_bn_fold(conv_weight, bn):
     """Eval-mode BatchNorm (norm_eval=True, backbones/resnet.py:640-649) folded into the preceding conv:
     w' = w * s, b' = beta - mean * s with s = gamma / sqrt(var + eps).  The backward of the fold returns exactly

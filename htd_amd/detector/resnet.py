@@ -17,7 +17,7 @@ from torch.nn.modules.batchnorm import _BatchNorm
 from .. import mmcv_ops as M
 from ..dense import ResStageBf16Function, ResStageFunction
 from ..registry import BACKBONES
-from .bricks import build_conv_layer, build_norm_layer, constant_init, frozen_bn_fold, kaiming_init
+from .bricks import build_conv_layer, build_norm_layer, constant_init, frozen_bn_fold, frozen_bn_fold_many, kaiming_init
 
 CL = torch.channels_last
 FUSE_BF16_STAGE = os.environ.get('HTD_BF16_STAGE', '1') != '0'
@@ -140,12 +140,18 @@ class ResLayer(nn.Sequential):
         if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or not self._fusable() or \
                 (x.dtype == torch.bfloat16 and not FUSE_BF16_STAGE):
             return super().forward(x)           # CPU / DCN or grouped blocks: block by block
-        params = []
+        pairs = []
         for blk in self:
-            for conv, bn in ((blk.conv1, blk.norm1), (blk.conv2, blk.norm2), (blk.conv3, blk.norm3)):
-                params += frozen_bn_fold(conv.weight, bn)
+            pairs += [(blk.conv1.weight, blk.norm1), (blk.conv2.weight, blk.norm2), (blk.conv3.weight, blk.norm3)]
             if blk.downsample is not None:
-                params += frozen_bn_fold(blk.downsample[0].weight, blk.downsample[1])
+                pairs.append((blk.downsample[0].weight, blk.downsample[1]))
+        if x.dtype == torch.float32:
+            # every fold of the stage in one launch; it also leaves the flipped weight images for the data gradients
+            params = frozen_bn_fold_many(pairs, want_flips=x.requires_grad or any(w.requires_grad for w, _ in pairs))
+        else:
+            params = []
+            for w, bn in pairs:
+                params += frozen_bn_fold(w, bn)
         fn = ResStageFunction if x.dtype == torch.float32 else ResStageBf16Function
         return fn.apply(x, tuple(blk.conv2_stride for blk in self), self[0].dilation,
                         tuple(blk.downsample is not None for blk in self), *params)
