@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_rows_kernel(const float *__
 // Footprint boxes are precomputed per RoI (roi_bbox_kernel: 16 bytes each); a strip finds its RoIs with one ballot per
 // 64 boxes.  Uncovered strips are written as zeros (accumulate = 0: the map needs no memset) or left alone
 // (accumulate = 1: the map already holds another consumer's gradient).
-constexpr int GW_TILE = 16;
+constexpr int GW_TILE = 8;
 
 struct RoiBox { short b, r_lo, r_hi, c_lo, c_hi, pad0, pad1, pad2; };      // b < 0: not on this level / degenerate
 
@@ -371,17 +371,16 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *
                             for (int k = 0; k < CPL; ++k) T[r][q][k] += wy[r] * v[k];
                     }
             }
-            // x weights of the tile: lane (q, xi) = (lane / 16, lane % 16) holds bins q and q + 4
-            const int xi_l = lane & 15, q_l = lane >> 4;
-            const bool xin = x0 + xi_l <= x1;
-            const float wx_a = (xin && q_l < pw) ? axis_weight(g.start_w, g.bin_w, q_l, g.grid_w, x0 + xi_l, W) : 0.f;
-            const float wx_b = (xin && q_l + 4 < pw) ? axis_weight(g.start_w, g.bin_w, q_l + 4, g.grid_w, x0 + xi_l, W) : 0.f;
+            // x weights of the tile: lane (q, xi) = (lane / GW_TILE, lane % GW_TILE) holds Wx[q][x0 + xi]
+            static_assert(GW_TILE * MAXP == 64, "one lane per (bin, pixel) weight");
+            const int xi_l = lane % GW_TILE, q_l = lane / GW_TILE;
+            const float wx_l = (x0 + xi_l <= x1 && q_l < pw) ? axis_weight(g.start_w, g.bin_w, q_l, g.grid_w, x0 + xi_l, W) : 0.f;
 #pragma unroll
             for (int xi = 0; xi < GW_TILE; ++xi) {
 #pragma unroll
                 for (int q = 0; q < MAXP; ++q) {
                     if (q >= pw) continue;
-                    const float w = q < 4 ? lane_bcast(wx_a, q * 16 + xi) : lane_bcast(wx_b, (q - 4) * 16 + xi);
+                    const float w = lane_bcast(wx_l, q * GW_TILE + xi);
                     if (w != 0.f) {
 #pragma unroll
                         for (int r = 0; r < ROWS; ++r)
@@ -477,10 +476,10 @@ extern "C" int htd_roi_align_bwd_gather(const float *grad_out, const float *rois
     hipLaunchKernelGGL(roi_bbox_kernel, dim3((unsigned)htd::ceil_div(n, 256)), dim3(256), 0, s, rois, roi_level, level, box, n, B,
                        H, W, ph, pw, spatial_scale, sampling_ratio, aligned);
     const int segs = (W + GW_TILE - 1) / GW_TILE;
-    // one-row strips, float4 lanes (256-channel chunks).  Measured on the P2..P5 maps of B = 4 @ 800x1344 with 2048
-    // RoIs: 0.89 ms against 1.08 ms for 4-row x 128-channel tiles (fewer gout reads, but 225 VGPRs = 2 waves per SIMD)
-    // and 1.34 ms for 64-channel strips: the kernel is bound by the chain of dependent loads per RoI, i.e. by how many
-    // wavefronts are in flight, not by bytes
+    // one-row strips of 8 pixels, float4 lanes (256-channel chunks).  Measured on the P2..P5 maps of B = 4 @ 800x1344 with
+    // 2048 RoIs: 0.70 ms (96 VGPRs, 5 waves per SIMD) against 0.89 ms for 16-pixel strips (130 VGPRs), 1.08 ms for 4-row x
+    // 128-channel tiles (fewer gout reads, but 225 VGPRs = 2 waves per SIMD) and 0.87 ms for the atomic scatter: the kernel
+    // is bound by the chain of dependent loads per RoI, i.e. by how many wavefronts are in flight, not by bytes
     constexpr int rows = 1;
     const int chunks = (C + 255) / 256;
     const int hts = (H + rows - 1) / rows;

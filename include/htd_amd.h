@@ -54,7 +54,7 @@ int htd_roi_align_fwd(const float *feat, const float *rois, const int64_t *roi_l
 int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
                       float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,
                       float spatial_scale, int sampling_ratio, int aligned, void *stream);
-/* Gather form of the same backward: a wavefront owns a strip of 16 pixels of one feature-map row and sums the RoIs that
+/* Gather form of the same backward: a wavefront owns a strip of 8 pixels of one feature-map row and sums the RoIs that
  * cover it in ascending RoI order -- no float atomics (the scatter form is bound by their 1.3 TB/s and is not bit-stable
  * from run to run), every pixel written once.  accumulate = 0: grad_feat is overwritten everywhere (no memset needed);
  * 1: added to, strips no RoI covers are left alone.  workspace: htd_roi_align_bwd_gather_workspace_bytes(n). */
