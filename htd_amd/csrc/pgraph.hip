@@ -1,8 +1,8 @@
 // PGraph adjacency kernels (HTDBBoxHead.forward, roi_heads/bbox_heads/htd_bbox_head.py:198-219), batched over the
 // (image, pyramid level) groups of a call: group g holds counts[g] RoIs in rows 0..counts[g]-1 of a [G][npad] padding.
 //
-//   pgraph_adjacency_kernel    boxes -> A_local = D^-1/2 M D^-1/2,  M = (IoU with unit diagonal) > 0,  D = rowsum(M)
-//                              (:207-210): IoU, mask, degree and normalisation in ONE pass, no (G, n, n) temporaries
+//   pgraph_degree_kernel +     boxes -> A_local = D^-1/2 M D^-1/2,  M = (IoU with unit diagonal) > 0,  D = rowsum(M)
+//   pgraph_adjacency_kernel    (:207-210): one wavefront per row in both, no (G, n, n) temporaries
 //   pgraph_softmax_fwd_kernel  A_glob = softmax_row((1 - M) * sim)  (:211,214-215): local pairs keep logit 0 (not -inf:
 //                              SURVEY fact 6), padding columns carry no mass; one wavefront per row, shuffle reductions
 //   pgraph_softmax_bwd_kernel  its gradient with respect to sim
@@ -20,38 +20,47 @@ __device__ __forceinline__ bool overlaps(float4 a, float4 b)
     return inter / uni > 0.f;
 }
 
-// grid (npad / 64, G), 256 threads: a workgroup owns 64 rows of one group.  Degrees of ALL rows of the group are
-// recomputed by every workgroup of the group into LDS (n^2 / 256 box tests per thread; n <= ~1000: a few microseconds)
-// so that the normalisation needs no second launch.
-__global__ __launch_bounds__(256) void pgraph_adjacency_kernel(const float4 *__restrict__ boxes, const int64_t *__restrict__ counts,
-                                                               float *__restrict__ A, int npad)
+// degrees: one wavefront per row, lanes across the columns (ballot + popcount); dinv = D^-1/2, 1 for padded rows
+__global__ __launch_bounds__(256) void pgraph_degree_kernel(const float4 *__restrict__ boxes, const int64_t *__restrict__ counts,
+                                                            float *__restrict__ dinv, int npad, int64_t rows)
 {
-    extern __shared__ float dinv[];                  // [npad]
-    float4 *sbox = reinterpret_cast<float4 *>(dinv + npad);       // [npad]
-    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int g = (int)(r / npad), i = (int)(r % npad);
+    const int cnt = (int)counts[g];
+    int deg = 0;
+    if (i < cnt) {
+        const float4 *bx = boxes + (size_t)g * npad;
+        const float4 bi = bx[i];
+        for (int j0 = 0; j0 < cnt; j0 += 64) {
+            const int j = j0 + lane;
+            const bool m = j < cnt && (j == i || overlaps(bi, bx[j]));
+            deg += __popcll(__ballot(m));
+        }
+    }
+    if (lane == 0) dinv[r] = 1.f / sqrtf((float)(deg > 0 ? deg : 1));
+}
+
+// A_local rows: one wavefront per row, A[i][j] = M_ij * dinv_i * dinv_j (zeros in the padding)
+__global__ __launch_bounds__(256) void pgraph_adjacency_kernel(const float4 *__restrict__ boxes, const int64_t *__restrict__ counts,
+                                                               const float *__restrict__ dinv, float *__restrict__ A, int npad,
+                                                               int64_t rows)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int g = (int)(r / npad), i = (int)(r % npad);
     const int cnt = (int)counts[g];
     const float4 *bx = boxes + (size_t)g * npad;
-    for (int j = tid; j < npad; j += 256) sbox[j] = j < cnt ? bx[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    for (int j = tid; j < npad; j += 256) {
-        int deg = 0;
-        if (j < cnt) {
-            const float4 bj = sbox[j];
-            for (int k = 0; k < cnt; ++k) deg += (k == j || overlaps(bj, sbox[k])) ? 1 : 0;
-        }
-        dinv[j] = 1.f / sqrtf((float)(deg > 0 ? deg : 1));                 // padded rows: 1 (never used)
-    }
-    __syncthreads();
-    const int i0 = blockIdx.x * 64 + wave * 16;
-    for (int i = i0; i < i0 + 16 && i < npad; ++i) {
-        float *row = A + ((size_t)g * npad + i) * npad;
-        const bool vi = i < cnt;
-        const float4 bi = sbox[i];
-        const float di = dinv[i];
-        for (int j = lane; j < npad; j += 64) {
-            const bool m = vi && j < cnt && (i == j || overlaps(bi, sbox[j]));
-            row[j] = m ? di * dinv[j] : 0.f;
-        }
+    const float *dg = dinv + (size_t)g * npad;
+    float *row = A + (size_t)r * npad;
+    const bool vi = i < cnt;
+    const float4 bi = vi ? bx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float di = dg[i];
+    for (int j = lane; j < npad; j += 64) {
+        const bool m = vi && j < cnt && (i == j || overlaps(bi, bx[j]));
+        row[j] = m ? di * dg[j] : 0.f;
     }
 }
 
@@ -143,13 +152,17 @@ __global__ __launch_bounds__(256) void pgraph_softmax_bwd_kernel(const float *__
 }  // namespace
 
 // boxes [G][npad][4] (x1,y1,x2,y2; rows >= counts[g] ignored), counts [G] int64 on the device -> A_local [G][npad][npad].
-extern "C" int htd_pgraph_adjacency(const float *boxes, const int64_t *counts, float *A_local, int G, int npad, void *stream)
+// dinv: scratch of G * npad floats (receives D^-1/2).
+extern "C" int htd_pgraph_adjacency(const float *boxes, const int64_t *counts, float *A_local, float *dinv, int G, int npad,
+                                    void *stream)
 {
     HTD_REQUIRE(G > 0 && npad > 0 && npad % 64 == 0 && npad <= 64 * SM_MAX, "pgraph_adjacency: bad sizes G=%d npad=%d", G, npad);
-    HTD_REQUIRE(boxes && counts && A_local, "pgraph_adjacency: null pointer");
-    HTD_REQUIRE(G <= 65535, "pgraph_adjacency: too many groups");
-    hipLaunchKernelGGL(pgraph_adjacency_kernel, dim3((unsigned)(npad / 64), (unsigned)G), dim3(256), (size_t)npad * 20, (hipStream_t)stream,
-                       (const float4 *)boxes, counts, A_local, npad);
+    HTD_REQUIRE(boxes && counts && A_local && dinv, "pgraph_adjacency: null pointer");
+    const int64_t rows = (int64_t)G * npad;
+    const unsigned blocks = (unsigned)htd::ceil_div(rows, 4);
+    hipLaunchKernelGGL(pgraph_degree_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)boxes, counts, dinv, npad, rows);
+    hipLaunchKernelGGL(pgraph_adjacency_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)boxes, counts, dinv,
+                       A_local, npad, rows);
     return htd::check_launch("pgraph_adjacency");
 }
 

@@ -22,7 +22,8 @@ def local_adjacency(bx, counts):
     diagonal) > 0 (htd_bbox_head.py:207-210): one launch, no gradient (a function of the boxes only)."""
     G, npad = bx.shape[:2]
     A = torch.empty(G, npad, npad, device=bx.device, dtype=torch.float32)
-    capi.call('htd_pgraph_adjacency', _P(bx.contiguous()), _P(counts), _P(A), G, npad, _S())
+    dinv = torch.empty(G, npad, device=bx.device, dtype=torch.float32)
+    capi.call('htd_pgraph_adjacency', _P(bx.contiguous()), _P(counts), _P(A), _P(dinv), G, npad, _S())
     return A
 
 

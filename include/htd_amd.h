@@ -387,12 +387,14 @@ int htd_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, 
 /* ----------------------------------------------------------------------------------
  * PGraph adjacency (HTDBBoxHead.forward, mmdet/models/roi_heads/bbox_heads/htd_bbox_head.py:198-219), batched over the
  * (image, level) groups of a call: group g = rows 0..counts[g]-1 of a [G][npad] padding (npad % 64 == 0, <= 1024).
- *   adjacency    boxes [G][npad][4] -> A_local = D^-1/2 M D^-1/2, M = (bbox_overlaps with unit diagonal) > 0 (:207-210)
+ *   adjacency    boxes [G][npad][4] -> A_local = D^-1/2 M D^-1/2, M = (bbox_overlaps with unit diagonal) > 0 (:207-210);
+ *                dinv_scratch: G * npad floats
  *   softmax_fwd  A_glob = softmax_row((1 - M) * sim) over the valid columns (:211,214-215; local pairs keep logit 0);
  *                M is read back as A_local > 0; rows past counts[g] are zeros
  *   softmax_bwd  gradient of A_glob with respect to sim
  * ---------------------------------------------------------------------------------- */
-int htd_pgraph_adjacency(const float *boxes, const int64_t *counts, float *A_local, int G, int npad, void *stream);
+int htd_pgraph_adjacency(const float *boxes, const int64_t *counts, float *A_local, float *dinv_scratch, int G, int npad,
+                         void *stream);
 int htd_pgraph_softmax_fwd(const float *sim, const float *A_local, const int64_t *counts, float *A_glob, int G, int npad,
                            void *stream);
 int htd_pgraph_softmax_bwd(const float *gA, const float *A_glob, const float *A_local, const int64_t *counts, float *gsim,
