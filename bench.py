@@ -259,7 +259,8 @@ def main():
     else:
         model = build_htd_detector(args.depth, dcn=args.dcn, bf16=args.bf16, resnext=args.resnext)  # init_weights(), seed 0
         model = model.to(dev).train()
-        trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015)
+        # bf16 configurations: gradients cross xGMI as bf16 (186.8 MB for R101 instead of 373.6 MB), fp32 master buffers
+        trainer = Trainer(model, lr=0.02 if args.depth == 50 else 0.015, comm_dtype=torch.bfloat16 if args.bf16 else None)
         data = synthetic_batch(args.batch, args.height, args.width, args.width - 11, device=dev, seed=rank)
         if args.trained_like:
             trained_like_proposals(model, data, args.batch)

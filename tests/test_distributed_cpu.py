@@ -16,7 +16,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, comm_dtype=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from htd_amd.runner import FlatParams, GradientExchange
@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     unused = torch.nn.Linear(3, 3)                     # never receives a gradient (graph_lvl{i}_cls of an empty level)
     holder = torch.nn.ModuleList([model, unused])
     flat = FlatParams(holder, bucket_mb=0)             # tiny buckets: several collectives per step
-    ex = GradientExchange(flat)
+    ex = GradientExchange(flat, comm_dtype=comm_dtype)
     assert ex.enabled and len(flat.buckets) > 1
     x = torch.full((5, 8), float(rank + 1))
     flat.zero_grad()
@@ -40,18 +40,24 @@ def _worker(rank, world, port, q):
         ref.zero_grad()
         ref(torch.full((5, 8), float(r + 1))).sum().backward()
         tot = [t + p.grad for t, p in zip(tot, ref.parameters())]
-    ok = all(torch.allclose(p.grad, t, atol=1e-5) for p, t in zip(model.parameters(), tot))
+    # bf16 payload: every rank's bucket is rounded to bf16 (8 bits) before the sum
+    tol = dict(atol=1e-5) if comm_dtype is None else dict(rtol=2 ** -7, atol=1e-3)
+    ok = all(torch.allclose(p.grad, t, **tol) for p, t in zip(model.parameters(), tot))
     ok = ok and all(float(p.grad.abs().sum()) == 0.0 for p in unused.parameters())
     ok = ok and all(p.grad.data_ptr() >= flat.grad.data_ptr() for p in holder.parameters())   # still views of the flat buffer
     q.put((rank, ok))
     dist.destroy_process_group()
 
 
-def test_gradient_exchange_world2():
+import pytest
+
+
+@pytest.mark.parametrize('comm_dtype', [None, torch.bfloat16], ids=['fp32', 'bf16_payload'])
+def test_gradient_exchange_world2(comm_dtype):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, comm_dtype)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
