@@ -320,6 +320,7 @@ def main():
                         'algorithmic TFLOP/s (the fp32-input MFMA peak, 157.3, is not the bound of this kernel)') if x3 else \
             'v_mfma_f32_32x32x2_f32'
         roof['issued_bf16_tflops'] = round(roof['achieved'] * 6.0, 1) if x3 else None
+        roof['frac_of_fp32_input_mfma_peak'] = round(roof['achieved'] / PEAK_F32_MFMA_TFLOPS, 4)      # 157.3: last round's yardstick
     # HBM bytes per launch of the dominant kernel class come from separate rocprofv3 PMC passes (FETCH_SIZE,
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:
