@@ -572,3 +572,39 @@ def test_fused_pgraph_kernels_match_the_tensor_formulation():
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1.0), (name, float((a - b).abs().max()), scale)
     assert float(out[True][0][~valid].abs().max()) == 0.0          # unused slots stay zero
+
+
+def test_reference_format_checkpoint_loads_and_reproduces_the_fixture(golden, tmp_path):
+    """a `.pth` in the reference's wire format (mmcv CheckpointHook: meta + state_dict with the reference's
+    keys and logical shapes under a `module.` prefix, the aliased att.1 / att.3 entries a real file carries, an optimizer
+    entry) goes through load_checkpoint into a freshly built detector, which then reproduces the reference run's
+    detections on the GPU; Trainer.resume picks up iteration and momentum from the same file."""
+    from htd_amd.checkpoint import load_checkpoint
+    from htd_amd.configs import build_htd_detector
+    from htd_amd.runner import Trainer
+    from golden_util import match_detections
+    from oracle import detector as D
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    ref = {k: torch.as_tensor(v) for k, v in seeded_state_dict(D.state_shapes(50), prefix='det.').items()}
+    ex = 'roi_head.bbox_roi_extractor.1.'
+    for a, b in (('att.1', 'conv1'), ('att.3', 'conv2')):
+        for t in ('weight', 'bias'):
+            ref[f'{ex}{a}.{t}'] = ref[f'{ex}{b}.{t}']
+    path = str(tmp_path / 'epoch_7.pth')
+    torch.save(dict(meta=dict(epoch=7, iter=51310, mmdet_version='2.7.0', CLASSES=('person', )),
+                    state_dict={'module.' + k: v for k, v in ref.items()}), path)
+    torch.manual_seed(123)                                   # different init: every value must come from the file
+    model = build_htd_detector(cfg=small_cfg())
+    ckpt = load_checkpoint(model, path, strict=True)
+    assert ckpt['meta']['epoch'] == 7
+    model = model.to(dev).eval()
+    img, metas, _, _ = inputs(g, dev)
+    with torch.no_grad():
+        res = model.simple_test(img, metas)
+    for i in range(2):
+        mine = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, dtype=np.float32)], 1) for c, r in enumerate(res[i])], 0)
+        match_detections(mine, g[f'test_dets{i}'])
+    tr = Trainer(model.train(), lr=0.02)
+    tr.resume(path)
+    assert tr.iter == 51310 and tr.epoch == 7 and abs(tr.schedule.lr(tr.iter) - 0.02) < 1e-12      # past warm-up, before epoch 8
