@@ -161,6 +161,69 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float *__restrict_
     }
 }
 
+// Forward over ALL pyramid levels of SingleRoIExtractor in one launch: a wavefront reads its RoI's level and takes that
+// level's map, size and scale from the table (four launches that each skip the other levels' RoIs start ~4x the waves).
+struct LevelTable {
+    const float *feat[8];
+    int H[8], W[8];
+    float scale[8];
+};
+
+__global__ __launch_bounds__(256) void roi_align_levels_fwd_kernel(LevelTable tab, const float *__restrict__ rois,
+                                                                   const int64_t *__restrict__ roi_level, float *__restrict__ out,
+                                                                   int64_t n, int B, int C, int L, int ph, int pw,
+                                                                   int sampling_ratio, int aligned, int chunks, int64_t tasks)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= tasks) return;
+    const int chunk = (int)(task % chunks);
+    const int64_t t2 = task / chunks;
+    const int bin = (int)(t2 % (ph * pw));
+    const int64_t ri = t2 / (ph * pw);
+    const int lv = (int)roi_level[ri];
+    const int ch = chunk * 256 + lane * 4;
+    const bool act = ch < C;
+    const size_t bin_off = ((size_t)ri * ph * pw + bin) * C;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    RoiGeom g{};
+    g.inv_count = 0.f;
+    if (lv >= 0 && lv < L) {                              // wave-uniform
+        const int H = tab.H[lv], W = tab.W[lv];
+        const float *feat = tab.feat[lv];
+        const int bi = bin / pw, bj = bin % pw;
+        g = roi_geometry(rois + 5 * ri, tab.scale[lv], ph, pw, sampling_ratio, aligned);
+        int r0, r1, c0, c1;
+        axis_span(g.start_h, g.bin_h, bi, g.grid_h, H, r0, r1);
+        axis_span(g.start_w, g.bin_w, bj, g.grid_w, W, c0, c1);
+        if (g.batch < 0 || g.batch >= B) { r0 = 0; r1 = -1; }
+        const size_t img_base = (size_t)g.batch * H * W * C;
+        for (int rb = r0; rb <= r1; rb += 64) {
+            const float wy_l = (rb + lane <= r1) ? axis_weight(g.start_h, g.bin_h, bi, g.grid_h, rb + lane, H) : 0.f;
+            for (int cb = c0; cb <= c1; cb += 64) {
+                const float wx_l = (cb + lane <= c1) ? axis_weight(g.start_w, g.bin_w, bj, g.grid_w, cb + lane, W) : 0.f;
+                const int rn = min(64, r1 - rb + 1), cn = min(64, c1 - cb + 1);
+                for (int r = 0; r < rn; ++r) {
+                    const float wy = lane_bcast(wy_l, r);
+                    const float *row = feat + img_base + ((size_t)(rb + r) * W + cb) * C + ch;
+#pragma unroll 4
+                    for (int c = 0; c < cn; ++c) {
+                        const float w = wy * lane_bcast(wx_l, c);
+                        if (act) {
+                            const float4 v = *reinterpret_cast<const float4 *>(row + (size_t)c * C);
+                            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (act) {
+        acc.x *= g.inv_count; acc.y *= g.inv_count; acc.z *= g.inv_count; acc.w *= g.inv_count;
+        *reinterpret_cast<float4 *>(out + bin_off + ch) = acc;
+    }
+}
+
 // Backward, row-wise: one wavefront owns (RoI, footprint row mod row_slots, 256-channel chunk); row_slots grows when
 // there are few RoIs (BA pools two dozen large RoIs from every level) so that the launch still fills the chip.  For its row r it
 // first folds the bins along y,  T[q][:] = sum_p Wy[p][r] * gout[p][q][:] / count  (registers), then walks the row's
@@ -449,6 +512,30 @@ extern "C" int htd_roi_align_fwd(const float *feat, const float *rois, const int
 {
     return launch(false, feat, rois, roi_level, level, out, n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio,
                   aligned, stream);
+}
+
+// feats[l] [B][H[l]][W[l]][C] for l < L (L <= 8); every RoI is pooled from level roi_level[i] (RoIs with a level outside
+// [0, L) get zeros): SingleRoIExtractor.forward (single_level_roi_extractor.py:81-99) in one launch.
+extern "C" int htd_roi_align_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                                        const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph,
+                                        int pw, int sampling_ratio, int aligned, void *stream)
+{
+    HTD_REQUIRE(L > 0 && L <= 8 && n >= 0 && B > 0 && C > 0 && ph > 0 && pw > 0, "roi_align_levels: bad sizes");
+    HTD_REQUIRE(C % 4 == 0, "roi_align_levels: C=%d must be a multiple of 4", C);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(feats && H && W && scales && rois && roi_level && out, "roi_align_levels: null pointer");
+    LevelTable tab{};
+    for (int l = 0; l < L; ++l) {
+        HTD_REQUIRE(feats[l] && H[l] > 0 && W[l] > 0, "roi_align_levels: bad level %d", l);
+        tab.feat[l] = feats[l]; tab.H[l] = H[l]; tab.W[l] = W[l]; tab.scale[l] = scales[l];
+    }
+    const int chunks = (C + 255) / 256;
+    const int64_t tasks = n * ph * pw * chunks;
+    const int64_t blocks = htd::ceil_div(tasks, 4);
+    HTD_REQUIRE(blocks < (1ll << 31), "roi_align_levels: too many tasks");
+    hipLaunchKernelGGL(roi_align_levels_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab, rois, roi_level, out,
+                       n, B, C, L, ph, pw, sampling_ratio, aligned, chunks, tasks);
+    return htd::check_launch("roi_align_levels");
 }
 
 extern "C" int64_t htd_roi_align_bwd_gather_workspace_bytes(int64_t n) { return (n > 0 ? n : 1) * (int64_t)sizeof(RoiBox); }

@@ -199,16 +199,21 @@ class _RoIAlignLevels(Function):
         n, C = rois.size(0), feats[0].size(1)
         # every RoI is written by exactly one level's launch (map_roi_levels clamps to [0, L)): no zero fill
         out = torch.empty((n, C, ph, pw), device=rois.device, dtype=torch.float32, memory_format=CL)
-        shapes = []
-        for i, f in enumerate(feats):
+        shapes, fs = [], []
+        for f in feats:
             f = nhwc(_f32(f, 'roi_align'))
-            B, _, H, W = f.shape
-            shapes.append((B, C, H, W))
-            # algorithmic bytes: each RoI is pooled on ONE level: write ph*pw*C*4 B, read its
-            # footprint, mid-range 21x21 px of the 14..28 px the level mapping yields -> counted on level 0's call
-            work = ('byte', n * C * 4.0 * (ph * pw + 21 * 21)) if i == 0 else ('byte', 0.0)
-            capi.call('htd_roi_align_fwd', _P(f), _P(rois), _P(lvls), i, _P(out), n, B, C, H, W, ph, pw,
-                      float(scales[i]), int(sampling_ratio), int(bool(aligned)), _S(), work=work)
+            fs.append(f)
+            shapes.append((f.size(0), C, f.size(2), f.size(3)))
+        L = len(fs)
+        if n:
+            # one launch for all levels; algorithmic bytes: each RoI is pooled on ONE level: write ph*pw*C*4 B,
+            # read its footprint, mid-range 21x21 px of the 14..28 px the level mapping yields
+            ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fs])
+            Hs = (ctypes.c_int * L)(*[s_[2] for s_ in shapes])
+            Ws = (ctypes.c_int * L)(*[s_[3] for s_ in shapes])
+            sc = (ctypes.c_float * L)(*[float(v) for v in scales])
+            capi.call('htd_roi_align_levels_fwd', ptrs, Hs, Ws, sc, L, _P(rois), _P(lvls), _P(out), n, shapes[0][0], C, ph, pw,
+                      int(sampling_ratio), int(bool(aligned)), _S(), work=('byte', n * C * 4.0 * (ph * pw + 21 * 21)))
         ctx.save_for_backward(rois, lvls)
         ctx.args = (shapes, ph, pw, scales, int(sampling_ratio), int(bool(aligned)))
         ctx.chain = bool(chain)

@@ -58,6 +58,12 @@ int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *r
  * cover it in ascending RoI order -- no float atomics (the scatter form is bound by their 1.3 TB/s and is not bit-stable
  * from run to run), every pixel written once.  accumulate = 0: grad_feat is overwritten everywhere (no memset needed);
  * 1: added to, strips no RoI covers are left alone.  workspace: htd_roi_align_bwd_gather_workspace_bytes(n). */
+/* All pyramid levels of SingleRoIExtractor.forward (single_level_roi_extractor.py:81-99) in one launch: RoI i is pooled
+ * from feats[roi_level[i]] ([B][H[l]][W[l]][C], spatial_scale scales[l], l < L <= 8; other levels: zeros).  feats, H, W,
+ * scales are HOST arrays of L entries. */
+int htd_roi_align_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                             const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph, int pw,
+                             int sampling_ratio, int aligned, void *stream);
 int64_t htd_roi_align_bwd_gather_workspace_bytes(int64_t n);
 int htd_roi_align_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
                              float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,
