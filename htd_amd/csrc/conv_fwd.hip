@@ -67,6 +67,15 @@ __device__ __forceinline__ float4 keep4(bool ok, float4 v)
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// One split-bf16 product step with the accumulator pinned to the ACC half of the register file ("a" operands): the
+// matrix core reads and writes C through the AGPR ports and leaves the VGPR ports to the operand split and the address
+// arithmetic of the other waves (MI355X: +2 % on the large 3x3 layers; the compiler's own choice at this register budget
+// is the VGPR form).
+__device__ __forceinline__ void mfma_x3(f32x16 &acc, const bf16x8 &a, const bf16x8 &b)
+{
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 struct ConvParams {
     const float *x, *w, *bias, *residual, *mask_src;
     float *y;
@@ -211,20 +220,20 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
 
     float4 ra[T::PASSES_A], rb[T::PASSES_B];
     unsigned ra_ok = 0u;                              // bit i: pass i of the staged A slice is in range
+    // element offset of the row's window origin (mod 2^32: only used when the tap is in range)
+    unsigned a_base[T::PASSES_A];
+#pragma unroll
+    for (int i = 0; i < T::PASSES_A; ++i)
+        a_base[i] = (a_img[i] + (unsigned)(a_hi0[i] * p.Wx + a_wi0[i])) * (unsigned)p.Ci + vcol * 4;
     auto load_slice = [&]() {
         // branch-free: out-of-range taps read element 0 (always mapped) and are replaced by zeros afterwards
+        const int dy = TAPS ? p.tap_dy[ld_ky] : ld_ky * p.dil;      // ld_ky indexes the tap table
+        const int dx = TAPS ? p.tap_dx[ld_ky] : ld_kx * p.dil;
+        const unsigned koff = (unsigned)((dy * p.Wx + dx) * p.Ci + ld_ci0);      // wave-uniform
 #pragma unroll
         for (int i = 0; i < T::PASSES_A; ++i) {
-            int hi, wi;
-            if constexpr (TAPS) {
-                hi = a_hi0[i] + p.tap_dy[ld_ky];        // ld_ky indexes the tap table
-                wi = a_wi0[i] + p.tap_dx[ld_ky];
-            } else {
-                hi = a_hi0[i] + ld_ky * p.dil;
-                wi = a_wi0[i] + ld_kx * p.dil;
-            }
-            const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned off = ok ? (a_img[i] + (unsigned)hi * (unsigned)p.Wx + (unsigned)wi) * (unsigned)p.Ci + ld_ci0 + vcol * 4 : 0u;
+            const bool ok = a_ok[i] & ((unsigned)(a_hi0[i] + dy) < (unsigned)p.H) & ((unsigned)(a_wi0[i] + dx) < (unsigned)p.W);
+            const unsigned off = (a_base[i] + koff) & (0u - (unsigned)ok);
             ra[i] = *reinterpret_cast<const float4 *>(p.x + off);      // zeroed at store time (keeps the load in flight)
             ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         }
@@ -330,12 +339,12 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {      // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                        mfma_x3(acc[i][j], fa[i][2], fb[j][0]);
+                        mfma_x3(acc[i][j], fa[i][0], fb[j][2]);
+                        mfma_x3(acc[i][j], fa[i][1], fb[j][1]);
+                        mfma_x3(acc[i][j], fa[i][1], fb[j][0]);
+                        mfma_x3(acc[i][j], fa[i][0], fb[j][1]);
+                        mfma_x3(acc[i][j], fa[i][0], fb[j][0]);
                     }
             }
         }
@@ -363,6 +372,15 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
             store_slice(0);                // the prefetched registers (global loads were in flight during the MFMAs)
         }
         __syncthreads();
+    }
+
+    if constexpr (X3) {
+        // the MFMAs above are inline asm, so the compiler's hazard recogniser does not see them: an 8-pass MFMA result may be
+        // read by a VALU instruction only 11 wait states after issue (one s_nop 15 per accumulator, once per tile)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("s_nop 15" : "+a"(acc[i][j]));
     }
 
     // ---- epilogue.  D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
