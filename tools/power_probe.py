@@ -1,5 +1,5 @@
 """Clock and power while ONE convolution shape runs back to back (is the matrix pipe power-limited?).
-usage: power_probe.py Ci H W Co k [seconds]   -- samples `rocm-smi` from a side thread while the kernel loops."""
+usage: power_probe.py Ci H W Co k [seconds] [fwd|wgrad]   -- samples `rocm-smi` from a side thread while the kernel loops."""
 import os
 import subprocess
 import sys
@@ -17,6 +17,9 @@ dev = torch.device('cuda:0')
 CL = torch.channels_last
 x = torch.randn(4, Ci, H, W, device=dev).contiguous(memory_format=CL)
 w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05).contiguous(memory_format=CL)
+mode = sys.argv[7] if len(sys.argv) > 7 else 'fwd'
+y = dense._fwd_raw(x, w, None, None, 1, k // 2, 1, True)
+g = torch.randn_like(y)
 samples = []
 
 
@@ -37,7 +40,10 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 while time.time() - t0 < secs:
     e0.record()
     for _ in range(50):
-        dense._fwd_raw(x, w, None, None, 1, k // 2, 1, True)
+        if mode == 'wgrad':
+            dense._wgrad_raw(x, g, w, 1, k // 2, 1)
+        else:
+            dense._fwd_raw(x, w, None, None, 1, k // 2, 1, True)
     e1.record()
     torch.cuda.synchronize()
     n += 1
