@@ -14,6 +14,7 @@ import torch.nn as nn
 from ..core import (anchor_inside_flags, images_to_levels, multi_apply, unmap)
 from ..core.bbox import delta2bbox, delta2bbox_clip_device
 from ..core.misc import const_tensor
+from .. import mmcv_ops as M
 from ..mmcv_ops import nms_sorted_mask
 from ..registry import (HEADS, build_anchor_generator, build_assigner, build_bbox_coder, build_loss, build_sampler)
 from .bricks import Conv2d, normal_init
@@ -278,19 +279,36 @@ class RPNHead(nn.Module):
         scores_l, deltas_l, anchors_l, seg_sizes = [], [], [], []
         record = getattr(self, 'record_trail', False)       # tests: which candidates survive, in which order
         flat_ids, level_off = [], 0
-        for lvl in range(len(cls_scores)):
-            s = cls_scores[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
+        L = len(cls_scores)
+        Ns = [int(c.shape[1] * c.shape[2] * c.shape[3]) for c in cls_scores]
+        ks = [n if cfg.nms_pre <= 0 else min(cfg.nms_pre, n) for n in Ns]
+        fused = dev.type == 'cuda' and max(ks) <= M.TOPK_KMAX and cls_scores[0].dtype == torch.float32
+        if fused:
+            # every (image, level) ranking of the call in one segmented top-k (htd_segmented_topk): the sorted first nms_pre of
+            # `scores.sort(descending=True)` (rpn_head.py:122-133), equal scores by ascending anchor index
+            total = sum(Ns)
+            sig = torch.cat([c.detach().permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1).sigmoid_()
+            offs = [sum(Ns[:l]) for l in range(L)]
+            top_idx, top_val = M.segmented_topk(sig, [(b * total + offs[l], Ns[l], ks[l]) for b in range(B) for l in range(L)])
+            top_idx, top_val = top_idx.view(B, sum(ks)), top_val.view(B, sum(ks))
+        koff = 0
+        for lvl in range(L):
             d = bbox_preds[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1, 4)
-            k = s.size(1) if cfg.nms_pre <= 0 else min(cfg.nms_pre, s.size(1))
-            ranked, idx = s.sort(dim=1, descending=True, stable=True)
-            ranked, idx = ranked[:, :k], idx[:, :k]
+            k = ks[lvl]
+            if fused:
+                ranked, idx = top_val[:, koff:koff + k], top_idx[:, koff:koff + k]
+                koff += k
+            else:
+                s = cls_scores[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
+                ranked, idx = s.sort(dim=1, descending=True, stable=True)
+                ranked, idx = ranked[:, :k], idx[:, :k]
             scores_l.append(ranked)
             deltas_l.append(torch.gather(d, 1, idx[..., None].expand(B, k, 4)))
             anchors_l.append(mlvl_anchors[lvl][idx])
             seg_sizes.append(k)
             if record:
                 flat_ids.append(idx + level_off)
-                level_off += s.size(1)
+                level_off += Ns[lvl]
         scores = torch.cat(scores_l, 1)                       # (B, K): level-major, descending inside a level
         K = scores.size(1)
         deltas = torch.cat(deltas_l, 1).reshape(B * K, 4)

@@ -506,3 +506,35 @@ def sgd_momentum_step_(flat_param, flat_grad, flat_momentum, lr_dev, momentum, w
     PARAM_EPOCH += 1        # parameters change behind autograd's version counters: invalidates folded-weight caches
     capi.call('htd_sgd_momentum_step', _P(flat_param), _P(flat_grad), _P(flat_momentum), flat_param.numel(),
               _P(lr_dev), float(momentum), float(weight_decay), float(grad_scale), _S())
+
+
+# ====================================================================== segmented top-k (RPN level ranking, samplers)
+TOPK_CHUNK, TOPK_KMAX = 4096, 2048
+
+
+def segmented_topk(keys, segments):
+    """keys: contiguous float32 tensor; segments: sequence of (start, length, k) over keys.view(-1), 0 <= k <= min(length, 2048).
+    -> (idx, val): for every segment, back to back, the positions (inside the segment) and values of its k largest keys in
+    descending order, equal keys by ascending position (= `keys[start:start+length].sort(descending=True, stable=True)[:k]`)."""
+    from .core.misc import const_tensor
+    _need_gpu(keys, 'segmented_topk')
+    keys = _f32(keys, 'segmented_topk')
+    assert keys.is_contiguous()
+    rows, chunks, out = [], [], 0
+    for s, (start, length, k) in enumerate(segments):
+        if not (0 <= k <= min(length, TOPK_KMAX)) or start < 0 or start + length > keys.numel():
+            raise ValueError('segmented_topk: segment %d = (%d, %d, %d) out of range' % (s, start, length, k))
+        rows.append((start, length, k, out))
+        out += k
+        chunks.extend((s, c) for c in range((length + TOPK_CHUNK - 1) // TOPK_CHUNK))
+    S, nchunks = len(rows), len(chunks)
+    idx = torch.empty(out, device=keys.device, dtype=torch.int64)
+    val = torch.empty(out, device=keys.device, dtype=torch.float32)
+    if S == 0 or out == 0:
+        return idx, val
+    segs = const_tensor(rows, keys.device, torch.int64)
+    tab = const_tensor(chunks, keys.device, torch.int32) if nchunks else None
+    ws = torch.empty(capi.lib().htd_segmented_topk_workspace_bytes(S, nchunks), dtype=torch.uint8, device=keys.device)
+    capi.call('htd_segmented_topk', _P(keys), _P(segs), _P(tab) if tab is not None else None, S, nchunks, _P(idx), _P(val),
+              _P(ws), _S())
+    return idx, val

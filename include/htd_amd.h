@@ -103,6 +103,19 @@ int htd_soft_nms_segments(const float *boxes, float *scores, const int64_t *seg_
                           int method, int offset, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Segmented exact top-k, sorted: for every segment of `keys` its k largest keys in descending order, equal keys by
+ * ascending position -- `scores.sort(descending=True)` + `[:nms_pre]` per level and image of RPNHead._get_bboxes_single
+ * (dense_heads/rpn_head.py:122-133) and the "n smallest random keys" of RandomSampler.random_choice
+ * (core/bbox/samplers/random_sampler.py:33-56) in six launches for all segments of a call.
+ *   segs [S][4] device int64: (first key, length, k, first output slot), 0 <= k <= min(length, 2048);
+ *   chunk_tab [nchunks][2] device int32: (segment, chunk inside it), the ceil(length / 4096) chunks of a segment
+ *   consecutive and ascending;  out_idx: position inside the segment;  out_val: the key.
+ * ---------------------------------------------------------------------------------- */
+int64_t htd_segmented_topk_workspace_bytes(int S, int64_t nchunks);
+int htd_segmented_topk(const float *keys, const int64_t *segs, const int32_t *chunk_tab, int S, int64_t nchunks,
+                       int64_t *out_idx, float *out_val, void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * _fuse_global (htd_roi_head.py:133-141 == htd_bbox_head.py:147-155):
  *   out[i][p][c] = roi_feats[i][p][c] + global_feat[img(i)][c],  img(i) = (int)rois[i][0]
  * optionally + alpha * extra[i][p][c]  (x_reg + g + alpha*enhanced, htd_bbox_head.py:163,184).

@@ -358,3 +358,45 @@ def test_roi_align_backward_gather_form(dev, C, H, W, stride, n):
               1.0 / stride, 0, 1, 0, capi.ptr(ws), capi.current_stream_ptr())
     gref1 = O.roi_align_bwd(go[::2], rois[::2], (B, C, H, W), 1.0 / stride, 0, True)
     torch.testing.assert_close(d.cpu(), gref1, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_segmented_topk_equals_stable_descending_sort(dev):
+    """htd_segmented_topk == keys.sort(descending=True, stable=True)[:k] per segment, positions included (rpn_head.py:122-133):
+    ties at the threshold (quantised keys), all-equal segments, segments shorter than k, one-element and empty picks,
+    negative keys and the full P2 level size."""
+    import htd_amd.mmcv_ops as M
+    g = torch.Generator().manual_seed(11)
+    parts = [
+        torch.rand(201600, generator=g),                                   # P2 level, k = 2000
+        (torch.rand(50400, generator=g) * 64).floor() / 64,                # heavy ties (64 distinct values)
+        torch.full((5000, ), 0.5),                                         # every key equal: the first k positions
+        torch.rand(819, generator=g),                                      # shorter than k: everything, sorted
+        torch.randn(12345, generator=g),                                   # negative keys
+        torch.tensor([3.0]),                                               # one key
+        torch.rand(4096 * 3, generator=g).round(decimals=2),               # chunk-aligned length, ties across chunks
+        torch.rand(100, generator=g),                                      # k = 0
+        torch.cat([torch.zeros(7000), torch.ones(3), -torch.zeros(10)]),   # +0 / -0 (sort treats them as equal? see below)
+    ]
+    ks = [2000, 2000, 777, 819, 2048, 1, 1000, 0, 5]
+    keys = torch.cat(parts)
+    segs, off = [], 0
+    for p, k in zip(parts, ks):
+        segs.append((off, p.numel(), k))
+        off += p.numel()
+    idx, val = M.segmented_topk(keys.to(dev), segs)
+    torch.cuda.synchronize()
+    idx, val = idx.cpu(), val.cpu()
+    o = 0
+    for i, (p, k) in enumerate(zip(parts, ks)):
+        if i == 8:
+            # the radix image orders -0 below +0 while a float compare calls them equal: such a tie is broken by sign first.
+            # Scores are sigmoid outputs / uniform keys in [0, 1): -0 does not occur; pin the documented behaviour.
+            assert val[o:o + k].tolist() == [1.0, 1.0, 1.0, 0.0, 0.0] and idx[o:o + k].tolist() == [7000, 7001, 7002, 0, 1]
+            o += k
+            continue
+        rv, ri = p.sort(descending=True, stable=True)
+        assert torch.equal(val[o:o + k], rv[:k]), i
+        assert torch.equal(idx[o:o + k], ri[:k]), i
+        o += k
+    assert o == idx.numel()
