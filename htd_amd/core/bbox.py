@@ -440,17 +440,57 @@ def sample_keys(cand):
     return torch.rand(cand.shape[:2], device=cand.device)
 
 
+_SAMPLE_PLANS = {}      # (B, A, kpos, kneg, device) -> device tables of htd_random_sample
+
+
+def random_sample_device(assigned, keys, num, pos_fraction, neg_pos_ub=-1, slots=0):
+    """RandomSampler for a batch in one C-ABI call (htd_random_sample: key staging, segmented top-k, masks).
+    -> pos_mask, neg_mask (B,A) bool, counts (B,2) drawn (pos, neg), order (B,slots) or None."""
+    from .. import capi
+    from ..mmcv_ops import TOPK_CHUNK
+    B, A = assigned.shape
+    dev = assigned.device
+    max_pos = int(num * pos_fraction)
+    kpos, kneg = min(max_pos, A), min(num, A)
+    key = (B, A, kpos, kneg, str(dev))
+    plan = _SAMPLE_PLANS.get(key)
+    if plan is None:
+        rows = [(b * A, A, kpos, b * kpos) for b in range(B)] + [(B * A + b * A, A, kneg, B * kpos + b * kneg) for b in range(B)]
+        per = (A + TOPK_CHUNK - 1) // TOPK_CHUNK
+        chunks = [(s, c) for s in range(2 * B) for c in range(per)]
+        if len(_SAMPLE_PLANS) > 64:
+            _SAMPLE_PLANS.clear()
+        plan = _SAMPLE_PLANS[key] = (torch.tensor(rows, dtype=torch.int64, device=dev),
+                                     torch.tensor(chunks, dtype=torch.int32, device=dev), len(chunks))
+    segs, tab, nchunks = plan
+    pos = torch.empty(B, A, dtype=torch.bool, device=dev)
+    neg = torch.empty(B, A, dtype=torch.bool, device=dev)
+    counts = torch.empty(B, 2, dtype=torch.int64, device=dev)
+    order = torch.empty(B, slots, dtype=torch.int64, device=dev) if slots > 0 else None
+    ws = torch.empty(capi.lib().htd_random_sample_workspace_bytes(B, A, nchunks), dtype=torch.uint8, device=dev)
+    capi.call('htd_random_sample', capi.ptr(assigned.contiguous()), capi.ptr(keys.contiguous()), B, A, int(num), max_pos,
+              float(neg_pos_ub), capi.ptr(segs), capi.ptr(tab), nchunks, capi.ptr(pos), capi.ptr(neg), capi.ptr(counts),
+              capi.ptr(order) if order is not None else None, int(slots), capi.ptr(ws), capi.current_stream_ptr())
+    return pos, neg, counts, order
+
+
+def _sample_on_device(assigned, keys, num):
+    return assigned.is_cuda and assigned.dtype == torch.int64 and keys.dtype == torch.float32 and 0 < num <= 2048
+
+
 def batched_random_sample(assigned, num, pos_fraction, neg_pos_ub=-1, keys=None):
     """RandomSampler (base_sampler.py:34-101, random_sampler.py:58-78) without host round trips: a uniformly random
     subset of size n is the n candidates with the smallest i.i.d. random keys.  -> (pos_mask, neg_mask) (B,A)."""
     B, A = assigned.shape
     if keys is None:
         keys = torch.rand(B, A, device=assigned.device)
+    if _sample_on_device(assigned, keys, num):
+        return random_sample_device(assigned, keys, num, pos_fraction, neg_pos_ub)[:2]
     is_pos, is_neg = assigned > 0, assigned == 0
     ar = torch.arange(A, device=assigned.device).expand(B, A)
 
     def pick(cand, limit):
-        order = torch.where(cand, keys, keys.new_full((1, ), 2.0)).argsort(dim=1)
+        order = torch.where(cand, keys, keys.new_full((1, ), 2.0)).argsort(dim=1, stable=True)
         rank = torch.empty_like(order).scatter_(1, order, ar)
         return cand & (rank < limit)
     pos_mask = pick(is_pos, torch.full((B, 1), int(num * pos_fraction), device=assigned.device))
@@ -602,10 +642,16 @@ def static_assign_and_sample(assigner, sampler, props, pvalid, gt_bboxes, gt_lab
         assigned = torch.cat([assigned, assigned.new_full((B, S - A), -1)], 1)
         is_gt = torch.cat([is_gt, is_gt.new_zeros(B, S - A)], 1)
         A = S
-    pos, neg = batched_random_sample(assigned, sampler.num, sampler.pos_fraction, sampler.neg_pos_ub, sample_keys(cand))
-    ar = torch.arange(A, device=dev).expand(B, A)
-    order = torch.where(pos, ar, torch.where(neg, ar + A, ar + 2 * A)).argsort(dim=1)[:, :S]      # (B,S)
-    npos, nneg = pos.sum(1), neg.sum(1)
+    keys = sample_keys(cand)
+    if _sample_on_device(assigned, keys, S):
+        # masks, drawn counts and the slot order (drawn positives, then drawn negatives, ascending index) from one call
+        pos, neg, counts, order = random_sample_device(assigned, keys, S, sampler.pos_fraction, sampler.neg_pos_ub, slots=S)
+        npos, nneg = counts[:, 0], counts[:, 1]
+    else:
+        pos, neg = batched_random_sample(assigned, S, sampler.pos_fraction, sampler.neg_pos_ub, keys)
+        ar = torch.arange(A, device=dev).expand(B, A)
+        order = torch.where(pos, ar, torch.where(neg, ar + A, ar + 2 * A)).argsort(dim=1)[:, :S]      # (B,S)
+        npos, nneg = pos.sum(1), neg.sum(1)
     slot = torch.arange(S, device=dev).expand(B, S)
     valid = slot < (npos + nneg)[:, None]
     is_pos = slot < npos[:, None]

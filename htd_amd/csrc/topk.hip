@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict_
     const int2 ct = chunk_tab[blockIdx.x];
     const int seg = ct.x;
     const Seg sg = segs[seg];
-    if (sg.len <= sg.k) return;                      // everything survives: no threshold to find (uniform per block)
+    if (sg.len <= sg.k || sg.k == 0) return;         // everything / nothing survives: no threshold to find (uniform per block)
     const int t = threadIdx.x;
     for (int b = t; b < NB; b += 256) lh[b] = 0u;
     unsigned prefix = 0u;
@@ -102,11 +102,24 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict_
 #pragma unroll 4
     for (int j = 0; j < CHUNK / 256; ++j) {
         const int64_t i = base + j * 256 + t;
-        if (i < sg.len) {
+        bool hit = i < sg.len;
+        unsigned bin = 0u;
+        if (hit) {
             const unsigned o = ord(kp[i]);
-            if (PASS == 0) atomicAdd(&lh[o >> 21], 1u);
-            else if (PASS == 1) { if ((o >> 21) == prefix) atomicAdd(&lh[(o >> 10) & 2047u], 1u); }
-            else { if ((o >> 10) == prefix) atomicAdd(&lh[o & 1023u], 1u); }
+            if (PASS == 0) bin = o >> 21;
+            else if (PASS == 1) { hit = (o >> 21) == prefix; bin = (o >> 10) & 2047u; }
+            else { hit = (o >> 10) == prefix; bin = o & 1023u; }
+        }
+        // a wavefront whose keys all fall into one bin (runs of equal keys: masked-out candidates, saturated scores) adds
+        // its count once instead of queueing 64 atomics on one LDS word
+        const unsigned long long hits = __ballot(hit);
+        if (hits) {
+            const int leader = __ffsll((long long)hits) - 1;
+            const unsigned lead_bin = __shfl(bin, leader, 64);
+            if (__ballot(hit && bin == lead_bin) == hits) {
+                if ((t & 63) == leader) atomicAdd(&lh[lead_bin], (unsigned)__popcll(hits));
+            } else if (hit)
+                atomicAdd(&lh[bin], 1u);
         }
     }
     __syncthreads();
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float *__restri
     const int2 ct = chunk_tab[blockIdx.x];
     const int seg = ct.x, t = threadIdx.x;
     const Seg sg = segs[seg];
-    if (sg.len == 0) return;
+    if (sg.len == 0 || sg.k == 0) return;
     const bool all = sg.len <= sg.k;
     unsigned thr = 0u, ties_wanted = 0u, tie_base = 0u, first_tie_slot = 0u;
     if (!all) {
@@ -218,16 +231,11 @@ extern "C" int64_t htd_segmented_topk_workspace_bytes(int S, int64_t nchunks)
     return (int64_t)3 * S * NB * 4 + (int64_t)2 * S * 8 + (int64_t)S * 4 + 16 + nchunks * 1024 * 4 + (int64_t)S * KMAX * 8 + 64;
 }
 
-// segs [S][4] int64 (start, len, k, out) and chunk_tab [nchunks][2] int32 (segment, chunk inside it; the ceil(len / 4096)
-// chunks of a segment consecutive and ascending) are DEVICE tables.  out_idx: position inside the segment.
-extern "C" int htd_segmented_topk(const float *keys, const int64_t *segs, const int32_t *chunk_tab, int S, int64_t nchunks,
-                                  int64_t *out_idx, float *out_val, void *workspace, void *stream)
+namespace {
+
+int run_topk(const float *keys, const int64_t *segs, const int32_t *chunk_tab, int S, int64_t nchunks, int64_t *out_idx,
+             float *out_val, void *workspace, hipStream_t s)
 {
-    HTD_REQUIRE(S >= 0 && nchunks >= 0, "segmented_topk: bad sizes");
-    if (S == 0) return HTD_OK;
-    HTD_REQUIRE(keys && segs && out_idx && out_val && workspace && (nchunks == 0 || chunk_tab), "segmented_topk: null pointer");
-    HTD_REQUIRE(nchunks < (1ll << 31), "segmented_topk: too many chunks");
-    hipStream_t s = (hipStream_t)stream;
     char *ws = (char *)workspace;
     unsigned *hist = (unsigned *)ws;
     size_t off = (size_t)3 * S * NB * 4;
@@ -255,4 +263,144 @@ extern "C" int htd_segmented_topk(const float *keys, const int64_t *segs, const 
     }
     hipLaunchKernelGGL(topk_sort_kernel, dim3((unsigned)S), dim3(1024), 0, s, sg, cand, out_idx, out_val);
     return htd::check_launch("segmented_topk");
+}
+
+// ---- RandomSampler on the device (base_sampler.py:34-101, random_sampler.py:33-78)
+// negated keys of the positive candidates (assigned > 0) and of the negative ones (assigned == 0); everything else -2
+__global__ __launch_bounds__(256) void sample_keys_kernel(const int64_t *__restrict__ assigned, const float *__restrict__ keys,
+                                                          float *__restrict__ neg_keys, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t a = assigned[i];
+    const float k = -keys[i];
+    neg_keys[i] = a > 0 ? k : -2.f;
+    neg_keys[n + i] = a == 0 ? k : -2.f;
+}
+
+// ascending bitonic sort of n (power of two <= 2048) unsigned words in LDS, 1024 threads
+__device__ void sort_ascending(unsigned *w, int n)
+{
+    const int t = threadIdx.x;
+    for (int size = 2; size <= n; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int p = t; p < n / 2; p += 1024) {
+                const int lo = 2 * p - (p & (stride - 1)), hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const unsigned a = w[lo], b = w[hi];
+                if ((a > b) == asc) { w[lo] = b; w[hi] = a; }
+            }
+            __syncthreads();
+        }
+}
+
+// one workgroup per image: how many of the ranked candidates are drawn, the two masks, the counts and (optionally) the
+// slot order of SamplingResult: drawn positives by ascending index, then drawn negatives by ascending index
+__global__ __launch_bounds__(1024) void sample_finish_kernel(const int64_t *__restrict__ idx, const float *__restrict__ val,
+                                                             int B, int64_t A, int kpos, int kneg, int num, float neg_pos_ub,
+                                                             unsigned char *__restrict__ pos_mask,
+                                                             unsigned char *__restrict__ neg_mask, int64_t *__restrict__ counts,
+                                                             int64_t *__restrict__ order, int slots)
+{
+    __shared__ unsigned w[KMAX];
+    __shared__ int cnt[2];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int64_t *ip = idx + (size_t)b * kpos, *in = idx + (size_t)B * kpos + (size_t)b * kneg;
+    const float *vp = val + (size_t)b * kpos, *vn = val + (size_t)B * kpos + (size_t)b * kneg;
+    if (t < 2) cnt[t] = 0;
+    __syncthreads();
+    // real candidates come before the -2 fillers in a descending ranking: the drawn ones are a prefix
+    int c = 0;
+    for (int j = t; j < kpos; j += 1024) c += vp[j] > -2.f;
+    if (c) atomicAdd(&cnt[0], c);
+    __syncthreads();
+    const int n_pos = cnt[0];
+    int64_t limit = num - n_pos;
+    if (neg_pos_ub >= 0.f) {
+        const int64_t ub = (int64_t)(neg_pos_ub * (float)(n_pos > 1 ? n_pos : 1));      // base_sampler.py:86-91
+        limit = limit < ub ? limit : ub;
+    }
+    const int lim = (int)(limit < 0 ? 0 : (limit < kneg ? limit : kneg));
+    c = 0;
+    for (int j = t; j < lim; j += 1024) c += vn[j] > -2.f;
+    if (c) atomicAdd(&cnt[1], c);
+    __syncthreads();
+    const int n_neg = cnt[1];
+    for (int j = t; j < n_pos; j += 1024) pos_mask[(size_t)b * A + ip[j]] = 1;
+    for (int j = t; j < n_neg; j += 1024) neg_mask[(size_t)b * A + in[j]] = 1;
+    if (t == 0) {
+        counts[2 * b] = n_pos;
+        counts[2 * b + 1] = n_neg;
+    }
+    if (!order) return;                                            // block-uniform
+    int64_t *ob = order + (size_t)b * slots;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int n_sel = pass ? n_neg : n_pos, first = pass ? n_pos : 0;
+        const int64_t *src = pass ? in : ip;
+        int n = 64;
+        while (n < n_sel) n <<= 1;
+        for (int j = t; j < n; j += 1024) w[j] = j < n_sel ? (unsigned)src[j] : 0xffffffffu;
+        __syncthreads();
+        sort_ascending(w, n);
+        for (int j = t; j < n_sel; j += 1024)
+            if (first + j < slots) ob[first + j] = (int64_t)w[j];
+        __syncthreads();
+    }
+    for (int j = n_pos + n_neg + t; j < slots; j += 1024) ob[j] = 0;      // unused slots (masked by the caller)
+}
+
+}  // namespace
+
+// segs [S][4] int64 (start, len, k, out) and chunk_tab [nchunks][2] int32 (segment, chunk inside it; the ceil(len / 4096)
+// chunks of a segment consecutive and ascending) are DEVICE tables.  out_idx: position inside the segment.
+extern "C" int htd_segmented_topk(const float *keys, const int64_t *segs, const int32_t *chunk_tab, int S, int64_t nchunks,
+                                  int64_t *out_idx, float *out_val, void *workspace, void *stream)
+{
+    HTD_REQUIRE(S >= 0 && nchunks >= 0, "segmented_topk: bad sizes");
+    if (S == 0) return HTD_OK;
+    HTD_REQUIRE(keys && segs && out_idx && out_val && workspace && (nchunks == 0 || chunk_tab), "segmented_topk: null pointer");
+    HTD_REQUIRE(nchunks < (1ll << 31), "segmented_topk: too many chunks");
+    return run_topk(keys, segs, chunk_tab, S, nchunks, out_idx, out_val, workspace, (hipStream_t)stream);
+}
+
+extern "C" int64_t htd_random_sample_workspace_bytes(int B, int64_t A, int64_t nchunks)
+{
+    if (B <= 0 || A <= 0) return 0;
+    // negated keys [2][B][A] f32 | ranked positions and keys [2B][2048] | top-k workspace
+    return 2 * (int64_t)B * A * 4 + 64 + (int64_t)2 * B * KMAX * 12 + 64 + htd_segmented_topk_workspace_bytes(2 * B, nchunks);
+}
+
+// assigned [B][A] (AssignResult.gt_inds: > 0 positive, 0 negative, < 0 ignored), keys [B][A] i.i.d. in [0, 1): the drawn sample
+// is the candidates with the smallest keys.  segs / chunk_tab: the tables of htd_segmented_topk for the 2B segments
+// (b * A, A, kpos, b * kpos) and (B * A + b * A, A, kneg, B * kpos + b * kneg), kpos = min(max_pos, A), kneg = min(num, A).
+// pos_mask / neg_mask [B][A] bytes (0 / 1), counts [B][2] = (positives, negatives) drawn, order [B][slots] (may be NULL).
+extern "C" int htd_random_sample(const int64_t *assigned, const float *keys, int B, int64_t A, int num, int max_pos,
+                                 float neg_pos_ub, const int64_t *segs, const int32_t *chunk_tab, int64_t nchunks,
+                                 unsigned char *pos_mask, unsigned char *neg_mask, int64_t *counts, int64_t *order, int slots,
+                                 void *workspace, void *stream)
+{
+    HTD_REQUIRE(B > 0 && A > 0 && num > 0 && num <= KMAX && max_pos >= 0 && max_pos <= num && slots >= 0,
+                "random_sample: bad sizes (num <= %d)", KMAX);
+    HTD_REQUIRE(assigned && keys && segs && chunk_tab && pos_mask && neg_mask && counts && workspace, "random_sample: null pointer");
+    HTD_REQUIRE(A < (1ll << 31) && nchunks > 0 && nchunks < (1ll << 31), "random_sample: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int kpos = (int)(max_pos < A ? max_pos : A), kneg = (int)(num < A ? num : A);
+    char *ws = (char *)workspace;
+    float *neg_keys = (float *)ws;
+    size_t off = ((size_t)2 * B * A * 4 + 63) / 64 * 64;
+    int64_t *idx = (int64_t *)(ws + off);
+    off += (size_t)2 * B * KMAX * 8;
+    float *val = (float *)(ws + off);
+    off += ((size_t)2 * B * KMAX * 4 + 63) / 64 * 64;
+    if (hipMemsetAsync(pos_mask, 0, (size_t)B * A, s) != hipSuccess || hipMemsetAsync(neg_mask, 0, (size_t)B * A, s) != hipSuccess) {
+        htd::set_error("random_sample: memset failed");
+        return HTD_ERR_LAUNCH;
+    }
+    const int64_t n = (int64_t)B * A;
+    hipLaunchKernelGGL(sample_keys_kernel, dim3((unsigned)htd::ceil_div(n, 256)), dim3(256), 0, s, assigned, keys, neg_keys, n);
+    const int rc = run_topk(neg_keys, segs, chunk_tab, 2 * B, nchunks, idx, val, ws + off, s);
+    if (rc != HTD_OK) return rc;
+    hipLaunchKernelGGL(sample_finish_kernel, dim3((unsigned)B), dim3(1024), 0, s, idx, val, B, A, kpos, kneg, num, neg_pos_ub,
+                       pos_mask, neg_mask, counts, order, slots);
+    return htd::check_launch("random_sample");
 }

@@ -349,9 +349,14 @@ class RPNHead(nn.Module):
         keep = nms_sorted_mask(shifted.reshape(B * K, 4), cfg.nms_thr, 0, seg, max(seg_sizes)).view(B, K).bool()
         # survivors in descending score order (ties: lower level / lower rank first), first nms_post of them
         masked = torch.where(keep, scores, scores.new_full((1, ), -1.0))
-        top, order = masked.sort(dim=1, descending=True, stable=True)
         n_keep = keep.sum(1).clamp(max=cfg.nms_post)
-        order = order[:, :cfg.nms_post]
+        kpost = min(cfg.nms_post, K)
+        if fused and kpost <= M.TOPK_KMAX:
+            order, top = M.segmented_topk(masked, [(b * K, K, kpost) for b in range(B)])
+            order, top = order.view(B, kpost), top.view(B, kpost)
+        else:
+            top, order = masked.sort(dim=1, descending=True, stable=True)
+            order = order[:, :cfg.nms_post]
         if record:
             # rows of the level-concatenated candidate list in kept order (= `keep` of rpn_head.py:166-168) and the
             # anchor each of them is (flat index over the levels); entries past n_keep[b] are meaningless

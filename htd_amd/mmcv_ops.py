@@ -510,30 +510,36 @@ def sgd_momentum_step_(flat_param, flat_grad, flat_momentum, lr_dev, momentum, w
 
 # ====================================================================== segmented top-k (RPN level ranking, samplers)
 TOPK_CHUNK, TOPK_KMAX = 4096, 2048
+_TOPK_PLANS = {}       # (segments, numel, device) -> device tables: built once per shape, never per call
 
 
 def segmented_topk(keys, segments):
     """keys: contiguous float32 tensor; segments: sequence of (start, length, k) over keys.view(-1), 0 <= k <= min(length, 2048).
     -> (idx, val): for every segment, back to back, the positions (inside the segment) and values of its k largest keys in
     descending order, equal keys by ascending position (= `keys[start:start+length].sort(descending=True, stable=True)[:k]`)."""
-    from .core.misc import const_tensor
     _need_gpu(keys, 'segmented_topk')
     keys = _f32(keys, 'segmented_topk')
     assert keys.is_contiguous()
-    rows, chunks, out = [], [], 0
-    for s, (start, length, k) in enumerate(segments):
-        if not (0 <= k <= min(length, TOPK_KMAX)) or start < 0 or start + length > keys.numel():
-            raise ValueError('segmented_topk: segment %d = (%d, %d, %d) out of range' % (s, start, length, k))
-        rows.append((start, length, k, out))
-        out += k
-        chunks.extend((s, c) for c in range((length + TOPK_CHUNK - 1) // TOPK_CHUNK))
-    S, nchunks = len(rows), len(chunks)
+    key = (tuple(segments), keys.numel(), str(keys.device))
+    plan = _TOPK_PLANS.get(key)
+    if plan is None:
+        rows, chunks, out = [], [], 0
+        for s, (start, length, k) in enumerate(segments):
+            if not (0 <= k <= min(length, TOPK_KMAX)) or start < 0 or start + length > keys.numel():
+                raise ValueError('segmented_topk: segment %d = (%d, %d, %d) out of range' % (s, start, length, k))
+            rows.append((start, length, k, out))
+            out += k
+            chunks.extend((s, c) for c in range((length + TOPK_CHUNK - 1) // TOPK_CHUNK))
+        if len(_TOPK_PLANS) > 256:
+            _TOPK_PLANS.clear()
+        plan = _TOPK_PLANS[key] = (len(rows), len(chunks), out,
+                                   torch.tensor(rows, dtype=torch.int64, device=keys.device).view(-1, 4) if rows else None,
+                                   torch.tensor(chunks, dtype=torch.int32, device=keys.device) if chunks else None)
+    S, nchunks, out, segs, tab = plan
     idx = torch.empty(out, device=keys.device, dtype=torch.int64)
     val = torch.empty(out, device=keys.device, dtype=torch.float32)
     if S == 0 or out == 0:
         return idx, val
-    segs = const_tensor(rows, keys.device, torch.int64)
-    tab = const_tensor(chunks, keys.device, torch.int32) if nchunks else None
     ws = torch.empty(capi.lib().htd_segmented_topk_workspace_bytes(S, nchunks), dtype=torch.uint8, device=keys.device)
     capi.call('htd_segmented_topk', _P(keys), _P(segs), _P(tab) if tab is not None else None, S, nchunks, _P(idx), _P(val),
               _P(ws), _S())

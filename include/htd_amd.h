@@ -114,6 +114,18 @@ int htd_soft_nms_segments(const float *boxes, float *scores, const int64_t *seg_
 int64_t htd_segmented_topk_workspace_bytes(int S, int64_t nchunks);
 int htd_segmented_topk(const float *keys, const int64_t *segs, const int32_t *chunk_tab, int S, int64_t nchunks,
                        int64_t *out_idx, float *out_val, void *workspace, void *stream);
+/* RandomSampler for a batch (core/bbox/samplers/base_sampler.py:34-101, random_sampler.py:33-78) without a host round trip:
+ * a uniformly random subset of n candidates is the n candidates with the smallest i.i.d. keys.  assigned [B][A] =
+ * AssignResult.gt_inds (> 0 positive, 0 negative, < 0 ignored), keys [B][A] in [0, 1).  Draws min(max_pos, #positives)
+ * positives, then min(num - drawn positives, neg_pos_ub bound, #negatives) negatives.  segs / chunk_tab: the device tables of
+ * htd_segmented_topk for the 2B segments (b*A, A, kpos, b*kpos) and (B*A + b*A, A, kneg, B*kpos + b*kneg), kpos =
+ * min(max_pos, A), kneg = min(num, A), num <= 2048.  pos_mask / neg_mask [B][A] bytes 0/1; counts [B][2] drawn (pos, neg);
+ * order [B][slots] (may be NULL): drawn positives by ascending index, then drawn negatives by ascending index (the row order
+ * of SamplingResult.bboxes, sampling_result.py:23-38), unused slots 0. */
+int64_t htd_random_sample_workspace_bytes(int B, int64_t A, int64_t nchunks);
+int htd_random_sample(const int64_t *assigned, const float *keys, int B, int64_t A, int num, int max_pos, float neg_pos_ub,
+                      const int64_t *segs, const int32_t *chunk_tab, int64_t nchunks, unsigned char *pos_mask,
+                      unsigned char *neg_mask, int64_t *counts, int64_t *order, int slots, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * _fuse_global (htd_roi_head.py:133-141 == htd_bbox_head.py:147-155):

@@ -400,3 +400,30 @@ def test_segmented_topk_equals_stable_descending_sort(dev):
         assert torch.equal(idx[o:o + k], ri[:k]), i
         o += k
     assert o == idx.numel()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,A,num,frac,ub,pos_rate', [(4, 268569, 256, 0.5, -1, 2e-4), (2, 2008, 512, 0.25, -1, 0.05),
+                                                      (3, 5000, 64, 0.5, 3, 0.001), (2, 300, 512, 0.25, -1, 0.5),
+                                                      (1, 9000, 128, 0.5, -1, 0.0)])
+def test_random_sample_kernel_equals_tensor_formulation(dev, B, A, num, frac, ub, pos_rate):
+    """htd_random_sample == the sort-based formulation of RandomSampler (base_sampler.py:34-101): same masks, counts and slot
+    order, with duplicate keys (ties by index), fewer candidates than slots, the neg_pos_ub bound and no positives at all."""
+    from htd_amd.core import bbox as Bx
+    g = torch.Generator().manual_seed(A + num)
+    r = torch.rand(B, A, generator=g)
+    assigned = torch.where(r < pos_rate, torch.randint(1, 9, (B, A), generator=g), torch.zeros(B, A, dtype=torch.long))
+    assigned = torch.where(torch.rand(B, A, generator=g) < 0.1, torch.full_like(assigned, -1), assigned)
+    keys = (torch.rand(B, A, generator=g) * 4096).floor() / 4096              # duplicates: ties go to the lower index
+    pos_ref, neg_ref = Bx.batched_random_sample(assigned, num, frac, ub, keys)  # CPU: the tensor formulation
+    slots = num
+    pos, neg, counts, order = Bx.random_sample_device(assigned.to(dev), keys.to(dev), num, frac, ub, slots=slots)
+    torch.cuda.synchronize()
+    assert torch.equal(pos.cpu(), pos_ref) and torch.equal(neg.cpu(), neg_ref)
+    assert counts[:, 0].cpu().tolist() == pos_ref.sum(1).tolist() and counts[:, 1].cpu().tolist() == neg_ref.sum(1).tolist()
+    ar = torch.arange(A).expand(B, A)
+    ref_order = torch.where(pos_ref, ar, torch.where(neg_ref, ar + A, ar + 2 * A)).argsort(dim=1, stable=True)[:, :slots]
+    for b in range(B):
+        n = int(pos_ref[b].sum() + neg_ref[b].sum())
+        assert order[b, :n].cpu().tolist() == ref_order[b, :n].tolist()
+        assert int(order[b, n:].abs().sum()) == 0
