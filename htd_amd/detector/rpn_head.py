@@ -93,7 +93,24 @@ class RPNHead(nn.Module):
         return self.rpn_cls(x), self.rpn_reg(x)
 
     def forward(self, feats):
-        return multi_apply(self.forward_single, feats)
+        if not feats[0].is_cuda:
+            return multi_apply(self.forward_single, feats)
+        # the two 1x1 heads read the same hidden map: as ONE 16-channel convolution (3 + 12 + a zero row) the hidden map gets
+        # one data gradient instead of two that autograd has to add, and every level is one launch less in each direction
+        nc, nr = self.rpn_cls.out_channels, self.rpn_reg.out_channels
+        pad = -(nc + nr) % 8
+        w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight] +
+                      ([self.rpn_cls.weight.new_zeros(pad, *self.rpn_cls.weight.shape[1:])] if pad else []))
+        b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias] + ([self.rpn_cls.bias.new_zeros(pad)] if pad else []))
+        cls, reg = [], []
+        for x in feats:
+            h = self.rpn_conv(x, relu=True)
+            if h.dtype != torch.float32:         # bf16 pyramid: the heads and all box math stay fp32
+                h = h.float()
+            y = self.rpn_cls(h, weight=w, bias=b)
+            cls.append(y[:, :nc])
+            reg.append(y[:, nc:nc + nr])
+        return cls, reg
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,
                       **kwargs):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Device time of the ATen glue operators of one train step, grouped by operator and input shapes (torch.profiler)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+from htd_amd.configs import build_htd_detector
+from htd_amd.runner import Trainer, synthetic_batch
+
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+model = build_htd_detector(50).to(dev).train()
+tr = Trainer(model)
+data = synthetic_batch(4, device=dev)
+for _ in range(3):
+    tr.train_step(data)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    tr.train_step(data)
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    if e.key.startswith('aten::') and e.self_device_time_total > 0:
+        rows.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:90]))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print('ATen self device time: %.3f ms in %d op groups' % (tot / 1e3, len(rows)))
+for t, n, k, sh in rows[:45]:
+    print('%8.1f us %4d  %-28s %s' % (t, n, k, sh))
