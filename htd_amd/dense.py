@@ -268,8 +268,12 @@ def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None):
 
 class Conv2dFunction(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu, res_up=False):
+    def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu, res_up=False, chain=False):
+        """chain=True: also returns an identity alias of x.  A later consumer of x that reads the alias instead hands its
+        gradient to THIS node's backward, where it joins in the data-gradient epilogue (`accum`) -- one gradient map
+        reaches x's producer and autograd has nothing to add (mmcv_ops.PyramidTaps does the same for the RoIAligns)."""
         _need_gpu(x, 'conv2d')
+        src = x
         x = x.contiguous(memory_format=CL)
         weight = weight.contiguous(memory_format=CL)
         res = residual.contiguous(memory_format=CL) if residual is not None else None
@@ -279,13 +283,19 @@ class Conv2dFunction(Function):
         ctx.cfg = (stride, padding, dilation, bool(relu), bias is not None, residual is not None)
         ctx.res_up = tuple(res.shape) if (res_up and res is not None) else None
         ctx.bias_ref = b                                  # only its address is used (gradient sink lookup)
+        ctx.chain = bool(chain)
+        if chain:
+            ctx.set_materialize_grads(False)              # an unused alias arrives as None, not as a map of zeros
+            return y, src.view_as(src)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, galias=None):
         x, weight, y = ctx.saved_tensors
         stride, padding, dilation, relu, has_bias, has_res = ctx.cfg
+        if g is None:                                     # (chain) the convolution's own output was not used
+            return (galias, ) + (None, ) * 9
         g = g.contiguous(memory_format=CL)
         need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
         gb = gw = None
@@ -298,7 +308,13 @@ class Conv2dFunction(Function):
                 g = _mask_raw(g, y)
         elif want_b and not need_w:
             gb = _colsum_raw(g, None, ctx.bias_ref)[1]
-        gx = _dgrad_raw(g, weight, x.shape, stride, padding, dilation) if need_x else None
+        gx = None
+        if need_x:
+            fuse = galias is not None and stride == 1 and galias.dtype == g.dtype and tuple(galias.shape) == tuple(x.shape)
+            gx = _dgrad_raw(g, weight, x.shape, stride, padding, dilation,
+                            accum=galias.contiguous(memory_format=CL) if fuse else None)
+            if galias is not None and not fuse:
+                gx = gx + galias
         if need_w:
             gw, gb = _wgrad_raw(x, g, weight, stride, padding, dilation, ctx.bias_ref if want_b else None)
         gr = None
@@ -306,7 +322,7 @@ class Conv2dFunction(Function):
             gr = g
             if ctx.res_up is not None:      # residual came in through nearest up-sampling: sum the gradient back down
                 gr = torch.ops.aten.upsample_nearest2d_backward(g, [g.size(2), g.size(3)], list(ctx.res_up), None, None)
-        return gx, gw, (gb if (has_bias and need_b) else None), gr, None, None, None, None, None
+        return gx, gw, (gb if (has_bias and need_b) else None), gr, None, None, None, None, None, None
 
 
 # ---- grouped convolutions (ResNeXt conv2): slab-packed weights, csrc/gconv.hip ------------------------------------
@@ -718,15 +734,17 @@ def _pad_channels(x, weight, mult=8):
     return x.contiguous(memory_format=CL), weight.contiguous(memory_format=CL)
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False, chain=False):
     """y = act(conv2d(x, w) + bias + residual); x (B,Ci,H,W) channels_last, weight (Co,Ci,kh,kw) channels_last.
-    residual_up: residual is a coarser map, added through nearest-neighbour up-sampling to the output size."""
+    residual_up: residual is a coarser map, added through nearest-neighbour up-sampling to the output size.
+    chain: -> (y, alias of x), see Conv2dFunction.forward."""
     if isinstance(stride, (tuple, list)):
         stride, padding, dilation = stride[0], padding[0], dilation[0]
     if x.size(1) % 8 != 0:
+        assert not chain
         x, weight = _pad_channels(x, weight)
     return Conv2dFunction.apply(x, weight, bias, residual, int(stride), int(padding), int(dilation), relu,
-                                bool(residual_up))
+                                bool(residual_up), bool(chain))
 
 
 def linear(x, weight, bias=None, relu=False):

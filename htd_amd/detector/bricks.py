@@ -14,14 +14,16 @@ from ..registry import CONV_LAYERS
 CL = torch.channels_last
 
 
-def dense_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False):
+def dense_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False,
+                 chain=False):
     """y = act(conv2d(x, w) + bias + residual) on NHWC activations / KRSC weights.  bf16 activations take the
     mixed-precision kernels (bf16 operands, fp32 accumulate, fp32 master parameters and parameter gradients)."""
     from .. import dense
     if x.dtype == torch.bfloat16:
         assert not residual_up, 'the bf16 kernels take same-size residuals only'
-        return dense.conv2d_bf16_autograd(x, weight, bias, stride, padding, dilation, relu, residual)
-    return dense.conv2d(x, weight, bias, stride, padding, dilation, relu, residual, residual_up)
+        y = dense.conv2d_bf16_autograd(x, weight, bias, stride, padding, dilation, relu, residual)
+        return (y, x) if chain else y                 # no chaining in the bf16 path: the alias is the tensor itself
+    return dense.conv2d(x, weight, bias, stride, padding, dilation, relu, residual, residual_up, chain)
 
 
 @CONV_LAYERS.register_module('Conv')
@@ -41,17 +43,17 @@ class Conv2d(nn.Conv2d):
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
         return self
 
-    def forward(self, x, relu=False, residual=None, weight=None, bias=None, residual_up=False):
+    def forward(self, x, relu=False, residual=None, weight=None, bias=None, residual_up=False, chain=False):
         w = self.weight if weight is None else weight
         b = self.bias if bias is None else bias
         if self.groups > 1:
             from .. import dense
-            assert residual is None
+            assert residual is None and not chain
             dt = x.dtype                              # fp32 kernels: bf16 stages cast around the grouped 3x3
             y = dense.grouped_conv2d(x.float() if dt != torch.float32 else x, w, b, self.stride[0], self.padding[0],
                                      self.dilation[0], self.groups, relu)
             return y.to(dt) if dt != torch.float32 else y
-        return dense_conv2d(x, w, b, self.stride[0], self.padding[0], self.dilation[0], relu, residual, residual_up)
+        return dense_conv2d(x, w, b, self.stride[0], self.padding[0], self.dilation[0], relu, residual, residual_up, chain)
 
 
 def build_conv_layer(cfg, *args, **kwargs):

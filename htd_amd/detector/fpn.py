@@ -59,11 +59,24 @@ class FPN(nn.Module):
         if self._fused_top_down(inputs):
             # top-down pathway (fpn.py:176-189) inside the lateral convolutions: level i-1's 1x1 conv adds the
             # nearest-up-sampled level i in its epilogue (no up-sampled map, no separate add)
-            laterals = [None] * n
+            # Each coarser level i + 1 has two readers, its output convolution and level i's lateral sum: the output
+            # convolution runs first and hands back an alias of its input (Conv2dFunction chain), the lateral reads the
+            # alias, so in backward the summed-down gradient joins in the output convolution's data-gradient epilogue.
+            laterals, outs_chain = [None] * n, [None] * n
+            chain = inputs[0].is_cuda and inputs[0].dtype == torch.float32 and torch.is_grad_enabled() and \
+                all(not c.with_norm and not c.with_activation and getattr(c, 'compute_dtype', None) is None
+                    for c in self.fpn_convs[:n])
             for i in range(n - 1, -1, -1):
                 m = self.lateral_convs[i]
                 up = laterals[i + 1] if i + 1 < n else None
                 laterals[i] = m.conv(inputs[i + self.start_level], residual=up, residual_up=up is not None)
+                if chain and i > 0:
+                    outs_chain[i], laterals[i] = self.fpn_convs[i].conv(laterals[i], chain=True)
+            if chain:
+                outs = [outs_chain[i] if i > 0 else self.fpn_convs[0](laterals[0]) for i in range(n)]
+                for _ in range(self.num_outs - n):
+                    outs.append(outs[-1][:, :, ::2, ::2])
+                return tuple(outs)
         else:
             laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
             for i in range(n - 1, 0, -1):

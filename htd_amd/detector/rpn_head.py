@@ -50,6 +50,31 @@ class _RPNLossFunction(torch.autograd.Function):
         return (gcls * g_cls, greg * g_box) + (None, ) * 9
 
 
+class _SplitHeads(torch.autograd.Function):
+    """(B, nc + nr + pad, H, W) -> channel slices [:nc], [nc:nc+nr] (views).  Backward assembles the gradient of the merged
+    map in ONE concatenation instead of two zero-filled slice scatters and their sum."""
+
+    @staticmethod
+    def forward(ctx, y, nc, nr):
+        ctx.dims = (nc, nr, y.size(1))
+        ctx.set_materialize_grads(False)
+        return y[:, :nc], y[:, nc:nc + nr]
+
+    @staticmethod
+    def backward(ctx, gc, gr):
+        nc, nr, C = ctx.dims
+        ref = gc if gc is not None else gr
+        if ref is None:
+            return None, None, None
+        B, _, H, W = ref.shape
+        parts = [gc if gc is not None else ref.new_zeros(B, nc, H, W), gr if gr is not None else ref.new_zeros(B, nr, H, W)]
+        if C > nc + nr:
+            parts.append(ref.new_zeros(B, C - nc - nr, H, W))
+        # (B, H, W, C) is the memory order of a channels_last map: concatenate there, hand back the NCHW view of it
+        g = torch.cat([p.permute(0, 2, 3, 1) for p in parts], 3).permute(0, 3, 1, 2)
+        return g, None, None
+
+
 @HEADS.register_module()
 class RPNHead(nn.Module):
     def __init__(self, in_channels, feat_channels=256,
@@ -103,13 +128,18 @@ class RPNHead(nn.Module):
                       ([self.rpn_cls.weight.new_zeros(pad, *self.rpn_cls.weight.shape[1:])] if pad else []))
         b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias] + ([self.rpn_cls.bias.new_zeros(pad)] if pad else []))
         cls, reg = [], []
-        for x in feats:
-            h = self.rpn_conv(x, relu=True)
+        taps = isinstance(feats, M.PyramidTaps)      # the pyramid as a chain of consumers: see Conv2dFunction(chain=True)
+        for i in range(len(feats)):
+            x = feats[i]
+            if taps and x.dtype == torch.float32:
+                h, feats.levels[i] = self.rpn_conv(x, relu=True, chain=True)
+            else:
+                h = self.rpn_conv(x, relu=True)
             if h.dtype != torch.float32:         # bf16 pyramid: the heads and all box math stay fp32
                 h = h.float()
-            y = self.rpn_cls(h, weight=w, bias=b)
-            cls.append(y[:, :nc])
-            reg.append(y[:, nc:nc + nr])
+            c, r = _SplitHeads.apply(self.rpn_cls(h, weight=w, bias=b), nc, nr)
+            cls.append(c)
+            reg.append(r)
         return cls, reg
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None,

@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from .. import mmcv_ops as M
 from ..registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -170,10 +171,14 @@ class TwoStageDetector(BaseDetector):
             proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn)
             static = x[0].is_cuda and gt_masks is None and not kwargs and \
                 getattr(self.roi_head, 'can_train_static', lambda *_: False)(gt_bboxes_ignore)
-            rpn_losses, proposal_list = self.rpn_head.forward_train(x, img_metas, gt_bboxes, gt_labels=None,
+            chain = x[0].is_cuda and x[0].dtype == torch.float32 and torch.is_grad_enabled()
+            feats = M.PyramidTaps(x) if chain else x
+            rpn_losses, proposal_list = self.rpn_head.forward_train(feats, img_metas, gt_bboxes, gt_labels=None,
                                                                     gt_bboxes_ignore=gt_bboxes_ignore,
                                                                     proposal_cfg=proposal_cfg, padded=static)
             losses.update(rpn_losses)
+            if chain:       # the RoI head reads the aliases the RPN convolutions handed back: one gradient map per level
+                x = x32 = tuple(feats.levels)
             if static:       # fixed-shape RoI head: the whole train step runs without a host/device synchronisation
                 losses.update(self.roi_head.forward_train_static(x32, img_metas, *proposal_list, gt_bboxes, gt_labels))
                 return losses

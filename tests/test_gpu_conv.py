@@ -352,3 +352,43 @@ def test_split_bf16_products_are_fp32_accurate(Ci, Co, k, H, W):
         # both: fp32 rounding of a K-term accumulation, relative to the accumulated magnitude (measured 2e-7 .. 2e-6)
         assert err[0][i] < 1.5e-7 * K ** 0.5 and err[1][i] < 1.5e-7 * K ** 0.5, (what, err, K)
         assert err[1][i] <= 1.5 * err[0][i] + 2e-8, (what, err, K)
+
+
+@pytest.mark.gpu
+def test_chained_conv_consumers_hand_one_gradient_to_the_producer():
+    """Conv2dFunction(chain=True): the second reader of a map reads the alias the first one returns; in backward its
+    gradient joins in the first reader's data-gradient epilogue.  Same gradients as two independent readers."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(2, 32, 20, 28, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    wa = (torch.randn(48, 32, 3, 3, generator=g) * 0.1).to(dev).contiguous(memory_format=torch.channels_last)
+    wb = (torch.randn(16, 32, 1, 1, generator=g) * 0.1).to(dev).contiguous(memory_format=torch.channels_last)
+    ra, rb = torch.randn(2, 48, 20, 28, generator=g).to(dev), torch.randn(2, 16, 20, 28, generator=g).to(dev)
+
+    def run(chain):
+        x = x0.clone().requires_grad_()
+        a, b = wa.clone().requires_grad_(), wb.clone().requires_grad_()
+        h = x * 1.0                                   # a produced map (not a leaf): its gradient is what gets summed
+        if chain:
+            ya, alias = dense.conv2d(h, a, None, 1, 1, 1, chain=True)
+            yb = dense.conv2d(alias, b, None, 1, 0, 1)
+        else:
+            ya, yb = dense.conv2d(h, a, None, 1, 1, 1), dense.conv2d(h, b, None, 1, 0, 1)
+        ((ya * ra).sum() + (yb * rb).sum()).backward()
+        return x.grad, a.grad, b.grad
+    ref, out = run(False), run(True)
+    for r, o in zip(ref, out):
+        assert torch.allclose(r, o, rtol=1e-5, atol=1e-5 * float(r.abs().max()))
+    # the alias alone (first reader's output unused) still carries the second reader's gradient
+    x = x0.clone().requires_grad_()
+    ya, alias = dense.conv2d(x * 1.0, wa, None, 1, 1, 1, chain=True)
+    (dense.conv2d(alias, wb, None, 1, 0, 1) * rb).sum().backward()
+    assert torch.allclose(x.grad, ref[0] - run_only_a(x0, wa, ra), rtol=1e-4, atol=1e-5 * float(ref[0].abs().max()))
+
+
+def run_only_a(x0, wa, ra):
+    from htd_amd import dense
+    x = x0.clone().requires_grad_()
+    (dense.conv2d(x * 1.0, wa, None, 1, 1, 1) * ra).sum().backward()
+    return x.grad
