@@ -258,13 +258,18 @@ class RPNHead(nn.Module):
         A = flat_anchors.size(0)
         from ..core.bbox import pad_gt_batch
         gts, gt_valid = pad_gt_batch(gt_bboxes)
-        from ..core.bbox import batched_max_iou_assign, batched_random_sample, sample_keys
+        from ..core.bbox import (_sample_on_device, batched_max_iou_assign, batched_random_sample, random_sample_device,
+                                 sample_keys)
         assigned, _ = batched_max_iou_assign(self.assigner, flat_anchors, inside, gts, gt_valid)
         sc = self.train_cfg.sampler
         if keys is None:
             keys = sample_keys(flat_anchors[None].expand(B, A, 4))
-        pos, neg = batched_random_sample(assigned, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1), keys)
-        n_pos, n_neg = pos.sum(1), neg.sum(1)
+        if _sample_on_device(assigned, keys, sc.num):       # masks and drawn counts from one call (htd_random_sample)
+            pos, neg, counts, _ = random_sample_device(assigned, keys, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1))
+            n_pos, n_neg = counts[:, 0], counts[:, 1]
+        else:
+            pos, neg = batched_random_sample(assigned, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1), keys)
+            n_pos, n_neg = pos.sum(1), neg.sum(1)
         num_total = (n_pos.clamp(min=1) + n_neg.clamp(min=1)).sum().to(torch.float32)       # anchor_head.py:354-355
         cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
         reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
