@@ -92,15 +92,31 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const int64_t *__restric
         if (rows < 64) cur |= ~0ull << rows;  // rows past the end are never kept
         // upper-triangular mask: no row before this chunk can change after this point
         const unsigned long long dword = lane < rows ? mask[(row0 + lane) * ncb + q] : 0ull;
+        // the words this lane will fold (column tile `lane`, all rows of the chunk) do not depend on which rows survive:
+        // their 64 loads are issued now and land while the diagonal tile is resolved -- the walk over the chunks is one
+        // dependent chain per segment, so every exposed load latency is paid n / 64 times
+        const bool own0 = lane > q && lane < ncb && (int64_t)lane * 64 < n;
+        unsigned long long pre[64];
+        if (own0) {
+            const unsigned long long *col = mask + row0 * ncb + lane;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) pre[t] = col[(int64_t)min(t, rows - 1) * ncb];
+        }
         for (int t = 0; t < rows; ++t) {
             const unsigned long long dt = bcast64(dword, t);
             if (!((cur >> t) & 1ull)) cur |= dt;
         }
-        const unsigned long long kept = ~cur;
+        const unsigned long long kept = ~cur;      // bits of the rows past the end are 0
         if (lane < rows) keep[row0 + lane] = (uint8_t)((kept >> lane) & 1ull);
         // fold the survivors' rows into the later column tiles this lane owns
+        if (own0) {
+            unsigned long long acc = remv[0];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
+            for (int t = 0; t < 64; ++t) acc |= ((kept >> t) & 1ull) ? pre[t] : 0ull;
+            remv[0] = acc;
+        }
+#pragma unroll
+        for (int k = 1; k < KMAX; ++k) {
             const int cb = lane + 64 * k;
             if (cb > q && cb < ncb && (int64_t)cb * 64 < n) {
                 unsigned long long acc = remv[k];
