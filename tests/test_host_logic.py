@@ -376,3 +376,24 @@ def test_gradient_sinks_are_scoped_to_their_trainer():
     assert key not in dense._GRAD_SINK and len(dense._GRAD_SINK) == n0 + 2
     fb.close()
     assert len(dense._GRAD_SINK) == n0
+
+
+def test_split_heads_backward_equals_slicing():
+    """rpn_head._SplitHeads: channel slices of the merged 1x1 head; its one-concatenation backward equals what autograd
+    computes for two plain slices (including a head that received no gradient)."""
+    import torch
+    from htd_amd.detector.rpn_head import _SplitHeads
+    torch.manual_seed(0)
+    y0 = torch.randn(2, 16, 5, 7).contiguous(memory_format=torch.channels_last)
+    rc, rr = torch.randn(2, 3, 5, 7), torch.randn(2, 12, 5, 7)
+    ya = y0.clone().requires_grad_()
+    c, r = _SplitHeads.apply(ya, 3, 12)
+    assert torch.equal(c, y0[:, :3]) and torch.equal(r, y0[:, 3:15])
+    ((c * rc).sum() + (r * rr).sum()).backward()
+    yb = y0.clone().requires_grad_()
+    ((yb[:, :3] * rc).sum() + (yb[:, 3:15] * rr).sum()).backward()
+    assert torch.equal(ya.grad, yb.grad) and float(ya.grad[:, 15:].abs().sum()) == 0.0
+    ya = y0.clone().requires_grad_()
+    c, r = _SplitHeads.apply(ya, 3, 12)
+    (r * rr).sum().backward()                       # the classification slice unused
+    assert float(ya.grad[:, :3].abs().sum()) == 0.0 and torch.equal(ya.grad[:, 3:15], rr)
