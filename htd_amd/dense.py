@@ -325,6 +325,63 @@ class Conv2dFunction(Function):
         return gx, gw, (gb if (has_bias and need_b) else None), gr, None, None, None, None, None, None
 
 
+class ConvReluHeadFunction(Function):
+    """y = conv1x1(relu(conv_kxk(x, w1) + b1), w2) + b2 as ONE autograd node (the RPN: rpn_head.py:24-33, a 3x3 convolution
+    + ReLU feeding the 1x1 heads).  In backward the ReLU mask of the hidden map is applied by the head's data-gradient
+    epilogue (mask_src) instead of a separate pass over the hidden gradient, and bias gradients come out of the wgrad
+    launches.  chain=True: also returns an identity alias of x (see Conv2dFunction)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, padding, chain):
+        _need_gpu(x, 'conv_relu_head')
+        src = x
+        x = x.contiguous(memory_format=CL)
+        w1, w2 = w1.contiguous(memory_format=CL), w2.contiguous(memory_format=CL)
+        b1 = b1.contiguous() if b1 is not None else None
+        b2 = b2.contiguous() if b2 is not None else None
+        h = _fwd_raw(x, w1, b1, None, 1, padding, 1, True)
+        y = _fwd_raw(h, w2, b2, None, 1, 0, 1, False)
+        ctx.save_for_backward(x, w1, w2, h)
+        ctx.cfg = (int(padding), b1, b2, bool(chain))          # the biases: only their addresses are used (sink lookup)
+        if chain:
+            ctx.set_materialize_grads(False)
+            return y, src.view_as(src)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, galias=None):
+        x, w1, w2, h = ctx.saved_tensors
+        padding, b1, b2, chain = ctx.cfg
+        if gy is None:
+            return (galias, ) + (None, ) * 6
+        need_x, need_w1, need_b1, need_w2, need_b2 = ctx.needs_input_grad[:5]
+        gy = gy.contiguous(memory_format=CL)
+        gw1 = gb1 = gw2 = gb2 = None
+        if need_w2:
+            gw2, gb2 = _wgrad_raw(h, gy, w2, 1, 0, 1, b2 if (need_b2 and b2 is not None) else None)
+        elif need_b2 and b2 is not None:
+            gb2 = _colsum_raw(gy, None, b2)[1]
+        gh = _dgrad_raw(gy, w2, h.shape, 1, 0, 1, mask_src=h)          # ReLU of the hidden map: in this epilogue
+        if need_w1:
+            gw1, gb1 = _wgrad_raw(x, gh, w1, 1, padding, 1, b1 if (need_b1 and b1 is not None) else None)
+        elif need_b1 and b1 is not None:
+            gb1 = _colsum_raw(gh, None, b1)[1]
+        gx = None
+        if need_x:
+            fuse = galias is not None and galias.dtype == gh.dtype and tuple(galias.shape) == tuple(x.shape)
+            gx = _dgrad_raw(gh, w1, x.shape, 1, padding, 1, accum=galias.contiguous(memory_format=CL) if fuse else None)
+            if galias is not None and not fuse:
+                gx = gx + galias
+        elif galias is not None:
+            gx = galias
+        return gx, gw1, gb1, gw2, gb2, None, None
+
+
+def conv_relu_head(x, w1, b1, w2, b2, padding=1, chain=False):
+    return ConvReluHeadFunction.apply(x, w1, b1, w2, b2, int(padding), bool(chain))
+
+
 # ---- grouped convolutions (ResNeXt conv2): slab-packed weights, csrc/gconv.hip ------------------------------------
 
 def _gconv_pack(weight, groups, transpose):

@@ -129,15 +129,20 @@ class RPNHead(nn.Module):
         b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias] + ([self.rpn_cls.bias.new_zeros(pad)] if pad else []))
         cls, reg = [], []
         taps = isinstance(feats, M.PyramidTaps)      # the pyramid as a chain of consumers: see Conv2dFunction(chain=True)
+        from .. import dense
         for i in range(len(feats)):
             x = feats[i]
-            if taps and x.dtype == torch.float32:
-                h, feats.levels[i] = self.rpn_conv(x, relu=True, chain=True)
+            if x.dtype == torch.float32 and x.size(1) % 8 == 0:
+                # 3x3 + ReLU + merged 1x1 heads as one autograd node (the hidden map's ReLU mask rides the head's dgrad)
+                y = dense.conv_relu_head(x, self.rpn_conv.weight, self.rpn_conv.bias, w, b, self.rpn_conv.padding[0], taps)
+                if taps:
+                    y, feats.levels[i] = y
             else:
                 h = self.rpn_conv(x, relu=True)
-            if h.dtype != torch.float32:         # bf16 pyramid: the heads and all box math stay fp32
-                h = h.float()
-            c, r = _SplitHeads.apply(self.rpn_cls(h, weight=w, bias=b), nc, nr)
+                if h.dtype != torch.float32:     # bf16 pyramid: the heads and all box math stay fp32
+                    h = h.float()
+                y = self.rpn_cls(h, weight=w, bias=b)
+            c, r = _SplitHeads.apply(y, nc, nr)
             cls.append(c)
             reg.append(r)
         return cls, reg
