@@ -50,14 +50,15 @@ class _GlobalSoftmax(torch.autograd.Function):
 
 
 def group_layout(rois, target_lvls, num_levels, num_imgs=None, roi_valid=None):
-    """Sort RoIs by (image, level).  -> perm (N,), counts (G,) device tensor with G = B*num_levels, B.
+    """Sort RoIs by (level, image): group g = level * B + image, so that the groups of one level -- the rows of that level's
+    Linear layer -- are one contiguous slab of the padded batch.  -> perm (N,), counts (G,) device tensor, G = B*num_levels, B.
     With num_imgs given nothing here reads the device (no .item(), no bincount size probe)."""
     img = rois[:, 0].long()
     if num_imgs is None:
         B = int(img.max().item()) + 1 if rois.numel() else 0
     else:
         B = num_imgs
-    key = img * num_levels + target_lvls
+    key = target_lvls * B + img
     if roi_valid is not None:                      # unused sample slots: a group of their own past the real ones
         key = torch.where(roi_valid, key, torch.full_like(key, B * num_levels))
     perm = torch.sort(key, stable=True)[1]
@@ -126,12 +127,8 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, ro
         logits = torch.where(pair, logits, logits.new_full((1, ), float('-inf')))   # padded columns carry no mass
         logits = torch.where(valid[:, :, None], logits, torch.zeros_like(logits))   # padded rows: finite, unused
         A_glob = torch.softmax(logits, dim=-1) * vf
-    agg = dense.bgemm_nt(A_glob, mixedT).view(B, L, npad, Fdim)             # A_glob @ mixed
-    outs = []
-    for i, layer in enumerate(graph_layers):
-        outs.append(dense.linear(agg[:, i].reshape(B * npad, Fdim), layer.weight, layer.bias, relu=True)
-                    .view(B, npad, Fdim))
-    out = torch.stack(outs, 1).view(G * npad, Fdim)
+    agg = dense.bgemm_nt(A_glob, mixedT).view(L, B * npad, Fdim)            # A_glob @ mixed; level-major groups
+    out = torch.cat([dense.linear(agg[i], layer.weight, layer.bias, relu=True) for i, layer in enumerate(graph_layers)], 0)
     # scatter back; padded rows all land on one extra row that is dropped (no boolean-mask gather = no host sync)
     dst = torch.where(valid, rows, torch.full_like(rows, N)).reshape(-1)
     return x.new_zeros(N + 1, Fdim).index_copy(0, dst, out)[:N]
