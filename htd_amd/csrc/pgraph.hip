@@ -188,3 +188,115 @@ extern "C" int htd_pgraph_softmax_bwd(const float *gA, const float *A_glob, cons
                        A_local, counts, gsim, npad, rows);
     return htd::check_launch("pgraph_softmax_bwd");
 }
+
+// ---- group gather / scatter (pgraph.py): RoI rows -> padded (group, slot) rows and back -------------------------------
+namespace {
+
+// out[i][0..Fo) = valid[i] ? x[rows[i]][0..F) followed by zeros : zeros         (one wavefront per output row)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ x, const int64_t *__restrict__ rows,
+                                                          const unsigned char *__restrict__ valid, float *__restrict__ out,
+                                                          int64_t n_out, int F, int Fo)
+{
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_out) return;
+    const int lane = threadIdx.x & 63;
+    const bool ok = valid[i] != 0;
+    const float *src = x + (ok ? rows[i] : 0) * (int64_t)F;
+    float *dst = out + i * (int64_t)Fo;
+    for (int f = lane; f < Fo; f += 64) dst[f] = (ok && f < F) ? src[f] : 0.f;
+}
+
+// gx[rows[i]][0..F) = g[i][0..F) for the valid i (every RoI sits in at most one slot: plain stores); gx is zeroed first
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restrict__ g, const int64_t *__restrict__ rows,
+                                                           const unsigned char *__restrict__ valid, float *__restrict__ gx,
+                                                           int64_t n_out, int F, int Fo)
+{
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_out || !valid[i]) return;
+    const int lane = threadIdx.x & 63;
+    const float *src = g + i * (int64_t)Fo;
+    float *dst = gx + rows[i] * (int64_t)F;
+    for (int f = lane; f < F; f += 64) dst[f] = src[f];
+}
+
+// transposed forms: outT[g][f][r] = valid[g][r] ? x[rows[g][r]][f] : 0 through a 32 (slots) x 64 (features) LDS tile;
+// TO_X: the adjoint, gx[rows[g][r]][f] = gT[g][f][r]
+template <bool TO_X>
+__global__ __launch_bounds__(256) void gather_rows_t_kernel(float *__restrict__ x, const int64_t *__restrict__ rows,
+                                                            const unsigned char *__restrict__ valid, float *__restrict__ outT,
+                                                            int npad, int F)
+{
+    __shared__ float tile[32][65];
+    const int g = blockIdx.z, r0 = blockIdx.y * 32, f0 = blockIdx.x * 64, t = threadIdx.x;
+    const int64_t slot0 = (int64_t)g * npad + r0;
+    if (!TO_X) {
+        for (int e = t; e < 32 * 64; e += 256) {
+            const int r = e >> 6, f = e & 63;
+            const bool ok = r0 + r < npad && f0 + f < F && valid[slot0 + r];
+            tile[r][f] = ok ? x[rows[slot0 + r] * (int64_t)F + f0 + f] : 0.f;
+        }
+        __syncthreads();
+        for (int e = t; e < 32 * 64; e += 256) {
+            const int f = e >> 5, r = e & 31;
+            if (r0 + r < npad && f0 + f < F) outT[((int64_t)g * F + f0 + f) * npad + r0 + r] = tile[r][f];
+        }
+    } else {
+        for (int e = t; e < 32 * 64; e += 256) {
+            const int f = e >> 5, r = e & 31;
+            tile[r][f] = (r0 + r < npad && f0 + f < F) ? outT[((int64_t)g * F + f0 + f) * npad + r0 + r] : 0.f;
+        }
+        __syncthreads();
+        for (int e = t; e < 32 * 64; e += 256) {
+            const int r = e >> 6, f = e & 63;
+            if (r0 + r < npad && f0 + f < F && valid[slot0 + r]) x[rows[slot0 + r] * (int64_t)F + f0 + f] = tile[r][f];
+        }
+    }
+}
+
+}  // namespace
+
+// x [N][F] -> out [n_out][Fo] (Fo >= F, zero tail), out[i] = valid[i] ? x[rows[i]] : 0: `x[mask]` group gathers of
+// HTDBBoxHead.forward (htd_bbox_head.py:198-206) for all groups at once.  transposed != 0: out is [G][F][npad] (n_out = G * npad,
+// Fo == F), the K-major operand of the adjacency product.
+extern "C" int htd_pgraph_gather(const float *x, const int64_t *rows, const unsigned char *valid, float *out, int64_t n_out,
+                                 int F, int Fo, int G, int transposed, void *stream)
+{
+    HTD_REQUIRE(n_out >= 0 && F > 0 && Fo >= F && G > 0 && n_out % G == 0, "pgraph_gather: bad sizes");
+    if (n_out == 0) return HTD_OK;
+    HTD_REQUIRE(x && rows && valid && out, "pgraph_gather: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (transposed) {
+        HTD_REQUIRE(Fo == F, "pgraph_gather: the transposed form has no padding columns");
+        const int npad = (int)(n_out / G);
+        const dim3 grid((unsigned)htd::ceil_div(F, 64), (unsigned)htd::ceil_div(npad, 32), (unsigned)G);
+        hipLaunchKernelGGL(gather_rows_t_kernel<false>, grid, dim3(256), 0, s, const_cast<float *>(x), rows, valid, out, npad, F);
+    } else
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)htd::ceil_div(n_out, 4)), dim3(256), 0, s, x, rows, valid, out, n_out,
+                           F, Fo);
+    return htd::check_launch("pgraph_gather");
+}
+
+// The adjoint: gx [N][F] = 0, then gx[rows[i]] = g[i][0..F) for the valid i (each RoI occupies at most one slot).
+extern "C" int htd_pgraph_scatter(const float *g, const int64_t *rows, const unsigned char *valid, float *gx, int64_t n_out,
+                                  int64_t N, int F, int Fo, int G, int transposed, void *stream)
+{
+    HTD_REQUIRE(n_out >= 0 && N >= 0 && F > 0 && Fo >= F && G > 0 && n_out % G == 0, "pgraph_scatter: bad sizes");
+    if (N == 0) return HTD_OK;
+    HTD_REQUIRE(gx, "pgraph_scatter: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(gx, 0, (size_t)N * F * sizeof(float), s) != hipSuccess) {
+        htd::set_error("pgraph_scatter: memset failed");
+        return HTD_ERR_LAUNCH;
+    }
+    if (n_out == 0) return HTD_OK;
+    HTD_REQUIRE(g && rows && valid, "pgraph_scatter: null pointer");
+    if (transposed) {
+        HTD_REQUIRE(Fo == F, "pgraph_scatter: the transposed form has no padding columns");
+        const int npad = (int)(n_out / G);
+        const dim3 grid((unsigned)htd::ceil_div(F, 64), (unsigned)htd::ceil_div(npad, 32), (unsigned)G);
+        hipLaunchKernelGGL(gather_rows_t_kernel<true>, grid, dim3(256), 0, s, gx, rows, valid, const_cast<float *>(g), npad, F);
+    } else
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)htd::ceil_div(n_out, 4)), dim3(256), 0, s, g, rows, valid, gx, n_out,
+                           F, Fo);
+    return htd::check_launch("pgraph_scatter");
+}

@@ -49,6 +49,36 @@ class _GlobalSoftmax(torch.autograd.Function):
         return gsim, None, None
 
 
+class _GatherGroups(torch.autograd.Function):
+    """x (N,F) -> the padded group slots: out[i] = valid[i] ? x[rows[i]] : 0 as (G*npad, Fo) rows (Fo >= F, zero tail) or, with
+    transposed=True, as (G, F, npad) -- the K-major operand of the adjacency product, written directly (no index_select,
+    mask multiply and transpose copy).  Backward is the adjoint scatter: every RoI occupies at most one valid slot, so it is
+    plain stores into a zeroed map (htd_pgraph_gather / htd_pgraph_scatter), not an index_add of 8 192 rows."""
+
+    @staticmethod
+    def forward(ctx, x, rows, valid, G, Fo, transposed):
+        x = x.contiguous()
+        N, Fdim = x.shape
+        n_out = rows.numel()
+        npad = n_out // G
+        out = torch.empty((G, Fdim, npad) if transposed else (n_out, Fo), device=x.device, dtype=x.dtype)
+        capi.call('htd_pgraph_gather', _P(x), _P(rows), _P(valid), _P(out), n_out, Fdim, Fdim if transposed else Fo, G,
+                  int(transposed), _S())
+        ctx.save_for_backward(rows, valid)
+        ctx.dims = (N, Fdim, Fo, G, bool(transposed))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        rows, valid = ctx.saved_tensors
+        N, Fdim, Fo, G, transposed = ctx.dims
+        gx = torch.empty(N, Fdim, device=g.device, dtype=g.dtype)
+        capi.call('htd_pgraph_scatter', _P(g.contiguous()), _P(rows), _P(valid), _P(gx), rows.numel(), N, Fdim,
+                  Fdim if transposed else Fo, G, int(transposed), _S())
+        return gx, None, None, None, None, None
+
+
 def group_layout(rois, target_lvls, num_levels, num_imgs=None, roi_valid=None):
     """Sort RoIs by (level, image): group g = level * B + image, so that the groups of one level -- the rows of that level's
     Linear layer -- are one contiguous slab of the padded batch.  -> perm (N,), counts (G,) device tensor, G = B*num_levels, B.
@@ -97,17 +127,24 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, ro
     src = (starts[:, None] + ar[None, :]).clamp(max=N - 1)
     rows = perm[src]                                                        # (G, npad) original RoI rows
     vf = valid[..., None].to(x.dtype)
-    flat_rows = rows.reshape(-1)
-    xg = torch.index_select(x, 0, flat_rows).view(G, npad, Fdim) * vf
+    flat_rows = rows.reshape(-1).contiguous()
+    flat_valid = valid.reshape(-1).contiguous()
     S8 = (sam.size(1) + 7) // 8 * 8
-    sg = torch.nn.functional.pad(torch.index_select(sam, 0, flat_rows).view(G, npad, -1) * vf, (0, S8 - sam.size(1)))
+    fused_gather = x.is_cuda and x.dtype == torch.float32 and sam.dtype == torch.float32
+    if fused_gather:
+        sg = _GatherGroups.apply(sam, flat_rows, flat_valid, G, S8, False).view(G, npad, S8)
+        xgT = _GatherGroups.apply(x, flat_rows, flat_valid, G, Fdim, True)            # (G, F, npad)
+    else:
+        xg = torch.index_select(x, 0, flat_rows).view(G, npad, Fdim) * vf
+        xgT = xg.transpose(1, 2).contiguous()
+        sg = torch.nn.functional.pad(torch.index_select(sam, 0, flat_rows).view(G, npad, -1) * vf, (0, S8 - sam.size(1)))
     bx = torch.index_select(rois, 0, flat_rows).view(G, npad, -1)[..., 1:5]
     counts = counts.contiguous()
     if npad <= FUSED_MAX_NPAD:
         # IoU -> mask -> degree -> normalisation in one kernel; (1 - M) * sim -> row soft-max in another
         A_local = local_adjacency(bx, counts)
         # mixed^T[f][i] = sum_j x^T[f][j] * A_local[i][j]   (A_local @ x, kept transposed: it is the NT operand below)
-        mixedT = dense.bgemm_nt(xg.transpose(1, 2).contiguous(), A_local)   # (G, F, npad)
+        mixedT = dense.bgemm_nt(xgT, A_local)                               # (G, F, npad)
         A_glob = _GlobalSoftmax.apply(dense.bgemm_nt(sg, sg), A_local, counts)
     else:       # groups beyond 1024 RoIs (no HTD config gets there): the same arithmetic as tensor expressions
         lt = torch.max(bx[:, :, None, :2], bx[:, None, :, :2])
@@ -121,7 +158,7 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, ro
         Mloc = (((inter / union > 0) | eye) & pair).to(x.dtype)             # (G, npad, npad), symmetric
         dinv = Mloc.sum(-1).clamp(min=1.0).pow(-0.5)                        # padded rows: avoid 0^-1/2
         A_local = dinv[:, :, None] * Mloc * dinv[:, None, :]
-        mixedT = dense.bgemm_nt(xg.transpose(1, 2).contiguous(), A_local)
+        mixedT = dense.bgemm_nt(xgT, A_local)
         sim = dense.bgemm_nt(sg, sg)                                        # (G, npad, npad)
         logits = (1.0 - Mloc) * sim
         logits = torch.where(pair, logits, logits.new_full((1, ), float('-inf')))   # padded columns carry no mass

@@ -430,6 +430,14 @@ int htd_pgraph_softmax_fwd(const float *sim, const float *A_local, const int64_t
                            void *stream);
 int htd_pgraph_softmax_bwd(const float *gA, const float *A_glob, const float *A_local, const int64_t *counts, float *gsim,
                            int G, int npad, void *stream);
+/* Group gathers of HTDBBoxHead.forward (`x[mask]` per (image, level), htd_bbox_head.py:198-206) for all groups at once:
+ * out[i] = valid[i] ? x[rows[i]] : 0 for the n_out = G * npad padded slots; out [n_out][Fo] (Fo >= F, zero tail) or, with
+ * transposed != 0, [G][F][npad] (the K-major operand of A_local @ x).  htd_pgraph_scatter is the adjoint (gx zeroed, then
+ * gx[rows[i]] = g[i]; every RoI occupies at most one valid slot). */
+int htd_pgraph_gather(const float *x, const int64_t *rows, const unsigned char *valid, float *out, int64_t n_out, int F,
+                      int Fo, int G, int transposed, void *stream);
+int htd_pgraph_scatter(const float *g, const int64_t *rows, const unsigned char *valid, float *gx, int64_t n_out, int64_t N,
+                       int F, int Fo, int G, int transposed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -608,3 +608,35 @@ def test_reference_format_checkpoint_loads_and_reproduces_the_fixture(golden, tm
     tr = Trainer(model.train(), lr=0.02)
     tr.resume(path)
     assert tr.iter == 51310 and tr.epoch == 7 and abs(tr.schedule.lr(tr.iter) - 0.02) < 1e-12      # past warm-up, before epoch 8
+
+
+@pytest.mark.gpu
+def test_pgraph_group_gather_and_its_adjoint():
+    """htd_pgraph_gather / htd_pgraph_scatter (row-major with a zero tail, and the transposed K-major form) against
+    index_select * mask, values and gradients."""
+    from htd_amd.detector.pgraph import _GatherGroups
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(2)
+    N, F, G, npad = 700, 1025, 6, 256
+    perm = torch.randperm(N, generator=g)
+    rows = torch.zeros(G * npad, dtype=torch.long)
+    valid = torch.zeros(G * npad, dtype=torch.bool)
+    used = 0
+    for gi, c in enumerate([200, 0, 256, 1, 143, 100]):           # group sizes (sum = 700): empty, full and one-row groups
+        rows[gi * npad:gi * npad + c] = perm[used:used + c]
+        valid[gi * npad:gi * npad + c] = True
+        used += c
+    rows[~valid] = N - 1                                           # padding slots point somewhere valid, masked out
+    x = torch.randn(N, F, generator=g)
+    for transposed, Fo in ((False, 1032), (True, F)):
+        xr = x.clone().requires_grad_()
+        ref = torch.nn.functional.pad(torch.index_select(xr, 0, rows) * valid[:, None].float(), (0, Fo - F))
+        if transposed:
+            ref = ref.view(G, npad, F).transpose(1, 2)
+        w = torch.randn(ref.shape, generator=g)
+        (ref * w).sum().backward()
+        xd = x.to(dev).requires_grad_()
+        out = _GatherGroups.apply(xd, rows.to(dev), valid.to(dev), G, Fo, transposed)
+        assert torch.equal(out.cpu(), ref.detach().contiguous())
+        (out * w.to(dev)).sum().backward()
+        assert torch.equal(xd.grad.cpu(), xr.grad)
