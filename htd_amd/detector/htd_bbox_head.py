@@ -104,7 +104,9 @@ class HTDBBoxHead(BBoxHead):
         prototype = torch.cat((fc_cls_0.weight, fc_cls_0.bias.unsqueeze(1)), 1).detach()
         if global_feat is not None:
             # the fcs run on the plain and on the global-fused tiles (:198,201): one batched pass over both
-            both = self._cls_fcs(torch.cat([x_cls, self._fuse_global(x_cls, global_feat, rois)], 0))
+            tiles = M.plain_and_fused(x_cls, rois, global_feat) if x_cls.is_cuda else \
+                torch.cat([x_cls, self._fuse_global(x_cls, global_feat, rois)], 0)
+            both = self._cls_fcs(tiles)
             x_cls, x_cls_glb = both[:x_cls.size(0)], both[x_cls.size(0):]
         else:
             x_cls, x_cls_glb = self._cls_fcs(x_cls), None

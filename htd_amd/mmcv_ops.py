@@ -385,6 +385,50 @@ class FuseGlobalFunction(Function):
         return go, None, gg, ge, None
 
 
+class PlainAndFusedFunction(Function):
+    """(2n, C, ph, pw) = [roi_feats ; roi_feats + global_feat[img(roi)]]: the two inputs the HTD classification FCs run on
+    (htd_bbox_head.py:198,201) as one batch.  The fused half is written straight into the batch (no fuse output + torch.cat
+    copy of both halves), and the gradient of roi_feats is ONE sum of the two halves (autograd would clone the first slice and
+    add the second)."""
+
+    @staticmethod
+    def forward(ctx, roi_feats, rois, global_feat):
+        _need_gpu(roi_feats, 'fuse_global')
+        assert roi_feats.size(0) == rois.size(0)
+        x = nhwc(_f32(roi_feats, 'fuse_global'))
+        n, C, ph, pw = x.shape
+        B = global_feat.size(0)
+        g = global_feat.reshape(B, C).contiguous()
+        rois = rois.contiguous()
+        both = torch.empty((2 * n, C, ph, pw), device=x.device, dtype=x.dtype, memory_format=CL)
+        both[:n].copy_(x)
+        if n:
+            capi.call('htd_fuse_global_fwd', _P(x), _P(rois), _P(g), None, 1.0, _P(both[n:]), n, ph * pw, C, B, _S())
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(global_feat.shape), n)
+        return both
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        rois, = ctx.saved_tensors
+        gshape, n = ctx.meta
+        go = nhwc(go)
+        C, ph, pw = go.shape[1:]
+        gg = None
+        if ctx.needs_input_grad[2]:
+            gg = torch.zeros(gshape[0], C, device=go.device, dtype=go.dtype)
+            if n:
+                capi.call('htd_fuse_global_bwd_global', _P(go[n:]), _P(rois), _P(gg), n, ph * pw, C, gshape[0], _S())
+            gg = gg.view(gshape)
+        gx = torch.add(go[:n], go[n:]) if ctx.needs_input_grad[0] else None
+        return gx, None, gg
+
+
+def plain_and_fused(roi_feats, rois, global_feat):
+    return PlainAndFusedFunction.apply(roi_feats, rois, global_feat)
+
+
 def fuse_global(roi_feats, rois, global_feat, extra=None, alpha=1.0):
     return FuseGlobalFunction.apply(roi_feats, rois, global_feat, extra, alpha)
 
