@@ -145,13 +145,10 @@ class ResLayer(nn.Sequential):
             pairs += [(blk.conv1.weight, blk.norm1), (blk.conv2.weight, blk.norm2), (blk.conv3.weight, blk.norm3)]
             if blk.downsample is not None:
                 pairs.append((blk.downsample[0].weight, blk.downsample[1]))
-        if x.dtype == torch.float32:
-            # every fold of the stage in one launch; it also leaves the flipped weight images for the data gradients
-            params = frozen_bn_fold_many(pairs, want_flips=x.requires_grad or any(w.requires_grad for w, _ in pairs))
-        else:
-            params = []
-            for w, bn in pairs:
-                params += frozen_bn_fold(w, bn)
+        # every fold of the stage in one launch; for the fp32 stages it also leaves the flipped weight images for the data
+        # gradients (the bf16 stages make their own bf16 operands from the folded weights)
+        params = frozen_bn_fold_many(pairs, want_flips=x.dtype == torch.float32 and
+                                     (x.requires_grad or any(w.requires_grad for w, _ in pairs)))
         fn = ResStageFunction if x.dtype == torch.float32 else ResStageBf16Function
         return fn.apply(x, tuple(blk.conv2_stride for blk in self), self[0].dilation,
                         tuple(blk.downsample is not None for blk in self), *params)
