@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, BBOX_SAMPLERS, IOU_CALCULATORS, build_iou_calculator
-from .misc import const_tensor
+from .misc import arange_cached, const_tensor
 
 
 # ------------------------------------------------------------------ IoU
@@ -546,7 +546,7 @@ def batched_assign_and_sample(assigner, sampler, proposal_list, gt_bboxes, gt_la
     assigned, _ = batched_max_iou_assign(assigner, props, pvalid, gts, gvalid)
     labels = torch.where(assigned > 0, torch.gather(glabels, 1, (assigned - 1).clamp(min=0)), torch.full_like(assigned, -1))
     if add_gt:      # AssignResult.add_gt_: gt i is a candidate matched to itself
-        self_inds = torch.where(gvalid, torch.arange(1, K + 1, device=dev).expand(B, K), torch.full((B, K), -1, device=dev))
+        self_inds = torch.where(gvalid, arange_cached(K, dev, start=1).expand(B, K), const_tensor([-1], dev, torch.int64))
         assigned = torch.cat([self_inds, assigned], 1)
         labels = torch.cat([torch.where(gvalid, glabels, torch.full_like(glabels, -1)), labels], 1)
         cand = torch.cat([gts, props], 1)
@@ -616,7 +616,7 @@ class StaticSamples:
     @property
     def rois(self):
         B, S = self.valid.shape
-        img = torch.arange(B, device=self.boxes.device, dtype=self.boxes.dtype).view(B, 1, 1).expand(B, S, 1)
+        img = arange_cached(B, self.boxes.device, self.boxes.dtype).view(B, 1, 1).expand(B, S, 1)
         return torch.cat([img, self.boxes], -1).view(B * S, 5)
 
 
@@ -630,7 +630,7 @@ def static_assign_and_sample(assigner, sampler, props, pvalid, gt_bboxes, gt_lab
     K = gts.size(1)
     assigned, _ = batched_max_iou_assign(assigner, props, pvalid, gts, gvalid)
     if sampler.add_gt_as_proposals:      # AssignResult.add_gt_: gt i is a candidate matched to itself
-        self_inds = torch.where(gvalid, torch.arange(1, K + 1, device=dev).expand(B, K), torch.full((B, K), -1, device=dev))
+        self_inds = torch.where(gvalid, arange_cached(K, dev, start=1).expand(B, K), const_tensor([-1], dev, torch.int64))
         assigned = torch.cat([self_inds, assigned], 1)
         cand = torch.cat([gts, props], 1)
         is_gt = torch.cat([gvalid, torch.zeros_like(pvalid)], 1)
@@ -652,7 +652,7 @@ def static_assign_and_sample(assigner, sampler, props, pvalid, gt_bboxes, gt_lab
         ar = torch.arange(A, device=dev).expand(B, A)
         order = torch.where(pos, ar, torch.where(neg, ar + A, ar + 2 * A)).argsort(dim=1)[:, :S]      # (B,S)
         npos, nneg = pos.sum(1), neg.sum(1)
-    slot = torch.arange(S, device=dev).expand(B, S)
+    slot = arange_cached(S, dev).expand(B, S)
     valid = slot < (npos + nneg)[:, None]
     is_pos = slot < npos[:, None]
     boxes = torch.gather(cand, 1, order[..., None].expand(B, S, 4)) * valid[..., None].to(cand.dtype)

@@ -31,3 +31,18 @@ def const_tensor(values, device, dtype=torch.float32):
             _CONSTS.clear()
         t = _CONSTS[key] = torch.tensor(values, dtype=dtype, device=device)
     return t
+
+
+_ARANGES = {}
+
+
+def arange_cached(n, device, dtype=torch.int64, start=0):
+    """torch.arange(start, start + n) built once per (n, device, dtype, start): READ-ONLY (the step builds the same index
+    ramps every iteration; each one is a kernel launch otherwise)."""
+    key = (int(n), str(device), dtype, int(start))
+    t = _ARANGES.get(key)
+    if t is None:
+        if len(_ARANGES) > 512:
+            _ARANGES.clear()
+        t = _ARANGES[key] = torch.arange(start, start + n, device=device, dtype=dtype)
+    return t

@@ -839,6 +839,7 @@ class BatchedGemmNT(Function):
     @staticmethod
     def forward(ctx, a, b):
         _need_gpu(a, 'bgemm_nt')
+        ctx.gram = a is b                       # a @ a^T (PGraph's similarity): one gradient product instead of two
         a, b = a.contiguous(), b.contiguous()
         ctx.save_for_backward(a, b)
         return BatchedGemmNT._run(a, b)
@@ -849,6 +850,9 @@ class BatchedGemmNT(Function):
         a, b = ctx.saved_tensors
         gc = gc.contiguous()
         ga = gb = None
+        if ctx.gram and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # d(a a^T): gc @ a + gc^T @ a = (gc + gc^T) @ a, handed back through the first argument
+            return BatchedGemmNT._run(gc + gc.transpose(1, 2), a.transpose(1, 2).contiguous()), None
         if ctx.needs_input_grad[0]:
             ga = BatchedGemmNT._run(gc, b.transpose(1, 2).contiguous())                 # (G,M,N) x (G,K,N)^T
         if ctx.needs_input_grad[1]:

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from .. import mmcv_ops as M
 from ..core import bbox2result, bbox2roi
-from ..core.misc import const_tensor
+from ..core.misc import arange_cached, const_tensor
 from ..registry import HEADS, build_assigner, build_head, build_roi_extractor, build_sampler
 
 
@@ -253,7 +253,7 @@ class HTDRoIHead(nn.Module):
         losses = dict()
         B, P = proposals.shape[:2]
         dev = proposals.device
-        pvalid = torch.arange(P, device=dev)[None, :] < n_keep[:, None]
+        pvalid = arange_cached(P, dev)[None, :] < n_keep[:, None]
         S0 = static_assign_and_sample(self.bbox_assigner[0], self.bbox_sampler[0], proposals[..., :4], pvalid,
                                       gt_bboxes, gt_labels)
         global_feat = None

@@ -11,7 +11,7 @@ result is scattered back -- a fixed, small number of launches with a single host
 import torch
 
 from .. import capi, dense
-from ..core.misc import const_tensor
+from ..core.misc import arange_cached, const_tensor
 
 _P, _S = capi.ptr, capi.current_stream_ptr
 FUSED_MAX_NPAD = 1024          # one wavefront holds a row of the (n, n) matrices in registers
@@ -92,7 +92,7 @@ def group_layout(rois, target_lvls, num_levels, num_imgs=None, roi_valid=None):
     if roi_valid is not None:                      # unused sample slots: a group of their own past the real ones
         key = torch.where(roi_valid, key, torch.full_like(key, B * num_levels))
     perm = torch.sort(key, stable=True)[1]
-    counts = (key[:, None] == torch.arange(B * num_levels, device=key.device)[None, :]).sum(0)
+    counts = (key[:, None] == arange_cached(B * num_levels, key.device)[None, :]).sum(0)
     return perm, counts, B
 
 
@@ -122,7 +122,7 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, ro
     # padded batch index: row r of group g  <-  sorted position start_g + r
     npad = (nmax + 127) // 128 * 128
     starts = torch.cumsum(counts, 0) - counts
-    ar = torch.arange(npad, device=x.device)
+    ar = arange_cached(npad, x.device)
     valid = ar[None, :] < counts[:, None]                                   # (G, npad)
     src = (starts[:, None] + ar[None, :]).clamp(max=N - 1)
     rows = perm[src]                                                        # (G, npad) original RoI rows

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from ..core import (anchor_inside_flags, images_to_levels, multi_apply, unmap)
 from ..core.bbox import delta2bbox, delta2bbox_clip_device
-from ..core.misc import const_tensor
+from ..core.misc import arange_cached, const_tensor
 from .. import mmcv_ops as M
 from ..mmcv_ops import nms_sorted_mask
 from ..registry import (HEADS, build_anchor_generator, build_assigner, build_bbox_coder, build_loss, build_sampler)
@@ -422,7 +422,7 @@ class RPNHead(nn.Module):
         boxes = torch.gather(proposals, 1, order[..., None].expand(-1, -1, 4))
         dets = torch.cat([boxes, top[:, :cfg.nms_post, None]], -1)
         if padded:
-            live = torch.arange(dets.size(1), device=dev)[None, :] < n_keep[:, None]
+            live = arange_cached(dets.size(1), dev)[None, :] < n_keep[:, None]
             if dets.size(1) < cfg.nms_post:
                 dets = torch.nn.functional.pad(dets, (0, 0, 0, cfg.nms_post - dets.size(1)))
                 live = torch.nn.functional.pad(live, (0, cfg.nms_post - live.size(1)))
