@@ -402,14 +402,16 @@ __global__ __launch_bounds__(256) void bn_fold_many_fwd_kernel(const FoldDesc *_
         const int co = co0 + r, ci = ci0 + tx;
         float v = 0.f;
         if (co < d.Co && ci < d.Ci) {
-            const float s = d.gamma[co] * rsqrtf(d.var[co] + eps);
             const int64_t i = ((int64_t)co * d.taps + t) * d.Ci + ci;
-            v = d.w[i] * s;
-            d.wf[i] = v;
+            if (d.gamma) {
+                v = d.w[i] * (d.gamma[co] * rsqrtf(d.var[co] + eps));
+                d.wf[i] = v;
+            } else
+                v = d.w[i];                  // no BN (gamma == NULL): the layer only wants its flipped image
         }
         tile[r][tx] = v;
     }
-    if (t == 0 && ci_t == 0 && ty == 0 && co0 + tx < d.Co) {
+    if (d.gamma && t == 0 && ci_t == 0 && ty == 0 && co0 + tx < d.Co) {
         const int co = co0 + tx;
         const float s = d.gamma[co] * rsqrtf(d.var[co] + eps);
         d.bf[co] = d.beta[co] - d.mean[co] * s;

@@ -146,6 +146,46 @@ def take_flipped(weight):
     return _FLIPPED.pop(weight.data_ptr(), None)
 
 
+# Flipped / transposed weight images made during this step, by (address, version, shape): a weight that several data gradients
+# read (the RPN's shared convolutions, five levels) is flipped once, and flip_many() makes the images of all plain
+# convolutions of the step in one launch.  new_step() drops them (the optimizer rewrites the weights in place).  Every entry
+# holds its weight tensor too: while the entry lives the allocator cannot hand that address to another weight.
+_STEP_FLIPS = {}
+
+
+def new_step():
+    _STEP_FLIPS.clear()
+
+
+def flip_many(weights):
+    """One launch (htd_bn_fold_many_fwd without BN entries) writing the dgrad images of `weights` (Co,Ci,kh,kw)
+    channels_last or (Co,Ci) -- picked up by _dgrad_raw through _STEP_FLIPS."""
+    import numpy as np
+    ws = []
+    for w in weights:
+        w4 = w if w.dim() == 4 else w.view(w.size(0), w.size(1), 1, 1)
+        if w4.is_cuda and w4.dtype == torch.float32 and w4.size(0) % 8 == 0 and w4.is_contiguous(memory_format=CL) and \
+                (w4.data_ptr(), w4._version, tuple(w4.shape)) not in _STEP_FLIPS:
+            ws.append(w4)
+    if not ws:
+        return
+    dev = ws[0].device
+    flat = torch.empty(sum(w.numel() for w in ws), device=dev, dtype=torch.float32)
+    desc = np.zeros((len(ws), 10), dtype=np.int64)
+    off = tile0 = 0
+    for i, w in enumerate(ws):
+        Co, Ci, taps = w.size(0), w.size(1), w.size(2) * w.size(3)
+        wT = flat[off:off + w.numel()]
+        off += w.numel()
+        desc[i, 0], desc[i, 7] = w.data_ptr(), wT.data_ptr()
+        desc[i, 8] = Co | (Ci << 32)
+        desc[i, 9] = taps | (tile0 << 32)
+        tile0 += taps * ((Co + 31) // 32) * ((Ci + 31) // 32)
+        _STEP_FLIPS[(w.data_ptr(), w._version, tuple(w.shape))] = (w, wT)
+    table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+    capi.call('htd_bn_fold_many_fwd', _P(table), len(ws), tile0, 0.0, _S())
+
+
 def join_side_stream():
     """Main stream waits for everything queued on the weight-gradient stream (call after backward)."""
     if _SIDE:
@@ -213,11 +253,16 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
         if gd.numel():
             capi.call('htd_pad_channels', _P(g), _P(gd), B * Ho * Wo, Co, Cod, _S())
     if wT is None or Cod != Co:
-        wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
-        if Cod != Co:
-            capi.call('htd_conv2d_flip_weights_padded', _P(weight), _P(wT), Co, Cod, kh, kw, Ci, _S())
-        else:
-            capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, kh, kw, Ci, _S())
+        key = (weight.data_ptr(), weight._version, tuple(weight.shape))      # one storage can be read as several shapes
+        hit = _STEP_FLIPS.get(key) if Cod == Co else None
+        wT = hit[1] if hit is not None else None
+        if wT is None:
+            wT = torch.empty(Ci * kh * kw * Cod, device=g.device, dtype=g.dtype)
+            if Cod != Co:
+                capi.call('htd_conv2d_flip_weights_padded', _P(weight), _P(wT), Co, Cod, kh, kw, Ci, _S())
+            else:
+                capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, kh, kw, Ci, _S())
+                _STEP_FLIPS[key] = (weight, wT)
     gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
     capi.call('htd_conv2d_bwd_data', _P(gd), _P(wT), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci, Cod, kh, kw, stride,
               padding, dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(),

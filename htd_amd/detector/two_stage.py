@@ -164,6 +164,12 @@ class TwoStageDetector(BaseDetector):
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
                       proposals=None, **kwargs):
+        if img.is_cuda:
+            from .. import dense
+            dense.new_step()
+            if torch.is_grad_enabled():
+                # the dgrad images of every plain convolution / Linear of neck and heads in one launch (dense.flip_many)
+                dense.flip_many(self._plain_weights())
         x = self.extract_feat(img)
         losses = dict()
         x32 = x if x[0].dtype == torch.float32 else tuple(f.float() for f in x)     # RoI head: fp32 (force_fp32 sites)
@@ -187,6 +193,21 @@ class TwoStageDetector(BaseDetector):
         losses.update(self.roi_head.forward_train(x32, img_metas, proposal_list, gt_bboxes, gt_labels,
                                                   gt_bboxes_ignore, gt_masks, **kwargs))
         return losses
+
+    def _plain_weights(self):
+        """Trainable fp32 weights of the convolutions / Linear layers outside the backbone (whose stages fold and flip their
+        own): the operands of this step's data gradients."""
+        ws = getattr(self, '_plain_weight_list', None)
+        if ws is None:
+            ws = []
+            for part in (getattr(self, 'neck', None), getattr(self, 'rpn_head', None), getattr(self, 'roi_head', None)):
+                if part is None:
+                    continue
+                for m in part.modules():
+                    if isinstance(m, (nn.Conv2d, nn.Linear)) and getattr(m, 'groups', 1) == 1 and m.weight.requires_grad:
+                        ws.append(m.weight)
+            self._plain_weight_list = ws
+        return ws
 
     def simple_test(self, img, img_metas, proposals=None, rescale=False):
         assert self.with_bbox, 'Bbox head must be implemented.'

@@ -352,6 +352,8 @@ class Trainer:
         if self.flat.flat.is_cuda:
             M.sgd_momentum_step_(self.flat.flat, self.flat.grad, self.flat.momentum, self.lr_dev, self.momentum,
                                  self.weight_decay, grad_scale=1.0 / self.exchange.world)
+            from . import dense
+            dense.new_step()        # the kernel rewrote the weights in place: this step's flipped images are stale
         else:   # gloo / CPU rehearsal of the distributed logic only (tests): same arithmetic in torch
             g = self.flat.grad / self.exchange.world + self.weight_decay * self.flat.flat
             self.flat.momentum.mul_(self.momentum).add_(g)

@@ -281,7 +281,8 @@ int htd_bn_fold_bwd(const float *w, const float *gamma, const float *mean, const
 /* The same two operations for MANY conv + BN pairs in one launch each (a whole ResNet stage: up to 70 pairs), driven by
  * a device table.  Forward table entry (80 bytes): { const float *w, *gamma, *beta, *mean, *var; float *wf, *bf, *wT;
  * int Co, Ci, taps, tile0; } -- wT (may be NULL) also receives the flipped / transposed image of the FOLDED weights that
- * htd_conv2d_bwd_data takes (htd_conv2d_flip_weights); tile0 = prefix sum of taps * ceil(Co/32) * ceil(Ci/32).
+ * htd_conv2d_bwd_data takes (htd_conv2d_flip_weights); tile0 = prefix sum of taps * ceil(Co/32) * ceil(Ci/32).  An entry with
+ * gamma == NULL has no BN: only wT is written, from w itself (every flip of a step's plain convolutions in one launch).
  * Backward table entry (88 bytes): { const float *w, *gamma, *mean, *var, *gwf, *gbf; float *gw, *ggamma, *gbeta;
  * int Co, K, row0, pad; } -- row0 = prefix sum of Co, K = taps * Ci (K % 4 == 0). */
 int htd_bn_fold_many_fwd(const void *desc, int n_layers, int total_tiles, float eps, void *stream);
