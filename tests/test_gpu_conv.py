@@ -392,3 +392,33 @@ def run_only_a(x0, wa, ra):
     x = x0.clone().requires_grad_()
     (dense.conv2d(x * 1.0, wa, None, 1, 1, 1) * ra).sum().backward()
     return x.grad
+
+
+@pytest.mark.gpu
+def test_step_flip_cache_never_serves_a_stale_or_misshapen_image():
+    """dense.flip_many / the per-step flip cache of _dgrad_raw: one storage read as two weight shapes gets two images, an
+    in-place weight update (version bump) or new_step() invalidates, and the cached result equals a fresh flip."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    CL = torch.channels_last
+    g = torch.Generator().manual_seed(9)
+    lin = (torch.randn(64, 32 * 9, generator=g) * 0.1).to(dev)                   # a Linear weight ...
+    as_conv = lin.view(64, 3, 3, 32).permute(0, 3, 1, 2)                          # ... and the same storage as a 3x3 conv (KRSC)
+    assert as_conv.data_ptr() == lin.data_ptr() and as_conv.is_contiguous(memory_format=CL)
+    gy_lin = torch.randn(5, 64, 1, 1, generator=g).to(dev).contiguous(memory_format=CL)
+    gy_conv = torch.randn(2, 64, 6, 6, generator=g).to(dev).contiguous(memory_format=CL)
+
+    def fresh(gy, w, xs, pad):
+        dense.new_step()
+        return dense._dgrad_raw(gy, w, xs, 1, pad, 1)
+    ref_lin = fresh(gy_lin, lin.view(64, 288, 1, 1), (5, 288, 1, 1), 0)
+    ref_conv = fresh(gy_conv, as_conv, (2, 32, 6, 6), 1)
+    dense.new_step()
+    dense.flip_many([lin])                                                        # registers the (64, 288, 1, 1) reading only
+    assert torch.equal(dense._dgrad_raw(gy_lin, lin.view(64, 288, 1, 1), (5, 288, 1, 1), 1, 0, 1), ref_lin)
+    assert torch.equal(dense._dgrad_raw(gy_conv, as_conv, (2, 32, 6, 6), 1, 1, 1), ref_conv)       # other shape: its own flip
+    assert torch.equal(dense._dgrad_raw(gy_conv, as_conv, (2, 32, 6, 6), 1, 1, 1), ref_conv)       # now from the cache
+    lin.mul_(2.0)                                                                 # in-place update: version changes
+    assert torch.allclose(dense._dgrad_raw(gy_conv, as_conv, (2, 32, 6, 6), 1, 1, 1), 2.0 * ref_conv, rtol=1e-6, atol=1e-6)
+    dense.new_step()
+    assert len(dense._STEP_FLIPS) == 0
