@@ -161,6 +161,69 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float *__restrict_
     }
 }
 
+// Forward for a FEW RoIs (BA pools two dozen large ones from every level: a 300-pixel box on the stride-4 level is a
+// 12 x 12-pixel footprint per bin, the whole image 48 x 29): one WORKGROUP per (RoI, bin, 256-channel chunk), its eight
+// wavefronts take every eighth footprint row and the partial sums meet in LDS in a fixed order.  With one wavefront per bin
+// such a launch is 1 176 long serial walks on a 256-CU chip.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void roi_align_fwd_split_kernel(const float *__restrict__ feat, const float *__restrict__ rois,
+                                                                  const int64_t *__restrict__ roi_level, int level,
+                                                                  float *__restrict__ out, int B, int C, int H, int W, int ph,
+                                                                  int pw, float scale, int sampling_ratio, int aligned,
+                                                                  int chunks)
+{
+    __shared__ float4 part[WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t task = blockIdx.x;
+    const int chunk = (int)(task % chunks);
+    const int64_t t2 = task / chunks;
+    const int bin = (int)(t2 % (ph * pw));
+    const int64_t ri = t2 / (ph * pw);
+    if (roi_level && roi_level[ri] != (int64_t)level) return;  // block-uniform
+    const int bi = bin / pw, bj = bin % pw;
+    const RoiGeom g = roi_geometry(rois + 5 * ri, scale, ph, pw, sampling_ratio, aligned);
+    int r0, r1, c0, c1;
+    axis_span(g.start_h, g.bin_h, bi, g.grid_h, H, r0, r1);
+    axis_span(g.start_w, g.bin_w, bj, g.grid_w, W, c0, c1);
+    if (g.batch < 0 || g.batch >= B) { r0 = 0; r1 = -1; }
+    const size_t img_base = (size_t)g.batch * H * W * C;
+    const int ch = chunk * 256 + lane * 4;
+    const bool act = ch < C;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rb = r0; rb <= r1; rb += 64) {
+        const float wy_l = (rb + lane <= r1) ? axis_weight(g.start_h, g.bin_h, bi, g.grid_h, rb + lane, H) : 0.f;
+        const int rn = min(64, r1 - rb + 1);
+        for (int cb = c0; cb <= c1; cb += 64) {
+            const float wx_l = (cb + lane <= c1) ? axis_weight(g.start_w, g.bin_w, bj, g.grid_w, cb + lane, W) : 0.f;
+            const int cn = min(64, c1 - cb + 1);
+            for (int r = wave; r < rn; r += WAVES) {
+                const float wy = lane_bcast(wy_l, r);
+                const float *row = feat + img_base + ((size_t)(rb + r) * W + cb) * C + ch;
+#pragma unroll 4
+                for (int c = 0; c < cn; ++c) {
+                    const float w = wy * lane_bcast(wx_l, c);
+                    if (act) {
+                        const float4 v = *reinterpret_cast<const float4 *>(row + (size_t)c * C);
+                        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                    }
+                }
+            }
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && act) {
+        float4 t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            const float4 v = part[w][lane];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        t.x *= g.inv_count; t.y *= g.inv_count; t.z *= g.inv_count; t.w *= g.inv_count;
+        *reinterpret_cast<float4 *>(out + ((size_t)ri * ph * pw + bin) * C + ch) = t;
+    }
+}
+
 // Forward over ALL pyramid levels of SingleRoIExtractor in one launch: a wavefront reads its RoI's level and takes that
 // level's map, size and scale from the table (four launches that each skip the other levels' RoIs start ~4x the waves).
 struct LevelTable {
@@ -493,6 +556,11 @@ int launch(bool backward, const float *in, const float *rois, const int64_t *roi
         return htd::check_launch("roi_align");
     }
     const int64_t tasks = n * ph * pw * chunks;
+    if (!backward && tasks < 8192) {        // too few bins to fill the chip with one wavefront each: a workgroup per bin
+        hipLaunchKernelGGL(roi_align_fwd_split_kernel<8>, dim3((unsigned)tasks), dim3(512), 0, s, in, rois, roi_level, level, out, B,
+                           C, H, W, ph, pw, scale, sr, aligned, chunks);
+        return htd::check_launch("roi_align");
+    }
     const int64_t blocks = htd::ceil_div(tasks, waves_per_block);
     HTD_REQUIRE(blocks < (1ll << 31), "roi_align: too many tasks");
     if (backward)
