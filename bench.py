@@ -285,7 +285,8 @@ def main():
     # --profile-kernels (costs ~6 % of the step)
     everything = args.profile_kernels or args.profile_detail
     capi.profile_begin(detail=args.profile_detail, only=None if everything else (
-        'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_bwd_weight', 'htd_bgemm_nt', 'htd_conv2d_fwd_bf16',
+        'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_fwd_x3p', 'htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_weight',
+        'htd_bgemm_nt', 'htd_conv2d_fwd_bf16',
         'htd_conv2d_dgrad_bf16', 'htd_conv2d_bwd_weight_bf16'))
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -58,6 +58,10 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
+        want = int(re.search(r'#define\s+HTD_ABI_VERSION\s+(\d+)', open(HEADER).read()).group(1))
+        got = L.htd_abi_version()
+        if got != want:                     # a stale .so next to a newer header (checked once after dlopen)
+            raise ImportError(f'{LIB_PATH}: ABI version {got}, include/htd_amd.h declares {want}: rebuild the library')
         _lib = L
         from . import tuning
         tuning.load(L)                      # tile table measured on MI355X (htd_amd/tuning/conv_tiles_gfx950.json)

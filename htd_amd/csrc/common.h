@@ -10,6 +10,7 @@
 namespace htd {
 
 void set_error(const char *fmt, ...);
+int conv_math();      // 1: fp32 products through three-way bf16 splits (htd_conv2d_set_math), 0: fp32-input MFMA
 
 inline int check_launch(const char *what)
 {

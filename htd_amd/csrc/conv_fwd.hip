@@ -756,6 +756,10 @@ int launch_conv(ConvParams p, hipStream_t s, void *workspace)
 
 }  // namespace
 
+namespace htd {
+int conv_math() { return g_conv_math; }      // conv_x3.hip: its kernels exist for the split-bf16 arithmetic only
+}
+
 // res_h / res_w > 0: residual is a [B][res_h][res_w][Co] map added through nearest-neighbour up-sampling to the
 // output size (0, 0: residual has the output's shape).
 extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, int res_h,

@@ -1,0 +1,606 @@
+// fp32 convolution on the bf16 matrix pipe with PRE-SPLIT weights and a halo-staged activation operand (round 3).
+//
+// Same arithmetic as the X3 form of conv_igemm_kernel (conv_fwd.hip): every fp32 operand is the sum of three bf16 numbers,
+// a product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the result is fp32-accurate.  What changes is where the
+// split happens.  conv_igemm_kernel cuts every staged float4 into its three pieces while a K slice is written to LDS -- once
+// per tile AND per filter tap: an input element of a 3x3 layer is split 9 taps x (Co / BN) times, a weight once per M tile
+// (2 100 times on a P2-sized map), and that vector work is serialised with the MFMAs (matrix pipe 36 % busy).
+// Here
+//   * the weights are split ONCE PER STEP by htd_conv2d_x3_planes into an image [tap][Ci/16][3 planes x 2 halves][Co][8 bf16]
+//     whose 16-byte chunks go global -> LDS with global_load_lds_dwordx4: no vector instruction, no register, no ds_write
+//     on the B side of the loop;
+//   * the activations of a stride-1 "same" convolution are staged as a HALO RUN: the BM consecutive output pixels of a tile
+//     read, for filter row ky, the BM + kw - 1 consecutive input pixels  m0 - pad + (ky - pad) * W ...  (NHWC: a pixel shift
+//     is a row shift of the operand), so one staged-and-split run serves the kw taps of the row -- the split work and the
+//     L2 -> LDS traffic of a 3x3 layer drop 3x; image borders are handled per lane: a lane whose tap falls outside the map
+//     reads a row of zeros instead (one v_cndmask on the LDS address);
+//   * 1x1 layers (any stride) and Linear layers run on the same kernel with kw = 1.
+// K loop: step = (16-channel slice, filter row); per step one A run (double-buffered in LDS, loaded into registers one step
+// ahead, split when written), per tap one B tile (double-buffered, LDS-DMA one tap ahead), ONE barrier per tap.
+// LDS images are chunk-major, [chunk][row][16 B]: the 16 lanes of a ds_read_b128 group read 256 consecutive bytes
+// (conflict-free without padding, which LDS-DMA could not honour), and the split's ds_write_b64 are conflict-free with a
+// row pitch = 4 (mod 8).
+#include <algorithm>
+
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int XK = 16;            // channels per K slice
+constexpr int NCH = 6;            // 16-byte chunks of a row slice: 3 planes x 2 halves of 8 channels
+
+// two floats -> three packed bf16 pairs (element 0 in the low half), see conv_fwd.hip
+__device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned &m, unsigned &l)
+{
+    union { bf16x2 v; unsigned u; } c;
+    c.v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    h = c.u;
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    c.v = __builtin_convertvector(f32x2{ra, rb}, bf16x2);
+    m = c.u;
+    c.v = __builtin_convertvector(f32x2{ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u)}, bf16x2);
+    l = c.u;
+}
+
+struct X3Params {
+    const float *x;            // [B][Hx][Wx][Ci] fp32
+    const uint4 *wp;           // weight planes [kh*kw][Ci/16][6][Cop] x 16 B
+    const float *bias, *residual, *mask_src;
+    float *y;
+    int Hx, Wx;                // input map
+    int Ho, Wo;                // output map (== input map when kw > 1)
+    int Ci, Co, Cop;
+    int kh;                    // filter rows; the filter width is the template parameter KW
+    int stride;                // kw == 1 only
+    int relu;
+    int res_H, res_W;          // > 0: residual is a coarser map read through nearest up-sampling (FPN top-down)
+    float res_sh, res_sw;
+    int64_t M;                 // B*Ho*Wo
+    int mt, nt;
+    int ncs;                   // Ci / 16
+    int splits, steps_per_split;
+    float *partial;            // [splits][M][Co] when splits > 1
+};
+
+template <int BM, int KW>
+struct Geo {
+    static constexpr int RUN = BM + KW - 1;                       // staged rows of a step
+    static constexpr int PITCH = ((RUN + 1 + 3) / 8) * 8 + 4;     // rows per chunk array: >= RUN + 1 (zero row), = 4 mod 8
+    static constexpr int PASSES = (RUN + 63) / 64;                // 64 rows x 4 float4 per pass of the 256 threads
+};
+
+template <int WGM, int WGN, int TM, int TN, int KW>
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_x3p_kernel(X3Params p)
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    using G = Geo<BM, KW>;
+    constexpr int PADX = (KW - 1) / 2;
+    constexpr int A_VEC = NCH * G::PITCH;                         // uint4 per A buffer
+    constexpr int B_VEC = NCH * BN;                               // uint4 per B buffer
+    constexpr int MAIN_VEC = 2 * A_VEC + 2 * B_VEC;
+    constexpr int EPI_STRIDE = BN + 4, EPI_ROWS = WGM * 32;
+    constexpr int EPI_VEC = EPI_ROWS * EPI_STRIDE / 4;
+    constexpr int LDS_VEC = MAIN_VEC > EPI_VEC ? MAIN_VEC : EPI_VEC;
+    __shared__ uint4 lds[LDS_VEC];
+    uint4 *const lA = lds, *const lB = lds + 2 * A_VEC;
+
+    // XCD-aware tile order (conv_fwd.hip): the blocks of one XCD walk a contiguous run of tiles, N tiles of an M tile adjacent
+    const int nblk = p.mt * p.nt;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.nt, tile_n = bid % p.nt;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int PADY = (p.kh - 1) / 2;
+
+    // ---- A staging coordinates: thread (vrow, vcol) handles row vrow + 64 i of the run, channels 4 vcol .. + 3 of the slice
+    const int vcol = tid & 3, vrow = tid >> 2;
+    unsigned a_off[G::PASSES];            // element offset (mod 2^32) of the row at filter row PADY (halo) / of the pixel (1x1)
+    int a_g[G::PASSES];                   // halo mode: linear input pixel of the row at filter row PADY
+    bool a_in[G::PASSES];                 // 1x1 mode: the row is an output pixel of the problem
+#pragma unroll
+    for (int i = 0; i < G::PASSES; ++i) {
+        const int j = vrow + 64 * i;
+        if constexpr (KW > 1) {
+            a_g[i] = (int)m0 + j - PADX;
+            a_off[i] = (unsigned)a_g[i] * (unsigned)p.Ci + vcol * 4;
+            a_in[i] = j < G::RUN;
+        } else {
+            const int64_t m = m0 + j;
+            a_in[i] = j < G::RUN && m < p.M;
+            const unsigned mm = a_in[i] ? (unsigned)m : 0u;
+            const unsigned wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+            const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+            a_g[i] = 0;
+            a_off[i] = ((b * (unsigned)p.Hx + ho * (unsigned)p.stride) * (unsigned)p.Wx + wo * (unsigned)p.stride) *
+                           (unsigned)p.Ci + vcol * 4;
+        }
+    }
+
+    // ---- per-lane tap validity of the MFMA rows (halo mode): bit ky * KW + kx of vmask[i] for block i
+    unsigned vmask[TM];
+    int a_frag[TM];                       // byte offset of the lane's fragment row inside a chunk array, tap kx = 0
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * TM * 32 + i * 32 + frow;
+        a_frag[i] = (fhalf * G::PITCH + r) * 16;
+        vmask[i] = 0xffffffffu;
+        if constexpr (KW > 1) {
+            const int64_t m = m0 + r;
+            const unsigned mm = m < p.M ? (unsigned)m : 0u;
+            const int xx = (int)(mm % (unsigned)p.Wx), yy = (int)((mm / (unsigned)p.Wx) % (unsigned)p.Hx);
+            unsigned v = 0u;
+            for (int ky = 0; ky < p.kh; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    const bool ok = m < p.M && (unsigned)(yy + ky - PADY) < (unsigned)p.Hx &&
+                                    (unsigned)(xx + kx - PADX) < (unsigned)p.Wx;
+                    v |= ok ? (1u << (ky * KW + kx)) : 0u;
+                }
+            vmask[i] = v;
+        }
+    }
+    const int zero_frag = (fhalf * G::PITCH + G::RUN) * 16;       // the zero row of the lane's chunk
+    int b_frag[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_frag[j] = (fhalf * BN + wn * TN * 32 + j * 32 + frow) * 16;
+
+    const int total_steps = p.ncs * p.kh;
+    const int s_begin = blockIdx.y * p.steps_per_split;
+    const int s_end = min(total_steps, s_begin + p.steps_per_split);
+
+    // zero rows of both A buffers (never overwritten: the staging writes rows < RUN only)
+    if (tid < 2 * NCH) lA[(tid / NCH) * A_VEC + (tid % NCH) * G::PITCH + G::RUN] = make_uint4(0u, 0u, 0u, 0u);
+
+    float4 ra[G::PASSES];
+    unsigned ra_ok = 0u;
+    auto load_run = [&](int s) {           // global -> registers, branch-free (out-of-range rows read element 0)
+        const int cs = s / p.kh, ky = s - cs * p.kh;
+        const int shift = (ky - PADY) * p.Wx;
+        const int koff = shift * p.Ci + cs * XK;
+#pragma unroll
+        for (int i = 0; i < G::PASSES; ++i) {
+            bool ok = a_in[i];
+            if constexpr (KW > 1) {
+                const int g = a_g[i] + shift;
+                ok = ok && g >= 0 && (int64_t)g < p.M;
+            }
+            const unsigned off = (a_off[i] + (unsigned)koff) & (0u - (unsigned)ok);
+            ra[i] = *reinterpret_cast<const float4 *>(p.x + off);
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+        }
+    };
+    auto store_run = [&](int buf) {        // registers -> three bf16 planes of the run, chunk-major
+        unsigned short *base = reinterpret_cast<unsigned short *>(lA + buf * A_VEC);
+#pragma unroll
+        for (int i = 0; i < G::PASSES; ++i) {
+            const int j = vrow + 64 * i;
+            if (G::RUN % 64 != 0 && i == G::PASSES - 1 && j >= G::RUN) continue;
+            const bool ok = (ra_ok >> i) & 1u;
+            const float4 v = make_float4(ok ? ra[i].x : 0.f, ok ? ra[i].y : 0.f, ok ? ra[i].z : 0.f, ok ? ra[i].w : 0.f);
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3x2(v.x, v.y, h0, m0_, l0);
+            split3x2(v.z, v.w, h1, m1, l1);
+            // chunk = plane * 2 + (vcol >> 1); 8 bytes at half (vcol & 1) of the row's 16
+            unsigned short *d = base + (((vcol >> 1) * G::PITCH + j) * 16 + (vcol & 1) * 8) / 2;
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + 2 * G::PITCH * 8) = make_uint2(m0_, m1);
+            *reinterpret_cast<uint2 *>(d + 4 * G::PITCH * 8) = make_uint2(l0, l1);
+        }
+    };
+    // B tile of (step s, tap kx) -> LDS buffer `buf`, LDS-DMA: instruction idx = chunk * (BN / 64) + half covers 64 rows
+    auto load_b = [&](int s, int kx, int buf) {
+        const int cs = s / p.kh, ky = s - cs * p.kh;
+        const int tap = ky * KW + kx;
+        const uint4 *src = p.wp + ((int64_t)(tap * p.ncs + cs) * NCH) * p.Cop + n0 + lane;
+        uint4 *dst = lB + buf * B_VEC;
+        constexpr int NI = NCH * BN / 64;
+#pragma unroll
+        for (int k = 0; k < (NI + 3) / 4; ++k) {
+            const int idx = wave + 4 * k;
+            if (NI % 4 != 0 && idx >= NI) continue;
+            const int c = idx / (BN / 64), hf = idx % (BN / 64);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (int64_t)c * p.Cop + hf * 64),
+                                             (__attribute__((address_space(3))) void *)(dst + c * BN + hf * 64), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_run(s_begin);
+        load_b(s_begin, 0, 0);
+        store_run(0);
+    }
+    __syncthreads();
+
+    int bbuf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int abuf = (s - s_begin) & 1;
+        const int ky = s % p.kh;
+        const bool more = s + 1 < s_end;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            // prefetch: the next tap's B tile by LDS-DMA, the next step's A run into registers
+            if (kx + 1 < KW) load_b(s, kx + 1, bbuf ^ 1);
+            else if (more) load_b(s + 1, 0, bbuf ^ 1);
+            if (kx == 0 && more) load_run(s + 1);
+
+            const char *la = reinterpret_cast<const char *>(lA + abuf * A_VEC);
+            const char *lb = reinterpret_cast<const char *>(lB + bbuf * B_VEC);
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int off = a_frag[i] + kx * 16;
+                if constexpr (KW > 1) off = ((vmask[i] >> (ky * KW + kx)) & 1u) ? off : zero_frag;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    fa[i][q] = *reinterpret_cast<const bf16x8 *>(la + off + q * 2 * G::PITCH * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + b_frag[j] + q * 2 * BN * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {      // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+            if (kx == KW - 1 && more) store_run(abuf ^ 1);
+            __syncthreads();               // LDS-DMA landed (vmcnt), every wave is done with this tap's buffers
+            bbuf ^= 1;
+        }
+    }
+
+    // ---- epilogue (conv_fwd.hip): accumulators through LDS, 16-byte stores along output rows, fused bias / residual /
+    // ReLU / producer's ReLU mask.  D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+    float *le = reinterpret_cast<float *>(lds);
+    const bool vec_ok = (p.Co & 3) == 0;
+    constexpr int V = BN / 4, RPP = 256 / V;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                le[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
+            }
+        __syncthreads();
+        const int c4 = tid % V;
+        const int n = n0 + c4 * 4;
+#pragma unroll
+        for (int pass = 0; pass < EPI_ROWS / RPP; ++pass) {
+            const int row = tid / V + pass * RPP;
+            const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+            if (m >= p.M || n >= p.Co) continue;
+            float4 v = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
+            const int64_t o = m * p.Co + n;
+            if (p.splits > 1) {
+                float *dst = p.partial + (int64_t)blockIdx.y * p.M * p.Co + o;
+                if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
+                else {
+                    dst[0] = v.x;
+                    if (n + 1 < p.Co) dst[1] = v.y;
+                    if (n + 2 < p.Co) dst[2] = v.z;
+                    if (n + 3 < p.Co) dst[3] = v.w;
+                }
+                continue;
+            }
+            if (vec_ok) {
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (p.residual) {
+                    int64_t ro = o;
+                    if (p.res_H > 0) {
+                        const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                        const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                        const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                        ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
+                    }
+                    const float4 rv = *reinterpret_cast<const float4 *>(p.residual + ro);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.mask_src) {
+                    const float4 mv = *reinterpret_cast<const float4 *>(p.mask_src + o);
+                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                    v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(p.y + o) = v;
+            } else {
+                auto put = [&](int e, float t) {
+                    if (n + e >= p.Co) return;
+                    t += p.bias ? p.bias[n + e] : 0.f;
+                    if (p.residual) t += p.residual[o + e];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (p.mask_src) t = p.mask_src[o + e] > 0.f ? t : 0.f;
+                    p.y[o + e] = t;
+                };
+                put(0, v.x); put(1, v.y); put(2, v.z); put(3, v.w);
+            }
+        }
+        if (i + 1 < TM) __syncthreads();
+    }
+}
+
+// sums the split-K partials in a fixed order and applies the epilogue
+__global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params p)
+{
+    const int64_t total = p.M * p.Co;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < p.splits; ++k) v += p.partial[(int64_t)k * total + o];
+        const int n = (int)(o % p.Co);
+        if (p.bias) v += p.bias[n];
+        if (p.residual) {
+            int64_t ro = o;
+            if (p.res_H > 0) {
+                const int64_t m = o / p.Co;
+                const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
+            }
+            v += p.residual[ro];
+        }
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
+        p.y[o] = v;
+    }
+}
+
+// ---- weight planes --------------------------------------------------------------------------------------------------
+// w [Co][taps][Ci] fp32 (KRSC) -> planes [taps][K/16][6][Np] x 16 B, chunk c = plane * 2 + half holds the bf16 piece `plane` of
+// the 8 reduction channels 16 cs + 8 half .. + 7 of output channel n (rows n >= N are zeros).
+//   transposed = 0 (forward operand):       N = Co, K = Ci, tap t      <- w[n][t][k]
+//   transposed = 1 (data-gradient operand): N = Ci, K = Co, tap t      <- w[k][taps - 1 - t][n]   (flipped, transposed filter)
+// One thread per (tap, slice, n): 16 loads, 6 x 16-byte stores that are contiguous across the threads of a wavefront.
+__global__ __launch_bounds__(256) void x3_planes_kernel(const float *__restrict__ w, uint4 *__restrict__ out, int Co, int taps,
+                                                        int Ci, int Np, int transposed)
+{
+    const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
+    const int ncs = K / XK;
+    const int64_t total = (int64_t)taps * ncs * Np;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int n = (int)(e % Np);
+        const int64_t t2 = e / Np;
+        const int cs = (int)(t2 % ncs), tap = (int)(t2 / ncs);
+        float v[XK];
+        if (n < N) {
+            if (!transposed) {
+                const float4 *src = reinterpret_cast<const float4 *>(w + ((int64_t)n * taps + tap) * Ci + cs * XK);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 f = src[q];
+                    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < XK; ++k) v[k] = w[((int64_t)(cs * XK + k) * taps + (taps - 1 - tap)) * Ci + n];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < XK; ++k) v[k] = 0.f;
+        }
+        unsigned pl[3][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split3x2(v[2 * k], v[2 * k + 1], pl[0][k], pl[1][k], pl[2][k]);
+        uint4 *dst = out + ((int64_t)(tap * ncs + cs) * NCH) * Np + n;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                dst[(int64_t)(q * 2 + h) * Np] = make_uint4(pl[q][4 * h], pl[q][4 * h + 1], pl[q][4 * h + 2], pl[q][4 * h + 3]);
+    }
+}
+
+inline int planes_np(int N) { return (int)htd::ceil_div(N, 128) * 128; }
+
+// Tile configurations (BM x BN): 0 64x64, 1 128x128, 2 128x64, 3 64x128 -- all 2x2 waves
+struct XCfg { int bm, bn; };
+constexpr XCfg kXCfg[] = {{64, 64}, {128, 128}, {128, 64}, {64, 128}};
+
+// HTD_X3P=0: every layer keeps conv_igemm_kernel.  HTD_X3P_TUNE=1 (tools/sweep_x3p.py, A/B runs inside one process) makes the
+// library re-read HTD_X3P and HTD_X3P_FORCE_TILE on every call; otherwise nothing is read after load.
+static const bool g_x3p_tune = getenv("HTD_X3P_TUNE") != nullptr;
+static const bool g_x3p_off = getenv("HTD_X3P") != nullptr && atoi(getenv("HTD_X3P")) == 0;
+bool x3p_off()
+{
+    if (!g_x3p_tune) return g_x3p_off;
+    const char *e = getenv("HTD_X3P");
+    return e && atoi(e) == 0;
+}
+int forced_cfg()
+{
+    if (!g_x3p_tune) return -1;
+    const char *e = getenv("HTD_X3P_FORCE_TILE");
+    const int v = e ? atoi(e) : -1;
+    return (v >= 0 && v < 4) ? v : -1;
+}
+
+int plan_splits_x3p(int64_t M, int Co, int total_steps)
+{
+    const int64_t tiles = htd::ceil_div(M, 128) * htd::ceil_div(Co, 64);
+    if (tiles <= 0 || tiles >= 384 || total_steps < 32) return 1;
+    int64_t want = htd::ceil_div(768, tiles);
+    want = std::min<int64_t>(want, total_steps / 16);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, 16));
+}
+
+// wave quantisation on 256 CUs x the useful fraction of the padded tiles x a per-tile base efficiency
+float cfg_score(int cfg, int64_t M, int Co, int splits)
+{
+    const int bm = kXCfg[cfg].bm, bn = kXCfg[cfg].bn;
+    const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
+    static const float base[4] = {0.80f, 1.00f, 0.90f, 0.92f};
+    const float w = (float)(tiles * splits) / 256.f;
+    const float per_cu = cfg == 0 ? 6.f : (cfg == 1 ? 3.f : 4.f);      // resident workgroups per CU
+    const float rounds = w / per_cu;
+    const float quant = rounds >= 4.f ? 1.f : rounds / ceilf(rounds) * 0.5f + 0.5f * (w / ceilf(w));
+    const float useful = (float)((double)M * Co / ((double)tiles * bm * bn));
+    return base[cfg] * quant * useful;
+}
+
+int choose_cfg(int64_t M, int Co, int splits)
+{
+    int cfg = forced_cfg();
+    if (cfg >= 0) return cfg;
+    float best = -1.f;
+    static const int cand[4] = {1, 3, 2, 0};
+    for (int c : cand) {
+        const float sc = cfg_score(c, M, Co, splits);
+        if (sc > best * 1.005f) { best = sc; cfg = c; }
+    }
+    return cfg;
+}
+
+template <int TM, int TN>
+void launch_tile(const X3Params &p, int kw, dim3 grid, hipStream_t s)
+{
+    if (kw == 1) hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 3>), grid, dim3(256), 0, s, p);
+}
+
+int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
+{
+    const int total_steps = p.ncs * p.kh;
+    p.splits = workspace ? plan_splits_x3p(p.M, p.Co, total_steps) : 1;
+    p.steps_per_split = (int)htd::ceil_div(total_steps, p.splits);
+    p.splits = (int)htd::ceil_div(total_steps, p.steps_per_split);
+    p.partial = (float *)workspace;
+    const int cfg = choose_cfg(p.M, p.Co, p.splits);
+    p.mt = (int)htd::ceil_div(p.M, kXCfg[cfg].bm);
+    p.nt = (int)htd::ceil_div(p.Co, kXCfg[cfg].bn);
+    const int64_t blocks = (int64_t)p.mt * p.nt;
+    HTD_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_x3p: bad grid");
+    const dim3 grid((unsigned)blocks, (unsigned)p.splits);
+    switch (cfg) {
+    case 0: launch_tile<1, 1>(p, kw, grid, s); break;
+    case 1: launch_tile<2, 2>(p, kw, grid, s); break;
+    case 2: launch_tile<2, 1>(p, kw, grid, s); break;
+    default: launch_tile<1, 2>(p, kw, grid, s); break;
+    }
+    if (p.splits > 1) {
+        const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(p.M * p.Co, 256), 4096);
+        hipLaunchKernelGGL(conv_x3p_splitk_epilogue_kernel, dim3(rb), dim3(256), 0, s, p);
+    }
+    return htd::check_launch("conv2d_x3p");
+}
+
+bool x3p_shape_ok(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
+{
+    if (Ci % XK != 0 || Co < 33 || dil != 1 || kh != kw) return false;
+    if (kh == 1) return pad == 0 && stride >= 1;
+    return kh == 3 && stride == 1 && pad == 1;
+}
+
+}  // namespace
+
+// 1 when htd_conv2d_fwd_x3p / htd_conv2d_bwd_data_x3p take this layer (else use htd_conv2d_fwd / htd_conv2d_bwd_data)
+extern "C" int htd_conv2d_x3p_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
+{
+    return (!x3p_off() && htd::conv_math() == 1 && x3p_shape_ok(Ci, Co, kh, kw, stride, pad, dil)) ? 1 : 0;
+}
+
+extern "C" int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, int transposed)
+{
+    const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
+    if (N <= 0 || K <= 0 || K % XK != 0 || kh <= 0 || kw <= 0) return 0;
+    return (int64_t)kh * kw * (K / XK) * NCH * planes_np(N) * 16;
+}
+
+extern "C" int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream)
+{
+    HTD_REQUIRE(w && planes && Co > 0 && Ci > 0 && kh > 0 && kw > 0, "x3_planes: bad arguments");
+    const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
+    HTD_REQUIRE(K % XK == 0, "x3_planes: reduction length %d must be a multiple of 16", K);
+    HTD_REQUIRE(transposed || Ci % 4 == 0, "x3_planes: Ci %% 4");
+    const int Np = planes_np(N);
+    const int64_t total = (int64_t)kh * kw * (K / XK) * Np;
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 16384);
+    hipLaunchKernelGGL(x3_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint4 *)planes, Co, kh * kw, Ci, Np,
+                       transposed);
+    return htd::check_launch("x3_planes");
+}
+
+extern "C" int64_t htd_conv2d_x3p_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw)
+{
+    (void)kw;
+    const int splits = plan_splits_x3p(M, Co, (Ci / XK) * kh);
+    return splits > 1 ? (int64_t)splits * M * Co * 4 : 0;
+}
+
+extern "C" int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const float *bias, const float *residual, int res_h,
+                                  int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                                  int relu, void *workspace, void *stream)
+{
+    HTD_REQUIRE(x && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3p: bad arguments");
+    HTD_REQUIRE(x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3p: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d", Ci,
+                Co, kh, kw, stride, pad);
+    HTD_REQUIRE((res_h > 0) == (res_w > 0) && res_h >= 0 && (res_h == 0 || ((Co & 3) == 0 && residual)),
+                "conv2d_fwd_x3p: bad residual up-sampling arguments");
+    X3Params p{};
+    p.x = x; p.wp = (const uint4 *)wplanes; p.bias = bias; p.residual = residual; p.y = y;
+    p.Hx = H; p.Wx = W;
+    p.Ho = (H + 2 * pad - kh) / stride + 1;
+    p.Wo = (W + 2 * pad - kw) / stride + 1;
+    p.Ci = Ci; p.Co = Co; p.Cop = planes_np(Co); p.kh = kh; p.stride = stride; p.relu = relu;
+    p.M = (int64_t)B * p.Ho * p.Wo;
+    p.ncs = Ci / XK;
+    HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.M * Co < (1ll << 40), "conv2d_fwd_x3p: operand too large");
+    if (res_h > 0) {
+        p.res_H = res_h; p.res_W = res_w;
+        p.res_sh = (float)res_h / (float)p.Ho; p.res_sw = (float)res_w / (float)p.Wo;
+    }
+    return launch_x3p(p, kw, (hipStream_t)stream, workspace);
+}
+
+// gx[B][H][W][Ci] from gy[B][Ho][Wo][Co] and the transposed planes of the layer's weights (htd_conv2d_x3_planes(...,
+// transposed = 1)); stride 1 only (kh = 1: pad 0; kh = 3: pad 1).  mask_src / accum as htd_conv2d_bwd_data.
+extern "C" int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, const float *mask_src, const float *accum,
+                                       float *gx, int B, int H, int W, int Ci, int Co, int kh, int kw, int pad, void *workspace,
+                                       void *stream)
+{
+    HTD_REQUIRE(gy && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3p: bad arguments");
+    HTD_REQUIRE(x3p_shape_ok(Co, Ci, kh, kw, 1, pad, 1), "conv2d_bwd_data_x3p: unsupported layer Ci=%d Co=%d k=%dx%d p=%d", Ci, Co,
+                kh, kw, pad);
+    X3Params p{};
+    p.x = gy; p.wp = (const uint4 *)wplanesT; p.residual = accum; p.mask_src = mask_src; p.y = gx;
+    p.Hx = H; p.Wx = W; p.Ho = H; p.Wo = W;          // stride 1, same size
+    p.Ci = Co; p.Co = Ci; p.Cop = planes_np(Ci); p.kh = kh; p.stride = 1;
+    p.M = (int64_t)B * H * W;
+    p.ncs = Co / XK;
+    HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3p: operand too large");
+    return launch_x3p(p, kw, (hipStream_t)stream, workspace);
+}

@@ -15,4 +15,4 @@ void set_error(const char *fmt, ...)
 }  // namespace htd
 
 extern "C" const char *htd_last_error(void) { return htd::g_err; }
-extern "C" int htd_abi_version(void) { return 3; }
+extern "C" int htd_abi_version(void) { return HTD_ABI_VERSION; }

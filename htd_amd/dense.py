@@ -146,15 +146,51 @@ def take_flipped(weight):
     return _FLIPPED.pop(weight.data_ptr(), None)
 
 
-# Flipped / transposed weight images made during this step, by (address, version, shape): a weight that several data gradients
+# Flipped / transposed weight images made during this step, by (address, version, shape, parameter epoch): a weight that several data gradients
 # read (the RPN's shared convolutions, five levels) is flipped once, and flip_many() makes the images of all plain
 # convolutions of the step in one launch.  new_step() drops them (the optimizer rewrites the weights in place).  Every entry
 # holds its weight tensor too: while the entry lives the allocator cannot hand that address to another weight.
 _STEP_FLIPS = {}
 
 
+def _flip_key(w):
+    # mmcv_ops.PARAM_EPOCH: the optimizer kernel and the rank-0 broadcast rewrite weights without touching tensor._version
+    from . import mmcv_ops as M
+    return (w.data_ptr(), w._version, tuple(w.shape), M.PARAM_EPOCH)
+
+
 def new_step():
     _STEP_FLIPS.clear()
+    _STEP_PLANES.clear()
+
+
+# bf16 plane images of the weights (csrc/conv_x3.hip: the B operand of conv_x3p_kernel, split once per step instead of
+# once per tile and tap).  Keyed like _STEP_FLIPS plus the parameter epoch of mmcv_ops (the optimizer kernel and the rank-0
+# broadcast rewrite weights without touching tensor._version); every entry keeps its weight alive; new_step() drops them.
+_STEP_PLANES = {}
+
+
+def _planes_key(w, transposed):
+    return _flip_key(w) + (bool(transposed), )
+
+
+def x3_planes(weight, transposed):
+    """weight (Co,Ci,kh,kw) channels_last fp32 -> its plane image (forward operand, or data-gradient operand when
+    `transposed`), made once per step."""
+    key = _planes_key(weight, transposed)
+    hit = _STEP_PLANES.get(key)
+    if hit is not None:
+        return hit[1]
+    Co, Ci, kh, kw = weight.shape
+    nbytes = capi.lib().htd_conv2d_x3_planes_bytes(Co, kh, kw, Ci, int(transposed))
+    planes = torch.empty(nbytes // 4, device=weight.device, dtype=torch.int32)
+    capi.call('htd_conv2d_x3_planes', _P(weight), _P(planes), Co, kh, kw, Ci, int(transposed), _S())
+    _STEP_PLANES[key] = (weight, planes)
+    return planes
+
+
+def _x3p_ok(Cred, Cout, kh, kw, stride, padding, dilation, dtype):
+    return dtype == torch.float32 and bool(capi.lib().htd_conv2d_x3p_supported(Cred, Cout, kh, kw, stride, padding, dilation))
 
 
 def flip_many(weights):
@@ -165,7 +201,7 @@ def flip_many(weights):
     for w in weights:
         w4 = w if w.dim() == 4 else w.view(w.size(0), w.size(1), 1, 1)
         if w4.is_cuda and w4.dtype == torch.float32 and w4.size(0) % 8 == 0 and w4.is_contiguous(memory_format=CL) and \
-                (w4.data_ptr(), w4._version, tuple(w4.shape)) not in _STEP_FLIPS:
+                _flip_key(w4) not in _STEP_FLIPS:
             ws.append(w4)
     if not ws:
         return
@@ -181,7 +217,7 @@ def flip_many(weights):
         desc[i, 8] = Co | (Ci << 32)
         desc[i, 9] = taps | (tile0 << 32)
         tile0 += taps * ((Co + 31) // 32) * ((Ci + 31) // 32)
-        _STEP_FLIPS[(w.data_ptr(), w._version, tuple(w.shape))] = (w, wT)
+        _STEP_FLIPS[_flip_key(w)] = (w, wT)
     table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
     capi.call('htd_bn_fold_many_fwd', _P(table), len(ws), tile0, 0.0, _S())
 
@@ -208,6 +244,13 @@ def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu, res_up=
         return y
     flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
     rh, rw = (residual.size(2), residual.size(3)) if (res_up and residual is not None) else (0, 0)
+    if _x3p_ok(Ci, Co, kh, kw, stride, padding, dilation, x.dtype):
+        nb = capi.lib().htd_conv2d_x3p_workspace_bytes(B * Ho * Wo, Co, Ci, kh, kw)
+        ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32) if nb > 0 else None
+        capi.call('htd_conv2d_fwd_x3p', _P(x), _P(x3_planes(weight, False)), _P(bias), _P(residual), rh, rw, _P(y), B, H, W, Ci,
+                  Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
+                  work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
+        return y
     capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), rh, rw, _P(y), B, H, W, Ci, Co, kh, kw, stride,
               padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
               work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
@@ -246,6 +289,15 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
     Ho, Wo = g.shape[2], g.shape[3]
     if B == 0:
         return torch.empty((0, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+    if stride == 1 and _x3p_ok(Co, Ci, kh, kw, 1, padding, dilation, g.dtype):
+        gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+        nb = capi.lib().htd_conv2d_x3p_workspace_bytes(B * H * W, Ci, Co, kh, kw)
+        ws = torch.empty(nb // 4, device=g.device, dtype=torch.float32) if nb > 0 else None
+        capi.call('htd_conv2d_bwd_data_x3p', _P(g), _P(x3_planes(weight, True)), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci,
+                  Co, kh, kw, padding, _P(ws), _S(),
+                  work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
+                        4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None)))))
+        return gx
     gd, Cod = g, Co
     if Co % 8 != 0:      # skinny heads (RPN cls+reg Co=15, fc_cls 81, fc_reg 4): zero-pad the reduction channels
         Cod = Co + (-Co) % 8
@@ -253,7 +305,7 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
         if gd.numel():
             capi.call('htd_pad_channels', _P(g), _P(gd), B * Ho * Wo, Co, Cod, _S())
     if wT is None or Cod != Co:
-        key = (weight.data_ptr(), weight._version, tuple(weight.shape))      # one storage can be read as several shapes
+        key = _flip_key(weight)                                               # one storage can be read as several shapes
         hit = _STEP_FLIPS.get(key) if Cod == Co else None
         wT = hit[1] if hit is not None else None
         if wT is None:
@@ -919,6 +971,10 @@ def roofline_report(prof, peak_tflops, peak_gbs, peak_bf16_tflops=2500.0):
     parts = [prof.pop(k) for k in ('htd_conv2d_fwd', 'htd_conv2d_bwd_data') if k in prof]
     if parts:
         prof['conv_igemm_kernel (htd_conv2d_fwd + htd_conv2d_bwd_data)'] = (
+            sum(p[0] for p in parts), sum(p[1] for p in parts), 'flop', sum(p[3] for p in parts), sum(p[4] for p in parts))
+    parts = [prof.pop(k) for k in ('htd_conv2d_fwd_x3p', 'htd_conv2d_bwd_data_x3p') if k in prof]
+    if parts:                                        # the pre-split-weights / halo kernel of csrc/conv_x3.hip
+        prof['conv_x3p_kernel (htd_conv2d_fwd_x3p + htd_conv2d_bwd_data_x3p)'] = (
             sum(p[0] for p in parts), sum(p[1] for p in parts), 'flop', sum(p[3] for p in parts), sum(p[4] for p in parts))
     parts = [prof.pop(k) for k in ('htd_conv2d_fwd_bf16', 'htd_conv2d_dgrad_bf16') if k in prof]
     if parts:                                        # same for the bf16 kernel

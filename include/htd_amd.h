@@ -30,7 +30,9 @@ extern "C" {
 #define HTD_ERR_LAUNCH 2
 
 const char *htd_last_error(void);
-/* ABI version, bumped on any signature change. */
+/* ABI version, bumped on any signature change (added entry points do not bump it).  A binding compares
+ * htd_abi_version() of the loaded library with the HTD_ABI_VERSION of the header it was written against. */
+#define HTD_ABI_VERSION 3
 int htd_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -218,6 +220,29 @@ int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbi
                           void *stream);
 int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows,
                             int C, void *workspace, void *stream);
+/* The same convolutions with the weight operand split into its three bf16 planes ONCE PER OPTIMIZER STEP instead of once per
+ * tile and filter tap inside the kernel (csrc/conv_x3.hip; the role cuDNN's pre-transformed filters play behind
+ * backbones/resnet.py:260-300, necks/fpn.py:190-192, dense_heads/rpn_head.py:37-43, htd_bbox_head.py:77-113).
+ *   htd_conv2d_x3_planes: w [Co][kh][kw][Ci] -> planes [kh*kw][K/16][3 planes x 2 halves][N rounded up to 128][8 bf16];
+ *       transposed = 0: the forward operand (N = Co, K = Ci); transposed = 1: the data-gradient operand (N = Ci, K = Co,
+ *       taps reversed) straight from w -- no htd_conv2d_flip_weights image is needed.  `planes` holds
+ *       htd_conv2d_x3_planes_bytes(...) bytes (caller-owned, 1.5 x the fp32 weights).
+ *   htd_conv2d_x3p_supported: 1 when the two entry points below take the layer: reduction channels % 16 == 0, more than 32
+ *       output channels, and either 1x1 (pad 0, any stride) or 3x3 with stride 1, pad 1; the split-bf16 arithmetic must be
+ *       selected (htd_conv2d_set_math(1), the default).  Other layers keep htd_conv2d_fwd / htd_conv2d_bwd_data.
+ *   htd_conv2d_fwd_x3p / htd_conv2d_bwd_data_x3p: the semantics (epilogue, residual up-sampling, mask_src, accum, split-K
+ *       workspace of htd_conv2d_x3p_workspace_bytes) of htd_conv2d_fwd / htd_conv2d_bwd_data; bwd_data is stride 1 only.
+ *       Same arithmetic as the default mode of those (six bf16 MFMAs on exact three-way splits, fp32 accumulation). */
+int htd_conv2d_x3p_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, int transposed);
+int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);
+int64_t htd_conv2d_x3p_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw);
+int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const float *bias, const float *residual, int res_h,
+                       int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                       int relu, void *workspace, void *stream);
+int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, const float *mask_src, const float *accum,
+                            float *gx, int B, int H, int W, int Ci, int Co, int kh, int kw, int pad, void *workspace,
+                            void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Deformable convolution v1 / v2 (mask == NULL => v1 = the 'DCN' the HTD config uses,

@@ -315,43 +315,146 @@ def test_balanced_tail_epilogue_mask_and_accum():
     torch.testing.assert_close(plain.double(), ref, rtol=1e-4, atol=1e-3)
 
 
+def _wide(shape, g, spread):
+    return torch.randn(shape, generator=g) * torch.exp(torch.randn(shape, generator=g) * spread)
+
+
 @pytest.mark.parametrize('Ci,Co,k,H,W', [(256, 256, 3, 40, 56), (1024, 256, 1, 50, 84), (64, 256, 1, 60, 80), (48, 96, 3, 33, 47)])
 def test_split_bf16_products_are_fp32_accurate(Ci, Co, k, H, W):
     """htd_conv2d_set_math(1): fp32 products through exact three-way bf16 splits (six bf16 MFMAs per 16 k, fp32
-    accumulation) against math 0 (the fp32-input MFMA) and an fp64 reference, on data with a wide dynamic range: the
-    split form must sit in the same error class as native fp32 -- its error against fp64 at most 1.5x the native
-    kernel's, both ~1e-7 relative to the accumulated magnitude -- for forward and data gradient."""
+    accumulation) against math 0 (the fp32-input MFMA) and an fp64 reference, on data with a wide dynamic range, for
+    forward, data gradient and weight gradient.  Error = |result - fp64| / accumulated magnitude (sum of |products|).
+      * absolute: the largest error of BOTH arithmetics stays under 1.5e-7 sqrt(K) -- fp32 rounding of a K-term sum;
+      * relative: the split form sits in the error class of the native fp32 MFMA: rms error <= 2x, largest error <= 3x
+        (+ 2e-8).  Measured over five seeds (tools/x3_accuracy.py, profiles/r03_x3_accuracy.log): rms 0.84-0.85x native
+        on 1x1 layers (fewer roundings: six per 16 k instead of sixteen), 1.20-1.45x on 3x3 layers, whose (channel slice,
+        filter row, tap) summation order differs from the native kernel's; largest error 0.6-1.9x depending on the seed
+        -- the maximum over 10^5 heavy-tailed outputs is a noisy statistic, which is why the class test is on the rms."""
     from htd_amd import capi, dense
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(Ci + k)
-    x = (torch.randn(2, Ci, H, W, generator=g) * torch.exp(torch.randn(2, Ci, H, W, generator=g) * 2)).to(dev)
-    w = (torch.randn(Co, Ci, k, k, generator=g) * torch.exp(torch.randn(Co, Ci, k, k, generator=g))).to(dev) / (Ci * k * k) ** 0.5
-    x = x.contiguous(memory_format=torch.channels_last)
-    w = w.contiguous(memory_format=torch.channels_last)
+    x = _wide((2, Ci, H, W), g, 2.0).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (_wide((Co, Ci, k, k), g, 1.0).to(dev) / (Ci * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
     p = k // 2
-    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, p)
-    scale = torch.nn.functional.conv2d(x.double().abs(), w.double().abs(), None, 1, p)       # accumulated magnitude
+    xd, wd = x.double(), w.double()
+    ref = F.conv2d(xd, wd, None, 1, p)
+    scale = F.conv2d(xd.abs(), wd.abs(), None, 1, p)       # accumulated magnitude
     gy = torch.randn(ref.shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
-    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 1, p)
-    gscale = torch.nn.grad.conv2d_input(x.shape, w.double().abs(), gy.double().abs(), 1, p)
+    gref = torch.nn.grad.conv2d_input(x.shape, wd, gy.double(), 1, p)
+    gscale = torch.nn.grad.conv2d_input(x.shape, wd.abs(), gy.double().abs(), 1, p)
+    wref = torch.nn.grad.conv2d_weight(xd, w.shape, gy.double(), 1, p)
+    wscale = torch.nn.grad.conv2d_weight(xd.abs(), w.shape, gy.double().abs(), 1, p)
     L = capi.lib()
     prev = L.htd_conv2d_set_math(-1)
     err = {}
     try:
         for mode in (0, 1):
             L.htd_conv2d_set_math(mode)
-            xr = x.clone().requires_grad_()
-            y = dense.conv2d(xr, w, None, 1, p, 1)
+            dense.new_step()
+            xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+            y = dense.conv2d(xr, wr, None, 1, p, 1)
             y.backward(gy)
-            err[mode] = (float(((y.detach().double() - ref).abs() / scale).max()),
-                         float(((xr.grad.double() - gref).abs() / gscale).max()))
+            e = [(y.detach().double() - ref).abs() / scale, (xr.grad.double() - gref).abs() / gscale,
+                 (wr.grad.double() - wref).abs() / wscale]
+            err[mode] = [(float(t.max()), float(t.pow(2).mean().sqrt())) for t in e]
     finally:
         L.htd_conv2d_set_math(prev)
-    K = Ci * k * k
-    for i, what in enumerate(('forward', 'data gradient')):
-        # both: fp32 rounding of a K-term accumulation, relative to the accumulated magnitude (measured 2e-7 .. 2e-6)
-        assert err[0][i] < 1.5e-7 * K ** 0.5 and err[1][i] < 1.5e-7 * K ** 0.5, (what, err, K)
-        assert err[1][i] <= 1.5 * err[0][i] + 2e-8, (what, err, K)
+        dense.new_step()
+    npix = ref.shape[0] * ref.shape[2] * ref.shape[3]
+    for i, (what, K) in enumerate((('forward', Ci * k * k), ('data gradient', Co * k * k), ('weight gradient', npix))):
+        (max0, rms0), (max1, rms1) = err[0][i], err[1][i]
+        assert max0 < 1.5e-7 * K ** 0.5 and max1 < 1.5e-7 * K ** 0.5, (what, err, K)
+        assert rms1 <= 2.0 * rms0, (what, err, K)
+        assert max1 <= 3.0 * max0 + 2e-8, (what, err, K)
+
+
+X3P_CASES = [
+    # B, Ci, H, W, Co, k, stride: layers conv_x3p_kernel takes (csrc/conv_x3.hip) -- borders, ragged tiles, narrow maps whose
+    # halo runs wrap over several rows and images, Co beyond the last tile, strided 1x1, split-K lengths
+    (2, 64, 20, 28, 128, 3, 1), (1, 256, 13, 17, 256, 3, 1), (5, 576, 7, 7, 576, 3, 1), (37, 32, 7, 7, 96, 3, 1),
+    (1, 16, 1, 1, 64, 3, 1), (1, 16, 3, 200, 40, 3, 1), (2, 48, 5, 3, 33, 3, 1), (1, 32, 130, 130, 256, 3, 1),
+    (2, 64, 20, 28, 64, 1, 1), (2, 256, 20, 28, 512, 1, 2), (3, 32, 9, 11, 576, 1, 3), (1, 12544, 37, 1, 1024, 1, 1),
+    (1, 1024, 200, 1, 81, 1, 1),
+]
+
+
+@pytest.mark.parametrize('B,Ci,H,W,Co,k,stride', X3P_CASES)
+def test_x3p_kernel_is_exact_on_integers_and_matches_the_igemm_kernel(B, Ci, H, W, Co, k, stride):
+    """conv_x3p_kernel (weights pre-split into bf16 planes once per step, activations staged as halo runs): on small-integer
+    data every product and partial sum is exact in fp32, so forward and data gradient must equal the fp64 convolution BIT FOR
+    BIT whatever the summation order -- any wrong tap, border mask, halo row or weight-plane chunk shows.  On real data it
+    agrees with conv_igemm_kernel<X3> (same products, other summation order) to fp32 rounding, with every epilogue operand
+    (bias, residual, ReLU; mask_src and accum in the data gradient)."""
+    import os
+    from htd_amd import capi, dense
+    L = capi.lib()
+    p = k // 2
+    if not L.htd_conv2d_x3p_supported(Ci, Co, k, k, stride, p, 1):
+        pytest.skip('conv_x3p_kernel switched off (HTD_X3P=0 / HTD_CONV_MATH=0)')
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B + Ci + Co + H)
+    xi = torch.randint(-4, 5, (B, Ci, H, W), generator=g).float()
+    wi = torch.randint(-3, 4, (Co, Ci, k, k), generator=g).float()
+    ref = F.conv2d(xi.double(), wi.double(), None, stride, p)
+    xd = xi.to(dev).contiguous(memory_format=CL)
+    wd = wi.to(dev).contiguous(memory_format=CL)
+    dense.new_step()
+    y = dense._fwd_raw(xd, wd, None, None, stride, p, 1, False)
+    assert torch.equal(y.cpu().double(), ref)
+    if stride == 1 and L.htd_conv2d_x3p_supported(Co, Ci, k, k, 1, p, 1):
+        gi = torch.randint(-4, 5, tuple(ref.shape), generator=g).float()
+        gref = torch.nn.grad.conv2d_input(xi.shape, wi.double(), gi.double(), 1, p)
+        gx = dense._dgrad_raw(gi.to(dev).contiguous(memory_format=CL), wd, xd.shape, 1, p, 1)
+        assert torch.equal(gx.cpu().double(), gref)
+    # real data, all epilogue operands, against the other kernel (direct C-ABI call of htd_conv2d_fwd / _bwd_data)
+    x = torch.randn(B, Ci, H, W, generator=g).to(dev).contiguous(memory_format=CL)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).to(dev).contiguous(memory_format=CL)
+    b = torch.randn(Co, generator=g).to(dev)
+    r = torch.randn(tuple(ref.shape), generator=g).to(dev).contiguous(memory_format=CL)
+    y = dense._fwd_raw(x, w, b, r, stride, p, 1, True)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y0 = torch.empty_like(y)
+    P, S = capi.ptr, capi.current_stream_ptr
+    capi.call('htd_conv2d_fwd', P(x), P(w), P(b), P(r), 0, 0, P(y0), B, H, W, Ci, Co, k, k, stride, p, 1, 1,
+              P(dense._splitk_ws(B * Ho * Wo, Co, Ci, k, k, dev)), S())
+    torch.testing.assert_close(y, y0, rtol=2e-5, atol=2e-6 * (Ci * k * k) ** 0.5)
+    if stride == 1 and L.htd_conv2d_x3p_supported(Co, Ci, k, k, 1, p, 1):
+        gy = torch.randn_like(y)
+        acc = torch.randn_like(x)
+        gx = dense._dgrad_raw(gy, w, x.shape, 1, p, 1, mask_src=x, accum=acc)
+        wT = torch.empty(w.numel(), device=dev)
+        capi.call('htd_conv2d_flip_weights', P(w), P(wT), Co, k, k, Ci, S())
+        gx0 = torch.empty_like(gx)
+        capi.call('htd_conv2d_bwd_data', P(gy), P(wT), P(x), P(acc), P(gx0), B, H, W, Ci, Co, k, k, 1, p, 1,
+                  P(dense._splitk_ws(B * H * W, Ci, Co, k, k, dev)), S())
+        torch.testing.assert_close(gx, gx0, rtol=2e-5, atol=2e-6 * (Co * k * k) ** 0.5)
+    dense.new_step()
+
+
+def test_x3p_weight_planes_follow_the_optimizer_kernel():
+    """the per-step caches of derived weight images are keyed on tensor._version, which the ctypes optimizer
+    kernel (mmcv_ops.sgd_momentum_step_) does not bump.  The plane cache also carries mmcv_ops.PARAM_EPOCH: a convolution
+    after such an update, with no dense.new_step() in between, must see the new weights (forward and data gradient)."""
+    from htd_amd import dense
+    from htd_amd import mmcv_ops as M
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    x = torch.randn(2, 64, 12, 14, device=dev).contiguous(memory_format=CL)
+    gy = torch.randn(2, 64, 12, 14, device=dev).contiguous(memory_format=CL)
+    wflat = torch.randn(64 * 3 * 3 * 64, device=dev) * 0.05            # KRSC memory, updated in place by the kernel
+    w = wflat.view(64, 3, 3, 64).permute(0, 3, 1, 2)
+    assert w.is_contiguous(memory_format=CL)
+    dense.new_step()
+    dense._fwd_raw(x, w, None, None, 1, 1, 1, False)
+    dense._dgrad_raw(gy, w, x.shape, 1, 1, 1)
+    grad, mom = torch.randn_like(wflat), torch.zeros_like(wflat)
+    M.sgd_momentum_step_(wflat, grad, mom, torch.tensor([0.5], device=dev), 0.9, 0.0)
+    y = dense._fwd_raw(x, w, None, None, 1, 1, 1, False)
+    gx = dense._dgrad_raw(gy, w, x.shape, 1, 1, 1)
+    torch.testing.assert_close(y.cpu().double(), F.conv2d(x.cpu().double(), w.cpu().double(), None, 1, 1), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gx.cpu().double(), torch.nn.grad.conv2d_input(x.shape, w.cpu().double(), gy.cpu().double(), 1, 1),
+                               rtol=1e-4, atol=1e-4)
+    dense.new_step()
 
 
 @pytest.mark.gpu

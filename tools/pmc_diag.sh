@@ -25,7 +25,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob(sys.argv[1] + '/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        cls = 'conv_igemm' if 'conv_igemm' in k else 'conv_wgrad' if 'conv_wgrad' in k else None
+        cls = 'conv_igemm' if 'conv_igemm' in k else 'conv_x3p' if 'conv_x3p_kernel' in k else 'conv_wgrad' if 'conv_wgrad' in k else None
         if cls is None: continue
         acc[cls][r['Counter_Name']] += float(r['Counter_Value'])
         n[(cls, r['Counter_Name'])].add(r.get('Dispatch_Id'))
