@@ -21,6 +21,9 @@
 // (conflict-free without padding, which LDS-DMA could not honour), and the split's ds_write_b64 are conflict-free with a
 // row pitch = 4 (mod 8).
 #include <algorithm>
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
 
 #include <stdlib.h>
 
@@ -32,6 +35,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int XK = 16;            // channels per K slice
 constexpr int NCH = 6;            // 16-byte chunks of a row slice: 3 planes x 2 halves of 8 channels
@@ -47,6 +51,40 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned
     m = c.u;
     c.v = __builtin_convertvector(f32x2{ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u)}, bf16x2);
     l = c.u;
+}
+
+// s_waitcnt vmcnt(N): all but the wave's N youngest vector-memory operations are done.  volatile asm statements keep their
+// order; landed() after the wait names the registers the inline-asm loads fill, so no use of them is scheduled above it and
+// the compiler has no reason to copy them earlier (a wait that took them as operands in two branches made hipcc insert
+// v_mov copies AHEAD of one of the waits: stale data).
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void landed(f32x4 &a) { asm volatile("" : "+v"(a)::"memory"); }
+
+// LDS-DMA of 64 x 16 bytes: lane l's 16 bytes at `src` go to LDS byte address lds_dst + 16 l (lds_dst wave-uniform, in M0).
+// Inline asm for the same reason as the loads above: hipcc puts s_waitcnt vmcnt(0) in front of any LDS access it cannot
+// prove disjoint from a pending LDS-DMA of its own -- with a ring of B buffers that is every fragment read, i.e. the
+// prefetched tile was waited for in the middle of the current tap's MFMAs.  M0 is saved and restored (hipcc owns it).
+__device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+// ds_write_b64 the compiler does not see: it puts s_waitcnt vmcnt(0) in front of its own LDS stores while an LDS-DMA is in
+// flight (possible overlap), which would drain the prefetched B tiles at every tap.  lds_barrier() waits lgkmcnt(0).
+template <int OFF>
+__device__ __forceinline__ void lds_store8(unsigned addr, unsigned lo, unsigned hi)
+{
+    const u32x2 v = {lo, hi};
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
 
 struct X3Params {
@@ -76,20 +114,44 @@ struct Geo {
     static constexpr int PASSES = (RUN + 63) / 64;                // 64 rows x 4 float4 per pass of the 256 threads
 };
 
-template <int WGM, int WGN, int TM, int TN, int KW>
-__global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_x3p_kernel(X3Params p)
+// MF16: the products run on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  Its 32 k per instruction carry TWO of
+// the six plane products at once -- the lane groups k = 0..15 and k = 16..31 read different planes: [a0|a1].[b0|b1] = a0 b0 +
+// a1 b1, [a0|a1].[b1|b0] = a0 b1 + a1 b0, [a0|a2].[b2|b0] = a0 b2 + a2 b0 -- so a 16-channel slice takes three instructions of
+// 16 cycles per 16x16 block: the same matrix-pipe cycles per FLOP, but the chip holds a higher clock on this shape under its
+// power cap (MI355X_MICROARCH.md, "DVFS give-back" item 7).
+// NB: LDS buffers of the B tile = prefetch distance + 1.  The LDS-DMA of tap t + NB - 1 is issued at the start of tap t and must
+// have landed at the end of tap t + NB - 2; it stays in flight across the barriers in between, which the compiler's
+// __syncthreads() would not allow (it drains vmcnt(0) while an LDS-DMA is outstanding): the loop uses raw s_barrier with its
+// own counted s_waitcnt, and the activation loads are inline asm so that hipcc has no vector-memory result of its own to wait
+// for inside the loop (cdna_hip_programming.md section 5, "Pipelining across barriers").  Small tiles, whose tap is a few
+// hundred matrix-pipe cycles, need the distance: with one tap of prefetch every tap waited for its weights (~1 us).
+// resident workgroups per CU (= waves per SIMD of a 4-wave workgroup): by registers 3 (128x128) or 4, by the 160 KB of LDS
+template <int WGM, int WGN, int TM, int TN, int KW, int NB>
+constexpr int x3p_occupancy()
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int main_bytes = (2 * NCH * Geo<BM, KW>::PITCH + NB * NCH * BN) * 16;
+    constexpr int epi_bytes = WGM * 32 * (BN + 4) * 4;
+    constexpr int by_lds = 163840 / (main_bytes > epi_bytes ? main_bytes : epi_bytes);
+    constexpr int by_regs = TM * TN >= 4 ? 3 : 4;
+    return by_lds < by_regs ? by_lds : by_regs;
+}
+
+template <int WGM, int WGN, int TM, int TN, int KW, bool MF16, int NB>
+__global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) void conv_x3p_kernel(X3Params p)
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     using G = Geo<BM, KW>;
     constexpr int PADX = (KW - 1) / 2;
     constexpr int A_VEC = NCH * G::PITCH;                         // uint4 per A buffer
     constexpr int B_VEC = NCH * BN;                               // uint4 per B buffer
-    constexpr int MAIN_VEC = 2 * A_VEC + 2 * B_VEC;
+    constexpr int MAIN_VEC = 2 * A_VEC + NB * B_VEC;
     constexpr int EPI_STRIDE = BN + 4, EPI_ROWS = WGM * 32;
     constexpr int EPI_VEC = EPI_ROWS * EPI_STRIDE / 4;
     constexpr int LDS_VEC = MAIN_VEC > EPI_VEC ? MAIN_VEC : EPI_VEC;
     __shared__ uint4 lds[LDS_VEC];
     uint4 *const lA = lds, *const lB = lds + 2 * A_VEC;
+    const unsigned lds_a0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lA;      // LDS byte address of the A buffers
 
     // XCD-aware tile order (conv_fwd.hip): the blocks of one XCD walk a contiguous run of tiles, N tiles of an M tile adjacent
     const int nblk = p.mt * p.nt;
@@ -109,35 +171,38 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_x3p_kernel(X
 
     // ---- A staging coordinates: thread (vrow, vcol) handles row vrow + 64 i of the run, channels 4 vcol .. + 3 of the slice
     const int vcol = tid & 3, vrow = tid >> 2;
-    unsigned a_off[G::PASSES];            // element offset (mod 2^32) of the row at filter row PADY (halo) / of the pixel (1x1)
-    int a_g[G::PASSES];                   // halo mode: linear input pixel of the row at filter row PADY
-    bool a_in[G::PASSES];                 // 1x1 mode: the row is an output pixel of the problem
+    // halo mode: row j of the run is input pixel m0 - PADX + j (+ (ky - PADY) * W): one base, rows 64 apart per pass;
+    // 1x1 mode: row j is output pixel m0 + j, whose input pixel is decoded once per pass (strided layers)
+    const int a_g0 = (int)m0 + vrow - PADX;
+    unsigned a_off[KW > 1 ? 1 : G::PASSES];            // element offsets mod 2^32
+    bool a_in[KW > 1 ? 1 : G::PASSES];
+    if constexpr (KW > 1) {
+        a_off[0] = (unsigned)a_g0 * (unsigned)p.Ci + vcol * 4;
+        a_in[0] = true;
+    } else {
 #pragma unroll
-    for (int i = 0; i < G::PASSES; ++i) {
-        const int j = vrow + 64 * i;
-        if constexpr (KW > 1) {
-            a_g[i] = (int)m0 + j - PADX;
-            a_off[i] = (unsigned)a_g[i] * (unsigned)p.Ci + vcol * 4;
-            a_in[i] = j < G::RUN;
-        } else {
-            const int64_t m = m0 + j;
-            a_in[i] = j < G::RUN && m < p.M;
+        for (int i = 0; i < G::PASSES; ++i) {
+            const int64_t m = m0 + vrow + 64 * i;
+            a_in[i] = vrow + 64 * i < G::RUN && m < p.M;
             const unsigned mm = a_in[i] ? (unsigned)m : 0u;
             const unsigned wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
             const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
-            a_g[i] = 0;
             a_off[i] = ((b * (unsigned)p.Hx + ho * (unsigned)p.stride) * (unsigned)p.Wx + wo * (unsigned)p.stride) *
                            (unsigned)p.Ci + vcol * 4;
         }
     }
 
-    // ---- per-lane tap validity of the MFMA rows (halo mode): bit ky * KW + kx of vmask[i] for block i
-    unsigned vmask[TM];
-    int a_frag[TM];                       // byte offset of the lane's fragment row inside a chunk array, tap kx = 0
+    // ---- per-lane tap validity of the MFMA rows (halo mode): bit ky * KW + kx of vmask[i] for row block i
+    // (32x32x16: block = 32 rows, lane row = lane & 31, k half = lane >> 5; 16x16x32: 16 rows, lane & 15, k group = lane >> 4)
+    constexpr int RBLK = MF16 ? 16 : 32;
+    constexpr int RB = TM * 32 / RBLK, CB = TN * 32 / RBLK;          // row / column blocks of the wave tile
+    const int lrow = MF16 ? (lane & 15) : frow;
+    const int kg = lane >> 4;
+    unsigned vmask[RB];
+    const int a_frag0 = (wm * TM * 32 + lrow) * 16;   // byte offset of the lane's fragment row in a chunk array: block 0, tap 0
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * TM * 32 + i * 32 + frow;
-        a_frag[i] = (fhalf * G::PITCH + r) * 16;
+    for (int i = 0; i < RB; ++i) {
+        const int r = wm * TM * 32 + i * RBLK + lrow;
         vmask[i] = 0xffffffffu;
         if constexpr (KW > 1) {
             const int64_t m = m0 + r;
@@ -154,10 +219,16 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_x3p_kernel(X
             vmask[i] = v;
         }
     }
-    const int zero_frag = (fhalf * G::PITCH + G::RUN) * 16;       // the zero row of the lane's chunk
-    int b_frag[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b_frag[j] = (fhalf * BN + wn * TN * 32 + j * 32 + frow) * 16;
+    const int zero_frag = G::RUN * 16;                            // the zero row of a chunk array
+    // chunk (= plane * 2 + channel half) the lane reads for each operand:
+    //   32x32x16: plane q -> chunk 2 q + (lane >> 5)
+    //   16x16x32: operand [p|q] -> plane p for k groups 0, 1 and plane q for k groups 2, 3, channel half = k group & 1
+    const int a_c0 = MF16 ? kg * G::PITCH * 16 : fhalf * G::PITCH * 16;                                // [a0|a1] / a0
+    const int a_c1 = MF16 ? ((kg >> 1) * 4 + (kg & 1)) * G::PITCH * 16 : 0;                            // [a0|a2]
+    const int b_row = (wn * TN * 32 + lrow) * 16;
+    const int b_c0 = (MF16 ? kg * BN * 16 : fhalf * BN * 16) + b_row;                                  // [b0|b1] / b0
+    const int b_c1 = MF16 ? ((1 - (kg >> 1)) * 2 + (kg & 1)) * BN * 16 + b_row : 0;                    // [b1|b0]
+    const int b_c2 = MF16 ? (((kg >> 1) ? 0 : 4) + (kg & 1)) * BN * 16 + b_row : 0;                    // [b2|b0]
 
     const int total_steps = p.ncs * p.kh;
     const int s_begin = blockIdx.y * p.steps_per_split;
@@ -166,115 +237,198 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_x3p_kernel(X
     // zero rows of both A buffers (never overwritten: the staging writes rows < RUN only)
     if (tid < 2 * NCH) lA[(tid / NCH) * A_VEC + (tid % NCH) * G::PITCH + G::RUN] = make_uint4(0u, 0u, 0u, 0u);
 
-    float4 ra[G::PASSES];
+    constexpr int PPT = (G::PASSES + KW - 1) / KW;                // passes of the next run staged per tap
+    f32x4 ra[PPT];
     unsigned ra_ok = 0u;
-    auto load_run = [&](int s) {           // global -> registers, branch-free (out-of-range rows read element 0)
-        const int cs = s / p.kh, ky = s - cs * p.kh;
-        const int shift = (ky - PADY) * p.Wx;
-        const int koff = shift * p.Ci + cs * XK;
-#pragma unroll
-        for (int i = 0; i < G::PASSES; ++i) {
-            bool ok = a_in[i];
-            if constexpr (KW > 1) {
-                const int g = a_g[i] + shift;
-                ok = ok && g >= 0 && (int64_t)g < p.M;
-            }
-            const unsigned off = (a_off[i] + (unsigned)koff) & (0u - (unsigned)ok);
-            ra[i] = *reinterpret_cast<const float4 *>(p.x + off);
-            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+    // (no divisions inside the K loop: the step's channel slice / filter row and the prefetch pointers advance incrementally)
+    auto load_pass = [&](int shift, int koff, int i, int slot) {   // pass i of the run at pixel shift `shift`, element offset koff
+        bool ok;
+        unsigned off;
+        if constexpr (KW > 1) {
+            const int g = a_g0 + 64 * i + shift;
+            ok = vrow + 64 * i < G::RUN && g >= 0 && (int64_t)g < p.M;
+            off = a_off[0] + (unsigned)(64 * i) * (unsigned)p.Ci + (unsigned)koff;
+        } else {
+            ok = a_in[i];
+            off = a_off[i] + (unsigned)koff;
         }
+        // out of range: element 0, zeroed at store time.  Inline asm: hipcc must not count this load (see NB above); its result
+        // is not touched before wait_vm() names it
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot]) : "v"(p.x + (off & (0u - (unsigned)ok))) : "memory");
+        ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
     };
-    auto store_run = [&](int buf) {        // registers -> three bf16 planes of the run, chunk-major
-        unsigned short *base = reinterpret_cast<unsigned short *>(lA + buf * A_VEC);
-#pragma unroll
-        for (int i = 0; i < G::PASSES; ++i) {
-            const int j = vrow + 64 * i;
-            if (G::RUN % 64 != 0 && i == G::PASSES - 1 && j >= G::RUN) continue;
-            const bool ok = (ra_ok >> i) & 1u;
-            const float4 v = make_float4(ok ? ra[i].x : 0.f, ok ? ra[i].y : 0.f, ok ? ra[i].z : 0.f, ok ? ra[i].w : 0.f);
-            unsigned h0, m0_, l0, h1, m1, l1;
-            split3x2(v.x, v.y, h0, m0_, l0);
-            split3x2(v.z, v.w, h1, m1, l1);
-            // chunk = plane * 2 + (vcol >> 1); 8 bytes at half (vcol & 1) of the row's 16
-            unsigned short *d = base + (((vcol >> 1) * G::PITCH + j) * 16 + (vcol & 1) * 8) / 2;
-            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(d + 2 * G::PITCH * 8) = make_uint2(m0_, m1);
-            *reinterpret_cast<uint2 *>(d + 4 * G::PITCH * 8) = make_uint2(l0, l1);
-        }
+    auto store_pass = [&](int buf, int i, int slot) {   // registers -> three bf16 planes of the run, chunk-major
+        const int j = vrow + 64 * i;
+        if (G::RUN % 64 != 0 && j >= G::RUN) return;
+        const bool ok = (ra_ok >> i) & 1u;
+        const float4 v = make_float4(ok ? ra[slot][0] : 0.f, ok ? ra[slot][1] : 0.f, ok ? ra[slot][2] : 0.f, ok ? ra[slot][3] : 0.f);
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3x2(v.x, v.y, h0, m0_, l0);
+        split3x2(v.z, v.w, h1, m1, l1);
+        // chunk = plane * 2 + (vcol >> 1); 8 bytes at half (vcol & 1) of the row's 16
+        const unsigned d = lds_a0 + (unsigned)(buf * A_VEC * 16 + ((vcol >> 1) * G::PITCH + j) * 16 + (vcol & 1) * 8);
+        lds_store8<0>(d, h0, h1);
+        lds_store8<2 * G::PITCH * 16>(d, m0_, m1);
+        lds_store8<4 * G::PITCH * 16>(d, l0, l1);
     };
+    // the passes of the NEXT step's run are spread over the taps of the current one: tap kx loads passes kx * PPT .. at its start
+    // and splits + stores them at its end (the other A buffer is free during the whole step), so PPT float4 are in flight per
+    // thread and the split work lands beside every tap's MFMAs instead of in one burst
     // B tile of (step s, tap kx) -> LDS buffer `buf`, LDS-DMA: instruction idx = chunk * (BN / 64) + half covers 64 rows
-    auto load_b = [&](int s, int kx, int buf) {
-        const int cs = s / p.kh, ky = s - cs * p.kh;
-        const int tap = ky * KW + kx;
-        const uint4 *src = p.wp + ((int64_t)(tap * p.ncs + cs) * NCH) * p.Cop + n0 + lane;
-        uint4 *dst = lB + buf * B_VEC;
-        constexpr int NI = NCH * BN / 64;
+    constexpr int NI = NCH * BN / 64;                             // LDS-DMA instructions per B tile, dealt round-robin to the waves
+    const uint4 *bsrc[(NI + 3) / 4];                              // the lane's source of the wave's k-th instruction, tile (tap 0, slice 0)
+#pragma unroll
+    for (int k = 0; k < (NI + 3) / 4; ++k) {
+        const int idx = (wave + 4 * k) % NI;
+        bsrc[k] = p.wp + (int64_t)(idx / (BN / 64)) * p.Cop + (idx % (BN / 64)) * 64 + n0 + lane;
+    }
+    const unsigned lds_b0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lB;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // provably wave-uniform (an SGPR) for the M0 operand
+    auto load_b = [&](unsigned tile_off, int buf) {                // tile_off: uint4 index of the (tap, slice) tile in the plane image
 #pragma unroll
         for (int k = 0; k < (NI + 3) / 4; ++k) {
-            const int idx = wave + 4 * k;
+            const int idx = wave_u + 4 * k;
             if (NI % 4 != 0 && idx >= NI) continue;
-            const int c = idx / (BN / 64), hf = idx % (BN / 64);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (int64_t)c * p.Cop + hf * 64),
-                                             (__attribute__((address_space(3))) void *)(dst + c * BN + hf * 64), 16, 0, 0);
+            // instruction idx = chunk * (BN / 64) + half covers rows half * 64 .. + 63 of chunk array `chunk`: LDS offset idx * 1 KiB
+            lds_dma16(bsrc[k] + tile_off, lds_b0 + (unsigned)((buf * B_VEC + idx * 64) * 16));
         }
     };
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto lds_barrier = [&]() {             // LDS writes of this wave done, then the workgroup barrier (no vmcnt drain)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    constexpr int DIST = NB - 1;                                  // prefetch distance of the B tiles, in taps
+    constexpr int NI_MIN = NCH * BN / 64 / 4;                     // LDS-DMA instructions every wave issues per B tile
+    static_assert(PPT <= 2 && NI_MIN >= 1, "wait_vm covers two staged registers");
+    // the next B tile to issue: step, tap of the filter (ky * KW + kx), channel slice, buffer, offset in the plane image
+    const int ntap = p.kh * KW;
+    const unsigned tile_stride = (unsigned)(NCH * p.Cop);         // uint4 per (tap, slice) tile
+    int ps = s_begin, pbuf = 0;
+    int pcs = s_begin / p.kh, ptap = (s_begin - pcs * p.kh) * KW;
+    unsigned poff = (unsigned)(ptap * p.ncs + pcs) * tile_stride;
+    auto issue_b = [&]() -> bool {
+        const bool any = ps < s_end;
+        if (any) load_b(poff, pbuf);
+        pbuf = pbuf + 1 == NB ? 0 : pbuf + 1;
+        ++ptap;
+        poff += (unsigned)p.ncs * tile_stride;
+        if (ptap % KW == 0) ++ps;
+        if (ptap == ntap) { ptap = 0; ++pcs; poff = (unsigned)pcs * tile_stride; }
+        return any;
+    };
 
+    using acc_t = typename std::conditional<MF16, f32x4, f32x16>::type;
+    acc_t acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < (MF16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+
+    int cs = s_begin / p.kh, ky = s_begin - cs * p.kh;            // channel slice and filter row of the current step
     if (s_begin < s_end) {
-        load_run(s_begin);
-        load_b(s_begin, 0, 0);
-        store_run(0);
+#pragma unroll
+        for (int d = 0; d < DIST; ++d) issue_b();
+        const int shift0 = (ky - PADY) * p.Wx, koff0 = shift0 * p.Ci + cs * XK;
+#pragma unroll
+        for (int i0 = 0; i0 < G::PASSES; i0 += PPT) {
+#pragma unroll
+            for (int ii = 0; ii < PPT; ++ii)
+                if (i0 + ii < G::PASSES) load_pass(shift0, koff0, i0 + ii, ii);
+            wait_vm<0>();
+#pragma unroll
+            for (int ii = 0; ii < PPT; ++ii) landed(ra[ii]);
+#pragma unroll
+            for (int ii = 0; ii < PPT; ++ii)
+                if (i0 + ii < G::PASSES) store_pass(0, i0 + ii, ii);
+        }
     }
-    __syncthreads();
+    lds_barrier();
 
     int bbuf = 0;
     for (int s = s_begin; s < s_end; ++s) {
         const int abuf = (s - s_begin) & 1;
-        const int ky = s % p.kh;
         const bool more = s + 1 < s_end;
-#pragma unroll
+        const int tap0 = ky * KW;                                  // mask bit of the step's first tap
+        if (++ky == p.kh) { ky = 0; ++cs; }                       // (cs, ky) now describe step s + 1, whose run is staged below
+        const int nshift = (ky - PADY) * p.Wx, nkoff = nshift * p.Ci + cs * XK;
+        // (a rolled tap loop: unrolled, hipcc hoists the three taps' address arithmetic and fragment loads and spills)
+#pragma unroll 1
         for (int kx = 0; kx < KW; ++kx) {
-            // prefetch: the next tap's B tile by LDS-DMA, the next step's A run into registers
-            if (kx + 1 < KW) load_b(s, kx + 1, bbuf ^ 1);
-            else if (more) load_b(s + 1, 0, bbuf ^ 1);
-            if (kx == 0 && more) load_run(s + 1);
+            // prefetch: the next step's A run into registers (oldest in the queue), then the B tile DIST taps ahead by LDS-DMA
+            if (more) {
+#pragma unroll
+                for (int ii = 0; ii < PPT; ++ii)
+                    if (kx * PPT + ii < G::PASSES) load_pass(nshift, nkoff, kx * PPT + ii, ii);
+            }
+            const bool issued = issue_b();
 
             const char *la = reinterpret_cast<const char *>(lA + abuf * A_VEC);
             const char *lb = reinterpret_cast<const char *>(lB + bbuf * B_VEC);
-            bf16x8 fa[TM][3], fb[TN][3];
+            int arow[RB];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                int off = a_frag[i] + kx * 16;
-                if constexpr (KW > 1) off = ((vmask[i] >> (ky * KW + kx)) & 1u) ? off : zero_frag;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    fa[i][q] = *reinterpret_cast<const bf16x8 *>(la + off + q * 2 * G::PITCH * 16);
+            for (int i = 0; i < RB; ++i) {
+                arow[i] = a_frag0 + (i * RBLK + kx) * 16;
+                if constexpr (KW > 1) arow[i] = ((vmask[i] >> (tap0 + kx)) & 1u) ? arow[i] : zero_frag;
             }
+            if constexpr (MF16) {
+                bf16x8 fa01[RB], fa02[RB];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + b_frag[j] + q * 2 * BN * 16);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {      // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < RB; ++i) {
+                    fa01[i] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c0);
+                    fa02[i] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c1);
                 }
-            if (kx == KW - 1 && more) store_run(abuf ^ 1);
-            __syncthreads();               // LDS-DMA landed (vmcnt), every wave is done with this tap's buffers
-            bbuf ^= 1;
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    const bf16x8 fb01 = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 16 * 16);
+                    const bf16x8 fb10 = *reinterpret_cast<const bf16x8 *>(lb + b_c1 + j * 16 * 16);
+                    const bf16x8 fb20 = *reinterpret_cast<const bf16x8 *>(lb + b_c2 + j * 16 * 16);
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) {      // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa02[i], fb20, acc[i][j], 0, 0, 0);   // a0 b2 + a2 b0
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb10, acc[i][j], 0, 0, 0);   // a0 b1 + a1 b0
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb01, acc[i][j], 0, 0, 0);   // a0 b0 + a1 b1
+                    }
+                }
+            } else {
+                bf16x8 fa[RB][3], fb[CB][3];
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        fa[i][q] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c0 + q * 2 * G::PITCH * 16);
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 32 * 16 + q * 2 * BN * 16);
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {      // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
+            // the staged A registers and the NEXT tap's B tile have landed once all but this tap's own LDS-DMA are done
+            if (DIST >= 2 && issued) wait_vm<NI_MIN>();
+            else wait_vm<0>();
+#pragma unroll
+            for (int ii = 0; ii < PPT; ++ii) landed(ra[ii]);
+            if (more) {
+#pragma unroll
+                for (int ii = 0; ii < PPT; ++ii)
+                    if (kx * PPT + ii < G::PASSES) store_pass(abuf ^ 1, kx * PPT + ii, ii);
+            }
+            lds_barrier();                 // every wave is done with this tap's buffers; the next tap's are complete
+            bbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
         }
     }
 
@@ -285,13 +439,23 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_x3p_kernel(X
     constexpr int V = BN / 4, RPP = 256 / V;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        if constexpr (MF16) {       // D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                le[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
-            }
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        le[(wm * 32 + ib * 16 + 4 * kg + r) * EPI_STRIDE + wn * TN * 32 + j * 16 + lrow] = acc[2 * i + ib][j][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    le[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
+                }
+        }
         __syncthreads();
         const int c4 = tid % V;
         const int n = n0 + c4 * 4;
@@ -386,43 +550,75 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
 //   transposed = 0 (forward operand):       N = Co, K = Ci, tap t      <- w[n][t][k]
 //   transposed = 1 (data-gradient operand): N = Ci, K = Co, tap t      <- w[k][taps - 1 - t][n]   (flipped, transposed filter)
 // One thread per (tap, slice, n): 16 loads, 6 x 16-byte stores that are contiguous across the threads of a wavefront.
-__global__ __launch_bounds__(256) void x3_planes_kernel(const float *__restrict__ w, uint4 *__restrict__ out, int Co, int taps,
-                                                        int Ci, int Np, int transposed)
+__device__ __forceinline__ void x3_planes_element(const float *__restrict__ w, uint4 *__restrict__ out, int Co, int taps,
+                                                  int Ci, int Np, int transposed, int64_t e)
 {
     const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
     const int ncs = K / XK;
-    const int64_t total = (int64_t)taps * ncs * Np;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int n = (int)(e % Np);
-        const int64_t t2 = e / Np;
-        const int cs = (int)(t2 % ncs), tap = (int)(t2 / ncs);
-        float v[XK];
-        if (n < N) {
-            if (!transposed) {
-                const float4 *src = reinterpret_cast<const float4 *>(w + ((int64_t)n * taps + tap) * Ci + cs * XK);
+    const int n = (int)(e % Np);
+    const int64_t t2 = e / Np;
+    const int cs = (int)(t2 % ncs), tap = (int)(t2 / ncs);
+    float v[XK];
+    if (n < N) {
+        if (!transposed) {
+            const float4 *src = reinterpret_cast<const float4 *>(w + ((int64_t)n * taps + tap) * Ci + cs * XK);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 f = src[q];
-                    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < XK; ++k) v[k] = w[((int64_t)(cs * XK + k) * taps + (taps - 1 - tap)) * Ci + n];
+            for (int q = 0; q < 4; ++q) {
+                const float4 f = src[q];
+                v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < XK; ++k) v[k] = 0.f;
+            for (int k = 0; k < XK; ++k) v[k] = w[((int64_t)(cs * XK + k) * taps + (taps - 1 - tap)) * Ci + n];
         }
-        unsigned pl[3][8];
+    } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) split3x2(v[2 * k], v[2 * k + 1], pl[0][k], pl[1][k], pl[2][k]);
-        uint4 *dst = out + ((int64_t)(tap * ncs + cs) * NCH) * Np + n;
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                dst[(int64_t)(q * 2 + h) * Np] = make_uint4(pl[q][4 * h], pl[q][4 * h + 1], pl[q][4 * h + 2], pl[q][4 * h + 3]);
+        for (int k = 0; k < XK; ++k) v[k] = 0.f;
     }
+    unsigned pl[3][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split3x2(v[2 * k], v[2 * k + 1], pl[0][k], pl[1][k], pl[2][k]);
+    uint4 *dst = out + ((int64_t)(tap * ncs + cs) * NCH) * Np + n;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            dst[(int64_t)(q * 2 + h) * Np] = make_uint4(pl[q][4 * h], pl[q][4 * h + 1], pl[q][4 * h + 2], pl[q][4 * h + 3]);
+}
+
+__global__ __launch_bounds__(256) void x3_planes_kernel(const float *__restrict__ w, uint4 *__restrict__ out, int Co, int taps,
+                                                        int Ci, int Np, int transposed)
+{
+    const int K = transposed ? Co : Ci;
+    const int64_t total = (int64_t)taps * (K / XK) * Np;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+        x3_planes_element(w, out, Co, taps, Ci, Np, transposed, e);
+}
+
+// one launch for the plane images of many weights (every plain convolution / Linear of neck and heads at the start of a
+// step, every folded weight of a backbone stage after its BN fold): workgroup b serves entry l with block0[l] <= b < block0[l + 1]
+struct PlanesDesc {
+    const float *w;
+    uint4 *out;
+    int Co, taps, Ci, transposed;
+    int64_t block0;
+};
+
+__global__ __launch_bounds__(256) void x3_planes_many_kernel(const PlanesDesc *__restrict__ descs, int n)
+{
+    int lo = 0, hi = n - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {                    // last entry whose first block is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PlanesDesc d = descs[lo];
+    const int N = d.transposed ? d.Ci : d.Co, K = d.transposed ? d.Co : d.Ci;
+    const int Np = ((N + 127) / 128) * 128;
+    const int64_t total = (int64_t)d.taps * (K / XK) * Np;
+    const int64_t e = (b - d.block0) * 256 + threadIdx.x;
+    if (e < total) x3_planes_element(d.w, d.out, d.Co, d.taps, d.Ci, Np, d.transposed, e);
 }
 
 inline int planes_np(int N) { return (int)htd::ceil_div(N, 128) * 128; }
@@ -472,9 +668,38 @@ float cfg_score(int cfg, int64_t M, int Co, int splits)
     return base[cfg] * quant * useful;
 }
 
-int choose_cfg(int64_t M, int Co, int splits)
+// Tuned tile table, (M, Co, Ci, taps, epilogue bits) -> configuration id: measured inside the train / inference step by
+// tools/tune_conv_tiles.py --kernel x3p, shipped as htd_amd/tuning/conv_x3p_tiles_gfx950.json and pushed in at load
+// (htd_conv2d_x3p_tile_table_set) -- what cuDNN's algorithm search does for the reference, without a search at run time.
+struct XKey {
+    int64_t M;
+    int Co, Ci, taps, epi;
+    bool operator==(const XKey &o) const { return M == o.M && Co == o.Co && Ci == o.Ci && taps == o.taps && epi == o.epi; }
+};
+struct XKeyHash {
+    size_t operator()(const XKey &k) const
+    {
+        uint64_t h = (uint64_t)k.M * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)k.Co << 40) ^ ((uint64_t)k.Ci << 20) ^ ((uint64_t)k.taps << 4) ^ (uint64_t)k.epi;
+        h *= 0xBF58476D1CE4E5B9ull;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+std::mutex g_xtable_mutex;
+std::unordered_map<XKey, int, XKeyHash> g_xtable;
+
+int table_cfg(int64_t M, int Co, int Ci, int taps, int epi)
+{
+    std::lock_guard<std::mutex> lock(g_xtable_mutex);
+    if (g_xtable.empty()) return -1;
+    const auto it = g_xtable.find(XKey{M, Co, Ci, taps, epi});
+    return it == g_xtable.end() ? -1 : it->second;
+}
+
+int choose_cfg(int64_t M, int Co, int Ci, int taps, int epi, int splits)
 {
     int cfg = forced_cfg();
+    if (cfg < 0) cfg = table_cfg(M, Co, Ci, taps, epi);
     if (cfg >= 0) return cfg;
     float best = -1.f;
     static const int cand[4] = {1, 3, 2, 0};
@@ -485,11 +710,49 @@ int choose_cfg(int64_t M, int Co, int splits)
     return cfg;
 }
 
+// HTD_X3P_MFMA=16 / 32 forces the instruction shape (0: per filter width, launch_tile_nb); re-read per call under HTD_X3P_TUNE
+static const int g_x3p_mfma = getenv("HTD_X3P_MFMA") ? atoi(getenv("HTD_X3P_MFMA")) : 0;
+int x3p_mfma()
+{
+    if (!g_x3p_tune) return g_x3p_mfma;
+    const char *e = getenv("HTD_X3P_MFMA");
+    return e ? atoi(e) : 0;
+}
+
+// HTD_X3P_NB (tune mode): B buffers, 0 = the per-tile default
+int x3p_nb()
+{
+    if (!g_x3p_tune) return 0;
+    const char *e = getenv("HTD_X3P_NB");
+    return e ? atoi(e) : 0;
+}
+
+template <int TM, int TN, int NB>
+void launch_tile_nb(const X3Params &p, int kw, dim3 grid, hipStream_t s)
+{
+    // the instruction shape per filter width (tools/sweep_x3p.py): 16x16x32 on the 1x1 layers, 32x32x16 on the 3x3 ones
+    const int mf = x3p_mfma() ? x3p_mfma() : (kw == 1 ? 16 : 32);
+    if (mf == 32) {
+        if (kw == 1) hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 1, false, NB>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 3, false, NB>), grid, dim3(256), 0, s, p);
+    } else {
+        if (kw == 1) hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 1, true, NB>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 3, true, NB>), grid, dim3(256), 0, s, p);
+    }
+}
+
+// Two B buffers (one tap of prefetch) everywhere: measured with three and four (tools/sweep_x3p.py, SWEEP_NB), the longer
+// prefetch never paid for the workgroup per CU its LDS costs -- co-resident workgroups already cover one tap of latency.
+// -DHTD_X3P_DEEP builds the deeper rings for that experiment.
 template <int TM, int TN>
 void launch_tile(const X3Params &p, int kw, dim3 grid, hipStream_t s)
 {
-    if (kw == 1) hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_x3p_kernel<2, 2, TM, TN, 3>), grid, dim3(256), 0, s, p);
+#ifdef HTD_X3P_DEEP
+    const int nb = x3p_nb();
+    if (nb == 3) return launch_tile_nb<TM, TN, 3>(p, kw, grid, s);
+    if (nb >= 4) return launch_tile_nb<TM, TN, 4>(p, kw, grid, s);
+#endif
+    launch_tile_nb<TM, TN, 2>(p, kw, grid, s);
 }
 
 int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
@@ -499,7 +762,8 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     p.steps_per_split = (int)htd::ceil_div(total_steps, p.splits);
     p.splits = (int)htd::ceil_div(total_steps, p.steps_per_split);
     p.partial = (float *)workspace;
-    const int cfg = choose_cfg(p.M, p.Co, p.splits);
+    const int epi = (p.residual ? 1 : 0) | (p.mask_src ? 2 : 0);
+    const int cfg = choose_cfg(p.M, p.Co, p.Ci, p.kh * kw, epi, p.splits);
     p.mt = (int)htd::ceil_div(p.M, kXCfg[cfg].bm);
     p.nt = (int)htd::ceil_div(p.Co, kXCfg[cfg].bn);
     const int64_t blocks = (int64_t)p.mt * p.nt;
@@ -533,6 +797,31 @@ extern "C" int htd_conv2d_x3p_supported(int Ci, int Co, int kh, int kw, int stri
     return (!x3p_off() && htd::conv_math() == 1 && x3p_shape_ok(Ci, Co, kh, kw, stride, pad, dil)) ? 1 : 0;
 }
 
+// Tuned tile table of conv_x3p_kernel (see choose_cfg).  cfg: 0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases the entry.
+// epi: bit 0 = residual / accum operand present, bit 1 = mask_src present.
+extern "C" int htd_conv2d_x3p_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg)
+{
+    HTD_REQUIRE(M > 0 && Co > 0 && Ci > 0 && taps > 0 && epi >= 0 && epi < 4 && cfg < 4,
+                "x3p_tile_table_set: bad entry M=%lld Co=%d Ci=%d taps=%d epi=%d cfg=%d", (long long)M, Co, Ci, taps, epi, cfg);
+    std::lock_guard<std::mutex> lock(g_xtable_mutex);
+    if (cfg < 0) g_xtable.erase(XKey{M, Co, Ci, taps, epi});
+    else g_xtable[XKey{M, Co, Ci, taps, epi}] = cfg;
+    return HTD_OK;
+}
+
+extern "C" int htd_conv2d_x3p_tile_table_clear()
+{
+    std::lock_guard<std::mutex> lock(g_xtable_mutex);
+    g_xtable.clear();
+    return HTD_OK;
+}
+
+// the configuration id a launch of this problem would use now (forced tile, table, then score)
+extern "C" int htd_conv2d_x3p_tile_query(int64_t M, int Co, int Ci, int taps, int epi)
+{
+    return choose_cfg(M, Co, Ci, taps, epi, plan_splits_x3p(M, Co, (Ci / XK) * (taps == 9 ? 3 : 1)));
+}
+
 extern "C" int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, int transposed)
 {
     const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
@@ -552,6 +841,17 @@ extern "C" int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh
     hipLaunchKernelGGL(x3_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint4 *)planes, Co, kh * kw, Ci, Np,
                        transposed);
     return htd::check_launch("x3_planes");
+}
+
+// desc: device array of n entries { const float *w; void *planes; int Co, taps, Ci, transposed; int64_t block0; } (40 bytes),
+// block0 = prefix sum of ceil(taps * (K / 16) * Np / 256) over the entries, total_blocks = its end.
+extern "C" int htd_conv2d_x3_planes_many(const void *desc, int n, int64_t total_blocks, void *stream)
+{
+    static_assert(sizeof(PlanesDesc) == 40, "PlanesDesc layout is part of the ABI");
+    HTD_REQUIRE(desc && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "x3_planes_many: bad arguments");
+    hipLaunchKernelGGL(x3_planes_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PlanesDesc *)desc, n);
+    return htd::check_launch("x3_planes_many");
 }
 
 extern "C" int64_t htd_conv2d_x3p_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw)

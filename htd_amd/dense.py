@@ -189,6 +189,46 @@ def x3_planes(weight, transposed):
     return planes
 
 
+def _planes_wanted(w, transposed):
+    """Could conv_x3p_kernel take a layer with this weight as its forward (transposed: data-gradient) operand?  Shape test only --
+    stride / padding are not known here; a 3x3 s2 layer's unused image costs one pass over its weights."""
+    Co, Ci, kh, kw = w.shape
+    cred, cout = (Co, Ci) if transposed else (Ci, Co)
+    return w.is_cuda and w.dtype == torch.float32 and kh == kw and kh in (1, 3) and w.is_contiguous(memory_format=CL) and \
+        bool(capi.lib().htd_conv2d_x3p_supported(cred, cout, kh, kw, 1, kh // 2, 1))
+
+
+def planes_many(items):
+    """items: [(weight (Co,Ci,kh,kw) channels_last fp32, transposed)] -> their plane images in ONE launch
+    (htd_conv2d_x3_planes_many), registered for x3_planes() to find.  Entries already made this step are skipped."""
+    import numpy as np
+    todo = []
+    for w, tr in items:
+        w4 = w if w.dim() == 4 else w.view(w.size(0), w.size(1), 1, 1)
+        if _planes_wanted(w4, tr) and _planes_key(w4, tr) not in _STEP_PLANES and not any(_planes_key(w4, tr) == k for k, _, _ in todo):
+            todo.append((_planes_key(w4, tr), w4, tr))
+    if not todo:
+        return
+    L = capi.lib()
+    dev = todo[0][1].device
+    sizes = [L.htd_conv2d_x3_planes_bytes(w.size(0), w.size(2), w.size(3), w.size(1), int(tr)) // 4 for _, w, tr in todo]
+    flat = torch.empty(sum(sizes), device=dev, dtype=torch.int32)
+    desc = np.zeros((len(todo), 5), dtype=np.int64)
+    off = block0 = 0
+    for i, ((key, w, tr), n32) in enumerate(zip(todo, sizes)):
+        out = flat[off:off + n32]
+        off += n32
+        Co, Ci, taps = w.size(0), w.size(1), w.size(2) * w.size(3)
+        desc[i, 0], desc[i, 1] = w.data_ptr(), out.data_ptr()
+        desc[i, 2] = Co | (taps << 32)                  # two int32 per int64 slot (little endian)
+        desc[i, 3] = Ci | (int(tr) << 32)
+        desc[i, 4] = block0
+        block0 += (n32 // 4 // 6 + 255) // 256          # elements = uint4 count / 6 chunks
+        _STEP_PLANES[key] = (w, out)
+    table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+    capi.call('htd_conv2d_x3_planes_many', _P(table), len(todo), block0, _S())
+
+
 def _x3p_ok(Cred, Cout, kh, kw, stride, padding, dilation, dtype):
     return dtype == torch.float32 and bool(capi.lib().htd_conv2d_x3p_supported(Cred, Cout, kh, kw, stride, padding, dilation))
 
@@ -197,12 +237,14 @@ def flip_many(weights):
     """One launch (htd_bn_fold_many_fwd without BN entries) writing the dgrad images of `weights` (Co,Ci,kh,kw)
     channels_last or (Co,Ci) -- picked up by _dgrad_raw through _STEP_FLIPS."""
     import numpy as np
-    ws = []
+    ws, pl = [], []
     for w in weights:
         w4 = w if w.dim() == 4 else w.view(w.size(0), w.size(1), 1, 1)
+        pl += [(w4, False), (w4, True)]
         if w4.is_cuda and w4.dtype == torch.float32 and w4.size(0) % 8 == 0 and w4.is_contiguous(memory_format=CL) and \
-                _flip_key(w4) not in _STEP_FLIPS:
-            ws.append(w4)
+                _flip_key(w4) not in _STEP_FLIPS and not _planes_wanted(w4, True):
+            ws.append(w4)                   # data gradient on conv_igemm_kernel: needs the fp32 flipped image
+    planes_many(pl)                         # conv_x3p_kernel operands (forward and data gradient) of every layer it takes
     if not ws:
         return
     dev = ws[0].device

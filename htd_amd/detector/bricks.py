@@ -173,6 +173,8 @@ class _BNFoldMany(torch.autograd.Function):
             flips.append(wT)
         table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
         capi.call('htd_bn_fold_many_fwd', capi.ptr(table), n, tile0, float(eps), capi.current_stream_ptr())
+        # bf16 plane images of the folded weights (conv_x3p_kernel operands, csrc/conv_x3.hip): one more launch per stage
+        dense.planes_many([(wf, False) for wf in outs[0::2]] + ([(wf, True) for wf in outs[0::2]] if want_flips else []))
         for wf, wT in zip(outs[0::2], flips):
             dense.mark_side_consumed(wf)
             if wT is not None:

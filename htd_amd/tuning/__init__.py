@@ -9,6 +9,7 @@ import json
 import os
 
 TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tiles_gfx950.json')
+X3P_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_x3p_tiles_gfx950.json')      # conv_x3p_kernel (csrc/conv_x3.hip)
 
 
 def read_table(path=TABLE):
@@ -33,4 +34,8 @@ def load(lib, path=TABLE):
     for (M, Co, Ci, taps, epi), cfg in read_table(path).items():
         if lib.htd_conv2d_tile_table_set(M, Co, Ci, taps, epi, cfg) == 0:
             n += 1
+    if path == TABLE:
+        for (M, Co, Ci, taps, epi), cfg in read_table(X3P_TABLE).items():
+            if lib.htd_conv2d_x3p_tile_table_set(M, Co, Ci, taps, epi, cfg) == 0:
+                n += 1
     return n

@@ -234,8 +234,18 @@ int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gb
  *       workspace of htd_conv2d_x3p_workspace_bytes) of htd_conv2d_fwd / htd_conv2d_bwd_data; bwd_data is stride 1 only.
  *       Same arithmetic as the default mode of those (six bf16 MFMAs on exact three-way splits, fp32 accumulation). */
 int htd_conv2d_x3p_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+/* Tile table of conv_x3p_kernel, as htd_conv2d_tile_table_set for conv_igemm_kernel: problem (M, Co, Ci, taps, epi) ->
+ * configuration id (0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases).  htd_amd/tuning loads the table measured on
+ * MI355X by tools/tune_conv_tiles.py --kernel x3p (cudnn_benchmark's role, mmdet/apis/train.py). */
+int htd_conv2d_x3p_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg);
+int htd_conv2d_x3p_tile_table_clear(void);
+int htd_conv2d_x3p_tile_query(int64_t M, int Co, int Ci, int taps, int epi);
 int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, int transposed);
 int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);
+/* The plane images of many weights in one launch.  desc: DEVICE array of n entries
+ *   { const float *w; void *planes; int32 Co, taps, Ci, transposed; int64 block0; }   (40 bytes each)
+ * block0 = prefix sum of ceil(taps * (K / 16) * Np / 256) over the entries (Np = N rounded up to 128), total_blocks its end. */
+int htd_conv2d_x3_planes_many(const void *desc, int n, int64_t total_blocks, void *stream);
 int64_t htd_conv2d_x3p_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw);
 int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const float *bias, const float *residual, int res_h,
                        int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,

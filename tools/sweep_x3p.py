@@ -40,6 +40,8 @@ LAYERS = [  # name, Ci, H, W, Co, k, stride, pad
     ('fc dgrad 1024-12544', 1024, 32, 16, 12544, 1, 1, 0),
 ]
 NAMES = ['auto', '64x64', '128x128', '128x64', '64x128']
+SHAPES = [s for s in os.environ.get('SWEEP_MFMA', '0').split(',')]          # 0: the launcher's choice per filter width
+NBS = [s for s in os.environ.get('SWEEP_NB', '2,3,4').split(',')]           # B buffers (prefetch distance + 1); 0: default
 
 
 def timed(fn, key, flop, n=6):
@@ -70,27 +72,31 @@ def main():
         for name, Ci, H, W, Co, k, s, p in LAYERS:
             if only and only not in name:
                 continue
-            Bn = 28 if 'n=28' in name else (1 if name.startswith('fc') or name.startswith('reg conv 3x3') else B)
+            Bn = 28 if 'n=28' in name else (1 if name.startswith('reg conv 3x3') else B)
             x = torch.randn(Bn, Ci, H, W, device=dev).contiguous(memory_format=CL)
             w = (torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5).contiguous(memory_format=CL)
             os.environ['HTD_X3P_FORCE_TILE'] = '-1'
             y_old = old_fwd(x, w, s, p)
             flop = 2.0 * y_old.numel() * Ci * k * k
             r_old = timed(lambda: old_fwd(x, w, s, p), 'htd_conv2d_fwd', flop)
-            out, err = [], 0.0
-            for cfg in range(-1, 4):
-                os.environ['HTD_X3P_FORCE_TILE'] = str(cfg)
-                y = dense._fwd_raw(x, w, None, None, s, p, 1, False)
-                err = max(err, float((y - y_old).abs().max()))
-                out.append(timed(lambda: dense._fwd_raw(x, w, None, None, s, p, 1, False), 'htd_conv2d_fwd_x3p', flop))
-            os.environ['HTD_X3P_FORCE_TILE'] = '-1'
-            line = f'{name:26s} {flop / 1e9:7.1f} | {r_old:7.1f} | ' + ' '.join(f'{r:8.1f}' for r in out) + \
-                f' | best/old {max(out[1:]) / r_old:.2f} auto/best {out[0] / max(out[1:]):.2f} err {err:.2e}'
-            if s == 1:       # data gradient of the same layer (new kernel, automatic tile)
-                g = torch.randn_like(y_old)
-                r_dg = timed(lambda: dense._dgrad_raw(g, w, x.shape, 1, p, 1), 'htd_conv2d_bwd_data_x3p', flop)
-                line += f' | dgrad {r_dg:6.1f}'
-            print(line, flush=True)
+            for shape, nb in [(a, b) for a in SHAPES for b in NBS]:
+                os.environ['HTD_X3P_MFMA'] = shape
+                os.environ['HTD_X3P_NB'] = nb
+                out, err = [], 0.0
+                for cfg in range(-1, 4):
+                    os.environ['HTD_X3P_FORCE_TILE'] = str(cfg)
+                    y = dense._fwd_raw(x, w, None, None, s, p, 1, False)
+                    err = max(err, float((y - y_old).abs().max()))
+                    out.append(timed(lambda: dense._fwd_raw(x, w, None, None, s, p, 1, False), 'htd_conv2d_fwd_x3p', flop))
+                os.environ['HTD_X3P_FORCE_TILE'] = '-1'
+                line = f'{name:22s} m{shape:2s} nb{nb} {flop / 1e9:7.1f} | {r_old:7.1f} | ' + ' '.join(f'{r:8.1f}' for r in out) + \
+                    f' | best/old {max(out[1:]) / r_old:.2f} auto/best {out[0] / max(out[1:]):.2f} err {err:.2e}'
+                if s == 1:       # data gradient of the same layer (new kernel, automatic tile)
+                    g = torch.randn_like(y_old)
+                    r_dg = timed(lambda: dense._dgrad_raw(g, w, x.shape, 1, p, 1), 'htd_conv2d_bwd_data_x3p', flop)
+                    line += f' | dgrad {r_dg:6.1f}'
+                print(line, flush=True)
+            os.environ['HTD_X3P_MFMA'] = os.environ['HTD_X3P_NB'] = '0'
 
 
 if __name__ == '__main__':

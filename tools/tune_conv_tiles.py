@@ -15,16 +15,24 @@ import re
 import sys
 
 os.environ['HTD_CONV_TUNE'] = '1'
+os.environ['HTD_X3P_TUNE'] = '1'
 os.environ['HTD_CONV_TABLE'] = '0'          # start from the heuristic; the table is applied by hand below
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-KEY = re.compile(r'^(htd_conv2d_fwd|htd_conv2d_bwd_data)\(([-\d,]+)\)\[([01]+)\]$')
+KEY = re.compile(r'^(htd_conv2d_fwd|htd_conv2d_bwd_data|htd_conv2d_fwd_x3p|htd_conv2d_bwd_data_x3p)\(([-\d,]+)\)\[([01]+)\]$')
 
 
 def signature(name, ints, mask):
     """(M, Co, Ci, taps, epi) as conv_fwd.hip::launch_conv keys the launch, or None when the table does not apply."""
+    if name == 'htd_conv2d_fwd_x3p':         # conv_x3.hip::launch_x3p
+        res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, relu = ints
+        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        return (B * Ho * Wo, Co, Ci, kh * kw, int(mask[3] == '1'))
+    if name == 'htd_conv2d_bwd_data_x3p':
+        B, H, W, Ci, Co, kh, kw, pad = ints
+        return (B * H * W, Ci, Co, kh * kw, int(mask[3] == '1') | (int(mask[2] == '1') << 1))
     if name == 'htd_conv2d_fwd':
         res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, dil, relu = ints
         Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
@@ -46,6 +54,8 @@ def main():
     ap.add_argument('--trained-like', action='store_true')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--margin', type=float, default=0.02)
+    ap.add_argument('--kernel', default='igemm', choices=('igemm', 'x3p'),
+                    help='igemm: conv_igemm_kernel (conv_tiles_gfx950.json); x3p: conv_x3p_kernel (conv_x3p_tiles_gfx950.json)')
     ap.add_argument('--dry', action='store_true', help='measure and print, do not write the table')
     ap.add_argument('--table', default=None, help='table file to merge into (default: the in-tree one)')
     args = ap.parse_args()
@@ -74,10 +84,16 @@ def main():
         def step():
             trainer.train_step(data)
 
-    only = ('htd_conv2d_fwd', 'htd_conv2d_bwd_data')
+    x3p = args.kernel == 'x3p'
+    only = ('htd_conv2d_fwd_x3p', 'htd_conv2d_bwd_data_x3p') if x3p else ('htd_conv2d_fwd', 'htd_conv2d_bwd_data')
+    ids = (0, 1, 2, 3) if x3p else (0, 2, 3, 4, 5)
+    force = 'HTD_X3P_FORCE_TILE' if x3p else 'HTD_CONV_FORCE_TILE'
+    query = L.htd_conv2d_x3p_tile_query if x3p else L.htd_conv2d_tile_query
+    default_table = tuning.X3P_TABLE if x3p else tuning.TABLE
+    L.htd_conv2d_x3p_tile_table_clear()
     times = {}                               # cfg -> {signature: [total_ms, calls]}
-    for cfg_id in (-1, 0, 2, 3, 4, 5):
-        os.environ['HTD_CONV_FORCE_TILE'] = str(cfg_id)
+    for cfg_id in (-1, ) + ids:
+        os.environ[force] = str(cfg_id)
         step()
         capi.profile_begin(detail=True, only=only)
         for _ in range(args.steps):
@@ -85,7 +101,7 @@ def main():
         per = {}
         for key, (calls, ms, *_rest) in capi.profile_end().items():
             m = KEY.match(key)
-            if not m:
+            if not m or m.group(1) not in only:
                 continue
             sig = signature(m.group(1), [int(v) for v in m.group(2).split(',')], m.group(3))
             if sig is None:
@@ -96,18 +112,18 @@ def main():
         times[cfg_id] = per
         print(f'# cfg {cfg_id:2d}: {sum(v[0] for v in per.values()) / args.steps:8.2f} ms of tabled conv time per step',
               flush=True)
-    os.environ['HTD_CONV_FORCE_TILE'] = '-1'
-    path = args.table or tuning.TABLE
-    table = tuning.read_table(path if os.path.exists(path) else tuning.TABLE)
+    os.environ[force] = '-1'
+    path = args.table or default_table
+    table = tuning.read_table(path if os.path.exists(path) else default_table)
     gained = 0.0
-    print(f'{"M":>8s} {"Co":>5s} {"Ci":>5s} taps epi | {"auto":>8s} ' + ' '.join(f'{"cfg" + str(c):>8s}' for c in (0, 2, 3, 4, 5)) +
+    print(f'{"M":>8s} {"Co":>5s} {"Ci":>5s} taps epi | {"auto":>8s} ' + ' '.join(f'{"cfg" + str(c):>8s}' for c in ids) +
           ' | pick   us/call')
     for sig in sorted(times[-1], key=lambda s_: -times[-1][s_][0]):
         auto_ms, calls = times[-1][sig]
-        auto_cfg = L.htd_conv2d_tile_query(*sig)
+        auto_cfg = query(*sig)
         cand = {}
-        for c in (0, 2, 3, 4, 5):
-            if sig[1] <= 64 and c in (3, 5):
+        for c in ids:
+            if not x3p and sig[1] <= 64 and c in (3, 5):
                 continue                     # bn = 128 on a narrow output: never
             if sig in times[c]:
                 cand[c] = times[c][sig][0]
@@ -119,11 +135,11 @@ def main():
         elif sig in table:
             del table[sig]                   # the score already picks (about) the best: no entry needed
         print(f'{sig[0]:8d} {sig[1]:5d} {sig[2]:5d} {sig[3]:4d} {sig[4]:3d} | {auto_ms / calls * 1e3:8.1f} ' +
-              ' '.join(f'{cand[c] / calls * 1e3:8.1f}' if c in cand else f'{"-":>8s}' for c in (0, 2, 3, 4, 5)) +
+              ' '.join(f'{cand[c] / calls * 1e3:8.1f}' if c in cand else f'{"-":>8s}' for c in ids) +
               f' | {("cfg" + str(pick)) if pick is not None else "auto=" + str(auto_cfg):7s} x{calls // args.steps}')
     print(f'# expected gain over the score-based choice: {gained:.2f} ms per step; table now has {len(table)} entries')
     if not args.dry:
-        tuning.write_table(table, meta=dict(device='MI355X (gfx950)', tool='tools/tune_conv_tiles.py',
+        tuning.write_table(table, meta=dict(device='MI355X (gfx950)', tool='tools/tune_conv_tiles.py' + (' --kernel x3p' if x3p else ''),
                                             note='tile id per (M,Co,Ci,taps,epi); see include/htd_amd.h'), path=path)
 
 
