@@ -82,14 +82,15 @@ def check(status, what=''):
 # measured inside the timed region itself.  `work` = (kind, amount): algorithmic FLOPs ('flop') or bytes
 # ('byte') of that call, summed per entry point for the roofline line.
 _PROFILE = None
+_PAUSED = False
 
 
 _DETAIL = False
 
 
 def profiling():
-    """True while bench.py's per-call device-event timing is active (calls must then stay on one stream)."""
-    return _PROFILE is not None
+    """True while bench.py's per-call device-event timing is active and not paused (calls must then stay on one stream)."""
+    return _PROFILE is not None and not _PAUSED
 
 
 _ONLY = None

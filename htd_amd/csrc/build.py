@@ -12,7 +12,7 @@ LIB = os.path.join(os.path.dirname(HERE), 'libhtd_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
-          '-fhip-fp32-correctly-rounded-divide-sqrt']
+          '-fhip-fp32-correctly-rounded-divide-sqrt'] + os.environ.get('HTD_EXTRA_HIPCC', '').split()      # experiment builds (-D...)
 # per-file extra flags: NMS keeps the CPU path's unfused arithmetic (bit-exact keep sets)
 EXTRA = {'nms.hip': ['-ffp-contract=off'], 'box_ops.hip': ['-ffp-contract=off'],
          'image_pipeline.hip': ['-ffp-contract=off']}

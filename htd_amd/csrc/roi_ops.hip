@@ -702,6 +702,48 @@ __global__ __launch_bounds__(256) void max_pool_bwd_kernel(const float *__restri
 
 }  // namespace
 
+namespace {
+// Gradient of nearest-neighbour up-sampling (the FPN top-down sum, necks/fpn.py:177-186, fused into the lateral convolution's
+// epilogue in the forward pass): out[b][rh][rw][:] = sum of g[b][ho][wo][:] over the fine pixels whose source is (rh, rw)
+// under ATen's rule  source = min(floor(dst * in / out), in - 1).  One thread per coarse pixel and float4 of channels; the
+// candidate fine rows / columns are tested with that very expression, so odd sizes agree with the forward bit for bit.
+__global__ __launch_bounds__(256) void upsample_nearest_bwd_kernel(const float4 *__restrict__ g, float4 *__restrict__ out, int B,
+                                                                   int H, int W, int h, int w, int C4, float sh, float sw)
+{
+    const int64_t total = (int64_t)B * h * w * C4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        int64_t t = e / C4;
+        const int rw = (int)(t % w);
+        t /= w;
+        const int rh = (int)(t % h), b = (int)(t / h);
+        const int ho0 = max(0, (int)floorf(rh / sh) - 1), ho1 = min(H - 1, (int)ceilf((rh + 1) / sh) + 1);
+        const int wo0 = max(0, (int)floorf(rw / sw) - 1), wo1 = min(W - 1, (int)ceilf((rw + 1) / sw) + 1);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ho = ho0; ho <= ho1; ++ho) {
+            if (min((int)floorf(ho * sh), h - 1) != rh) continue;
+            for (int wo = wo0; wo <= wo1; ++wo) {
+                if (min((int)floorf(wo * sw), w - 1) != rw) continue;
+                const float4 v = g[(((int64_t)b * H + ho) * W + wo) * C4 + c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        out[e] = acc;
+    }
+}
+}  // namespace
+
+// g [B][H][W][C] (fine) -> out [B][h][w][C] (coarse); replaces aten::upsample_nearest2d_backward on the FPN top-down path
+extern "C" int htd_upsample_nearest_bwd(const float *g, float *out, int B, int H, int W, int h, int w, int C, void *stream)
+{
+    HTD_REQUIRE(g && out && B > 0 && H > 0 && W > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "upsample_nearest_bwd: bad arguments");
+    const int64_t total = (int64_t)B * h * w * (C / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 65536);
+    hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)g,
+                       (float4 *)out, B, H, W, h, w, C / 4, (float)h / (float)H, (float)w / (float)W);
+    return htd::check_launch("upsample_nearest_bwd");
+}
+
 extern "C" int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride,
                                   int pad, void *stream)
 {

@@ -112,10 +112,12 @@ def grad_out2(like):
 # instead of leaving CUs idle.  Rules: the side stream waits for the main stream before every launch (operands ready);
 # a result that autograd will consume on the main stream (not a flat-buffer sink, not an input of a BN fold that itself
 # runs on the side stream) makes the main stream wait at once; runner joins the streams after backward.
-# Measured (HTD-R50, B=4): 75.2 -> 74.0 ms per step, while every overlapped kernel's own duration grows (they share
-# the CUs), which blurs the per-kernel roofline timing of bench.py -- so it is opt-in: HTD_OVERLAP_WGRAD=1.
-OVERLAP_WGRAD = bool(int(__import__('os').environ.get('HTD_OVERLAP_WGRAD', '0')))
-_OVERLAP_IN_PROFILE = True
+# Measured (HTD-R50, B=4): round 1 75.2 -> 74.0 ms per step, round 3 91.2 -> 92.5..93.2 img/s.  Every overlapped kernel's own
+# duration grows (they share the CUs), which would blur the per-kernel roofline timing of bench.py: on the steps whose calls
+# are bracketed by device events (capi.profiling(): every 4th step of the timed region) the weight gradients stay on the
+# main stream, so a kernel's measured duration is its duration alone on the chip.  HTD_OVERLAP_WGRAD=0 switches it off.
+OVERLAP_WGRAD = bool(int(__import__('os').environ.get('HTD_OVERLAP_WGRAD', '1')))
+_OVERLAP_IN_PROFILE = False
 _SIDE = {}
 _SIDE_CONSUMED = set()          # data_ptr of folded weights whose gradient is consumed by _BNFold.backward (side stream)
 
@@ -460,7 +462,10 @@ class Conv2dFunction(Function):
         if has_res and need_r:
             gr = g
             if ctx.res_up is not None:      # residual came in through nearest up-sampling: sum the gradient back down
-                gr = torch.ops.aten.upsample_nearest2d_backward(g, [g.size(2), g.size(3)], list(ctx.res_up), None, None)
+                rB, rC, rh, rw = ctx.res_up
+                gr = torch.empty((rB, rC, rh, rw), device=g.device, dtype=g.dtype, memory_format=CL)
+                capi.call('htd_upsample_nearest_bwd', _P(g), _P(gr), rB, g.size(2), g.size(3), rh, rw, rC, _S(),
+                          work=('byte', 4.0 * (g.numel() + gr.numel())))
         return gx, gw, (gb if (has_bias and need_b) else None), gr, None, None, None, None, None, None
 
 

@@ -367,6 +367,10 @@ int htd_rpn_loss(const float *cls, const float *reg, const float *anchors, const
  * x [B][H][W][C] -> y [B][Ho][Wo][C], C % 4 == 0, padding = -inf, floor mode.  idx (may be NULL for inference; int32
  * [B][Ho][Wo][C]) records the input pixel hi*W+wi of the first maximum of each window; bwd sends the gradient there
  * (gather form, no atomics). */
+/* Gradient of the nearest-neighbour up-sampling of the FPN top-down path (necks/fpn.py:177-186; its forward lives in the
+ * lateral convolution's epilogue, htd_conv2d_fwd res_h / res_w): out [B][h][w][C] = sum of g [B][H][W][C] over the fine pixels
+ * whose source pixel it is under ATen's rule min(floor(dst * in / out), in - 1).  C % 4 == 0. */
+int htd_upsample_nearest_bwd(const float *g, float *out, int B, int H, int W, int h, int w, int C, void *stream);
 int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride, int pad,
                        void *stream);
 int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, int W, int C, int k, int stride,

@@ -18,15 +18,19 @@ data = synthetic_batch(4, device=dev)
 for _ in range(3):
     tr.train_step(data)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+STACK = '--stack' in sys.argv          # also print the Python frames of the top groups (which module launches them)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=STACK) as prof:
     tr.train_step(data)
     torch.cuda.synchronize()
 rows = []
-for e in prof.key_averages(group_by_input_shape=True):
+for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6 if STACK else 0):
     if e.key.startswith('aten::') and e.self_device_time_total > 0:
-        rows.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:90]))
-rows.sort(reverse=True)
+        frames = [f for f in (getattr(e, 'stack', None) or []) if 'htd_amd' in f or 'bench' in f][:3]
+        rows.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:90], frames))
+rows.sort(reverse=True, key=lambda r: r[0])
 tot = sum(r[0] for r in rows)
-print('ATen self device time: %.3f ms in %d op groups' % (tot / 1e3, len(rows)))
-for t, n, k, sh in rows[:45]:
+print('ATen self device time: %.3f ms in %d op groups, %d launches' % (tot / 1e3, len(rows), sum(r[1] for r in rows)))
+for t, n, k, sh, frames in rows[:int(os.environ.get('ATEN_TOP', '70'))]:
     print('%8.1f us %4d  %-28s %s' % (t, n, k, sh))
+    for f in frames:
+        print('              ' + f.replace(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + '/', '')[:150])

@@ -38,5 +38,5 @@ for e in ops:
     by_frame[frame] += 1
     by_frame_ops[frame][e.name] += 1
 print('top-level aten ops', len(ops))
-for f, n in by_frame.most_common(45):
-    print(f'{n:5d}  {f[:90]:90s} ' + ', '.join(f'{k[6:]}x{v}' for k, v in by_frame_ops[f].most_common(4)))
+for f, n in by_frame.most_common(110):
+    print(f'{n:5d}  {f[:90]:90s} ' + ', '.join(f'{k[6:]}x{v}' for k, v in by_frame_ops[f].most_common(6)))
