@@ -220,6 +220,75 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// out_y[c] = sum over `rows` rows of ws[y * rows + r][c], y = blockIdx.y in {0, 1} (out0 / out1): few columns, many rows.  A
+// workgroup takes 16 columns and spreads the rows over 16 thread groups, folded through LDS in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float *__restrict__ ws, float *__restrict__ out0,
+                                                          float *__restrict__ out1, int n, int rows)
+{
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + col;
+    const float *src = ws + (int64_t)blockIdx.y * rows * n;
+    float s = 0.f;
+    if (c < n)
+        for (int k = grp; k < rows; k += 16) s += src[(int64_t)k * n + c];
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && c < n) {
+        float t = red[0][col];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][col];
+        (blockIdx.y ? out1 : out0)[c] = t;
+    }
+}
+
+// Bit-reproducible form of fuse_global_bwd: (1) tile[i][c] = sum_p grad[i][p][c], one workgroup per RoI, the four waves take
+// every fourth tile position and meet in LDS in a fixed order; (2) gg[b][c] = sum of tile[i][c] over the RoIs of image b in
+// ascending i (the RoI list need not be grouped by image).  No float atomics: the gradient of the SFA feature -- and with it
+// everything upstream of P6 -- is the same on every run.
+__global__ __launch_bounds__(256) void roi_tile_sums_kernel(const float *__restrict__ grad, float *__restrict__ tile, int P,
+                                                            int C4)
+{
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x;
+    for (int c0 = 0; c0 < C4; c0 += 64) {
+        const int c4 = c0 + lane;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 < C4) {
+            const float4 *p = reinterpret_cast<const float4 *>(grad) + (i * P) * C4 + c4;
+            for (int q = wave; q < P; q += 4) {
+                const float4 v = p[(int64_t)q * C4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        red[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && c4 < C4) {
+            float4 t = red[0][lane];
+            for (int w = 1; w < 4; ++w) { t.x += red[w][lane].x; t.y += red[w][lane].y; t.z += red[w][lane].z; t.w += red[w][lane].w; }
+            reinterpret_cast<float4 *>(tile)[i * C4 + c4] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void image_sums_kernel(const float *__restrict__ tile, const float *__restrict__ rois,
+                                                        float *__restrict__ gg, int64_t n, int C4, int B)
+{
+    const int b = blockIdx.x, c4 = blockIdx.y * 64 + threadIdx.x;
+    if (c4 >= C4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = 0; i < n; ++i) {
+        int rb = (int)rois[5 * i];
+        rb = rb < 0 ? 0 : (rb >= B ? B - 1 : rb);
+        if (rb != b) continue;                      // uniform across the workgroup
+        const float4 v = reinterpret_cast<const float4 *>(tile)[i * C4 + c4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4 *>(gg)[(int64_t)b * C4 + c4] = acc;
+}
+
 // ------------------------------------------------------------------ GroupNorm (+ReLU)
 // One block per RoI tile; thread = channel, so a group's `cpg` channels sit on adjacent
 // lanes and the group statistics are a segmented wave reduction (cpg must divide 64).
@@ -254,7 +323,8 @@ __global__ void gn_fwd_kernel(const float *__restrict__ x, const float *__restri
 __global__ void gn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
                               const float *__restrict__ gamma, const float *__restrict__ mean,
                               const float *__restrict__ rstd, const float *__restrict__ gy, float *__restrict__ gx,
-                              float *__restrict__ ggamma, float *__restrict__ gbeta, int P, int C, int G, int relu)
+                              float *__restrict__ ggamma, float *__restrict__ gbeta, int P, int C, int G, int relu,
+                              float *__restrict__ partial)
 {
     const int64_t i = blockIdx.x;
     const int c = threadIdx.x;
@@ -272,7 +342,17 @@ __global__ void gn_bwd_kernel(const float *__restrict__ x, const float *__restri
             sg += d;
             sgx += d * (xp[(int64_t)q * C] - mu) * rs;
         }
-    if (act) { atomicAdd(ggamma + c, sgx); atomicAdd(gbeta + c, sg); }
+    // partial != NULL: this tile's sums go to partial[tile][c] (gamma) and partial[n + tile][c] (beta), added up in a fixed
+    // order by colsum_rows_kernel -- bit-reproducible; NULL: float atomics into ggamma / gbeta (htd_group_norm_relu_bwd)
+    if (act) {
+        if (partial) {
+            partial[i * C + c] = sgx;
+            partial[((int64_t)gridDim.x + i) * C + c] = sg;
+        } else {
+            atomicAdd(ggamma + c, sgx);
+            atomicAdd(gbeta + c, sg);
+        }
+    }
     float a = sg * ga, b = sgx * ga;
     for (int o = 1; o < cpg; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
     const float m = 1.f / (float)(P * cpg);
@@ -491,6 +571,24 @@ extern "C" int htd_fuse_global_bwd_global(const float *grad, const float *rois, 
     return htd::check_launch("fuse_global_bwd");
 }
 
+// Bit-reproducible form (no float atomics): grad_global [B][C] is OVERWRITTEN; workspace holds n * C floats; C % 4 == 0.
+extern "C" int htd_fuse_global_bwd_global_ws(const float *grad, const float *rois, float *grad_global, int64_t n, int P,
+                                             int C, int B, void *workspace, void *stream)
+{
+    HTD_REQUIRE(P > 0 && C > 0 && B > 0 && n >= 0 && (C & 3) == 0, "fuse_global_bwd_ws: bad sizes");
+    HTD_REQUIRE(grad_global, "fuse_global_bwd_ws: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        hipMemsetAsync(grad_global, 0, (size_t)B * C * 4, s);
+        return HTD_OK;
+    }
+    HTD_REQUIRE(grad && rois && workspace, "fuse_global_bwd_ws: null pointer");
+    hipLaunchKernelGGL(roi_tile_sums_kernel, dim3((unsigned)n), dim3(256), 0, s, grad, (float *)workspace, P, C / 4);
+    hipLaunchKernelGGL(image_sums_kernel, dim3((unsigned)B, (unsigned)htd::ceil_div(C / 4, 64)), dim3(64), 0, s,
+                       (const float *)workspace, rois, grad_global, n, C / 4, B);
+    return htd::check_launch("fuse_global_bwd_ws");
+}
+
 extern "C" int htd_ba_fuse_fwd(const float *const *lvl, int L, const float *border, const float *att, float *out,
                                int64_t n, int ph, int pw, int C, int edge, void *stream)
 {
@@ -569,8 +667,35 @@ extern "C" int htd_group_norm_relu_bwd(const float *x, const float *y, const flo
     HTD_REQUIRE(x && y && gamma && mean && rstd && gy && gx && ggamma && gbeta, "group_norm_bwd: null pointer");
     const int threads = (int)htd::ceil_div(C, 64) * 64;
     hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, y, gamma, mean,
-                       rstd, gy, gx, ggamma, gbeta, P, C, G, relu);
+                       rstd, gy, gx, ggamma, gbeta, P, C, G, relu, (float *)nullptr);
     return htd::check_launch("group_norm_bwd");
+}
+
+// The same with bit-reproducible parameter gradients: per-tile sums go through `workspace` (2 * n * C floats) and are
+// added in a fixed order; ggamma / gbeta are overwritten (no zero-initialisation needed).
+extern "C" int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const float *gamma, const float *mean,
+                                          const float *rstd, const float *gy, float *gx, float *ggamma, float *gbeta,
+                                          int64_t n, int P, int C, int G, int relu, void *workspace, void *stream)
+{
+    HTD_REQUIRE(G > 0 && C % G == 0, "group_norm: C=%d not divisible by G=%d", C, G);
+    const int cpg = C / G;
+    HTD_REQUIRE(cpg <= 64 && (cpg & (cpg - 1)) == 0, "group_norm: channels/group=%d must be a power of two <= 64", cpg);
+    HTD_REQUIRE(C <= 1024, "group_norm: C=%d > 1024", C);
+    HTD_REQUIRE(ggamma && gbeta, "group_norm_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        hipMemsetAsync(ggamma, 0, (size_t)C * 4, s);
+        hipMemsetAsync(gbeta, 0, (size_t)C * 4, s);
+        return HTD_OK;
+    }
+    HTD_REQUIRE(x && y && gamma && mean && rstd && gy && gx && workspace, "group_norm_bwd: null pointer");
+    const int threads = (int)htd::ceil_div(C, 64) * 64;
+    float *ws = (float *)workspace;
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)n), dim3(threads), 0, s, x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta,
+                       P, C, G, relu, ws);
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)htd::ceil_div(C, 16), 2), dim3(256), 0, s, (const float *)ws, ggamma,
+                       gbeta, C, (int)n);
+    return htd::check_launch("group_norm_bwd_ws");
 }
 
 extern "C" int htd_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, int64_t n,

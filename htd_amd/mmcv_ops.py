@@ -378,11 +378,22 @@ class FuseGlobalFunction(Function):
         n, C, ph, pw = go.shape
         gg = None
         if ctx.needs_input_grad[2]:
-            gg = torch.zeros(gshape[0], C, device=go.device, dtype=go.dtype)
-            capi.call('htd_fuse_global_bwd_global', _P(go), _P(rois), _P(gg), n, ph * pw, C, gshape[0], _S())
-            gg = gg.view(gshape)
+            gg = _fuse_global_grad(go, rois, n, ph * pw, C, gshape[0]).view(gshape)
         ge = go * alpha if (has_extra and ctx.needs_input_grad[3]) else None
         return go, None, gg, ge, None
+
+
+def _fuse_global_grad(go, rois, n, P, C, B):
+    """grad_global [B, C] = per-image sums of the RoI tile gradients: the bit-reproducible two-pass kernel (no float atomics)."""
+    gg = torch.empty(B, C, device=go.device, dtype=go.dtype)
+    if C % 4 == 0:
+        ws = torch.empty(max(n, 1) * C, device=go.device, dtype=go.dtype)
+        capi.call('htd_fuse_global_bwd_global_ws', _P(go), _P(rois), _P(gg), n, P, C, B, _P(ws), _S())
+    else:
+        gg.zero_()
+        if n:
+            capi.call('htd_fuse_global_bwd_global', _P(go), _P(rois), _P(gg), n, P, C, B, _S())
+    return gg
 
 
 class PlainAndFusedFunction(Function):
@@ -417,10 +428,7 @@ class PlainAndFusedFunction(Function):
         C, ph, pw = go.shape[1:]
         gg = None
         if ctx.needs_input_grad[2]:
-            gg = torch.zeros(gshape[0], C, device=go.device, dtype=go.dtype)
-            if n:
-                capi.call('htd_fuse_global_bwd_global', _P(go[n:]), _P(rois), _P(gg), n, ph * pw, C, gshape[0], _S())
-            gg = gg.view(gshape)
+            gg = _fuse_global_grad(go[n:], rois, n, ph * pw, C, gshape[0]).view(gshape)
         gx = torch.add(go[:n], go[n:]) if ctx.needs_input_grad[0] else None
         return gx, None, gg
 
@@ -528,10 +536,11 @@ class GroupNormReLUFunction(Function):
         n, C, h, w = x.shape
         gy = nhwc(gy)
         gx = torch.empty_like(x, memory_format=CL)
-        gw = torch.zeros_like(weight)
-        gb = torch.zeros_like(weight)
-        capi.call('htd_group_norm_relu_bwd', _P(x), _P(y), _P(weight), _P(mean), _P(rstd), _P(gy), _P(gx), _P(gw),
-                  _P(gb), n, h * w, C, G, relu, _S())
+        gw = torch.empty_like(weight)
+        gb = torch.empty_like(weight)
+        ws = torch.empty(2 * max(n, 1) * C, device=x.device, dtype=torch.float32)      # per-tile sums, added in a fixed order
+        capi.call('htd_group_norm_relu_bwd_ws', _P(x), _P(y), _P(weight), _P(mean), _P(rstd), _P(gy), _P(gx), _P(gw),
+                  _P(gb), n, h * w, C, G, relu, _P(ws), _S())
         return gx, gw, gb, None, None, None
 
 

@@ -300,6 +300,15 @@ int htd_group_norm_relu_fwd(const float *x, const float *gamma, const float *bet
 int htd_group_norm_relu_bwd(const float *x, const float *y, const float *gamma, const float *mean,
                             const float *rstd, const float *gy, float *gx, float *ggamma,
                             float *gbeta, int64_t n, int P, int C, int G, int relu, void *stream);
+/* Bit-reproducible forms of the two backward passes that summed with float atomics (their run-to-run rounding differences
+ * reached every parameter upstream of P6 and made two ranks' replicas drift apart in the last bit): per-tile sums go through a
+ * caller-owned workspace and are added in a fixed order.  htd_group_norm_relu_bwd_ws: workspace 2 * n * C floats, ggamma /
+ * gbeta overwritten.  htd_fuse_global_bwd_global_ws: workspace n * C floats, grad_global [B][C] overwritten, C % 4 == 0. */
+int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const float *gamma, const float *mean, const float *rstd,
+                               const float *gy, float *gx, float *ggamma, float *gbeta, int64_t n, int P, int C, int G,
+                               int relu, void *workspace, void *stream);
+int htd_fuse_global_bwd_global_ws(const float *grad, const float *rois, float *grad_global, int64_t n, int P, int C, int B,
+                                  void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Frozen-statistics BatchNorm (norm_eval=True, backbones/resnet.py:640-649) folded into the preceding
