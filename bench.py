@@ -223,6 +223,13 @@ def main():
         print(json.dumps(cpu_baseline(args.depth, args.height, args.width, full=True, dcn=args.dcn)))
         return
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP ops have no CPU path)'
+    # HTD_BENCH_BACKEND=gloo HTD_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a ONE-GPU box (tests/test_gpu_distributed.py):
+    # every rank runs the real detector on cuda:0 and the exchange goes over gloo instead of RCCL -- rank-0 broadcast, autograd
+    # hooks + side stream, packed log all-reduce, barrier, MAX-over-ranks timing and the JSON line are the code of the real run.
+    backend = os.environ.get('HTD_BENCH_BACKEND', 'nccl')
+    share_gpu = backend == 'gloo' and bool(int(os.environ.get('HTD_BENCH_SHARE_GPU', '0')))
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     # HTD_REHEARSE_RCCL=1: initialise RCCL and run the bucketed gradient exchange even with ONE rank -- the only way
@@ -233,7 +240,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     n_ranks = dist.get_world_size() if dist.is_initialized() else 1      # what RCCL actually sees
     if n_ranks != args.gpus and not rehearse:
         raise SystemExit(f'bench.py: process group has {n_ranks} ranks, --gpus says {args.gpus}')
@@ -354,6 +364,10 @@ def main():
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}'},
         'roofline': roof,
     }
+    if backend != 'nccl' and world > 1:
+        out['rehearsal'] = f'{backend} backend' + (f', {world} ranks sharing cuda:0' if share_gpu else '') + \
+            ': exercises the rank protocol, NOT a multi-GPU measurement'
+
     if not args.infer and hasattr(model.roi_head, '_last_static'):
         # how much of the HTD regression branch (3x3 256->576->576->576->1024 on 7x7, htd_bbox_head.py:77-113) the timed
         # step contained: it runs on stage-2 positives only (1.2355 GFLOP forward per positive RoI)
