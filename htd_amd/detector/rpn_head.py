@@ -419,6 +419,7 @@ class RPNHead(nn.Module):
             # anchor each of them is (flat index over the levels); entries past n_keep[b] are meaningless
             self._last_proposal_trail = (order, torch.gather(torch.cat(flat_ids, 1), 1, order), n_keep)
             self._last_candidates = (proposals, scores, ids)        # what the NMS stage was fed: (B,K,4), (B,K), (K,)
+            self._last_candidate_anchors = torch.cat(flat_ids, 1)   # (B,K): flat anchor index of every candidate
         boxes = torch.gather(proposals, 1, order[..., None].expand(-1, -1, 4))
         dets = torch.cat([boxes, top[:, :cfg.nms_post, None]], -1)
         if padded:

@@ -165,7 +165,8 @@ def rpn_loss(cls_scores, bbox_preds, gt_bboxes, img_metas, cfg, strides):
 
 def rpn_get_bboxes(cls_scores, bbox_preds, img_metas, pcfg, cfg, strides, trace=None):
     """AnchorHead.get_bboxes anchor_head.py:491-579 + RPNHead._get_bboxes_single rpn_head.py:78-168.
-    trace (list): per image (keep rows of the level-concatenated candidate list, flat anchor index of each kept box)."""
+    trace (list): per image (keep rows of the level-concatenated candidate list, flat anchor index of each kept box,
+    then what the NMS was fed: decoded candidate boxes, scores, level ids, flat anchor index of every candidate)."""
     sizes = [c.shape[-2:] for c in cls_scores]
     level_off = [0]
     for c in cls_scores:
@@ -197,7 +198,8 @@ def rpn_get_bboxes(cls_scores, bbox_preds, img_metas, pcfg, cfg, strides, trace=
             flat_l = [torch.cat(flat_l)[v]]
         dets, keep = ops.batched_nms(proposals, scores, ids, dict(type='nms', iou_threshold=pcfg['nms_thr']))
         if trace is not None:
-            trace.append((keep[:pcfg['nms_post']], torch.cat(flat_l)[keep[:pcfg['nms_post']]]))
+            trace.append((keep[:pcfg['nms_post']], torch.cat(flat_l)[keep[:pcfg['nms_post']]], proposals, scores, ids,
+                          torch.cat(flat_l)))
         results.append(dets[:pcfg['nms_post']])
     return results
 

@@ -73,7 +73,7 @@ def test_train_step_matches_reference_fixture(det, golden):
     params = dict(det.named_parameters())
     for k in [f[5:-5] for f in g.files if f.startswith('grad.') and f.endswith('.sums')]:
         gr = params[k].grad if params[k].grad is not None else torch.zeros_like(params[k])
-        check_digest(g, 'grad.' + k, gr, rtol=1e-2, atol=2e-3)
+        check_digest(g, 'grad.' + k, gr, rtol=1e-3, atol=2e-4)
 
 
 def test_inference_matches_reference_fixture(det, golden):
@@ -90,7 +90,8 @@ def test_inference_matches_reference_fixture(det, golden):
     for i in range(2):
         ref_p = g[f'test_props{i}']
         assert props[i].shape == ref_p.shape
-        np.testing.assert_allclose(props[i].cpu().numpy(), ref_p, rtol=1e-4, atol=2e-3)
+        # own RPN logits (within 1e-4 of the reference's) through exp() and anchors of up to 362 px: measured 1.1e-3 px
+        np.testing.assert_allclose(props[i].cpu().numpy(), ref_p, rtol=1e-5, atol=2e-3)
         mine = np.concatenate([np.concatenate([r, np.full((len(r), 1), c, dtype=np.float32)], 1)
                                for c, r in enumerate(res[i])], 0)
         ref = g[f'test_dets{i}']
@@ -100,7 +101,7 @@ def test_inference_matches_reference_fixture(det, golden):
         for r in ref:
             d = np.abs(mine[:, :5] - r[:5]).max(1) + 1e3 * (mine[:, 5] != r[5]) + 1e3 * used
             j = int(d.argmin())
-            assert d[j] <= 1e-2 + 1e-3 * np.abs(r[:4]).max(), (r, mine[j], d[j])
+            assert d[j] <= 1e-3 + 1e-5 * np.abs(r[:4]).max(), (r, mine[j], d[j])
             used[j] = True
 
 
@@ -265,6 +266,68 @@ def test_train_step_matches_oracle_other_seed(det):
         a = a.reshape(b.shape)                           # TileLinear keeps its (out, C*h*w) matrix as (out, C, h, w)
         scale = max(b.abs().max().item(), 1e-6)
         assert (a - b).abs().max().item() <= 2e-3 * scale + 1e-6, (k, (a - b).abs().max().item(), scale)
+
+
+def test_train_step_b3_end_to_end_against_the_oracle(det):
+    """B = 3 END TO END (every B >= 3 comparison fed the RoI head the oracle's proposals and sample picks): product
+    RPN -> product proposals -> product assigner / sampler (the CPU generator replayed) -> both RoI stages with
+    the generalised stage-2 positives, against the oracle's forward_train on the same inputs and seed.  When the proposal
+    lists agree row for row the samples are the same and losses / gradients must agree like in the B = 2 fixture test; rows may
+    differ only where two candidates' scores sit within one ulp of each other (device sigmoid vs host sigmoid reorders them:
+    tests/test_gpu_configs.py::test_r101_inference_512_proposals_against_the_oracle proves that cause) -- then the kept sets
+    must still share all but a few boxes and the losses agree to the looser bound a handful of swapped samples allow."""
+    from oracle import detector as D
+    dev = torch.device('cuda:0')
+    H, W, B = 96, 160, 3
+    imgs, gts, labels = demo_inputs(B, H, W, np.random.RandomState(11))
+    imgs = (imgs - 0.5) * 4
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3),
+                  scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(B)]
+    cfg = D.htd_config(50)
+    cfg['train_cfg']['rpn_proposal'].update(nms_pre=200, nms_post=100, max_num=100)
+    for r in cfg['train_cfg']['rcnn']:
+        r['sampler']['num'] = 48
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+          for k, v in seeded_state_dict(D.state_shapes(50), prefix='det.').items()}
+    torch.manual_seed(21)
+    trace = {}
+    ref_losses = D.forward_train(sd, T(imgs), metas, [T(x) for x in gts], [T(x) for x in labels], cfg, trace)
+    ref_loss, ref_log = D.parse_losses(ref_losses)
+    ref_loss.backward()
+    det.train()
+    torch.manual_seed(21)
+    gts_d, labels_d = [T(x).to(dev) for x in gts], [T(x).to(dev) for x in labels]
+    x = det.extract_feat(T(imgs).to(dev))
+    losses, proposals = det.rpn_head.forward_train(x, metas, gts_d, proposal_cfg=det.train_cfg.rpn_proposal)
+    exact = True
+    for mine, ref in zip(proposals, trace['proposals']):
+        mine = mine.cpu()
+        if mine.shape != ref.shape or not torch.allclose(mine, ref, rtol=1e-5, atol=2e-3):
+            exact = False
+            # the two lists still hold (nearly) the same boxes: every reference box but a few has a partner within 2e-3
+            d = (mine[None, :, :4] - ref[:, None, :4]).abs().max(-1)[0]
+            assert int((d.min(1)[0] > 2e-3).sum()) <= 4, 'proposal lists differ by more than a reordering of near-ties'
+    losses.update(det.roi_head.forward_train(x, metas, proposals, gts_d, labels_d))
+    loss, log_vars = det._parse_losses(losses)
+    for k, v in log_vars.items():
+        np.testing.assert_allclose(v, ref_log[k], rtol=5e-4 if exact else 5e-2, atol=1e-4 if exact else 2e-2, err_msg=k)
+    det.zero_grad()
+    loss.backward()
+    if exact:
+        params = dict(det.named_parameters())
+        for k in ('backbone.layer2.0.conv1.weight', 'neck.fpn_convs.0.conv.weight', 'rpn_head.rpn_cls.weight',
+                  'roi_head.bbox_head.0.fc_cls.weight', 'roi_head.bbox_head.1.fcs.0.weight',
+                  'roi_head.bbox_head.1.graph_lvl1_cls.weight', 'roi_head.bbox_head.1.convs.2.gn.bias',
+                  'roi_head.bbox_roi_extractor.1.conv2.weight', 'roi_head.glbctx_head.convs.3.conv.weight'):
+            a = params[k].grad.detach().cpu() if params[k].grad is not None else torch.zeros_like(params[k]).cpu()
+            b = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+            a = a.reshape(b.shape)
+            scale = max(b.abs().max().item(), 1e-6)
+            # 1e-2 of the largest entry: the product's own proposals (within 2e-3 px of the oracle's) move every RoIAlign
+            # sample a little; fed the oracle's proposals (test_train_step_matches_oracle_other_seed) the bound is 2e-3.
+            # Measured here: 4.1e-3 (backbone.layer2.0.conv1.weight), the others below 2e-3.
+            assert (a - b).abs().max().item() <= 1e-2 * scale + 1e-6, (k, (a - b).abs().max().item(), scale)
+    print('B=3 end to end: proposal lists', 'identical' if exact else 'differ in near-tie rows')
 
 
 def test_batched_pgraph_matches_reference_fixture(golden):
