@@ -109,7 +109,7 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(depth, H, W, full=False, dcn=False):
+def cpu_baseline(depth, H, W, full=False, dcn=False, batch=4, infer=False, proposals=512):
     """The CPU oracle (oracle/detector.py, pinned against reference-generated fixtures): train step = forward + losses
     + backward, fp32, all host threads, the synthetic inputs of the GPU run.
 
@@ -123,20 +123,27 @@ def cpu_baseline(depth, H, W, full=False, dcn=False):
     from htd_amd.runner import synthetic_batch
     threads = torch.get_num_threads()
     cfg = D.htd_config(depth, dcn)
-    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
+    if infer:                                   # BASELINE configs[4] shape: hard NMS, `proposals` RoIs per image into the head
+        cfg['test_cfg']['rpn'].update(nms_post=proposals, max_num=proposals)
+        cfg['test_cfg']['rcnn']['nms'] = dict(type='nms', iou_threshold=0.5)
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k and not infer)
           for k, v in seeded_state_dict(D.state_shapes(depth, dcn), prefix='det.').items()}
 
     def step(data):
         for v in sd.values():
             v.grad = None
         t0 = time.perf_counter()
+        if infer:
+            with torch.no_grad():
+                D.simple_test(sd, data['img'].contiguous(), data['img_metas'], cfg)
+            return time.perf_counter() - t0
         losses = D.forward_train(sd, data['img'].contiguous(), data['img_metas'], data['gt_bboxes'], data['gt_labels'], cfg)
         loss, _ = D.parse_losses(losses)
         loss.backward()
         return time.perf_counter() - t0
 
     torch.manual_seed(0)
-    B, warm, timed = (4, 3, 10) if full else (1, 1, 2)
+    B, warm, timed = (batch, 3, 10) if full else (1, 1, 2)
     data = synthetic_batch(B, H, W, W - 11, device='cpu', seed=0)
     small = synthetic_batch(1, 256, 320, 309, device='cpu', seed=0)
     for i in range(warm):
@@ -148,7 +155,7 @@ def cpu_baseline(depth, H, W, full=False, dcn=False):
         print(f'# cpu_baseline step {i + 1}/{timed}: {ts[-1]:.1f} s', file=sys.stderr, flush=True)
     mean = sum(ts) / len(ts)
     return dict(value=round(B / mean, 5), unit='images/sec', cores=threads, kind='port',
-                sample=(f'oracle (CPU restatement of the reference path) train step fwd+loss+bwd, R{depth}{"-DCN" if dcn else ""} fp32, '
+                sample=(f'oracle (CPU restatement of the reference path) ' + (f'simple_test ({proposals} proposals/img, hard NMS)' if infer else 'train step fwd+loss+bwd') + f', R{depth}{"-DCN" if dcn else ""} fp32, '
                         f'B={B} @{H}x{W}, {warm} warm-up + {timed} timed steps, mean {mean:.1f} s/step '
                         f'(min {min(ts):.1f}, max {max(ts):.1f})' +
                         ('' if full else '; bounded sample -- the BASELINE.md section 3 protocol (3 + 10 steps at B=4) is '
@@ -220,7 +227,8 @@ def main():
     if args.dry_launch:
         return dry_launch(args, world, rank)
     if args.cpu_baseline_full:
-        print(json.dumps(cpu_baseline(args.depth, args.height, args.width, full=True, dcn=args.dcn)))
+        print(json.dumps(cpu_baseline(args.depth, args.height, args.width, full=True, dcn=args.dcn, batch=args.batch,
+                                      infer=args.infer, proposals=args.proposals)))
         return
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP ops have no CPU path)'
     # HTD_BENCH_BACKEND=gloo HTD_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a ONE-GPU box (tests/test_gpu_distributed.py):

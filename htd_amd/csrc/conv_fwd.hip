@@ -93,6 +93,11 @@ struct ConvParams {
     int res_H, res_W;
     float res_sh, res_sw;
     int64_t w_bstride;  // >0: batched GEMM, image b uses weights w + b*w_bstride (tiles never straddle images)
+    // batched GEMM over zero-padded groups (PGraph): group_count[b] rows / columns / reduction entries of group b are real,
+    // the rest is padding that is known to be zero.  lim bits: 1 = rows (M), 2 = columns (N), 4 = reduction (K).  Tiles
+    // beyond the count store zeros without computing, the K loop stops at the count -- no host read of the group sizes.
+    const int64_t *group_count;
+    int lim;
     int64_t M;          // B*Ho*Wo
     int mt, nt;         // tiles along M, N
     int splits;         // split-K: gridDim.y workgroups share one output tile, partials go to `partial`
@@ -163,6 +168,26 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
+    int k_limit = 0x7fffffff;                        // real reduction length of the tile's group (padded groups only)
+    if (p.group_count) {
+        const int rows_per_group = p.Ho * p.Wo;
+        const int g = (int)(m0 / rows_per_group);
+        const int cnt = (int)p.group_count[g];
+        const bool dead = ((p.lim & 1) && (int)(m0 - (int64_t)g * rows_per_group) >= cnt) || ((p.lim & 2) && n0 >= cnt);
+        if (dead) {                                  // padding only: the tile is zeros (wave-uniform exit before any barrier)
+            for (int e = tid; e < T::BM * (T::BN / 4); e += 256) {
+                const int64_t m = m0 + e / (T::BN / 4);
+                const int n = n0 + (e % (T::BN / 4)) * 4;
+                if (m < p.M && n + 3 < p.Co) *reinterpret_cast<float4 *>(p.y + m * p.Co + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (m < p.M)
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < p.Co) p.y[m * p.Co + n + q] = 0.f;
+            }
+            return;
+        }
+        if (p.lim & 4) k_limit = cnt;
+    }
+
     // ---- per-thread staging coordinates
     const int vcol = tid % T::VEC_PER_ROW;            // which float4 of the K slice
     const int vrow = tid / T::VEC_PER_ROW;            // first row handled
@@ -198,7 +223,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
     const int slices_per_tap = p.Ci / BK;
     const int total_slices = (TAPS ? p.ntaps : p.kh * p.kw) * slices_per_tap;
     const int s_begin = tail_split >= 0 ? tail_split * p.tail_sps : blockIdx.y * p.slices_per_split;
-    const int num_slices = min(total_slices, s_begin + (tail_split >= 0 ? p.tail_sps : p.slices_per_split));
+    int num_slices = min(total_slices, s_begin + (tail_split >= 0 ? p.tail_sps : p.slices_per_split));
+    if (k_limit != 0x7fffffff) num_slices = min(num_slices, (k_limit + BK - 1) / BK);       // 1x1 problems: slice s = k / BK
 
     // state of the NEXT slice to stage (advanced incrementally: no divisions inside the K loop)
     int ld_ci0, ld_ky, ld_kx;
@@ -854,6 +880,27 @@ extern "C" int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int
     p.Ho = M; p.Wo = 1; p.Hx = M; p.Wx = 1; p.relu = 0;
     p.w_bstride = (int64_t)N * K;
     p.M = (int64_t)G * M;
+    return launch_conv(p, (hipStream_t)stream, nullptr);
+}
+
+// The same over zero-padded groups: counts[g] (device, int64) entries of group g are real.  limit bits: 1 = rows of a / c,
+// 2 = rows of b = columns of c, 4 = the reduction index; what lies beyond the count must be zero in the operands (it is
+// not read) and is written as zeros in c.  PGraph's three contractions (htd_bbox_head.py:210,213-216) at B = 64 x 512
+// proposals pad 256 groups to the largest image: 584 GFLOP issued for 123 GFLOP of real groups without this.
+extern "C" int htd_bgemm_nt_counts(const float *a, const float *b, float *c, int G, int M, int N, int K,
+                                   const int64_t *counts, int limit, void *stream)
+{
+    HTD_REQUIRE(G > 0 && M > 0 && N > 0 && K > 0, "bgemm_nt_counts: bad sizes G=%d M=%d N=%d K=%d", G, M, N, K);
+    HTD_REQUIRE(K % 8 == 0 && M % 128 == 0, "bgemm_nt_counts: K=%d %% 8, M=%d %% 128", K, M);
+    HTD_REQUIRE(a && b && c && counts && limit >= 0 && limit < 8, "bgemm_nt_counts: bad arguments");
+    ConvParams p{};
+    p.x = a; p.w = b; p.y = c;
+    p.B = G; p.H = M; p.W = 1; p.Ci = K; p.Co = N; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+    p.Ho = M; p.Wo = 1; p.Hx = M; p.Wx = 1; p.relu = 0;
+    p.w_bstride = (int64_t)N * K;
+    p.M = (int64_t)G * M;
+    p.group_count = counts;
+    p.lim = limit;
     return launch_conv(p, (hipStream_t)stream, nullptr);
 }
 

@@ -973,20 +973,25 @@ class BatchedGemmNT(Function):
     Backward is two more NT products on transposed copies: ga = gc @ b, gb = gc^T @ a."""
 
     @staticmethod
-    def _run(a, b):
+    def _run(a, b, counts=None, limit=0):
         G, M, K = a.shape
         N = b.size(1)
         c = torch.empty(G, M, N, device=a.device, dtype=a.dtype)
-        capi.call('htd_bgemm_nt', _P(a), _P(b), _P(c), G, M, N, K, _S(), work=('flop', 2.0 * G * M * N * K))
+        if counts is not None and limit and M % 128 == 0:
+            # zero-padded groups: tiles and reduction ranges beyond the group's size are skipped on the device
+            capi.call('htd_bgemm_nt_counts', _P(a), _P(b), _P(c), G, M, N, K, _P(counts), int(limit), _S(),
+                      work=('flop', 2.0 * G * M * N * K))
+        else:
+            capi.call('htd_bgemm_nt', _P(a), _P(b), _P(c), G, M, N, K, _S(), work=('flop', 2.0 * G * M * N * K))
         return c
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, counts=None, limit=0):
         _need_gpu(a, 'bgemm_nt')
         ctx.gram = a is b                       # a @ a^T (PGraph's similarity): one gradient product instead of two
         a, b = a.contiguous(), b.contiguous()
         ctx.save_for_backward(a, b)
-        return BatchedGemmNT._run(a, b)
+        return BatchedGemmNT._run(a, b, counts, limit)
 
     @staticmethod
     @once_differentiable
@@ -996,18 +1001,20 @@ class BatchedGemmNT(Function):
         ga = gb = None
         if ctx.gram and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             # d(a a^T): gc @ a + gc^T @ a = (gc + gc^T) @ a, handed back through the first argument
-            return BatchedGemmNT._run(gc + gc.transpose(1, 2), a.transpose(1, 2).contiguous()), None
+            return BatchedGemmNT._run(gc + gc.transpose(1, 2), a.transpose(1, 2).contiguous()), None, None, None
         if ctx.needs_input_grad[0]:
             ga = BatchedGemmNT._run(gc, b.transpose(1, 2).contiguous())                 # (G,M,N) x (G,K,N)^T
         if ctx.needs_input_grad[1]:
             gb = BatchedGemmNT._run(gc.transpose(1, 2).contiguous(), a.transpose(1, 2).contiguous())   # (G,N,M) x (G,K,M)^T
-        return ga, gb
+        return ga, gb, None, None
 
 
-def bgemm_nt(a, b):
+def bgemm_nt(a, b, counts=None, limit=0):
     """Batched a @ b^T; every dimension that becomes a row count must be a multiple of 128 when G > 1 and every
-    reduction length a multiple of 8 (PGraph pads its groups accordingly)."""
-    return BatchedGemmNT.apply(a, b)
+    reduction length a multiple of 8 (PGraph pads its groups accordingly).  counts (G,) int64 device tensor + limit bits
+    (1 rows of a, 2 rows of b, 4 reduction): group g has counts[g] real entries along those axes, zeros beyond -- the padding
+    is then neither read nor multiplied (htd_bgemm_nt_counts)."""
+    return BatchedGemmNT.apply(a, b, counts, int(limit))
 
 
 def roofline_report(prof, peak_tflops, peak_gbs, peak_bf16_tflops=2500.0):

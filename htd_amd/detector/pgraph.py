@@ -5,8 +5,9 @@ The reference runs a Python double loop over images and levels with boolean-mask
 host syncs and five tiny mm's per group.  Here ALL groups of the call are one padded batch
 [G, n_pad, .] (n_pad = largest group rounded up to the 128-row MFMA tile): one stable sort puts each
 group's RoIs next to each other, the three adjacency x feature contractions are three launches of the
-batched fp32-MFMA GEMM (htd_bgemm_nt), the four per-level Linear layers run on the same kernels, and the
-result is scattered back -- a fixed, small number of launches with a single host read (group sizes).
+batched split-bf16 MFMA GEMM (htd_bgemm_nt_counts: tiles and reduction ranges beyond a group's size are skipped on the
+device), the four per-level Linear layers run on the same kernels, and the result is scattered back -- a fixed, small
+number of launches; with rois_per_img given (the static train path, inference) no host read at all.
 """
 import torch
 
@@ -144,8 +145,10 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, ro
         # IoU -> mask -> degree -> normalisation in one kernel; (1 - M) * sim -> row soft-max in another
         A_local = local_adjacency(bx, counts)
         # mixed^T[f][i] = sum_j x^T[f][j] * A_local[i][j]   (A_local @ x, kept transposed: it is the NT operand below)
-        mixedT = dense.bgemm_nt(xgT, A_local)                               # (G, F, npad)
-        A_glob = _GlobalSoftmax.apply(dense.bgemm_nt(sg, sg), A_local, counts)
+        # counts + limit bits: the products skip tiles / reduction ranges beyond each group's size on the device (at B = 64 x 512
+        # proposals the groups are padded to the largest image: 4.75x the real work otherwise), no host read of the sizes
+        mixedT = dense.bgemm_nt(xgT, A_local, counts, 2 | 4)                # (G, F, npad): columns and reduction < count
+        A_glob = _GlobalSoftmax.apply(dense.bgemm_nt(sg, sg, counts, 1 | 2), A_local, counts)
     else:       # groups beyond 1024 RoIs (no HTD config gets there): the same arithmetic as tensor expressions
         lt = torch.max(bx[:, :, None, :2], bx[:, None, :, :2])
         rb = torch.min(bx[:, :, None, 2:], bx[:, None, :, 2:])
@@ -164,7 +167,8 @@ def pgraph_refine(x, sam, rois, target_lvls, graph_layers, rois_per_img=None, ro
         logits = torch.where(pair, logits, logits.new_full((1, ), float('-inf')))   # padded columns carry no mass
         logits = torch.where(valid[:, :, None], logits, torch.zeros_like(logits))   # padded rows: finite, unused
         A_glob = torch.softmax(logits, dim=-1) * vf
-    agg = dense.bgemm_nt(A_glob, mixedT).view(L, B * npad, Fdim)            # A_glob @ mixed; level-major groups
+    lim = (counts, 1 | 4) if npad <= FUSED_MAX_NPAD else (None, 0)          # rows and reduction < count
+    agg = dense.bgemm_nt(A_glob, mixedT, *lim).view(L, B * npad, Fdim)      # A_glob @ mixed; level-major groups
     out = torch.cat([dense.linear(agg[i], layer.weight, layer.bias, relu=True) for i, layer in enumerate(graph_layers)], 0)
     # scatter back; padded rows all land on one extra row that is dropped (no boolean-mask gather = no host sync)
     dst = torch.where(valid, rows, torch.full_like(rows, N)).reshape(-1)

@@ -201,6 +201,12 @@ int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const floa
  * K % 8 == 0, M % 128 == 0 when G > 1.  Carries PGraph's adjacency x feature contractions
  * (torch.mm calls of htd_bbox_head.py:210,213,214,216 batched over all (image, level) groups). */
 int htd_bgemm_nt(const float *a, const float *b, float *c, int G, int M, int N, int K, void *stream);
+/* The same over zero-padded groups: counts [G] (DEVICE, int64) says how many leading entries of group g are real; limit
+ * bits: 1 = rows of a / c, 2 = rows of b (= columns of c), 4 = the reduction index.  Operands must be zero beyond the count
+ * (not read); c is written as zeros there.  No host read of the group sizes (the reference's per-group loop reads them,
+ * htd_bbox_head.py:198-219). */
+int htd_bgemm_nt_counts(const float *a, const float *b, float *c, int G, int M, int N, int K, const int64_t *counts, int limit,
+                        void *stream);
 int htd_conv2d_flip_weights(const float *w, float *wT, int Co, int kh, int kw, int Ci, void *stream);
 /* Skinny heads (RPN 3+12 channels, fc_cls 81, fc_reg 4): the data gradient reduces over Co, which the MFMA kernel wants
  * as a multiple of 8.  One launch each instead of ATen pad / copy chains: wT rows zero-padded to Co_padded, and
