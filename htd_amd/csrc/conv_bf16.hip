@@ -328,6 +328,49 @@ __global__ __launch_bounds__(256) void weights_prep_bf16_kernel(const float *__r
     }
 }
 
+// the same for many layers in one launch (every layer of a backbone stage): workgroup b serves entry l with tile0[l] <= b
+struct PrepDesc {
+    const float *w;
+    unsigned short *wb, *wT;
+    int Co, taps, Ci, pad_;
+    int64_t tile0;
+};
+
+__global__ __launch_bounds__(256) void weights_prep_bf16_many_kernel(const PrepDesc *__restrict__ descs, int n)
+{
+    __shared__ unsigned short tile[32][34];
+    int lo = 0, hi = n - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PrepDesc d = descs[lo];
+    const int tci = (d.Ci + 31) / 32, tco = (d.Co + 31) / 32;
+    int rel = (int)(b - d.tile0);
+    const int ci0 = (rel % tci) * 32;
+    rel /= tci;
+    const int co0 = (rel % tco) * 32, t = rel / tco;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        unsigned short v = 0;
+        if (co < d.Co && ci < d.Ci) {
+            const int64_t i = ((int64_t)co * d.taps + t) * d.Ci + ci;
+            v = f2bf(d.w[i]);
+            if (d.wb) d.wb[i] = v;
+        }
+        tile[r][tx] = v;
+    }
+    if (!d.wT) return;                                  // uniform across the workgroup
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < d.Ci && co < d.Co) d.wT[((int64_t)ci * d.taps + (d.taps - 1 - t)) * d.Co + co] = tile[tx][r];
+    }
+}
+
 // column sums of a bf16 matrix g [rows][C] in fp32, two deterministic stages
 __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned short *__restrict__ g,
                                                                   float *__restrict__ partial, int64_t rows, int C,
@@ -404,6 +447,17 @@ extern "C" int htd_weights_prep_bf16(const float *w, void *wb, void *wT, int Co,
     return htd::check_launch("weights_prep_bf16");
 }
 
+// desc: DEVICE array of n entries { const float *w; void *wb; void *wT (may be 0); int32 Co, taps, Ci, 0; int64 tile0 } (48 bytes),
+// tile0 = prefix sum of taps * ceil(Co / 32) * ceil(Ci / 32), total_tiles its end.
+extern "C" int htd_weights_prep_bf16_many(const void *desc, int n, int64_t total_tiles, void *stream)
+{
+    static_assert(sizeof(PrepDesc) == 48, "PrepDesc layout is part of the ABI");
+    HTD_REQUIRE(desc && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "weights_prep_bf16_many: bad arguments");
+    hipLaunchKernelGGL(weights_prep_bf16_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const PrepDesc *)desc, n);
+    return htd::check_launch("weights_prep_bf16_many");
+}
+
 extern "C" int64_t htd_colsum_bf16_workspace_bytes(int64_t rows, int C)
 {
     if (rows <= 0 || C <= 0) return -1;
@@ -440,6 +494,7 @@ using s16x4 = __attribute__((ext_vector_type(4))) short;
 struct BfWgradParams {
     const unsigned short *x, *gy;
     float *out;
+    float *bias_out;       // NULL, or column sums of gy: gbias if splits == 1 else workspace [splits][Co]
     int B, H, W, Ci, Co, kh, kw, stride, pad, dil, Ho, Wo;
     int64_t K;
     int Ntot, mt, nt, splits;
@@ -504,11 +559,24 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(BfWgradParams p
             ok_b = ob ? (ok_b | (1u << i)) : (ok_b & ~(1u << i));
         }
     };
+    // the tiles of the first N column see every gy element of their rows exactly once: they add them up (the bias gradient
+    // of the layer, csrc/conv_wgrad.hip does the same in fp32) -- no separate column-sum launches
+    const bool do_bias = p.bias_out != nullptr && tile_n == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto store_slice = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4 *>(la + (row0 + 16 * i) * WB_ROW + chunk * 8) = keep16((ok_a >> i) & 1u, ra[i]);
+            const uint4 va = keep16((ok_a >> i) & 1u, ra[i]);
+            *reinterpret_cast<uint4 *>(la + (row0 + 16 * i) * WB_ROW + chunk * 8) = va;
             *reinterpret_cast<uint4 *>(lb + (row0 + 16 * i) * WB_ROW + chunk * 8) = keep16((ok_b >> i) & 1u, rb[i]);
+            if (do_bias) {
+                const unsigned u[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(u[e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(u[e] & 0xffff0000u);
+                }
+            }
         }
     };
 
@@ -547,6 +615,20 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(BfWgradParams p
         __syncthreads();
     }
 
+    if (do_bias) {          // threads sharing a column chunk (tid & 15) fold their 16 row partials through LDS in a fixed order
+        float *red = reinterpret_cast<float *>(lds);              // the slice buffers are free after the last barrier
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128) {
+            const int c = tid >> 3, e = tid & 7;                    // column chunk, element
+            float t = 0.f;
+            for (int r = 0; r < 16; ++r) t += red[(r * 16 + c) * 8 + e];
+            const int m = m0 + c * 8 + e;
+            if (m < p.Co) p.bias_out[(int64_t)split * p.Co + m] = t;
+        }
+        __syncthreads();
+    }
     float *out = p.out + (int64_t)split * p.Co * p.Ntot;
     const int fcol = lane & 31, fhalf = lane >> 5;
 #pragma unroll
@@ -563,10 +645,23 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(BfWgradParams p
         }
 }
 
+// out[i] = sum_k ws[k][i]; a second, small set of partials (the bias gradient [splits][n2]) rides along in extra workgroups
 __global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
-                                                                 int64_t n4, int64_t n, int splits)
+                                                                 int64_t n4, int64_t n, int splits,
+                                                                 const float *__restrict__ ws2 = nullptr,
+                                                                 float *__restrict__ out2 = nullptr, int n2 = 0, int extra = 0)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    if ((int)blockIdx.x >= (int)gridDim.x - extra) {
+        const int i = ((int)blockIdx.x - ((int)gridDim.x - extra)) * 256 + threadIdx.x;
+        if (i < n2) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += ws2[(int64_t)k * n2 + i];
+            out2[i] = s;
+        }
+        return;
+    }
+    const int64_t main_threads = (int64_t)(gridDim.x - extra) * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += main_threads) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < splits; ++k) {
             const float4 v = *reinterpret_cast<const float4 *>(ws + (int64_t)k * n + i * 4);
@@ -594,12 +689,12 @@ extern "C" int64_t htd_conv2d_wgrad_bf16_workspace_bytes(int B, int H, int W, in
 {
     const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
-    return (int64_t)bf16_wgrad_splits(Co, kh * kw * Ci, (int64_t)B * Ho * Wo) * Co * kh * kw * Ci * 4 + 256;
+    return (int64_t)bf16_wgrad_splits(Co, kh * kw * Ci, (int64_t)B * Ho * Wo) * Co * (kh * kw * Ci + 1) * 4 + 256;   // + bias partials
 }
 
 // x [B][H][W][Ci] bf16, gy [B][Ho][Wo][Co] bf16 -> gw [Co][kh][kw][Ci] fp32.  Ci % 8 == 0, Co % 8 == 0.
-extern "C" int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *gw, int B, int H, int W, int Ci, int Co,
-                                          int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream)
+static int bwd_weight_bf16_impl(const void *x, const void *gy, float *gw, float *gbias, int B, int H, int W, int Ci, int Co,
+                                int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_bwd_weight_bf16: bad sizes");
@@ -619,13 +714,32 @@ extern "C" int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *
     p.splits = bf16_wgrad_splits(Co, p.Ntot, p.K);
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, WB_K), p.splits);
     p.out = p.splits == 1 ? gw : (float *)workspace;
+    float *bias_partial = (float *)workspace + (int64_t)p.splits * Co * p.Ntot;
+    p.bias_out = !gbias ? nullptr : (p.splits == 1 ? gbias : bias_partial);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)(p.mt * p.nt * p.splits)), dim3(256), 0, s, p);
     if (p.splits > 1) {
         const int64_t n = (int64_t)Co * p.Ntot;
         const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n / 4, 256), 2048);
-        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float *)workspace, gw, n / 4,
-                           n, p.splits);
+        const unsigned extra = gbias ? (unsigned)htd::ceil_div(Co, 256) : 0u;
+        hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3(blocks + extra), dim3(256), 0, s, (const float *)workspace, gw, n / 4,
+                           n, p.splits, (const float *)(gbias ? bias_partial : nullptr), gbias, Co, (int)extra);
     }
     return htd::check_launch("conv2d_bwd_weight_bf16");
+}
+
+extern "C" int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *gw, int B, int H, int W, int Ci, int Co,
+                                          int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream)
+{
+    return bwd_weight_bf16_impl(x, gy, gw, nullptr, B, H, W, Ci, Co, kh, kw, stride, pad, dil, workspace, stream);
+}
+
+// The same, also returning gbias [Co] = column sums of gy (fp32), accumulated by the tiles of the first N column: the bias
+// gradient of the layer without column-sum launches of its own.  Same workspace (it already counts the bias partials).
+extern "C" int htd_conv2d_bwd_weight_bf16_bias(const void *x, const void *gy, float *gw, float *gbias, int B, int H, int W,
+                                               int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
+                                               void *stream)
+{
+    HTD_REQUIRE(gbias, "conv2d_bwd_weight_bf16_bias: null pointer");
+    return bwd_weight_bf16_impl(x, gy, gw, gbias, B, H, W, Ci, Co, kh, kw, stride, pad, dil, workspace, stream);
 }

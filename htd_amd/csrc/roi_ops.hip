@@ -273,20 +273,34 @@ __global__ __launch_bounds__(256) void roi_tile_sums_kernel(const float *__restr
     }
 }
 
+// partial[k][b][c] = sum of tile[i][c] over the RoIs i of chunk k (IMG_CHUNK consecutive RoIs) that belong to image b, ascending i
+constexpr int IMG_CHUNK = 64;
 __global__ __launch_bounds__(64) void image_sums_kernel(const float *__restrict__ tile, const float *__restrict__ rois,
-                                                        float *__restrict__ gg, int64_t n, int C4, int B)
+                                                        float *__restrict__ partial, int64_t n, int C4, int B)
 {
     const int b = blockIdx.x, c4 = blockIdx.y * 64 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.z * IMG_CHUNK, i1 = min(n, i0 + IMG_CHUNK);
     if (c4 >= C4) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = i0; i < i1; ++i) {
         int rb = (int)rois[5 * i];
         rb = rb < 0 ? 0 : (rb >= B ? B - 1 : rb);
         if (rb != b) continue;                      // uniform across the workgroup
         const float4 v = reinterpret_cast<const float4 *>(tile)[i * C4 + c4];
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    reinterpret_cast<float4 *>(gg)[(int64_t)b * C4 + c4] = acc;
+    reinterpret_cast<float4 *>(partial)[((int64_t)blockIdx.z * B + b) * C4 + c4] = acc;
+}
+
+// gg[e] = sum_k partial[k][e] in ascending k
+__global__ __launch_bounds__(256) void chunk_sums_kernel(const float *__restrict__ partial, float *__restrict__ gg, int64_t total,
+                                                         int chunks)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * total + e];
+    gg[e] = s;
 }
 
 // ------------------------------------------------------------------ GroupNorm (+ReLU)
@@ -571,7 +585,8 @@ extern "C" int htd_fuse_global_bwd_global(const float *grad, const float *rois, 
     return htd::check_launch("fuse_global_bwd");
 }
 
-// Bit-reproducible form (no float atomics): grad_global [B][C] is OVERWRITTEN; workspace holds n * C floats; C % 4 == 0.
+// Bit-reproducible form (no float atomics): grad_global [B][C] is OVERWRITTEN; workspace holds (n + ceil(n / 64) * B) * C
+// floats; C % 4 == 0.
 extern "C" int htd_fuse_global_bwd_global_ws(const float *grad, const float *rois, float *grad_global, int64_t n, int P,
                                              int C, int B, void *workspace, void *stream)
 {
@@ -583,9 +598,13 @@ extern "C" int htd_fuse_global_bwd_global_ws(const float *grad, const float *roi
         return HTD_OK;
     }
     HTD_REQUIRE(grad && rois && workspace, "fuse_global_bwd_ws: null pointer");
-    hipLaunchKernelGGL(roi_tile_sums_kernel, dim3((unsigned)n), dim3(256), 0, s, grad, (float *)workspace, P, C / 4);
-    hipLaunchKernelGGL(image_sums_kernel, dim3((unsigned)B, (unsigned)htd::ceil_div(C / 4, 64)), dim3(64), 0, s,
-                       (const float *)workspace, rois, grad_global, n, C / 4, B);
+    float *tile = (float *)workspace, *partial = tile + n * C;
+    const int chunks = (int)htd::ceil_div(n, IMG_CHUNK);
+    hipLaunchKernelGGL(roi_tile_sums_kernel, dim3((unsigned)n), dim3(256), 0, s, grad, tile, P, C / 4);
+    hipLaunchKernelGGL(image_sums_kernel, dim3((unsigned)B, (unsigned)htd::ceil_div(C / 4, 64), (unsigned)chunks), dim3(64), 0, s,
+                       (const float *)tile, rois, partial, n, C / 4, B);
+    hipLaunchKernelGGL(chunk_sums_kernel, dim3((unsigned)htd::ceil_div((int64_t)B * C, 256)), dim3(256), 0, s,
+                       (const float *)partial, grad_global, (int64_t)B * C, chunks);
     return htd::check_launch("fuse_global_bwd_ws");
 }
 

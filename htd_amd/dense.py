@@ -726,9 +726,10 @@ def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=Fals
     return y
 
 
-def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1):
+def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1, with_bias=False):
     """fp32 weight gradient of a convolution from bf16 activations x (B,Ci,H,W) and bf16 output gradient gy
-    (htd_conv2d_bwd_weight_bf16) -> (Co,Ci,kh,kw) fp32 channels_last."""
+    (htd_conv2d_bwd_weight_bf16) -> (Co,Ci,kh,kw) fp32 channels_last.  with_bias: -> (gw, gbias), the column sums of gy
+    (fp32) from the same launch (htd_conv2d_bwd_weight_bf16_bias)."""
     _need_gpu(x, 'conv2d_wgrad_bf16')
     x = x.contiguous(memory_format=CL)
     gy = gy.contiguous(memory_format=CL)
@@ -737,6 +738,11 @@ def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1):
     gw = torch.empty((Co, Ci, kh, kw), device=x.device, dtype=torch.float32, memory_format=CL)
     nbytes = capi.lib().htd_conv2d_wgrad_bf16_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
     ws = torch.empty(nbytes // 4 + 1, device=x.device, dtype=torch.float32)
+    if with_bias:
+        gb = torch.empty(Co, device=x.device, dtype=torch.float32)
+        capi.call('htd_conv2d_bwd_weight_bf16_bias', _P(x), _P(gy), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, int(stride),
+                  int(padding), int(dilation), _P(ws), _S(), work=('flop', 2.0 * gy.numel() * kh * kw * Ci))
+        return gw, gb
     capi.call('htd_conv2d_bwd_weight_bf16', _P(x), _P(gy), _P(gw), B, H, W, Ci, Co, kh, kw, int(stride), int(padding),
               int(dilation), _P(ws), _S(), work=('flop', 2.0 * gy.numel() * kh * kw * Ci))
     return gw
@@ -755,6 +761,37 @@ def _prep_bf16(weight, want_wT=True):
     wT = torch.empty((Ci, Co, kh, kw), device=weight.device, dtype=BF16, memory_format=CL) if want_wT else None
     capi.call('htd_weights_prep_bf16', _P(weight), _P(wb), _P(wT), Co, kh, kw, Ci, _S())
     return wb, wT
+
+
+def _prep_bf16_many(items):
+    """[(fp32 weight (Co,Ci,kh,kw), want_wT)] -> [(wb, wT or None)]: the bf16 operands of many layers in ONE launch
+    (htd_weights_prep_bf16_many) instead of one ~6-microsecond launch per layer (R101: 104 per step)."""
+    import numpy as np
+    if not items:
+        return []
+    ws = [w.contiguous(memory_format=CL) for w, _ in items]
+    dev = ws[0].device
+    total = sum(w.numel() * (2 if want else 1) for w, (_, want) in zip(ws, items))
+    flat = torch.empty(total, device=dev, dtype=BF16)
+    desc = np.zeros((len(ws), 6), dtype=np.int64)
+    out, off, tile0 = [], 0, 0
+    for i, (w, (_, want)) in enumerate(zip(ws, items)):
+        Co, Ci, kh, kw = w.shape
+        wb = flat[off:off + w.numel()].view(Co, kh, kw, Ci).permute(0, 3, 1, 2)           # KRSC memory = channels_last
+        off += w.numel()
+        wT = None
+        if want:
+            wT = flat[off:off + w.numel()].view(Ci, kh, kw, Co).permute(0, 3, 1, 2)
+            off += w.numel()
+        desc[i, 0], desc[i, 1], desc[i, 2] = w.data_ptr(), wb.data_ptr(), wT.data_ptr() if wT is not None else 0
+        desc[i, 3] = Co | ((kh * kw) << 32)
+        desc[i, 4] = Ci
+        desc[i, 5] = tile0
+        tile0 += kh * kw * ((Co + 31) // 32) * ((Ci + 31) // 32)
+        out.append((wb, wT))
+    table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+    capi.call('htd_weights_prep_bf16_many', _P(table), len(ws), tile0, _S())
+    return out
 
 
 def _dgrad_bf16_raw(g, wT, kh, pad, dil, mask_src=None, accum=None):
@@ -823,11 +860,14 @@ class Conv2dBf16Function(Function):
             else:
                 gx = _dgrad_raw(g.float().contiguous(memory_format=CL), wsaved.float().contiguous(memory_format=CL),
                                 x.shape, stride, padding, dilation).to(torch.bfloat16)
-        if need_w:
-            gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation)
-        if has_bias and need_b:
-            gb = _colsum_bf16_raw(g) if g.size(1) % 4 == 0 else \
-                torch.sum(g.permute(0, 2, 3, 1).reshape(-1, g.size(1)), dim=0, dtype=torch.float32)
+        if need_w and has_bias and need_b:
+            gw, gb = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation, with_bias=True)      # one launch for both
+        else:
+            if need_w:
+                gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation)
+            if has_bias and need_b:
+                gb = _colsum_bf16_raw(g) if g.size(1) % 4 == 0 else \
+                    torch.sum(g.permute(0, 2, 3, 1).reshape(-1, g.size(1)), dim=0, dtype=torch.float32)
         return gx, gw, gb, (g if (has_res and need_r) else None), None, None, None, None
 
 
@@ -844,17 +884,25 @@ class ResStageBf16Function(Function):
         params = [t.contiguous(memory_format=CL) if t.dim() == 4 else t.contiguous() for t in params]
         saved, wTs, k = [], [], 0
         bwd = any(ctx.needs_input_grad)           # inference: forward operands only
+        todo, kk = [], 0                          # the bf16 operands of every layer of the stage: one launch
+        for stride, ds in zip(strides, has_ds):
+            todo += [(params[kk], bwd), (params[kk + 2], bwd and stride == 1), (params[kk + 4], bwd)]
+            kk += 6
+            if ds:
+                todo.append((params[kk], bwd and stride == 1))
+                kk += 2
+        prepped = iter(_prep_bf16_many(todo))
         for stride, ds in zip(strides, has_ds):
             w1, b1, w2, b2, w3, b3 = params[k:k + 6]
             k += 6
-            (wb1, wT1), (wb2, wT2), (wb3, wT3) = _prep_bf16(w1, bwd), _prep_bf16(w2, bwd and stride == 1), _prep_bf16(w3, bwd)
+            (wb1, wT1), (wb2, wT2), (wb3, wT3) = next(prepped), next(prepped), next(prepped)
             h1 = conv2d_bf16(x, wb1, b1, 1, 0, 1, True)
             h2 = conv2d_bf16(h1, wb2, b2, stride, dilation, dilation, True)
             wTd = None
             if ds:
                 wd, bd = params[k:k + 2]
                 k += 2
-                wbd, wTd = _prep_bf16(wd, bwd and stride == 1)
+                wbd, wTd = next(prepped)
                 idn = conv2d_bf16(x, wbd, bd, stride, 0, 1, False)
             else:
                 idn = x
@@ -891,18 +939,30 @@ class ResStageBf16Function(Function):
             first = i == 0
             need_x = need[0] if first else True
             gm3 = g if premasked else torch.ops.aten.threshold_backward(g, out, 0)
-            if pneed[4]:
-                grads[k + 4] = conv2d_wgrad_bf16(h2, gm3, w3.shape, 1, 0, 1)
-            gb3 = _colsum_bf16_raw(gm3) if (pneed[5] or (ds and pneed[7])) else None
+            # bias (= BN beta) gradients are by-products of the wgrad launches; stand-alone column sums only without a wgrad
+            want_b3 = pneed[5] or (ds and pneed[7])
+            gb3 = None
+            if pneed[4] and want_b3 and w3.size(0) % 8 == 0:
+                grads[k + 4], gb3 = conv2d_wgrad_bf16(h2, gm3, w3.shape, 1, 0, 1, with_bias=True)
+            else:
+                if pneed[4]:
+                    grads[k + 4] = conv2d_wgrad_bf16(h2, gm3, w3.shape, 1, 0, 1)
+                gb3 = _colsum_bf16_raw(gm3) if want_b3 else None
             grads[k + 5] = gb3 if pneed[5] else None
             gm2 = _dgrad_bf16_raw(gm3, wT3, 1, 0, 1, mask_src=h2)
-            if pneed[2]:
-                grads[k + 2] = conv2d_wgrad_bf16(h1, gm2, w2.shape, stride, dilation, dilation)
-            grads[k + 3] = _colsum_bf16_raw(gm2) if pneed[3] else None
+            if pneed[2] and pneed[3]:
+                grads[k + 2], grads[k + 3] = conv2d_wgrad_bf16(h1, gm2, w2.shape, stride, dilation, dilation, with_bias=True)
+            else:
+                if pneed[2]:
+                    grads[k + 2] = conv2d_wgrad_bf16(h1, gm2, w2.shape, stride, dilation, dilation)
+                grads[k + 3] = _colsum_bf16_raw(gm2) if pneed[3] else None
             gm1 = _dgrad_bf16_any(gm2, wT2, w2, h1.shape, 3, stride, dilation, dilation, mask_src=h1)
-            if pneed[0]:
-                grads[k] = conv2d_wgrad_bf16(x, gm1, w1.shape, 1, 0, 1)
-            grads[k + 1] = _colsum_bf16_raw(gm1) if pneed[1] else None
+            if pneed[0] and pneed[1]:
+                grads[k], grads[k + 1] = conv2d_wgrad_bf16(x, gm1, w1.shape, 1, 0, 1, with_bias=True)
+            else:
+                if pneed[0]:
+                    grads[k] = conv2d_wgrad_bf16(x, gm1, w1.shape, 1, 0, 1)
+                grads[k + 1] = _colsum_bf16_raw(gm1) if pneed[1] else None
             acc = gm3
             if ds:
                 wd = params[k + 6]

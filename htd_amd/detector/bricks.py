@@ -143,7 +143,7 @@ class _BNFoldMany(torch.autograd.Function):
     step).  Inputs per pair: w, gamma, beta, mean, var; outputs per pair: w', b'."""
 
     @staticmethod
-    def forward(ctx, eps, want_flips, *tensors):
+    def forward(ctx, eps, want_flips, want_planes, *tensors):
         import numpy as np
         from .. import capi, dense
         n = len(tensors) // 5
@@ -174,7 +174,8 @@ class _BNFoldMany(torch.autograd.Function):
         table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
         capi.call('htd_bn_fold_many_fwd', capi.ptr(table), n, tile0, float(eps), capi.current_stream_ptr())
         # bf16 plane images of the folded weights (conv_x3p_kernel operands, csrc/conv_x3.hip): one more launch per stage
-        dense.planes_many([(wf, False) for wf in outs[0::2]] + ([(wf, True) for wf in outs[0::2]] if want_flips else []))
+        if want_planes:                                      # fp32 stages only: the bf16 stages make bf16 operands of their own
+            dense.planes_many([(wf, False) for wf in outs[0::2]] + ([(wf, True) for wf in outs[0::2]] if want_flips else []))
         for wf, wT in zip(outs[0::2], flips):
             dense.mark_side_consumed(wf)
             if wT is not None:
@@ -227,13 +228,13 @@ class _BNFoldMany(torch.autograd.Function):
                     for t in trio:
                         t.record_stream(main)
                 main.wait_stream(side)
-        res = [None, None]
+        res = [None, None, None]
         for gw, gg, gb in outs:
             res += [gw, gg, gb, None, None]
         return tuple(res)
 
 
-def frozen_bn_fold_many(pairs, want_flips=True):
+def frozen_bn_fold_many(pairs, want_flips=True, want_planes=True):
     """[(conv_weight, bn), ...] -> [w'_0, b'_0, w'_1, b'_1, ...]: every fold of a stage in one launch (training, fp32
     weights with K % 4 == 0 on the GPU); otherwise pair by pair."""
     ok = torch.is_grad_enabled() and all(w.is_cuda and w.dtype == torch.float32 and (w.numel() // w.size(0)) % 4 == 0 and
@@ -246,7 +247,7 @@ def frozen_bn_fold_many(pairs, want_flips=True):
     args = []
     for w, bn in pairs:
         args += [w, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-    return list(_BNFoldMany.apply(pairs[0][1].eps, bool(want_flips), *args))
+    return list(_BNFoldMany.apply(pairs[0][1].eps, bool(want_flips), bool(want_planes), *args))
 
 
 def frozen_bn_fold(conv_weight, bn):

@@ -148,7 +148,8 @@ class ResLayer(nn.Sequential):
         # every fold of the stage in one launch; for the fp32 stages it also leaves the flipped weight images for the data
         # gradients (the bf16 stages make their own bf16 operands from the folded weights)
         params = frozen_bn_fold_many(pairs, want_flips=x.dtype == torch.float32 and
-                                     (x.requires_grad or any(w.requires_grad for w, _ in pairs)))
+                                     (x.requires_grad or any(w.requires_grad for w, _ in pairs)),
+                                     want_planes=x.dtype == torch.float32)
         fn = ResStageFunction if x.dtype == torch.float32 else ResStageBf16Function
         return fn.apply(x, tuple(blk.conv2_stride for blk in self), self[0].dilation,
                         tuple(blk.downsample is not None for blk in self), *params)

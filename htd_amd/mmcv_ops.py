@@ -387,7 +387,7 @@ def _fuse_global_grad(go, rois, n, P, C, B):
     """grad_global [B, C] = per-image sums of the RoI tile gradients: the bit-reproducible two-pass kernel (no float atomics)."""
     gg = torch.empty(B, C, device=go.device, dtype=go.dtype)
     if C % 4 == 0:
-        ws = torch.empty(max(n, 1) * C, device=go.device, dtype=go.dtype)
+        ws = torch.empty((max(n, 1) + (max(n, 1) + 63) // 64 * B) * C, device=go.device, dtype=go.dtype)
         capi.call('htd_fuse_global_bwd_global_ws', _P(go), _P(rois), _P(gg), n, P, C, B, _P(ws), _S())
     else:
         gg.zero_()

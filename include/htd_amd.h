@@ -309,7 +309,8 @@ int htd_group_norm_relu_bwd(const float *x, const float *y, const float *gamma, 
 /* Bit-reproducible forms of the two backward passes that summed with float atomics (their run-to-run rounding differences
  * reached every parameter upstream of P6 and made two ranks' replicas drift apart in the last bit): per-tile sums go through a
  * caller-owned workspace and are added in a fixed order.  htd_group_norm_relu_bwd_ws: workspace 2 * n * C floats, ggamma /
- * gbeta overwritten.  htd_fuse_global_bwd_global_ws: workspace n * C floats, grad_global [B][C] overwritten, C % 4 == 0. */
+ * gbeta overwritten.  htd_fuse_global_bwd_global_ws: workspace (n + ceil(n / 64) * B) * C floats, grad_global [B][C]
+ * overwritten, C % 4 == 0. */
 int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const float *gamma, const float *mean, const float *rstd,
                                const float *gy, float *gx, float *ggamma, float *gbeta, int64_t n, int P, int C, int G,
                                int relu, void *workspace, void *stream);
@@ -406,6 +407,10 @@ int htd_conv2d_dgrad_bf16(const void *gy, const void *wT, const void *mask_src, 
 /* One launch per layer and step: fp32 (BN-folded) weights w [Co][kh][kw][Ci] -> wb (bf16, same layout) and
  * wT [Ci][kh][kw][Co] (bf16, taps flipped); either output may be NULL. */
 int htd_weights_prep_bf16(const float *w, void *wb, void *wT, int Co, int kh, int kw, int Ci, void *stream);
+/* The same for many layers in one launch.  desc: DEVICE array of n entries
+ *   { const float *w; void *wb; void *wT (may be 0); int32 Co, taps, Ci, 0; int64 tile0 }   (48 bytes each),
+ * tile0 = prefix sum of taps * ceil(Co / 32) * ceil(Ci / 32) over the entries, total_tiles its end. */
+int htd_weights_prep_bf16_many(const void *desc, int n, int64_t total_tiles, void *stream);
 /* fp32 column sums of a bf16 matrix g [rows][C] (bias gradients), deterministic two-stage; C % 4 == 0. */
 int64_t htd_colsum_bf16_workspace_bytes(int64_t rows, int C);
 int htd_colsum_bf16(const void *g, float *out, int64_t rows, int C, void *workspace, void *stream);
@@ -416,6 +421,10 @@ int64_t htd_conv2d_wgrad_bf16_workspace_bytes(int B, int H, int W, int Ci, int C
                                               int dil);
 int htd_conv2d_bwd_weight_bf16(const void *x, const void *gy, float *gw, int B, int H, int W, int Ci, int Co, int kh,
                                int kw, int stride, int pad, int dil, void *workspace, void *stream);
+/* ... and gbias [Co] (fp32) = column sums of gy from the same launch (the bias / BN-beta gradient of the layer), as
+ * htd_conv2d_bwd_weight does in fp32. */
+int htd_conv2d_bwd_weight_bf16_bias(const void *x, const void *gy, float *gw, float *gbias, int B, int H, int W, int Ci, int Co,
+                                    int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Grouped convolutions of the ResNeXt bottlenecks: conv2 of backbones/resnext.py:33-84 is
