@@ -526,6 +526,226 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradParams p)
         }
 }
 
+// ---- 3x3 layers: the three taps of a filter ROW in one workgroup (round 3) ------------------------------------------------------
+// conv_wgrad_x3_kernel gives every (128 co x 128 n) tile its own copy of the staging work: a gy element is loaded and split
+// once per N tile (18 times for a 3x3 256 -> 256 layer), an x element once per M tile and tap.  Here a workgroup owns
+// 128 co x 64 ci x the THREE taps kx of one filter row ky: per K slice the gy rows are staged and split once for three taps, and
+// the x operand is ONE run of 32 + 2 pixels read at row shifts 0 / 1 / 2 by the transposing LDS reads -- 6.1 staged float4
+// per thread and 72 MFMAs per wave and slice instead of 8 and 48 (the split and its address arithmetic were 7.6 vector
+// instructions per MFMA, PMC r03).  Borders need no masks: the reduction runs over a VIRTUAL pixel index with one padding
+// column per image row (W + 1 columns, the last one zero in both operands), so the neighbours of the first / last pixel of a
+// row are zeros by construction; rows above / below the image are zeroed when the x run is staged (ky is fixed per workgroup).
+constexpr int XH_KS = 32;                       // virtual pixels per K slice
+constexpr int XH_RUN = XH_KS + 2;               // x rows staged per slice
+constexpr int XH_ROWB = 96;                     // half-words per LDS row of the x run: 64 + 32 pad (rows 48 banks apart)
+constexpr int XH_PLANE_A = XH_KS * X3_ROW, XH_PLANE_B = XH_RUN * XH_ROWB;
+
+template <int ROW>
+__device__ __forceinline__ bf16x8w tr_frag_row(const unsigned short *img, int k0, int c0, int lane)
+{
+    const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned short *a = img + (k0 + 8 * h + q) * ROW + c0 + 16 * g + 4 * pp;
+    const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w *)a);
+    const s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w *)(a + 4 * ROW));
+    union { struct { s16x4w a, b; } s; bf16x8w v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+// WIDE: W + 1 >= 32 (a slice advances a row's coordinates by at most one carry), else the pixel is decoded per slice
+template <bool WIDE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3h_kernel(WgradParams p)
+{
+    constexpr int BM = 128, BNC = 64;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[3 * XH_PLANE_A + 3 * XH_PLANE_B];
+    unsigned short *la = lds, *lb = lds + 3 * XH_PLANE_A;
+    const int ntc = (p.Ci + BNC - 1) / BNC;
+    const int tiles = p.mt * ntc * 3;
+    int tile, split;
+    {
+        const int L = blockIdx.x;
+        if (p.splits % 8 == 0) {                 // the splits of a tile spread over the XCD groups, its tiles share one
+            const int xcd = L % 8, idx = L / 8;
+            tile = idx % tiles;
+            split = (idx / tiles) * 8 + xcd;
+        } else {
+            tile = L % tiles;
+            split = L / tiles;
+        }
+    }
+    const int tile_m = tile % p.mt, rest = tile / p.mt;
+    const int tile_nc = rest % ntc, ky = rest / ntc;
+    const int m0 = tile_m * BM, ci0 = tile_nc * BNC, dy = ky - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int Wv = p.W + 1;                                   // virtual row length
+    const int64_t V = (int64_t)p.B * p.H * Wv;
+    const int64_t total_slices = (V + XH_KS - 1) / XH_KS;
+    const int64_t s_begin = (int64_t)split * p.slices_per_split;
+    const int64_t s_end = min(total_slices, s_begin + p.slices_per_split);
+
+    // staging: gy 32 rows x 32 float4 (4 per thread), x run 34 rows x 16 float4 (3 passes, the last one rows 32, 33 only)
+    const int a_col = (tid & 31) * 4, a_row0 = tid >> 5;      // rows a_row0 + 8 i
+    const int b_col = (tid & 15) * 4, b_row0 = tid >> 4;      // rows b_row0 + 16 i
+    const bool a_cok = m0 + a_col < p.Co, b_cok = ci0 + b_col < p.Ci;
+    // coordinates of every staged row in the virtual index: image-row pixel x in [0, Wv), row y, image b
+    int ax[4], ay[4], ab[4], bx[3], by[3], bb[3];
+    auto decode = [&](int64_t v, int &x, int &y, int &b) {
+        const int64_t vv = v < 0 ? 0 : v;
+        x = (int)(vv % Wv);
+        const int64_t t = vv / Wv;
+        y = (int)(t % p.H);
+        b = (int)(t / p.H);
+        if (v < 0) { x = Wv - 1; y = -1; }                     // v = -1, the entry before the first pixel: padding column of "row -1"
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) decode(s_begin * XH_KS + a_row0 + 8 * i, ax[i], ay[i], ab[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) decode(s_begin * XH_KS - 1 + b_row0 + 16 * i, bx[i], by[i], bb[i]);
+    auto advance = [&](int &x, int &y, int &b) {              // + XH_KS virtual pixels
+        if constexpr (WIDE) {
+            x += XH_KS;
+            const bool c1 = x >= Wv;
+            x = c1 ? x - Wv : x;
+            y += c1 ? 1 : 0;
+            const bool c2 = y >= p.H;
+            y = c2 ? y - p.H : y;
+            b += c2 ? 1 : 0;
+        } else {
+            const int64_t v = ((int64_t)b * p.H + y) * Wv + x + XH_KS;
+            x = (int)(v % Wv);
+            const int64_t t = v / Wv;
+            y = (int)(t % p.H);
+            b = (int)(t / p.H);
+        }
+    };
+
+    float4 ra[4], rb[3];
+    unsigned ok_a = 0u, ok_b = 0u;
+    auto load_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = a_cok && ab[i] < p.B && ax[i] < p.W;
+            const unsigned off = (((unsigned)ab[i] * p.H + ay[i]) * (unsigned)p.W + ax[i]) * (unsigned)p.Co + m0 + a_col;
+            ra[i] = *reinterpret_cast<const float4 *>(p.gy + (ok ? off : 0u));
+            ok_a = ok ? (ok_a | (1u << i)) : (ok_a & ~(1u << i));
+            advance(ax[i], ay[i], ab[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int yy = by[i] + dy;
+            const bool ok = b_cok && (i < 2 || b_row0 < 2) && bb[i] < p.B && bx[i] < p.W && (unsigned)yy < (unsigned)p.H;
+            const unsigned off = (((unsigned)bb[i] * p.H + yy) * (unsigned)p.W + bx[i]) * (unsigned)p.Ci + ci0 + b_col;
+            rb[i] = *reinterpret_cast<const float4 *>(p.x + (ok ? off : 0u));
+            ok_b = ok ? (ok_b | (1u << i)) : (ok_b & ~(1u << i));
+            advance(bx[i], by[i], bb[i]);
+        }
+    };
+    const bool do_bias = p.bias_out != nullptr && tile_nc == 0 && ky == 1;       // the centre row sees every gy row once
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto put = [&](unsigned short *img, int plane, int rowpitch, int row, int col, float4 v) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3x2w(v.x, v.y, h0, m0_, l0);
+        split3x2w(v.z, v.w, h1, m1, l1);
+        unsigned short *d = img + row * rowpitch + col;
+        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m0_, m1);
+        *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l0, l1);
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = keep4((ok_a >> i) & 1u, ra[i]);
+            put(la, XH_PLANE_A, X3_ROW, a_row0 + 8 * i, a_col, v);
+            if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i < 2 || b_row0 < 2) put(lb, XH_PLANE_B, XH_ROWB, b_row0 + 16 * i, b_col, keep4((ok_b >> i) & 1u, rb[i]));
+    };
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_slice();
+        store_slice();
+    }
+    __syncthreads();
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) load_slice();
+#pragma unroll
+        for (int kk = 0; kk < XH_KS / 16; ++kk) {
+            bf16x8w fa[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag_row<X3_ROW>(la + q * XH_PLANE_A, kk * 16, wm * 64 + i * 32, lane);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {          // tap kx = t reads the run one row further: gy row k meets x row k + t
+                bf16x8w fb[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fb[q] = tr_frag_row<XH_ROWB>(lb + q * XH_PLANE_B, kk * 16 + t, wn * 32, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {      // smallest terms first
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[0], acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[2], acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[1], acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[0], acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[1], acc[t][i], 0, 0, 0);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[0], acc[t][i], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < s_end) {
+            __syncthreads();
+            store_slice();
+        }
+        __syncthreads();
+    }
+
+    if (do_bias) {          // threads sharing a column quad (tid & 31) fold their 8 row partials in a fixed order
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float4 t = red[tid];
+            for (int r = 1; r < 8; ++r) {
+                const float4 v = red[r * 32 + tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            float *dst = p.bias_out + (int64_t)split * p.Co;
+            const int m = m0 + tid * 4;
+            if (m < p.Co) dst[m] = t.x;
+            if (m + 1 < p.Co) dst[m + 1] = t.y;
+            if (m + 2 < p.Co) dst[m + 2] = t.z;
+            if (m + 3 < p.Co) dst[m + 3] = t.w;
+        }
+    }
+    float *out = p.out + (int64_t)split * p.Co * p.Ntot;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+    const int ci = ci0 + wn * 32 + fcol;
+    if (ci < p.Ci) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int n = (ky * 3 + t) * p.Ci + ci;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[t][i][r];
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                             int64_t n, int splits, const float *__restrict__ ws2 = nullptr,
                                                             float *__restrict__ out2 = nullptr, int n2 = 0)
@@ -712,6 +932,26 @@ Cfg choose(int Co, int Ntot, int64_t K)
     return c;
 }
 
+// plan of the tap-fused 3x3 kernel: tiles = (Co / 128) x (Ci / 64) x 3 filter rows, K = virtual pixels B * H * (W + 1)
+static const bool g_wgrad_x3h_off = getenv("HTD_WGRAD_X3H") != nullptr && atoi(getenv("HTD_WGRAD_X3H")) == 0;
+bool x3h_takes(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
+{
+    return !g_wgrad_x3h_off && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && Co >= 64 && (Co & 3) == 0 &&
+           Ci >= 32 && (Ci & 3) == 0;
+}
+int x3h_splits(int B, int H, int W, int Ci, int Co)
+{
+    const int64_t tiles = htd::ceil_div(Co, 128) * htd::ceil_div(Ci, 64) * 3;
+    const int64_t slices = htd::ceil_div((int64_t)B * H * (W + 1), XH_KS);
+    int64_t want = htd::ceil_div(1536, tiles);                        // two workgroups per CU resident: ~3 rounds
+    int64_t cap = std::max<int64_t>(1, slices / 16);
+    if (tiles * cap < 256) cap = std::max(cap, std::min<int64_t>(htd::ceil_div(256, tiles), std::max<int64_t>(1, slices / 4)));
+    want = std::min<int64_t>(want, cap);
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 192));
+    if (splits >= 6) splits = (splits + 7) / 8 * 8;
+    return splits;
+}
+
 }  // namespace
 
 int g_wgrad_math = -1;       // -1: HTD_CONV_MATH / default; set together with the forward mode by htd_conv2d_set_math
@@ -722,7 +962,9 @@ extern "C" int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci,
     const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     const int Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
     const Cfg c = choose(Co, kh * kw * Ci, (int64_t)B * Ho * Wo);
-    return (int64_t)c.splits * Co * (kh * kw * Ci + 1) * 4 + 256;      // weight partials + bias partials
+    int splits = c.splits;
+    if (x3h_takes(Ci, Co, kh, kw, stride, pad, dil)) splits = std::max(splits, x3h_splits(B, H, W, Ci, Co));
+    return (int64_t)splits * Co * (kh * kw * Ci + 1) * 4 + 256;        // weight partials + bias partials
 }
 
 // gbias (may be NULL): also returns the bias gradient, column sums of gy, accumulated by the same kernel.
@@ -744,6 +986,31 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.K * Co < (1ll << 31),
                 "conv2d_bwd_weight: operand larger than 2^31 elements (32-bit element offsets)");
     p.Ntot = kh * kw * Ci;
+    static const int math_env0 = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
+    if ((g_wgrad_math < 0 ? math_env0 : g_wgrad_math) == 1 && x3h_takes(Ci, Co, kh, kw, stride, pad, dil)) {
+        // 3x3, stride 1: the three taps of a filter row per workgroup (conv_wgrad_x3h_kernel)
+        p.mt = (int)htd::ceil_div(Co, 128);
+        p.nt = (int)htd::ceil_div(Ci, 64);
+        p.splits = x3h_splits(B, H, W, Ci, Co);
+        const int64_t slices = htd::ceil_div((int64_t)B * H * (W + 1), XH_KS);
+        p.slices_per_split = htd::ceil_div(slices, p.splits);
+        p.splits = (int)htd::ceil_div(slices, p.slices_per_split);
+        p.out = p.splits == 1 ? gw : (float *)workspace;
+        float *bias_part = (float *)workspace + (int64_t)p.splits * Co * p.Ntot;
+        p.bias_out = !gbias ? nullptr : (p.splits == 1 ? gbias : bias_part);
+        hipStream_t s = (hipStream_t)stream;
+        const dim3 grid((unsigned)(p.mt * p.nt * 3 * p.splits));
+        if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_wgrad_x3h_kernel<false>, grid, dim3(256), 0, s, p);
+        if (p.splits > 1) {
+            const int64_t n = (int64_t)Co * p.Ntot;
+            const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
+            const unsigned extra = gbias ? (unsigned)htd::ceil_div(Co, 256) : 0u;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + extra), dim3(256), 0, s, (const float *)workspace, gw, n,
+                               p.splits, (const float *)(gbias ? bias_part : nullptr), gbias, Co);
+        }
+        return htd::check_launch("conv2d_bwd_weight");
+    }
     const Cfg c = choose(Co, p.Ntot, p.K);
     p.mt = c.mt; p.nt = c.nt; p.splits = c.splits;
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
