@@ -943,7 +943,8 @@ int x3h_splits(int B, int H, int W, int Ci, int Co)
 {
     const int64_t tiles = htd::ceil_div(Co, 128) * htd::ceil_div(Ci, 64) * 3;
     const int64_t slices = htd::ceil_div((int64_t)B * H * (W + 1), XH_KS);
-    int64_t want = htd::ceil_div(1536, tiles);                        // two workgroups per CU resident: ~3 rounds
+    static const int target = getenv("HTD_WGRAD_X3H_UNITS") ? atoi(getenv("HTD_WGRAD_X3H_UNITS")) : 1536;
+    int64_t want = htd::ceil_div(target, tiles);                      // two workgroups per CU resident: ~3 rounds
     int64_t cap = std::max<int64_t>(1, slices / 16);
     if (tiles * cap < 256) cap = std::max(cap, std::min<int64_t>(htd::ceil_div(256, tiles), std::max<int64_t>(1, slices / 4)));
     want = std::min<int64_t>(want, cap);
