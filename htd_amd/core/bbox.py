@@ -242,10 +242,16 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     gx, gy = px + pw * dx, py + ph * dy
     x1, y1, x2, y2 = gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5
     if clip_border and max_shape is not None:
-        x1 = x1.clamp(min=0, max=max_shape[1])
-        y1 = y1.clamp(min=0, max=max_shape[0])
-        x2 = x2.clamp(min=0, max=max_shape[1])
-        y2 = y2.clamp(min=0, max=max_shape[0])
+        if isinstance(max_shape, torch.Tensor):
+            # (N, 2) [h, w] per row: rows of several images in one call; min(max(x, 0), lim) is clamp's arithmetic
+            mh, mw = max_shape[:, 0:1].to(x1.dtype), max_shape[:, 1:2].to(x1.dtype)
+            x1, x2 = torch.minimum(x1.clamp(min=0), mw), torch.minimum(x2.clamp(min=0), mw)
+            y1, y2 = torch.minimum(y1.clamp(min=0), mh), torch.minimum(y2.clamp(min=0), mh)
+        else:
+            x1 = x1.clamp(min=0, max=max_shape[1])
+            y1 = y1.clamp(min=0, max=max_shape[0])
+            x2 = x2.clamp(min=0, max=max_shape[1])
+            y2 = y2.clamp(min=0, max=max_shape[0])
     return torch.stack([x1, y1, x2, y2], dim=-1).view(deltas.size())
 
 
@@ -346,6 +352,22 @@ def bbox2roi(bbox_list):
         else:
             rois_list.append(bboxes.new_zeros((0, 5)))
     return torch.cat(rois_list, 0)
+
+
+def bbox2result_many(bboxes_list, labels_list, num_classes):
+    """bbox2result of every image of a batch with ONE device-to-host copy (the per-image form copies twice per image)."""
+    counts = [int(b.shape[0]) for b in bboxes_list]
+    if not counts or not isinstance(bboxes_list[0], torch.Tensor) or sum(counts) == 0:
+        return [bbox2result(b, l, num_classes) for b, l in zip(bboxes_list, labels_list)]
+    packed = torch.cat([torch.cat(bboxes_list), torch.cat(labels_list).to(bboxes_list[0].dtype)[:, None]], 1)
+    host = packed.detach().cpu().numpy()                    # labels < 2**24 are exact in fp32
+    out, at = [], 0
+    for c in counts:
+        b, l = host[at:at + c, :5], host[at:at + c, 5].astype(np.int64)
+        at += c
+        out.append([np.zeros((0, 5), dtype=np.float32) for _ in range(num_classes)] if c == 0
+                   else [b[l == i, :] for i in range(num_classes)])
+    return out
 
 
 def bbox2result(bboxes, labels, num_classes):

@@ -29,6 +29,62 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, s
     return dets, labels[keep]
 
 
+def multiclass_nms_images(multi_bboxes, multi_scores, img_of, num_imgs, score_thr, nms_cfg, max_num=-1):
+    """multiclass_nms of EVERY image of a batch in one pass: rows of multi_bboxes / multi_scores belong to image
+    img_of[row] (int64, rows grouped by image in ascending order).  -> (dets list, labels list), element i bit-identical to
+    multiclass_nms(rows of image i): the per-image class shift idx * (max coordinate of that image's candidates + 1), the
+    stable score order and the cut to max_num are the per-image ones; (image, class) pairs are the segments of one NMS launch.
+    Hard NMS only -- callers route soft_nms (a sequential per-class decay) through the per-image form."""
+    from ..mmcv_ops import nms_sorted_mask
+    cfg = dict(nms_cfg)
+    assert cfg.pop('type', 'nms') == 'nms'
+    class_agnostic = cfg.pop('class_agnostic', False)
+    cfg.pop('split_thr', None)
+    thr = cfg.pop('iou_threshold', cfg.pop('iou_thr', None))
+    offset = cfg.pop('offset', 0)
+    num_classes = multi_scores.size(1) - 1
+    n = multi_scores.size(0)
+    dev = multi_scores.device
+    if multi_bboxes.shape[1] > 4:
+        bboxes = multi_bboxes.view(n, -1, 4)
+    else:
+        bboxes = multi_bboxes[:, None].expand(n, num_classes, 4)
+    scores = multi_scores[:, :-1]
+    valid = scores > score_thr
+    pos = valid.nonzero(as_tuple=False)                       # row-major: per image, the per-image call's candidate order
+    empty = (multi_bboxes.new_zeros((0, 5)), multi_bboxes.new_zeros((0, ), dtype=torch.long))
+    if pos.size(0) == 0:
+        return [empty[0]] * num_imgs, [empty[1]] * num_imgs
+    boxes, sc, labels = bboxes[valid], scores[valid], pos[:, 1]
+    img = img_of[pos[:, 0]]
+    if class_agnostic:
+        boxes_for_nms, seg_id = boxes, img
+    else:
+        max_c = torch.full((num_imgs, ), float('-inf'), device=dev, dtype=boxes.dtype)
+        max_c.scatter_reduce_(0, img, boxes.max(dim=1)[0], 'amax')
+        boxes_for_nms = boxes + (labels.to(boxes) * (max_c[img] + 1))[:, None]
+        seg_id = img * num_classes + labels
+    order = torch.sort(sc, descending=True, stable=True)[1]
+    perm = order[torch.sort(seg_id[order], stable=True)[1]]
+    counts = torch.bincount(seg_id, minlength=num_imgs * (1 if class_agnostic else num_classes))
+    seg = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=dev)
+    seg[1:] = torch.cumsum(counts, 0)
+    keep_sorted = nms_sorted_mask(boxes_for_nms[perm], thr, offset, seg, int(counts.max().item()))
+    keep_global = torch.zeros(sc.size(0), dtype=torch.bool, device=dev)
+    keep_global[perm] = keep_sorted.bool()
+    kept = order[keep_global[order]]                          # descending score over the whole batch
+    kept = kept[torch.sort(img[kept], stable=True)[1]]        # grouped by image, score order kept inside
+    per_img = torch.bincount(img[kept], minlength=num_imgs)
+    if max_num > 0:
+        start = torch.cumsum(per_img, 0) - per_img
+        rank = torch.arange(kept.numel(), device=dev) - start[img[kept]]
+        kept = kept[rank < max_num]
+        per_img = per_img.clamp(max=max_num)
+    dets = torch.cat([boxes[kept], sc[kept, None]], -1)
+    sizes = per_img.tolist()
+    return list(dets.split(sizes)), list(labels[kept].split(sizes))
+
+
 def merge_aug_proposals(aug_proposals, img_metas, rpn_test_cfg):
     """merge_augs.py:9-51: proposals (n,5) of every augmentation of ONE image, mapped back to the original image
     scale, de-duplicated by one NMS and cut to max_num.  -> (k,5)."""

@@ -314,6 +314,16 @@ class HTDRoIHead(nn.Module):
         return losses
 
     # ------------------------------------------------------------------ test
+    batched_test = True      # post-process the whole batch in one pass (False: the per-image loop of the reference)
+
+    def _batched_test_ok(self, rois, img_metas, rescale):
+        if not (self.batched_test and rois.is_cuda and len(img_metas) > 1):
+            return False
+        if dict(self.test_cfg.nms).get('type', 'nms') != 'nms':
+            return False                                            # soft-NMS decays sequentially per class: per image
+        kinds = {isinstance(m['scale_factor'], float) for m in img_metas}
+        return not rescale or len(kinds) == 1
+
     def simple_test_bboxes(self, x, proposal_list, img_metas, rescale=False):
         """-> (det_bboxes list, det_labels list) on the device."""
         num_imgs = len(proposal_list)
@@ -324,10 +334,20 @@ class HTDRoIHead(nn.Module):
         cls0, reg0 = res['cls_score'], res['bbox_pred']
         # stage-1 refinement with the arg-max foreground class (:346-352); class-agnostic => label unused
         label = cls0[:, :-1].argmax(dim=1)
-        rois = torch.cat([self.bbox_head[0].regress_by_class(r, l, p, m) for r, l, p, m in
-                          zip(rois.split(n_per), label.split(n_per), reg0.split(n_per), img_metas)])
+        batched = self._batched_test_ok(rois, img_metas, rescale)
+        if batched:
+            # every row carries its image's clip limits / scale: the same arithmetic as the per-image calls, one pass
+            img_of = rois[:, 0].long()
+            hw = torch.tensor([[float(m['img_shape'][0]), float(m['img_shape'][1])] for m in img_metas],
+                              dtype=rois.dtype).to(rois.device, non_blocking=True)[img_of]
+            rois = self.bbox_head[0].regress_by_class(rois, label, reg0, dict(img_shape=hw))
+        else:
+            rois = torch.cat([self.bbox_head[0].regress_by_class(r, l, p, m) for r, l, p, m in
+                              zip(rois.split(n_per), label.split(n_per), reg0.split(n_per), img_metas)])
         res = self._bbox_forward(1, x, rois, global_feat)
         cls_score = (cls0 + res['cls_score']) / 2.0              # logits averaged over the stages (:363-366)
+        if batched:
+            return self._get_bboxes_images(rois, cls_score, res['bbox_pred'], img_of, hw, img_metas, rescale)
         det_bboxes, det_labels = [], []
         for i, (r, c, p) in enumerate(zip(rois.split(n_per), cls_score.split(n_per), res['bbox_pred'].split(n_per))):
             b, l = self.bbox_head[-1].get_bboxes(r, c, p, img_metas[i]['img_shape'], img_metas[i]['scale_factor'],
@@ -336,8 +356,29 @@ class HTDRoIHead(nn.Module):
             det_labels.append(l)
         return det_bboxes, det_labels
 
+    def _get_bboxes_images(self, rois, cls_score, bbox_pred, img_of, hw, img_metas, rescale):
+        """BBoxHead.get_bboxes (bbox_heads/bbox_head.py:309-341) of every image at once; results equal the per-image calls
+        bit for bit (tests/test_gpu_detector.py::test_batched_test_postprocessing_equals_the_per_image_loop)."""
+        from ..core.post_processing import multiclass_nms_images
+        head = self.bbox_head[-1]
+        bboxes, scores = head.get_bboxes(rois, cls_score, bbox_pred, hw, None, rescale=False, cfg=None)
+        if rescale and bboxes.size(0) > 0:
+            if isinstance(img_metas[0]['scale_factor'], float):
+                # tensor / python scalar multiplies by the fp32 reciprocal on the device; same here, per row
+                inv = (1.0 / torch.tensor([m['scale_factor'] for m in img_metas], dtype=torch.float32))
+                bboxes = bboxes * inv.to(bboxes.device, non_blocking=True)[img_of][:, None]
+            else:
+                sf = torch.tensor([[float(v) for v in m['scale_factor']] for m in img_metas], dtype=torch.float32)
+                sf = sf.to(bboxes.device, non_blocking=True)[img_of]
+                bboxes = (bboxes.view(bboxes.size(0), -1, 4) / sf[:, None, :]).view(bboxes.size(0), -1)
+        return multiclass_nms_images(bboxes, scores, img_of, len(img_metas), self.test_cfg.score_thr, self.test_cfg.nms,
+                                     self.test_cfg.max_per_img)
+
     def simple_test(self, x, proposal_list, img_metas, rescale=False):
+        from ..core.bbox import bbox2result_many
         det_bboxes, det_labels = self.simple_test_bboxes(x, proposal_list, img_metas, rescale)
+        if self.batched_test:
+            return bbox2result_many(det_bboxes, det_labels, self.bbox_head[-1].num_classes)
         return [bbox2result(b, l, self.bbox_head[-1].num_classes) for b, l in zip(det_bboxes, det_labels)]
 
     def aug_test(self, features, proposal_list, img_metas, rescale=False):

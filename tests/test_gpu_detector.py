@@ -105,6 +105,48 @@ def test_inference_matches_reference_fixture(det, golden):
             used[j] = True
 
 
+@pytest.mark.parametrize('scale', ['array', 'float', None])
+def test_batched_test_postprocessing_equals_the_per_image_loop(det, golden, scale):
+    """HTDRoIHead.simple_test post-processes the whole batch in one pass (per-row clip limits and scale factors,
+    (image, class) segments of one NMS launch, one device-to-host copy); the reference loops over the images
+    (roi_heads/htd_roi_head.py:346-386).  Both forms must agree BIT FOR BIT, with images of different shapes and scale
+    factors, an image without detections, and the cut to max_per_img active."""
+    g = golden('detector')
+    dev = torch.device('cuda:0')
+    img, metas, _, _ = inputs(g, dev)
+    H, W = img.shape[-2:]
+    img = torch.cat([img, img.flip(0) * 0.5, img[:1] * 0.0])                     # 5 images, the last one blank
+    shapes = [(H, W - 24), (H - 16, W), (H - 32, W - 40), (H, W), (H - 8, W - 8)]
+    metas = []
+    for i, (h, w) in enumerate(shapes):
+        sf = {'array': np.array([1.0 + 0.13 * i, 0.9 + 0.07 * i] * 2, dtype=np.float32), 'float': 0.7 + 0.3 * i,
+              None: np.ones(4, dtype=np.float32)}[scale]
+        metas.append(dict(img_shape=(h, w, 3), pad_shape=(H, W, 3), ori_shape=(h, w, 3), scale_factor=sf, flip=False))
+    det.eval()
+    head = det.roi_head
+    old_cfg = copy.deepcopy(head.test_cfg)
+    try:
+        head.test_cfg.max_per_img = 37
+        with torch.no_grad():
+            feats = det.extract_feat(img)
+            props = det.rpn_head.simple_test_rpn(feats, metas)
+            out = {}
+            for mode in (True, False):
+                head.batched_test = mode
+                b, l = head.simple_test_bboxes(feats, props, metas, rescale=scale is not None)
+                out[mode] = (b, l, head.simple_test(feats, props, metas, rescale=scale is not None))
+    finally:
+        head.batched_test = True
+        head.test_cfg = old_cfg
+    counts = [int(x.shape[0]) for x in out[False][0]]
+    assert max(counts) == 37 and sum(counts) > 60, counts                        # the cut is active; boxes to compare
+    for i in range(len(shapes)):
+        assert torch.equal(out[True][0][i], out[False][0][i]), i
+        assert torch.equal(out[True][1][i], out[False][1][i]), i
+        for a, b in zip(out[True][2][i], out[False][2][i]):
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
+
+
 def test_proposal_indices_and_stage_logits_match_reference_fixture(det, golden):
     """north_star's parity clause at path level.  (1) Fed the RPN logits of the reference run (detector.npz), the
     product's proposal stage -- per-level sort, decode, one batched NMS launch -- keeps the SAME candidates in the SAME
