@@ -103,8 +103,13 @@ struct X3Params {
     int64_t M;                 // B*Ho*Wo
     int mt, nt;
     int ncs;                   // Ci / 16
-    int splits, steps_per_split;
-    float *partial;            // [splits][M][Co] when splits > 1
+    // Work decomposition (plan_x3p).  Tiles [0, tiles_a) -- region A, output rows < m_rem0 -- are cut along K into splits_a
+    // ranges of sps_a steps, the later tiles -- region B -- into splits_b ranges of sps_b steps; one workgroup per (tile,
+    // range).  A region with one range writes y; otherwise its workgroups write partial sums, [split][row][Co] per region
+    // (region A first), which conv_x3p_splitk_epilogue_kernel adds in split order.
+    int tiles_a, splits_a, sps_a, splits_b, sps_b;
+    int64_t m_rem0;
+    float *partial;
 };
 
 template <int BM, int KW>
@@ -153,11 +158,24 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
     uint4 *const lA = lds, *const lB = lds + 2 * A_VEC;
     const unsigned lds_a0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lA;      // LDS byte address of the A buffers
 
-    // XCD-aware tile order (conv_fwd.hip): the blocks of one XCD walk a contiguous run of tiles, N tiles of an M tile adjacent
-    const int nblk = p.mt * p.nt;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+    // XCD-aware tile order (conv_fwd.hip): the blocks of one XCD walk a contiguous run of tiles, N tiles of an M tile adjacent.
+    // Blocks past the whole tiles are (remainder tile, K split) pairs in plain order.
+    int bid = blockIdx.x, split = 0, sps = 0;
+    bool part = false;
+    const bool region_b = bid >= p.tiles_a * p.splits_a;
+    if (region_b) {
+        const int r = bid - p.tiles_a * p.splits_a;
+        bid = p.tiles_a + r / p.splits_b;
+        split = r % p.splits_b;
+        part = p.splits_b > 1;
+        sps = p.sps_b;
+    } else if (p.splits_a > 1) {
+        split = bid % p.splits_a;
+        bid = bid / p.splits_a;
+        part = true;
+        sps = p.sps_a;
+    } else {
+        const int q = p.tiles_a / 8, r = p.tiles_a % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_m = bid / p.nt, tile_n = bid % p.nt;
@@ -231,36 +249,52 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
     const int b_c2 = MF16 ? (((kg >> 1) ? 0 : 4) + (kg & 1)) * BN * 16 + b_row : 0;                    // [b2|b0]
 
     const int total_steps = p.ncs * p.kh;
-    const int s_begin = blockIdx.y * p.steps_per_split;
-    const int s_end = min(total_steps, s_begin + p.steps_per_split);
+    const int s_begin = part ? split * sps : 0;
+    const int s_end = part ? min(total_steps, s_begin + sps) : total_steps;
 
     // zero rows of both A buffers (never overwritten: the staging writes rows < RUN only)
     if (tid < 2 * NCH) lA[(tid / NCH) * A_VEC + (tid % NCH) * G::PITCH + G::RUN] = make_uint4(0u, 0u, 0u, 0u);
 
-    constexpr int PPT = (G::PASSES + KW - 1) / KW;                // passes of the next run staged per tap
-    f32x4 ra[PPT];
+    // ---- A staging registers.  A pass (64 rows x one float4 per thread) is IN FLIGHT FOR A WHOLE TAP: issued at the start of
+    // one tap, waited for and split into LDS at the end of the NEXT one, so the matrix work of two taps (and of the
+    // co-resident workgroups) covers the HBM latency; with the wait in the same tap, a 64-row tile -- a few hundred matrix
+    // cycles per tap -- stalled ~1 us per tap on it.
+    //   KW > 1: tap kx issues pass kx + 1 of the NEXT step's run (the last tap: pass 0 of the run after it) and stores pass kx;
+    //   KW = 1: a step is one tap; it issues the NP passes of the run two steps ahead and stores the run of the next step.
+    // Two register sets alternate tap by tap: the tap loop is unrolled by two so that the set is a literal.  hipcc does not
+    // know that a load into these registers is outstanding, so it must never have a reason to MOVE them: every asm statement
+    // that touches them ties them through "+v", none sits under a branch (a pass that does not exist is loaded from element 0
+    // and dropped at store time), and the chain init -> load -> landed -> load ... keeps one physical register per slot
+    // around the loop.  tools/x3p_check_isa.py (tests/test_build.py) checks the ISA of every instantiation for such moves.
+    constexpr int NP = G::PASSES;
+    constexpr int NPT = KW > 1 ? 1 : NP;                          // staging registers per set = A loads per tap
+    static_assert(KW == 1 || NP <= KW, "one pass per tap");
+    f32x4 ra[2 * NPT];
+#pragma unroll
+    for (int i = 0; i < 2 * NPT; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned ra_ok = 0u;
     // (no divisions inside the K loop: the step's channel slice / filter row and the prefetch pointers advance incrementally)
-    auto load_pass = [&](int shift, int koff, int i, int slot) {   // pass i of the run at pixel shift `shift`, element offset koff
+    auto load_pass = [&](int shift, int koff, int i, int slot, bool live) __attribute__((always_inline)) {   // pass i of the run at pixel shift `shift`
         bool ok;
         unsigned off;
         if constexpr (KW > 1) {
             const int g = a_g0 + 64 * i + shift;
-            ok = vrow + 64 * i < G::RUN && g >= 0 && (int64_t)g < p.M;
+            ok = live && vrow + 64 * i < G::RUN && g >= 0 && (int64_t)g < p.M;
             off = a_off[0] + (unsigned)(64 * i) * (unsigned)p.Ci + (unsigned)koff;
+            ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         } else {
-            ok = a_in[i];
+            ok = live && a_in[i];
             off = a_off[i] + (unsigned)koff;
         }
-        // out of range: element 0, zeroed at store time.  Inline asm: hipcc must not count this load (see NB above); its result
-        // is not touched before wait_vm() names it
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot]) : "v"(p.x + (off & (0u - (unsigned)ok))) : "memory");
-        ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
+        // out of range / not live: element 0, zeroed or dropped at store time.  Inline asm: hipcc must not count this load (see NB above)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(ra[slot]) : "v"(p.x + (off & (0u - (unsigned)ok))) : "memory");
     };
-    auto store_pass = [&](int buf, int i, int slot) {   // registers -> three bf16 planes of the run, chunk-major
+    auto store_pass = [&](int buf, int i, int slot) __attribute__((always_inline)) {   // registers -> three bf16 planes, chunk-major
         const int j = vrow + 64 * i;
         if (G::RUN % 64 != 0 && j >= G::RUN) return;
-        const bool ok = (ra_ok >> i) & 1u;
+        bool ok;
+        if constexpr (KW > 1) ok = (ra_ok >> i) & 1u;
+        else ok = a_in[i];
         const float4 v = make_float4(ok ? ra[slot][0] : 0.f, ok ? ra[slot][1] : 0.f, ok ? ra[slot][2] : 0.f, ok ? ra[slot][3] : 0.f);
         unsigned h0, m0_, l0, h1, m1, l1;
         split3x2(v.x, v.y, h0, m0_, l0);
@@ -271,9 +305,6 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
         lds_store8<2 * G::PITCH * 16>(d, m0_, m1);
         lds_store8<4 * G::PITCH * 16>(d, l0, l1);
     };
-    // the passes of the NEXT step's run are spread over the taps of the current one: tap kx loads passes kx * PPT .. at its start
-    // and splits + stores them at its end (the other A buffer is free during the whole step), so PPT float4 are in flight per
-    // thread and the split work lands beside every tap's MFMAs instead of in one burst
     // B tile of (step s, tap kx) -> LDS buffer `buf`, LDS-DMA: instruction idx = chunk * (BN / 64) + half covers 64 rows
     constexpr int NI = NCH * BN / 64;                             // LDS-DMA instructions per B tile, dealt round-robin to the waves
     const uint4 *bsrc[(NI + 3) / 4];                              // the lane's source of the wave's k-th instruction, tile (tap 0, slice 0)
@@ -301,7 +332,14 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
     };
     constexpr int DIST = NB - 1;                                  // prefetch distance of the B tiles, in taps
     constexpr int NI_MIN = NCH * BN / 64 / 4;                     // LDS-DMA instructions every wave issues per B tile
-    static_assert(PPT <= 2 && NI_MIN >= 1, "wait_vm covers two staged registers");
+    static_assert(NI_MIN >= 1, "every wave issues at least one LDS-DMA per B tile");
+    // At the end of a tap the A pass issued in the PREVIOUS tap and the B tile of the next tap must have landed.  A tap issues
+    // its B tile first, then its A pass(es): with DIST = 1 the B tile is this tap's own and only the A loads behind it may stay
+    // outstanding; with DIST >= 2 it is older than everything this tap issued.  Vector-memory operations retire in order.
+    auto wait_tap = [&](bool b_issued) __attribute__((always_inline)) {
+        if (DIST >= 2 && b_issued) wait_vm<NPT + NI_MIN>();
+        else wait_vm<NPT>();
+    };
     // the next B tile to issue: step, tap of the filter (ky * KW + kx), channel slice, buffer, offset in the plane image
     const int ntap = p.kh * KW;
     const unsigned tile_stride = (unsigned)(NCH * p.Cop);         // uint4 per (tap, slice) tile
@@ -328,109 +366,161 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
 #pragma unroll
             for (int r = 0; r < (MF16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
-    int cs = s_begin / p.kh, ky = s_begin - cs * p.kh;            // channel slice and filter row of the current step
-    if (s_begin < s_end) {
+    // the matrix work of one tap: fragments of A buffer `abuf` at row shift kx against B buffer `bbuf`
+    auto mma_tap = [&](int abuf, int bbuf, int kx, int tap0) __attribute__((always_inline)) {
+        const char *la = reinterpret_cast<const char *>(lA + abuf * A_VEC);
+        const char *lb = reinterpret_cast<const char *>(lB + bbuf * B_VEC);
+        int arow[RB];
 #pragma unroll
-        for (int d = 0; d < DIST; ++d) issue_b();
+        for (int i = 0; i < RB; ++i) {
+            arow[i] = a_frag0 + (i * RBLK + kx) * 16;
+            if constexpr (KW > 1) arow[i] = ((vmask[i] >> (tap0 + kx)) & 1u) ? arow[i] : zero_frag;
+        }
+        if constexpr (MF16) {
+            bf16x8 fa01[RB], fa02[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                fa01[i] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c0);
+                fa02[i] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c1);
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const bf16x8 fb01 = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 16 * 16);
+                const bf16x8 fb10 = *reinterpret_cast<const bf16x8 *>(lb + b_c1 + j * 16 * 16);
+                const bf16x8 fb20 = *reinterpret_cast<const bf16x8 *>(lb + b_c2 + j * 16 * 16);
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {      // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa02[i], fb20, acc[i][j], 0, 0, 0);   // a0 b2 + a2 b0
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb10, acc[i][j], 0, 0, 0);   // a0 b1 + a1 b0
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb01, acc[i][j], 0, 0, 0);   // a0 b0 + a1 b1
+                }
+            }
+        } else {
+            bf16x8 fa[RB][3], fb[CB][3];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    fa[i][q] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c0 + q * 2 * G::PITCH * 16);
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 32 * 16 + q * 2 * BN * 16);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {      // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    int s = s_begin;                                              // current step: channel slice cs, filter row ky
+    int cs = s_begin / p.kh, ky = s_begin - cs * p.kh;
+    int cs1 = cs, ky1 = ky;                                       // step s + 1
+    if (++ky1 == p.kh) { ky1 = 0; ++cs1; }
+    int cs2 = cs1, ky2 = ky1;                                     // step s + 2
+    if (++ky2 == p.kh) { ky2 = 0; ++cs2; }
+    // prologue (every split has at least one step): the first B tiles, the whole run of the first step through the staging
+    // registers, then the first pass(es) of the next run in flight in set 1 -- the loop's first tap stores from set 1
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) issue_b();
+    {
         const int shift0 = (ky - PADY) * p.Wx, koff0 = shift0 * p.Ci + cs * XK;
+        if constexpr (KW == 1) {
 #pragma unroll
-        for (int i0 = 0; i0 < G::PASSES; i0 += PPT) {
-#pragma unroll
-            for (int ii = 0; ii < PPT; ++ii)
-                if (i0 + ii < G::PASSES) load_pass(shift0, koff0, i0 + ii, ii);
+            for (int i = 0; i < NP; ++i) load_pass(0, koff0, i, i, true);
             wait_vm<0>();
 #pragma unroll
-            for (int ii = 0; ii < PPT; ++ii) landed(ra[ii]);
+            for (int i = 0; i < NP; ++i) landed(ra[i]);
 #pragma unroll
-            for (int ii = 0; ii < PPT; ++ii)
-                if (i0 + ii < G::PASSES) store_pass(0, i0 + ii, ii);
+            for (int i = 0; i < NP; ++i) store_pass(0, i, i);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) load_pass(0, (s_begin + 1) * XK, i, NP + i, s_begin + 1 < s_end);
+        } else {
+            load_pass(shift0, koff0, 0, 0, true);
+            load_pass(shift0, koff0, 1, 1, true);
+            wait_vm<0>();
+            landed(ra[0]);
+            landed(ra[1]);
+            store_pass(0, 0, 0);
+            store_pass(0, 1, 1);
+            if constexpr (NP > 2) {
+                load_pass(shift0, koff0, 2, 0, true);
+                wait_vm<0>();
+                landed(ra[0]);
+                store_pass(0, 2, 0);
+            }
+            const int sh = (ky1 - PADY) * p.Wx;
+            load_pass(sh, sh * p.Ci + cs1 * XK, 0, 1, s_begin + 1 < s_end);
         }
     }
     lds_barrier();
 
-    int bbuf = 0;
-    for (int s = s_begin; s < s_end; ++s) {
-        const int abuf = (s - s_begin) & 1;
-        const bool more = s + 1 < s_end;
-        const int tap0 = ky * KW;                                  // mask bit of the step's first tap
-        if (++ky == p.kh) { ky = 0; ++cs; }                       // (cs, ky) now describe step s + 1, whose run is staged below
-        const int nshift = (ky - PADY) * p.Wx, nkoff = nshift * p.Ci + cs * XK;
-        // (a rolled tap loop: unrolled, hipcc hoists the three taps' address arithmetic and fragment loads and spills)
-#pragma unroll 1
-        for (int kx = 0; kx < KW; ++kx) {
-            // prefetch: the next step's A run into registers (oldest in the queue), then the B tile DIST taps ahead by LDS-DMA
-            if (more) {
+    int bbuf = 0, abuf = 0, kx = 0;
+    int n1shift = (ky1 - PADY) * p.Wx, n1koff = n1shift * p.Ci + cs1 * XK;
+    int n2shift = (ky2 - PADY) * p.Wx, n2koff = n2shift * p.Ci + cs2 * XK;
+    // one tap; P (a literal at the call sites) is the register set this tap LOADS into, the other one is stored
+    // (TAIL: the split's last tap when their number is odd -- it has nothing to put in flight)
+    auto tap = [&](int P, bool TAIL) __attribute__((always_inline)) {
+        const bool more = s + 1 < s_end, more2 = s + 2 < s_end;
+        const bool issued = issue_b();
+        if (!TAIL) {
+            if constexpr (KW == 1) {
 #pragma unroll
-                for (int ii = 0; ii < PPT; ++ii)
-                    if (kx * PPT + ii < G::PASSES) load_pass(nshift, nkoff, kx * PPT + ii, ii);
-            }
-            const bool issued = issue_b();
-
-            const char *la = reinterpret_cast<const char *>(lA + abuf * A_VEC);
-            const char *lb = reinterpret_cast<const char *>(lB + bbuf * B_VEC);
-            int arow[RB];
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                arow[i] = a_frag0 + (i * RBLK + kx) * 16;
-                if constexpr (KW > 1) arow[i] = ((vmask[i] >> (tap0 + kx)) & 1u) ? arow[i] : zero_frag;
-            }
-            if constexpr (MF16) {
-                bf16x8 fa01[RB], fa02[RB];
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    fa01[i] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c0);
-                    fa02[i] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c1);
-                }
-#pragma unroll
-                for (int j = 0; j < CB; ++j) {
-                    const bf16x8 fb01 = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 16 * 16);
-                    const bf16x8 fb10 = *reinterpret_cast<const bf16x8 *>(lb + b_c1 + j * 16 * 16);
-                    const bf16x8 fb20 = *reinterpret_cast<const bf16x8 *>(lb + b_c2 + j * 16 * 16);
-#pragma unroll
-                    for (int i = 0; i < RB; ++i) {      // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa02[i], fb20, acc[i][j], 0, 0, 0);   // a0 b2 + a2 b0
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb10, acc[i][j], 0, 0, 0);   // a0 b1 + a1 b0
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb01, acc[i][j], 0, 0, 0);   // a0 b0 + a1 b1
-                    }
-                }
+                for (int i = 0; i < NP; ++i) load_pass(0, n2koff, i, P * NP + i, more2);
             } else {
-                bf16x8 fa[RB][3], fb[CB][3];
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        fa[i][q] = *reinterpret_cast<const bf16x8 *>(la + arow[i] + a_c0 + q * 2 * G::PITCH * 16);
-#pragma unroll
-                for (int j = 0; j < CB; ++j)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 32 * 16 + q * 2 * BN * 16);
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int j = 0; j < CB; ++j) {      // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-                    }
+                const bool last = kx == KW - 1;
+                load_pass(last ? n2shift : n1shift, last ? n2koff : n1koff, last ? 0 : kx + 1, P, last ? more2 : more);
             }
-            // the staged A registers and the NEXT tap's B tile have landed once all but this tap's own LDS-DMA are done
-            if (DIST >= 2 && issued) wait_vm<NI_MIN>();
-            else wait_vm<0>();
-#pragma unroll
-            for (int ii = 0; ii < PPT; ++ii) landed(ra[ii]);
-            if (more) {
-#pragma unroll
-                for (int ii = 0; ii < PPT; ++ii)
-                    if (kx * PPT + ii < G::PASSES) store_pass(abuf ^ 1, kx * PPT + ii, ii);
-            }
-            lds_barrier();                 // every wave is done with this tap's buffers; the next tap's are complete
-            bbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
         }
+        mma_tap(abuf, bbuf, kx, ky * KW);
+        // the other set (issued one tap ago) and the next tap's B tile have landed
+        if (TAIL) wait_vm<0>();
+        else wait_tap(issued);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) landed(ra[(P ^ 1) * NPT + i]);
+        if (more) {
+            if constexpr (KW == 1) {
+#pragma unroll
+                for (int i = 0; i < NP; ++i) store_pass(abuf ^ 1, i, (P ^ 1) * NP + i);
+            } else {
+                store_pass(abuf ^ 1, kx, P ^ 1);
+            }
+        }
+        lds_barrier();               // every wave is done with this tap's buffers; the next tap's are complete
+        bbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
+        if (++kx == KW) {            // next step (no divisions: slice / filter row advance incrementally)
+            kx = 0;
+            ++s;
+            abuf ^= 1;
+            cs = cs1; ky = ky1;
+            cs1 = cs2; ky1 = ky2;
+            if (++ky2 == p.kh) { ky2 = 0; ++cs2; }
+            n1shift = n2shift; n1koff = n2koff;
+            n2shift = (ky2 - PADY) * p.Wx;
+            n2koff = n2shift * p.Ci + cs2 * XK;
+        }
+    };
+    const int taps_total = (s_end - s_begin) * KW;
+    int t = 0;
+#pragma unroll 1
+    for (; t + 1 < taps_total; t += 2) {
+        tap(0, false);
+        tap(1, false);
     }
+    if (t < taps_total) tap(0, true);
+    // the last taps' loads fetch nothing that is used, but they still WRITE their registers when they land: drain them before
+    // the epilogue may reuse the registers
+    wait_vm<0>();
+#pragma unroll
+    for (int i = 0; i < 2 * NPT; ++i) landed(ra[i]);
 
     // ---- epilogue (conv_fwd.hip): accumulators through LDS, 16-byte stores along output rows, fused bias / residual /
     // ReLU / producer's ReLU mask.  D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
@@ -466,8 +556,10 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
             if (m >= p.M || n >= p.Co) continue;
             float4 v = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
             const int64_t o = m * p.Co + n;
-            if (p.splits > 1) {
-                float *dst = p.partial + (int64_t)blockIdx.y * p.M * p.Co + o;
+            if (part) {
+                float *dst = region_b ? p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * p.m_rem0 * p.Co : 0) +
+                                            ((int64_t)split * (p.M - p.m_rem0) + (m - p.m_rem0)) * p.Co + n
+                                      : p.partial + ((int64_t)split * p.m_rem0 + m) * p.Co + n;
                 if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
                 else {
                     dst[0] = v.x;
@@ -517,13 +609,19 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
     }
 }
 
-// sums the split-K partials in a fixed order and applies the epilogue
+// sums the K-range partials of the regions that have them, in range order, and applies the epilogue
 __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params p)
 {
-    const int64_t total = p.M * p.Co;
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lo = p.splits_a > 1 ? 0 : p.m_rem0 * p.Co, hi = p.splits_b > 1 ? p.M * p.Co : p.m_rem0 * p.Co;
+    const int64_t na = p.m_rem0 * p.Co, nb = (p.M - p.m_rem0) * p.Co;
+    const float *pb = p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * na : 0);
+    for (int64_t o = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < hi; o += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
-        for (int k = 0; k < p.splits; ++k) v += p.partial[(int64_t)k * total + o];
+        if (o < na) {
+            for (int k = 0; k < p.splits_a; ++k) v += p.partial[(int64_t)k * na + o];
+        } else {
+            for (int k = 0; k < p.splits_b; ++k) v += pb[(int64_t)k * nb + (o - na)];
+        }
         const int n = (int)(o % p.Co);
         if (p.bias) v += p.bias[n];
         if (p.residual) {
@@ -645,25 +743,80 @@ int forced_cfg()
     return (v >= 0 && v < 4) ? v : -1;
 }
 
-int plan_splits_x3p(int64_t M, int Co, int total_steps)
+// tune mode: HTD_X3P_BASE_SPLITS / HTD_X3P_REM_SPLITS force the two split factors of plan_x3p (0 = planned)
+int forced_splits(const char *name)
 {
-    const int64_t tiles = htd::ceil_div(M, 128) * htd::ceil_div(Co, 64);
-    if (tiles <= 0 || tiles >= 384 || total_steps < 32) return 1;
-    int64_t want = htd::ceil_div(768, tiles);
-    want = std::min<int64_t>(want, total_steps / 16);
-    return (int)std::max<int64_t>(1, std::min<int64_t>(want, 16));
+    if (!g_x3p_tune) return 0;
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
+// Work decomposition of one launch.  A layer whose tiles all fit on the chip at once (l3 / l4 of the backbone, P4-P6, the FC
+// layers: a few hundred tiles for 256 CUs) runs as long as its most loaded CU -- 526 tiles put three on some CUs and two on
+// the others, 68 % of the chip's time -- and a CU with a single workgroup cannot hide its own latencies.  So
+//   * every tile is cut along K into `base` ranges when there are too few tiles for ~3 workgroups per CU, and
+//   * the (tile, range) units beyond the last multiple of 256 -- the remainder -- are cut `rem` times more, into about 256
+//     small workgroups that spread over every CU.
+// Partial sums are added in range order by the epilogue kernel: deterministic, like the classic split-K this generalises.
+// The factors minimise a small time model (rounds x unit time x a latency penalty for < 3 resident workgroups + the
+// partial-sum traffic); tools/sweep_x3p.py measures it against forced factors.
+struct XPlan {
+    int tiles_a, splits_a, sps_a, splits_b, sps_b;
+    int64_t m_rem0, grid, partial_floats;
+};
+constexpr int kXOcc[4] = {5, 3, 4, 4};           // resident workgroups per CU of the four tiles (x3p_occupancy)
+
+XPlan plan_x3p(int cfg, int64_t M, int Co, int total_steps, int kw, bool have_ws)
+{
+    const int bm = kXCfg[cfg].bm, bn = kXCfg[cfg].bn;
+    const int64_t mt = htd::ceil_div(M, bm), nt = htd::ceil_div(Co, bn), tiles = mt * nt;
+    XPlan pl{(int)tiles, 1, total_steps, 1, total_steps, M, tiles, 0};
+    const int fbase = forced_splits("HTD_X3P_BASE_SPLITS"), frem = forced_splits("HTD_X3P_REM_SPLITS");
+    if (!have_ws || total_steps < 8 || tiles > 256 * kXOcc[cfg]) return pl;   // more than one resident round: dispatch balances
+    const double tile_s = 2.0 * bm * bn * total_steps * XK * kw / (200e12 / 256);      // one tile on one CU at the large-layer rate
+    const double ov = 8.0 / (double)(total_steps * kw);                               // prologue + partial epilogue, in tile times
+    double best_t = 1e30;
+    for (int base = 1; base <= 8; ++base) {
+        if (fbase > 0 && base != fbase) continue;
+        if (base > 1 && total_steps / base < 8) break;
+        const int64_t units = tiles * base;
+        int64_t ua = (units / 256) * 256;
+        ua -= ua % (nt * base);                                       // whole rows of tiles
+        const int64_t ta = ua / base, r = tiles - ta, m0 = std::min<int64_t>((ta / nt) * bm, M);
+        for (int rem = 1; rem <= 16; ++rem) {
+            if (frem > 0 && rem != frem) continue;
+            if (r == 0 && rem > 1) break;
+            const int sb = base * rem;
+            if (sb > 1 && total_steps / sb < 3) break;
+            const double t_a = (double)(ua / 256) * (1.0 / base + (base > 1 ? ov : 0.0));
+            const double t_b = r ? (double)htd::ceil_div(r * sb, 256) * (1.0 / sb + (sb > 1 ? ov : 0.0)) : 0.0;
+            const double resident = std::min<double>((double)(ua + r * sb) / 256.0, kXOcc[cfg]);
+            const double latency = resident < 1.5 ? 1.45 : (resident < 2.5 ? 1.12 : 1.0);
+            const int64_t pf = (base > 1 ? (int64_t)base * m0 * Co : 0) + (sb > 1 ? (int64_t)sb * (M - m0) * Co : 0);
+            if (pf * 4 > (128ll << 20)) continue;
+            const double t = (t_a + t_b) * latency * tile_s + (double)pf * 8.0 / 4e12 + (pf ? 4e-6 : 0.0);
+            if (t < best_t * 0.98) {
+                best_t = t;
+                const int spa = (int)htd::ceil_div(total_steps, base), spb = (int)htd::ceil_div(total_steps, sb);
+                pl = XPlan{(int)ta, (int)htd::ceil_div(total_steps, spa), spa, (int)htd::ceil_div(total_steps, spb), spb, m0, 0, 0};
+                pl.grid = ta * pl.splits_a + r * pl.splits_b;
+                pl.partial_floats = (pl.splits_a > 1 ? (int64_t)pl.splits_a * m0 * Co : 0) +
+                                    (pl.splits_b > 1 ? (int64_t)pl.splits_b * (M - m0) * Co : 0);
+            }
+        }
+    }
+    return pl;
 }
 
 // wave quantisation on 256 CUs x the useful fraction of the padded tiles x a per-tile base efficiency
-float cfg_score(int cfg, int64_t M, int Co, int splits)
+float cfg_score(int cfg, int64_t M, int Co)
 {
     const int bm = kXCfg[cfg].bm, bn = kXCfg[cfg].bn;
     const int64_t tiles = htd::ceil_div(M, bm) * htd::ceil_div(Co, bn);
     static const float base[4] = {0.80f, 1.00f, 0.90f, 0.92f};
-    const float w = (float)(tiles * splits) / 256.f;
-    const float per_cu = cfg == 0 ? 6.f : (cfg == 1 ? 3.f : 4.f);      // resident workgroups per CU
-    const float rounds = w / per_cu;
-    const float quant = rounds >= 4.f ? 1.f : rounds / ceilf(rounds) * 0.5f + 0.5f * (w / ceilf(w));
+    const float w = (float)tiles / 256.f;
+    // one resident round: the remainder is spread by plan_x3p (a small loss); more: the last round is partly empty
+    const float quant = tiles <= 256 * kXOcc[cfg] ? (w < 1.f ? 0.85f : 0.95f) : w / ceilf(w) * 0.3f + 0.7f;
     const float useful = (float)((double)M * Co / ((double)tiles * bm * bn));
     return base[cfg] * quant * useful;
 }
@@ -696,7 +849,7 @@ int table_cfg(int64_t M, int Co, int Ci, int taps, int epi)
     return it == g_xtable.end() ? -1 : it->second;
 }
 
-int choose_cfg(int64_t M, int Co, int Ci, int taps, int epi, int splits)
+int choose_cfg(int64_t M, int Co, int Ci, int taps, int epi)
 {
     int cfg = forced_cfg();
     if (cfg < 0) cfg = table_cfg(M, Co, Ci, taps, epi);
@@ -704,7 +857,7 @@ int choose_cfg(int64_t M, int Co, int Ci, int taps, int epi, int splits)
     float best = -1.f;
     static const int cand[4] = {1, 3, 2, 0};
     for (int c : cand) {
-        const float sc = cfg_score(c, M, Co, splits);
+        const float sc = cfg_score(c, M, Co);
         if (sc > best * 1.005f) { best = sc; cfg = c; }
     }
     return cfg;
@@ -758,25 +911,25 @@ void launch_tile(const X3Params &p, int kw, dim3 grid, hipStream_t s)
 int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
 {
     const int total_steps = p.ncs * p.kh;
-    p.splits = workspace ? plan_splits_x3p(p.M, p.Co, total_steps) : 1;
-    p.steps_per_split = (int)htd::ceil_div(total_steps, p.splits);
-    p.splits = (int)htd::ceil_div(total_steps, p.steps_per_split);
-    p.partial = (float *)workspace;
     const int epi = (p.residual ? 1 : 0) | (p.mask_src ? 2 : 0);
-    const int cfg = choose_cfg(p.M, p.Co, p.Ci, p.kh * kw, epi, p.splits);
+    const int cfg = choose_cfg(p.M, p.Co, p.Ci, p.kh * kw, epi);
+    const XPlan pl = plan_x3p(cfg, p.M, p.Co, total_steps, kw, workspace != nullptr);
+    p.tiles_a = pl.tiles_a; p.splits_a = pl.splits_a; p.sps_a = pl.sps_a; p.splits_b = pl.splits_b; p.sps_b = pl.sps_b;
+    p.m_rem0 = pl.m_rem0;
+    p.partial = (float *)workspace;
     p.mt = (int)htd::ceil_div(p.M, kXCfg[cfg].bm);
     p.nt = (int)htd::ceil_div(p.Co, kXCfg[cfg].bn);
-    const int64_t blocks = (int64_t)p.mt * p.nt;
-    HTD_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv2d_x3p: bad grid");
-    const dim3 grid((unsigned)blocks, (unsigned)p.splits);
+    HTD_REQUIRE(pl.grid > 0 && pl.grid < (1ll << 31), "conv2d_x3p: bad grid");
+    const dim3 grid((unsigned)pl.grid);
     switch (cfg) {
     case 0: launch_tile<1, 1>(p, kw, grid, s); break;
     case 1: launch_tile<2, 2>(p, kw, grid, s); break;
     case 2: launch_tile<2, 1>(p, kw, grid, s); break;
     default: launch_tile<1, 2>(p, kw, grid, s); break;
     }
-    if (p.splits > 1) {
-        const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(p.M * p.Co, 256), 4096);
+    if (pl.partial_floats > 0) {
+        const int64_t rows = (p.splits_a > 1 ? p.m_rem0 : 0) + (p.splits_b > 1 ? p.M - p.m_rem0 : 0);
+        const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * p.Co, 256), 4096);
         hipLaunchKernelGGL(conv_x3p_splitk_epilogue_kernel, dim3(rb), dim3(256), 0, s, p);
     }
     return htd::check_launch("conv2d_x3p");
@@ -819,7 +972,19 @@ extern "C" int htd_conv2d_x3p_tile_table_clear()
 // the configuration id a launch of this problem would use now (forced tile, table, then score)
 extern "C" int htd_conv2d_x3p_tile_query(int64_t M, int Co, int Ci, int taps, int epi)
 {
-    return choose_cfg(M, Co, Ci, taps, epi, plan_splits_x3p(M, Co, (Ci / XK) * (taps == 9 ? 3 : 1)));
+    return choose_cfg(M, Co, Ci, taps, epi);
+}
+
+// the work decomposition a launch of this problem would use with tile configuration cfg (0..3) and a workspace:
+// out = {tiles_a, splits_a, steps_a, splits_b, steps_b, first row of region B, grid, partial floats}
+extern "C" int htd_conv2d_x3p_plan_query(int cfg, int64_t M, int Co, int Ci, int kh, int kw, int64_t *out)
+{
+    HTD_REQUIRE(cfg >= 0 && cfg < 4 && M > 0 && Co > 0 && Ci >= XK && Ci % XK == 0 && kh > 0 && kw > 0 && out,
+                "x3p_plan_query: bad arguments");
+    const XPlan pl = plan_x3p(cfg, M, Co, (Ci / XK) * kh, kw, true);
+    out[0] = pl.tiles_a; out[1] = pl.splits_a; out[2] = pl.sps_a; out[3] = pl.splits_b; out[4] = pl.sps_b;
+    out[5] = pl.m_rem0; out[6] = pl.grid; out[7] = pl.partial_floats;
+    return HTD_OK;
 }
 
 extern "C" int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, int transposed)
@@ -854,11 +1019,13 @@ extern "C" int htd_conv2d_x3_planes_many(const void *desc, int n, int64_t total_
     return htd::check_launch("x3_planes_many");
 }
 
+// bytes of partial sums a launch of this problem may need: the largest over the tile configurations (the table / a forced
+// tile picks one at launch time)
 extern "C" int64_t htd_conv2d_x3p_workspace_bytes(int64_t M, int Co, int Ci, int kh, int kw)
 {
-    (void)kw;
-    const int splits = plan_splits_x3p(M, Co, (Ci / XK) * kh);
-    return splits > 1 ? (int64_t)splits * M * Co * 4 : 0;
+    int64_t need = 0;
+    for (int cfg = 0; cfg < 4; ++cfg) need = std::max(need, plan_x3p(cfg, M, Co, (Ci / XK) * kh, kw, true).partial_floats * 4);
+    return need;
 }
 
 extern "C" int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const float *bias, const float *residual, int res_h,

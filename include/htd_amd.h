@@ -246,6 +246,10 @@ int htd_conv2d_x3p_supported(int Ci, int Co, int kh, int kw, int stride, int pad
 int htd_conv2d_x3p_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg);
 int htd_conv2d_x3p_tile_table_clear(void);
 int htd_conv2d_x3p_tile_query(int64_t M, int Co, int Ci, int taps, int epi);
+/* The work decomposition htd_conv2d_fwd_x3p / _bwd_data_x3p use for this problem with tile configuration cfg: layers
+ * whose tiles fit on the chip at once are cut along K so that every CU carries the same load (conv_x3.hip, plan_x3p).
+ * out[8] = {tiles_a, splits_a, steps_a, splits_b, steps_b, first output row of region B, workgroups, partial floats}. */
+int htd_conv2d_x3p_plan_query(int cfg, int64_t M, int Co, int Ci, int kh, int kw, int64_t *out);
 int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, int transposed);
 int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);
 /* The plane images of many weights in one launch.  desc: DEVICE array of n entries

@@ -41,7 +41,8 @@ LAYERS = [  # name, Ci, H, W, Co, k, stride, pad
 ]
 NAMES = ['auto', '64x64', '128x128', '128x64', '64x128']
 SHAPES = [s for s in os.environ.get('SWEEP_MFMA', '0').split(',')]          # 0: the launcher's choice per filter width
-NBS = [s for s in os.environ.get('SWEEP_NB', '2,3,4').split(',')]           # B buffers (prefetch distance + 1); 0: default
+NBS = [s for s in os.environ.get('SWEEP_NB', '0').split(',')]               # B buffers (-DHTD_X3P_DEEP builds); 0: default
+REMS = [s for s in os.environ.get('SWEEP_REM', '1,0').split(',')]           # K splits of the remainder tiles: 1 none, 0 planned, n forced
 
 
 def timed(fn, key, flop, n=6):
@@ -79,9 +80,10 @@ def main():
             y_old = old_fwd(x, w, s, p)
             flop = 2.0 * y_old.numel() * Ci * k * k
             r_old = timed(lambda: old_fwd(x, w, s, p), 'htd_conv2d_fwd', flop)
-            for shape, nb in [(a, b) for a in SHAPES for b in NBS]:
+            for shape, nb, rem in [(a, b, c) for a in SHAPES for b in NBS for c in REMS]:
                 os.environ['HTD_X3P_MFMA'] = shape
                 os.environ['HTD_X3P_NB'] = nb
+                os.environ['HTD_X3P_REM_SPLITS'] = rem
                 out, err = [], 0.0
                 for cfg in range(-1, 4):
                     os.environ['HTD_X3P_FORCE_TILE'] = str(cfg)
@@ -89,14 +91,14 @@ def main():
                     err = max(err, float((y - y_old).abs().max()))
                     out.append(timed(lambda: dense._fwd_raw(x, w, None, None, s, p, 1, False), 'htd_conv2d_fwd_x3p', flop))
                 os.environ['HTD_X3P_FORCE_TILE'] = '-1'
-                line = f'{name:22s} m{shape:2s} nb{nb} {flop / 1e9:7.1f} | {r_old:7.1f} | ' + ' '.join(f'{r:8.1f}' for r in out) + \
+                line = f'{name:22s} m{shape:2s} nb{nb} rem{rem:2s} {flop / 1e9:7.1f} | {r_old:7.1f} | ' + ' '.join(f'{r:8.1f}' for r in out) + \
                     f' | best/old {max(out[1:]) / r_old:.2f} auto/best {out[0] / max(out[1:]):.2f} err {err:.2e}'
                 if s == 1:       # data gradient of the same layer (new kernel, automatic tile)
                     g = torch.randn_like(y_old)
                     r_dg = timed(lambda: dense._dgrad_raw(g, w, x.shape, 1, p, 1), 'htd_conv2d_bwd_data_x3p', flop)
                     line += f' | dgrad {r_dg:6.1f}'
                 print(line, flush=True)
-            os.environ['HTD_X3P_MFMA'] = os.environ['HTD_X3P_NB'] = '0'
+            os.environ['HTD_X3P_MFMA'] = os.environ['HTD_X3P_NB'] = os.environ['HTD_X3P_REM_SPLITS'] = '0'
 
 
 if __name__ == '__main__':
