@@ -343,12 +343,17 @@ def main():
     # HBM bytes per launch of the dominant kernel class come from separate rocprofv3 PMC passes (FETCH_SIZE,
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:
-        name = 'r02_hbm_traffic.json' if x3 else 'r01_hbm_traffic.json'     # passes taken on the kernels of that arithmetic
-        tr = json.load(open(os.path.join(ROOT, 'profiles', name)))['kernels']
-        cls = 'conv_wgrad' if 'wgrad' in roof['kernel'] else 'conv_igemm'
-        if roof and 'conv' in roof['kernel'] and 'bf16' not in roof['kernel'] and args.depth == 50 and not args.infer:
-            roof['traffic'] = tr[cls]['hbm_bytes_per_launch_corrected']
-            roof['traffic_unit'] = f'bytes/launch (rocprofv3 PMC passes of this command, profiles/{name})'
+        # passes taken on the kernels of that arithmetic: the newest round that has them
+        names = ['r03_hbm_traffic.json', 'r02_hbm_traffic.json'] if x3 else ['r01_hbm_traffic.json']
+        cls = 'conv_wgrad' if 'wgrad' in roof['kernel'] else ('conv_x3p' if 'x3p' in roof['kernel'] else 'conv_igemm')
+        for name in names:
+            path = os.path.join(ROOT, 'profiles', name)
+            tr = json.load(open(path))['kernels'] if os.path.exists(path) else {}
+            if cls in tr and 'conv' in roof['kernel'] and 'bf16' not in roof['kernel'] and args.depth == 50 and not args.infer \
+                    and args.batch == 4 and not args.trained_like:
+                roof['traffic'] = tr[cls]['hbm_bytes_per_launch_corrected']
+                roof['traffic_unit'] = f'bytes/launch (rocprofv3 PMC passes of this command, profiles/{name})'
+                break
     except Exception:
         pass
     if args.profile_kernels or args.profile_detail:

@@ -2,7 +2,7 @@
 # Evidence runs of a round (MI355X box, through gpurun): bench lines, rocprofv3 kernel stats and PMC passes.
 # usage: bash tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>/*
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=$(pwd)
 OUT=$R/gpurun_out/$TAG
@@ -26,7 +26,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/b -o b -- py
 head -61 /tmp/p_$TAG/b/*kernel_stats.csv > $OUT/kernel_stats_r101_bf16_top60.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/c -o c -- python3 $R/bench.py --steps 3 --warmup 1 --infer --depth 101 --batch 64 > $OUT/prof_infer.log 2>&1
 head -61 /tmp/p_$TAG/c/*kernel_stats.csv > $OUT/kernel_stats_infer_r101_b64_top60.csv
-echo "== PMC passes (each alone)"
+echo "== PMC passes (each alone; every set validated by tools/pmc_plan.py)"
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do python3 $R/tools/pmc_plan.py $set || exit 2; done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_$TAG/f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_$TAG/w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py /tmp/p_$TAG/f/*counter_collection.csv /tmp/p_$TAG/w/*counter_collection.csv $OUT/hbm_traffic.json > /dev/null

@@ -1,5 +1,8 @@
 #!/bin/bash
-# (passes with TCP_* / TA_* / TD_* or TCC_* next to SQ_* counters hung rocprofv3 on this pool: left out)
+# Every pass is checked by tools/pmc_plan.py first (per-block slot limits of gfx950, one cache-side block per pass, no cache-side
+# block next to a set of SQ counters): the round-2 passes that never returned mixed TCC_* / TCP_* / TA_* / TD_* counters with a
+# full SQ set, i.e. over-subscribed a block once derived counters were expanded (pmc_plan.py's header has the accounting).
+# Cache-side counters therefore get passes of their own, below; a refused set stops the script before anything is launched.
 # PMC diagnosis of ONE convolution (tools/one_conv.py arguments): several rocprofv3 --pmc passes, each alone, summed over
 # the launches of the kernel class.   usage: bash tools/pmc_diag.sh <tag> <one_conv.py args...>     -> gpurun_out/<tag>.txt
 TAG=$1; shift
@@ -10,7 +13,10 @@ SETS=(
  "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY"
  "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_RD"
  "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_CVT SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_CYCLES"
+ "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+ "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
 )
+for s in "${SETS[@]}"; do python3 $R/tools/pmc_plan.py $s > /dev/null || { python3 $R/tools/pmc_plan.py $s; exit 2; }; done
 rm -rf /tmp/pd_$TAG; i=0; : > $R/gpurun_out/$TAG.progress
 for s in "${SETS[@]}"; do
   echo "pass $i: $s" >> $R/gpurun_out/$TAG.progress
