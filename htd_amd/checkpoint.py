@@ -13,6 +13,7 @@ Only local files: there is no network on this path.  `torchvision://` / `open-mm
 `pretrained`) resolve to files in $HTD_PRETRAINED_DIR, `http(s)://` raises.
 """
 import os
+import pickle
 import time
 from collections import OrderedDict
 
@@ -90,7 +91,9 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=No
         trusted = os.environ.get('HTD_TRUST_CHECKPOINTS') == '1'
     try:
         checkpoint = torch.load(filename, map_location=map_location, weights_only=True)
-    except Exception as e:                          # pickle.UnpicklingError and friends
+    except pickle.UnpicklingError as e:
+        # ONLY the weights-only refusal leads to the trusted path; a truncated / corrupt / mistyped file raises its own error
+        # (zip, EOF, map_location ...) and must not nudge anyone towards arbitrary-code unpickling
         if not trusted:
             raise RuntimeError(f'{filename} holds pickled objects beyond tensors and plain containers ({e}); pass '
                                'trusted=True / set HTD_TRUST_CHECKPOINTS=1 only for files from a source you trust') from e

@@ -22,15 +22,15 @@ struct Seg {                         // one row of the segment table (device, in
     int64_t out;                     // first output slot
 };
 
-// ascending unsigned image of a float: larger float <=> larger image (-0 < +0; a positive NaN is the largest)
+// ascending unsigned image of a float with torch.sort's equivalences: larger float <=> larger image, -0 and +0 share an image
+// (ties then go by position, as the stable sort has them), every NaN -- either sign, any payload -- is the largest key.
+// Output values are read back from the keys at the winning positions, so a -0 or a NaN payload comes out as it went in.
 __device__ __forceinline__ unsigned ord(float v)
 {
-    const unsigned u = __float_as_uint(v);
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+    if ((u << 1) == 0u) u = 0u;
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float unord(unsigned o)
-{
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
 // Block-wide (256 threads): the bin b, counted from the TOP, in which the running count reaches `want` (1-based):
@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float *__restri
 }
 
 // one workgroup per segment: bitonic sort of the k survivors, descending (key, then lower position first)
-__global__ __launch_bounds__(1024) void topk_sort_kernel(const Seg *__restrict__ segs, const unsigned long long *__restrict__ cand,
-                                                         int64_t *__restrict__ out_idx, float *__restrict__ out_val)
+__global__ __launch_bounds__(1024) void topk_sort_kernel(const Seg *__restrict__ segs, const float *__restrict__ keys,
+                                                         const unsigned long long *__restrict__ cand, int64_t *__restrict__ out_idx,
+                                                         float *__restrict__ out_val)
 {
     __shared__ unsigned long long w[KMAX];
     const int seg = blockIdx.x, t = threadIdx.x;
@@ -217,8 +218,9 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const Seg *__restrict__
     }
     for (int i = t; i < k; i += 1024) {
         const unsigned long long v = w[i];
-        out_idx[sg.out + i] = (int64_t)(0xffffffffu - (unsigned)(v & 0xffffffffull));
-        out_val[sg.out + i] = unord((unsigned)(v >> 32));
+        const int64_t pos = (int64_t)(0xffffffffu - (unsigned)(v & 0xffffffffull));
+        out_idx[sg.out + i] = pos;
+        out_val[sg.out + i] = keys[sg.start + pos];
     }
 }
 
@@ -261,7 +263,7 @@ int run_topk(const float *keys, const int64_t *segs, const int32_t *chunk_tab, i
         hipLaunchKernelGGL(topk_hist_kernel<2>, g, b, 0, s, keys, sg, ct, hist, state, chunk_hist, S);
         hipLaunchKernelGGL(topk_compact_kernel, g, b, 0, s, keys, sg, ct, hist, state, chunk_hist, n_above, cand, S);
     }
-    hipLaunchKernelGGL(topk_sort_kernel, dim3((unsigned)S), dim3(1024), 0, s, sg, cand, out_idx, out_val);
+    hipLaunchKernelGGL(topk_sort_kernel, dim3((unsigned)S), dim3(1024), 0, s, sg, keys, cand, out_idx, out_val);
     return htd::check_launch("segmented_topk");
 }
 

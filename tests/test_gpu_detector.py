@@ -681,9 +681,10 @@ def test_fused_pgraph_kernels_match_the_tensor_formulation():
 
 def test_reference_format_checkpoint_loads_and_reproduces_the_fixture(golden, tmp_path):
     """a `.pth` in the reference's wire format (mmcv CheckpointHook: meta + state_dict with the reference's
-    keys and logical shapes under a `module.` prefix, the aliased att.1 / att.3 entries a real file carries, an optimizer
-    entry) goes through load_checkpoint into a freshly built detector, which then reproduces the reference run's
-    detections on the GPU; Trainer.resume picks up iteration and momentum from the same file."""
+    keys and logical shapes under a `module.` prefix, the aliased att.1 / att.3 entries a real file carries, and an
+    'optimizer' entry numbered like torch.optim.SGD(model.parameters()) in the reference's module order) goes through
+    load_checkpoint into a freshly built detector, which then reproduces the reference run's detections on the GPU;
+    Trainer.resume picks up iteration and every momentum buffer, by parameter name, from the same file."""
     from htd_amd.checkpoint import load_checkpoint
     from htd_amd.configs import build_htd_detector
     from htd_amd.runner import Trainer
@@ -697,10 +698,21 @@ def test_reference_format_checkpoint_loads_and_reproduces_the_fixture(golden, tm
         for t in ('weight', 'bias'):
             ref[f'{ex}{a}.{t}'] = ref[f'{ex}{b}.{t}']
     path = str(tmp_path / 'epoch_7.pth')
-    torch.save(dict(meta=dict(epoch=7, iter=51310, mmdet_version='2.7.0', CLASSES=('person', )),
-                    state_dict={'module.' + k: v for k, v in ref.items()}), path)
     torch.manual_seed(123)                                   # different init: every value must come from the file
     model = build_htd_detector(cfg=small_cfg())
+    # the 'optimizer' entry as mmcv's CheckpointHook writes it: torch.optim.SGD(model.parameters()).state_dict() -- the
+    # indices count EVERY parameter in the reference's module order (= its state_dict order without the BN statistics and
+    # the att.* aliases: conv1 / conv2 are registered first, adaptative_roi_extractor.py:39-46), frozen ones have no state
+    trainable = {n for n, q in model.named_parameters() if q.requires_grad}
+    ref_params = [k for k in D.state_shapes(50) if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    assert len(ref_params) == sum(1 for _ in model.parameters()) and trainable <= set(ref_params)
+    momenta = {k: torch.as_tensor(seeded_tensor('mom.' + k, tuple(ref[k].shape))) for k in ref_params if k in trainable}
+    optimizer = dict(state={i: dict(momentum_buffer=momenta[k]) for i, k in enumerate(ref_params) if k in trainable},
+                     param_groups=[dict(lr=0.02, momentum=0.9, dampening=0, weight_decay=1e-4, nesterov=False, initial_lr=0.02,
+                                        params=list(range(len(ref_params))))])
+    assert 0 < len(optimizer['state']) < len(ref_params)          # frozen stem / layer1 / BN: numbered, stateless
+    torch.save(dict(meta=dict(epoch=7, iter=51310, mmdet_version='2.7.0', CLASSES=('person', )),
+                    state_dict={'module.' + k: v for k, v in ref.items()}, optimizer=optimizer), path)
     ckpt = load_checkpoint(model, path, strict=True)
     assert ckpt['meta']['epoch'] == 7
     model = model.to(dev).eval()
@@ -713,6 +725,16 @@ def test_reference_format_checkpoint_loads_and_reproduces_the_fixture(golden, tm
     tr = Trainer(model.train(), lr=0.02)
     tr.resume(path)
     assert tr.iter == 51310 and tr.epoch == 7 and abs(tr.schedule.lr(tr.iter) - 0.02) < 1e-12      # past warm-up, before epoch 8
+    # every momentum buffer landed in the flat slice of the parameter of the SAME NAME (same-shaped neighbours would hide an
+    # ordering mistake: the buffers are distinct per name)
+    from htd_amd.runner import FlatParams
+    name_of = {id(q): n for n, q in model.named_parameters()}
+    seen = 0
+    for q, o in zip(tr.flat.params, tr.flat.offsets):
+        got = FlatParams._view(tr.flat.momentum, q, o).detach().cpu()
+        assert torch.equal(got, momenta[name_of[id(q)]].reshape(got.shape)), name_of[id(q)]
+        seen += 1
+    assert seen == len(momenta)
 
 
 @pytest.mark.gpu

@@ -364,7 +364,7 @@ def test_roi_align_backward_gather_form(dev, C, H, W, stride, n):
 def test_segmented_topk_equals_stable_descending_sort(dev):
     """htd_segmented_topk == keys.sort(descending=True, stable=True)[:k] per segment, positions included (rpn_head.py:122-133):
     ties at the threshold (quantised keys), all-equal segments, segments shorter than k, one-element and empty picks,
-    negative keys and the full P2 level size."""
+    negative keys, the full P2 level size, and torch.sort's treatment of -0 / +0 (equal) and NaN (largest, either sign)."""
     import htd_amd.mmcv_ops as M
     g = torch.Generator().manual_seed(11)
     parts = [
@@ -376,9 +376,10 @@ def test_segmented_topk_equals_stable_descending_sort(dev):
         torch.tensor([3.0]),                                               # one key
         torch.rand(4096 * 3, generator=g).round(decimals=2),               # chunk-aligned length, ties across chunks
         torch.rand(100, generator=g),                                      # k = 0
-        torch.cat([torch.zeros(7000), torch.ones(3), -torch.zeros(10)]),   # +0 / -0 (sort treats them as equal? see below)
-    ]
-    ks = [2000, 2000, 777, 819, 2048, 1, 1000, 0, 5]
+        torch.cat([-torch.zeros(10), torch.zeros(7000), torch.ones(3), -torch.zeros(10)]),   # -0 == +0: ties by position
+        torch.cat([torch.rand(5000, generator=g) - 0.5, torch.tensor([float('nan'), -float('nan')]),      # NaNs of either sign
+                   torch.tensor([float('inf'), -float('inf'), -0.0, 0.0])]),                             # sort first, like torch
+    ks = [2000, 2000, 777, 819, 2048, 1, 1000, 0, 15, 2048]
     keys = torch.cat(parts)
     segs, off = [], 0
     for p, k in zip(parts, ks):
@@ -389,14 +390,9 @@ def test_segmented_topk_equals_stable_descending_sort(dev):
     idx, val = idx.cpu(), val.cpu()
     o = 0
     for i, (p, k) in enumerate(zip(parts, ks)):
-        if i == 8:
-            # the radix image orders -0 below +0 while a float compare calls them equal: such a tie is broken by sign first.
-            # Scores are sigmoid outputs / uniform keys in [0, 1): -0 does not occur; pin the documented behaviour.
-            assert val[o:o + k].tolist() == [1.0, 1.0, 1.0, 0.0, 0.0] and idx[o:o + k].tolist() == [7000, 7001, 7002, 0, 1]
-            o += k
-            continue
         rv, ri = p.sort(descending=True, stable=True)
-        assert torch.equal(val[o:o + k], rv[:k]), i
+        # bit-level equality: a -0 key comes back as -0, a NaN as the NaN it was (values are read back from the keys)
+        assert torch.equal(val[o:o + k].view(torch.int32), rv[:k].view(torch.int32)), i
         assert torch.equal(idx[o:o + k], ri[:k]), i
         o += k
     assert o == idx.numel()

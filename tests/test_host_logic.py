@@ -343,6 +343,13 @@ def test_checkpoint_loader_rules(tmp_path, monkeypatch):
                          meta=dict(obj=pytest.approx(1.0))), f)
     with pytest.raises(RuntimeError, match='trust'):
         load_checkpoint(net, str(tmp_path / 'b.pth'))
+    # a merely BROKEN file keeps its own error -- it must not advertise the unsafe path, trusted or not
+    whole = (tmp_path / 'a.pth').read_bytes()
+    (tmp_path / 'c.pth').write_bytes(whole[:len(whole) // 2])
+    for trusted in (False, True):
+        with pytest.raises(Exception) as info:
+            load_checkpoint(net, str(tmp_path / 'c.pth'), trusted=trusted)
+        assert 'trust' not in str(info.value) and not isinstance(info.value, pickle.UnpicklingError)
     (tmp_path / 'zoo').mkdir()
     torch.save(net.state_dict(), tmp_path / 'zoo' / 'resnet50-19c8e357.pth')
     monkeypatch.setenv('HTD_PRETRAINED_DIR', str(tmp_path / 'zoo'))

@@ -26,6 +26,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/b -o b -- py
 head -61 /tmp/p_$TAG/b/*kernel_stats.csv > $OUT/kernel_stats_r101_bf16_top60.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/c -o c -- python3 $R/bench.py --steps 3 --warmup 1 --infer --depth 101 --batch 64 > $OUT/prof_infer.log 2>&1
 head -61 /tmp/p_$TAG/c/*kernel_stats.csv > $OUT/kernel_stats_infer_r101_b64_top60.csv
+python3 - /tmp/p_$TAG > $OUT/kernel_stats_totals.txt <<'PY'
+import csv, glob, sys
+for tag, name, steps in (('a', 'HTD-R50 fp32 train step', 13), ('b', 'HTD-R101 bf16 train step', 13), ('c', 'HTD-R101 fp32 inference B=64', 4)):
+    for f in glob.glob(f'{sys.argv[1]}/{tag}/*kernel_stats.csv'):
+        rows = list(csv.DictReader(open(f)))
+        calls = sum(int(r['Calls']) for r in rows)
+        ns = sum(float(r['TotalDurationNs']) for r in rows)
+        short = [(int(r['Calls']), float(r['TotalDurationNs'])) for r in rows if float(r['AverageNs']) < 20000]
+        print(f'{name}: {steps} steps (warm-up included), {len(rows)} kernels, {calls / steps:.0f} launches and {ns / steps / 1e6:.2f} ms of kernel time per step; '
+              f'kernels averaging < 20 us: {sum(c for c, _ in short) / steps:.0f} launches, {sum(t for _, t in short) / steps / 1e6:.2f} ms per step')
+PY
 echo "== PMC passes (each alone; every set validated by tools/pmc_plan.py)"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do python3 $R/tools/pmc_plan.py $set || exit 2; done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_$TAG/f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
