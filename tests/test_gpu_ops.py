@@ -379,6 +379,7 @@ def test_segmented_topk_equals_stable_descending_sort(dev):
         torch.cat([-torch.zeros(10), torch.zeros(7000), torch.ones(3), -torch.zeros(10)]),   # -0 == +0: ties by position
         torch.cat([torch.rand(5000, generator=g) - 0.5, torch.tensor([float('nan'), -float('nan')]),      # NaNs of either sign
                    torch.tensor([float('inf'), -float('inf'), -0.0, 0.0])]),                             # sort first, like torch
+    ]
     ks = [2000, 2000, 777, 819, 2048, 1, 1000, 0, 15, 2048]
     keys = torch.cat(parts)
     segs, off = [], 0

@@ -22,6 +22,9 @@ $B --steps 5 --warmup 2 --infer --depth 101 --batch 64 --bf16 > $OUT/bench_infer
 echo "== kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/a -o a -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_train.log 2>&1
 head -61 /tmp/p_$TAG/a/*kernel_stats.csv > $OUT/kernel_stats_top60.csv
+# the same with the weight gradients on the main stream, as in the steps bench.py brackets with events (overlapped kernels share CUs and each takes longer)
+HTD_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/a0 -o a0 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_train_no_overlap.log 2>&1
+head -61 /tmp/p_$TAG/a0/*kernel_stats.csv > $OUT/kernel_stats_no_overlap_top60.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/b -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --depth 101 --bf16 > $OUT/prof_bf16.log 2>&1
 head -61 /tmp/p_$TAG/b/*kernel_stats.csv > $OUT/kernel_stats_r101_bf16_top60.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/c -o c -- python3 $R/bench.py --steps 3 --warmup 1 --infer --depth 101 --batch 64 > $OUT/prof_infer.log 2>&1
