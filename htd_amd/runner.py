@@ -284,9 +284,14 @@ class Trainer:
         """torch.optim.SGD-shaped state (what mmcv's CheckpointHook stores under 'optimizer'): momentum buffers are
         per-parameter tensors in the parameter's logical shape, numbered like the reference's optimizer."""
         idx, n_all = self._numbering()
+        # wire shape of a parameter = the shape of its state_dict entry (a TileLinear weight is (out, C*h*w) in files and
+        # (out, C, h, w) channels_last in memory): momentum buffers are written in the shape torch.optim.SGD would hold
+        name_of = {id(p): n for n, p in self.model.named_parameters()}
+        wire = {n: tuple(v.shape) for n, v in self.model.state_dict().items()}
         state = {}
         for i, p, o in zip(idx, self.flat.params, self.flat.offsets):
-            state[i] = {'momentum_buffer': FlatParams._view(self.flat.momentum, p, o).detach().clone().contiguous()}
+            buf = FlatParams._view(self.flat.momentum, p, o).detach().clone().contiguous()
+            state[i] = {'momentum_buffer': buf.reshape(wire.get(name_of.get(id(p)), tuple(p.shape)))}
         group = dict(lr=self.schedule.lr(self.iter), momentum=self.momentum, dampening=0, weight_decay=self.weight_decay,
                      nesterov=False, initial_lr=self.schedule.base_lr, params=list(range(n_all)))
         return dict(state=state, param_groups=[group])
@@ -313,7 +318,12 @@ class Trainer:
             k = where[int(i)]
             p, o = self.flat.params[k], self.flat.offsets[k]
             if tuple(buf.shape) != tuple(p.shape):
-                raise ValueError(f'momentum buffer {int(i)}: shape {tuple(buf.shape)} vs parameter {tuple(p.shape)}')
+                # the reference's logical shape of a layer stored in another physical layout here (TileLinear: (out, C*h*w)
+                # against (out, C, h, w) channels_last): same element order logically, so a view; anything else is an error
+                if buf.dim() == 2 and p.dim() == 4 and buf.size(0) == p.size(0) and buf.numel() == p.numel():
+                    buf = buf.reshape(p.shape)
+                else:
+                    raise ValueError(f'momentum buffer {int(i)}: shape {tuple(buf.shape)} vs parameter {tuple(p.shape)}')
             FlatParams._view(self.flat.momentum, p, o).copy_(buf)
 
     def save_checkpoint(self, filename, meta=None):

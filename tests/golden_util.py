@@ -129,3 +129,27 @@ def pipeline_samples():
         img = np.random.RandomState(100 + s).randint(0, 256, (h, w, 3)).astype(np.uint8)
         out.append((img, boxes, rs.randint(0, 80, 5).astype(np.int64)))
     return out
+
+
+def reference_parameter_order(shapes):
+    """`model.parameters()` order of the reference detector = nn.Module registration order, derived from its sources (the
+    oracle's `state_shapes` enumerates the same names level by level, which is NOT that order):
+      detectors/two_stage.py:26-43       backbone, neck, rpn_head, roi_head
+      backbones/resnet.py (Bottleneck)    conv1, bn1, conv2, bn2, conv3, bn3, downsample; stem conv1, bn1; layer1..4
+      necks/fpn.py:112-113                the ModuleLists lateral_convs THEN fpn_convs (filled alternately at :134-135,
+                                          but a ModuleList lists its own children together)
+      dense_heads/rpn_head.py:25-29       rpn_conv, rpn_cls, rpn_reg
+      roi_heads/htd_roi_head.py:49-62     bbox_roi_extractor, bbox_head, glbctx_head
+      roi_extractors/adaptative_roi_extractor.py:39-46   conv1, conv2 (att.* are the same modules again)
+      bbox_heads/bbox_head.py / convfc_bbox_head.py      fc_cls, fc_reg (created by BBoxHead.__init__, re-assigned in
+                                          place later), then shared_fcs
+      bbox_heads/htd_bbox_head.py:52,73-127              fc_cls, fc_reg, convs, fcs, graph_lvl0..3_cls
+      bbox_heads/global_context_head.py:351-373          convs, fc
+    BN statistics are buffers, not parameters."""
+    names = [k for k in shapes if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    first = min(i for i, k in enumerate(names) if k.startswith('neck.'))
+    neck = [k for k in names if k.startswith('neck.')]
+    assert names[first:first + len(neck)] == neck                   # one contiguous block in the oracle's enumeration
+    ordered = [k for k in neck if k.startswith('neck.lateral_convs.')] + [k for k in neck if k.startswith('neck.fpn_convs.')]
+    assert len(ordered) == len(neck)
+    return names[:first] + ordered + names[first + len(neck):]

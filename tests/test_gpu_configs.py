@@ -9,8 +9,10 @@ weight perturbs it by at most 2^-9 relative (RMS 2^-9 / sqrt(3) ~ 1.1e-3).  The 
 weight tensors per bottleneck over 33 bottlenecks plus the FPN, independent perturbations that add in quadrature:
 relative L2 error of a pyramid level ~ 1.1e-3 * sqrt(2 * 100) ~ 1.6e-2 worst case.  The bounds below are 2x what this
 model predicts and are checked as RELATIVE L2 ERRORS against the fp32 oracle run on the same fp32 master weights:
-    pyramid levels            <= 2e-2       losses (each)        <= 2e-2 relative (+1e-3 abs)
-    RPN logits                <= 2e-2       gradients (rel. L2)  <= 1e-1 trunk / 6e-2 heads
+    pyramid levels            <= 3e-2       losses (each)        <= 3e-2 relative (+1e-3 abs)
+    RPN logits                <= 3e-2       gradients (rel. L2)  <= 1.5e-1 trunk / 6e-2 heads / 2e-1 PGraph-coupled and BA / SFA
+(the model's 1.6e-2 is met ON AVERAGE: over 8 (image, weight) seed pairs the worst pyramid level is 1.98e-2 -- the round-2
+bounds of 2e-2 / 1e-1 sat on the worst case of a sweep they had not run; see test_bf16_gradient_bounds_hold_over_seeds)
 (a trunk weight gradient is the product of a forward activation and a back-propagated gradient that has itself been
 rounded to bf16 at every layer on the way down, plus the ReLU masks that flip where a pre-activation sits within a
 rounding error of zero: about sqrt(2) x the forward error from each factor, measured 5e-2 .. 7.5e-2 on R101)
@@ -20,7 +22,7 @@ respect to the offsets is a finite difference of neighbouring pixels.  On the ro
 network with pixel-sized offsets that path is chaotic (a 3 % forward difference de-correlates d x / d p: trunk gradients
 50 % apart while every loss agrees to 0.5 %), which says nothing about the kernels.  The bf16 comparison therefore uses
 early-training offsets (seeded conv_offset x 0.1; the reference initialises it to zero, resnet.py:608-612) and the bounds
-    pyramid / RPN logits <= 3e-2,  losses <= 2e-2,  trunk gradients <= 1.5e-1,  heads <= 6e-2 (BA / SFA <= 1.5e-1);
+    pyramid / RPN logits <= 3e-2,  losses <= 3e-2,  trunk gradients <= 2e-1,  heads <= 6e-2 (PGraph-coupled, BA / SFA <= 2e-1);
 the fp32 R101-DCN step with FULL-size offsets is held to the oracle at fp32 bounds in
 test_r101_fp32_train_step_against_the_oracle[dcn], and single deformable layers to 1e-4 in tests/test_gpu_dcn.py.
 BA and SFA convolutions see only a handful of pixels at this image size (P6 is 2x3): their weight gradients are sums of
@@ -53,14 +55,15 @@ def _small(cfg_obj, ocfg):
         r['sampler']['num'] = 48
 
 
-@pytest.mark.parametrize('dcn', [False, True], ids=['configs2_r101_bf16', 'configs3_r101_dcn_bf16'])
-def test_r101_bf16_train_step_against_the_oracle(dcn):
+def bf16_step_errors(dcn, data_seed=11, weight_seed=1234):
+    """One HTD-R101(-DCN) bf16 train step on the GPU against the fp32 oracle on the same master weights, samples replayed.
+    -> (feature / logit errors, {loss: (product, oracle)}, {group: {parameter: relative L2 error of its gradient}})."""
     from htd_amd.configs import build_htd_detector, htd_config
     from htd_amd.core import set_randperm
     from oracle import detector as D
     dev = torch.device('cuda:0')
     H, W, B = 128, 160, 2
-    imgs, gts, labels = demo_inputs(B, H, W, np.random.RandomState(11))
+    imgs, gts, labels = demo_inputs(B, H, W, np.random.RandomState(data_seed))
     imgs = (imgs - 0.5) * 4
     metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), ori_shape=(H, W, 3),
                   scale_factor=np.array([1, 1, 1, 1], dtype=np.float32), flip=False) for _ in range(B)]
@@ -69,7 +72,7 @@ def test_r101_bf16_train_step_against_the_oracle(dcn):
     _small(cfg, ocfg)
     shapes = D.state_shapes(101, dcn)
     sd = {k: v.requires_grad_(v.dtype.is_floating_point and 'running' not in k)
-          for k, v in seeded_state_dict(shapes, prefix='det.').items()}
+          for k, v in seeded_state_dict(shapes, prefix='det.', seed=weight_seed).items()}
     if dcn:                                  # early-training offsets (the reference initialises conv_offset to zero)
         with torch.no_grad():
             for k, v in sd.items():
@@ -82,7 +85,7 @@ def test_r101_bf16_train_step_against_the_oracle(dcn):
     ref_loss.backward()
 
     det = build_htd_detector(cfg=cfg, bf16=True)
-    load_seeded_(det, 'det.')
+    load_seeded_(det, 'det.', seed=weight_seed)
     if dcn:
         with torch.no_grad():
             for k, p in det.named_parameters():
@@ -115,36 +118,89 @@ def test_r101_bf16_train_step_against_the_oracle(dcn):
     loss, log_vars = det._parse_losses(losses)
     det.zero_grad()
     loss.backward()
-    b_feat, b_loss, b_trunk, b_heads, b_small = (3e-2, 2e-2, 1.5e-1, 6e-2, 1.5e-1) if dcn else (2e-2, 2e-2, 1e-1, 6e-2, 1.5e-1)
-    failures = []
-    print('\nbf16 vs fp32 oracle (dcn=%s): relative L2 errors' % dcn, {k: round(v, 5) for k, v in errs.items()})
-    for k, v in errs.items():
-        if v > b_feat:
-            failures.append((k, v, b_feat))
-    for k, v in log_vars.items():
-        if 'acc' in k:
-            continue
-        print('  loss %-14s %.5f  oracle %.5f  rel %.2e' % (k, v, ref_log[k], abs(v - ref_log[k]) / max(abs(ref_log[k]), 1e-9)))
-        if abs(v - ref_log[k]) > b_loss * abs(ref_log[k]) + 1e-3:
-            failures.append((k, v, ref_log[k]))
+    losses_out = {k: (v, ref_log[k]) for k, v in log_vars.items() if 'acc' not in k}
     params = dict(det.named_parameters())
-    trunk = ['backbone.layer2.0.conv1.weight', 'backbone.layer3.10.conv2.weight', 'backbone.layer4.2.conv3.weight',
-             'neck.lateral_convs.2.conv.weight', 'neck.fpn_convs.0.conv.weight', 'rpn_head.rpn_conv.weight']
-    heads = ['roi_head.bbox_head.0.shared_fcs.1.weight', 'roi_head.bbox_head.0.fc_cls.weight',
-             'roi_head.bbox_head.1.fcs.0.weight', 'roi_head.bbox_head.1.graph_lvl0_cls.weight',
-             'roi_head.bbox_head.1.convs.1.conv.weight']
-    small = ['roi_head.bbox_roi_extractor.1.conv1.weight', 'roi_head.glbctx_head.convs.0.conv.weight']
-    if dcn:
-        trunk += ['backbone.layer3.5.conv2.conv_offset.weight']
-    for names, bound in ((trunk, b_trunk), (heads, b_heads), (small, b_small)):
+    groups = dict(trunk=['backbone.layer2.0.conv1.weight', 'backbone.layer3.10.conv2.weight', 'backbone.layer4.2.conv3.weight',
+                         'neck.lateral_convs.2.conv.weight', 'neck.fpn_convs.0.conv.weight', 'rpn_head.rpn_conv.weight'] +
+                  (['backbone.layer3.5.conv2.conv_offset.weight'] if dcn else []),
+                  heads=['roi_head.bbox_head.0.shared_fcs.1.weight', 'roi_head.bbox_head.0.fc_cls.weight',
+                         'roi_head.bbox_head.1.convs.1.conv.weight'],
+                  graph=['roi_head.bbox_head.1.fcs.0.weight', 'roi_head.bbox_head.1.graph_lvl0_cls.weight'],
+                  small=['roi_head.bbox_roi_extractor.1.conv1.weight', 'roi_head.glbctx_head.convs.0.conv.weight'])
+    grads = {}
+    for g, names in groups.items():
+        grads[g] = {}
         for k in names:
             a = params[k].grad.detach().cpu() if params[k].grad is not None else torch.zeros_like(params[k]).cpu()
             b = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
-            e = rel_l2(a.reshape(b.shape), b)
-            print('  grad %-48s rel L2 %.2e' % (k, e))
             assert params[k].grad.dtype == torch.float32                 # fp32 master gradients
-            if e > bound:
-                failures.append((k, e, bound))
+            grads[g][k] = rel_l2(a.reshape(b.shape), b)
+    return errs, losses_out, grads
+
+
+def bf16_bounds(dcn):
+    """Bounds of the bf16 step (relative L2 against the fp32 oracle), per group; the module docstring has the error model,
+    test_bf16_gradient_bounds_hold_over_seeds the measured worst cases they are set from."""
+    return dict(feat=3e-2, loss=3e-2, trunk=2e-1 if dcn else 1.5e-1, heads=6e-2, graph=2e-1, small=2e-1)
+
+
+def check_bf16_step(dcn, errs, losses, grads):
+    b = bf16_bounds(dcn)
+    failures = []
+    print('\nbf16 vs fp32 oracle (dcn=%s): relative L2 errors' % dcn, {k: round(v, 5) for k, v in errs.items()})
+    failures += [(k, v, b['feat']) for k, v in errs.items() if v > b['feat']]
+    for k, (v, r) in losses.items():
+        print('  loss %-14s %.5f  oracle %.5f  rel %.2e' % (k, v, r, abs(v - r) / max(abs(r), 1e-9)))
+        if abs(v - r) > b['loss'] * abs(r) + 1e-3:
+            failures.append((k, v, r))
+    for g in ('trunk', 'heads', 'graph', 'small'):
+        for k, e in grads[g].items():
+            print('  grad %-48s rel L2 %.2e' % (k, e))
+            if e > b[g]:
+                failures.append((k, e, b[g]))
+    return failures
+
+
+@pytest.mark.parametrize('dcn', [False, True], ids=['configs2_r101_bf16', 'configs3_r101_dcn_bf16'])
+def test_r101_bf16_train_step_against_the_oracle(dcn):
+    failures = check_bf16_step(dcn, *bf16_step_errors(dcn))
+    assert not failures, failures
+
+
+@pytest.mark.parametrize('dcn', [False, True], ids=['configs2_r101_bf16', 'configs3_r101_dcn_bf16'])
+def test_bf16_gradient_bounds_hold_over_seeds(dcn):
+    """the bounds of the bf16 step must not be fitted to one draw.  The same comparison over other images and
+    other seeded weights (3 further (data, weight) seed pairs in the suite; HTD_BF16_SEEDS=n extends the sweep) has to stay
+    inside the SAME bounds; the largest error per group is printed next to its bound.
+    Measured on MI355X over 8 pairs per configuration (`HTD_BF16_SEEDS=8`, profiles/r03_bf16_bounds.log), largest relative
+    L2 error, with the bound in brackets:
+                      features  losses    trunk grads     stage-1 head + reg convs   stage-2 fcs.0 / graph   BA / SFA
+        configs[2]    1.98e-2   1.90e-2   1.01e-1 [1.5e-1]   4.05e-2 [6e-2]           1.39e-1 [2e-1]          1.42e-1 [2e-1]
+        configs[3]    1.88e-2   1.52e-2   1.48e-1 [2e-1]     4.46e-2 [6e-2]           8.04e-2 [2e-1]          1.35e-1 [2e-1]
+                      [3e-2]    [3e-2]
+    Round 2's single draw had hidden two things the sweep shows: (1) the 2e-2 feature / loss bounds and the 1e-1 trunk bound
+    sat ON the worst case (1.98e-2, 1.90e-2, 1.01e-1), and (2) the gradients of the stage-2 classification branch that
+    passes through PGraph (fcs.0, graph_lvl*_cls) spread far more than the other head gradients (1.3e-2 .. 1.4e-1 across
+    draws, the rest <= 4.5e-2): A_glob = softmax((1 - M) * sim) exponentiates a similarity of bf16-rounded FC features, so
+    a 2^-9 relative rounding of a logit of magnitude s becomes a relative error of about s * 2^-9 in an attention weight,
+    and the logits of a seeded (untrained) network are not small (the amplification itself was not measured separately;
+    the same branch in fp32 agrees with the oracle to 1e-4, test_r101_fp32_train_step_against_the_oracle).  That group now
+    has its own bound.  Every bound is 1.35 - 1.5x the worst of the 8 draws of its configuration."""
+    import os
+    n = int(os.environ.get('HTD_BF16_SEEDS', '3'))
+    worst = dict(trunk=0.0, heads=0.0, graph=0.0, small=0.0, feat=0.0, loss=0.0)
+    failures = []
+    for i in range(n):
+        data_seed, weight_seed = 101 + 7 * i, 4321 + 13 * i
+        errs, losses, grads = bf16_step_errors(dcn, data_seed, weight_seed)
+        failures += [(data_seed, weight_seed) + f for f in check_bf16_step(dcn, errs, losses, grads)]
+        for g in ('trunk', 'heads', 'graph', 'small'):
+            worst[g] = max(worst[g], max(grads[g].values()))
+        worst['feat'] = max(worst['feat'], max(errs.values()))
+        worst['loss'] = max(worst['loss'], max(abs(v - r) / max(abs(r), 1e-9) for v, r in losses.values()))
+    b = bf16_bounds(dcn)
+    print('\nWORST over %d seed pairs (dcn=%s): ' % (n, dcn) +
+          '  '.join('%s %.2e (bound %.1e)' % (g, worst[g], b[g]) for g in ('feat', 'loss', 'trunk', 'heads', 'graph', 'small')))
     assert not failures, failures
 
 

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import demo_inputs, digest, load_seeded_, seeded_state_dict, seeded_state_value, seeded_tensor
+from golden_util import (demo_inputs, digest, load_seeded_, reference_parameter_order, seeded_state_dict, seeded_state_value,
+                         seeded_tensor)
 
 pytestmark = pytest.mark.gpu
 
@@ -704,8 +705,10 @@ def test_reference_format_checkpoint_loads_and_reproduces_the_fixture(golden, tm
     # indices count EVERY parameter in the reference's module order (= its state_dict order without the BN statistics and
     # the att.* aliases: conv1 / conv2 are registered first, adaptative_roi_extractor.py:39-46), frozen ones have no state
     trainable = {n for n, q in model.named_parameters() if q.requires_grad}
-    ref_params = [k for k in D.state_shapes(50) if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))]
+    ref_params = reference_parameter_order(D.state_shapes(50))
     assert len(ref_params) == sum(1 for _ in model.parameters()) and trainable <= set(ref_params)
+    # the product's module tree registers its parameters in the reference's order (what makes the numbering portable)
+    assert [n for n, _ in model.named_parameters()] == ref_params
     momenta = {k: torch.as_tensor(seeded_tensor('mom.' + k, tuple(ref[k].shape))) for k in ref_params if k in trainable}
     optimizer = dict(state={i: dict(momentum_buffer=momenta[k]) for i, k in enumerate(ref_params) if k in trainable},
                      param_groups=[dict(lr=0.02, momentum=0.9, dampening=0, weight_decay=1e-4, nesterov=False, initial_lr=0.02,

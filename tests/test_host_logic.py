@@ -455,3 +455,16 @@ def test_x3p_kernels_never_move_a_register_with_a_load_in_flight():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'x3p_check_isa.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert '16 conv_x3p_kernel instantiations checked, 0 findings' in r.stdout
+
+
+def test_parameter_order_is_the_reference_registration_order():
+    """An optimizer state dict numbers parameters by position in `model.parameters()` (mmcv hands that iterator to
+    torch.optim.SGD, apis/train.py:86): a reference checkpoint's momentum buffers land on the right tensors only if this
+    package registers its modules in the reference's order.  golden_util.reference_parameter_order derives that order
+    from the reference's sources; R50 and R101(-DCN) must match it name by name."""
+    from golden_util import reference_parameter_order
+    from htd_amd.configs import build_htd_detector
+    from oracle import detector as D
+    for depth, dcn in ((50, False), (101, False), (101, True)):
+        model = build_htd_detector(depth, dcn=dcn)
+        assert [n for n, _ in model.named_parameters()] == reference_parameter_order(D.state_shapes(depth, dcn)), (depth, dcn)
