@@ -170,7 +170,7 @@ def test_r101_bf16_train_step_against_the_oracle(dcn):
 @pytest.mark.parametrize('dcn', [False, True], ids=['configs2_r101_bf16', 'configs3_r101_dcn_bf16'])
 def test_bf16_gradient_bounds_hold_over_seeds(dcn):
     """the bounds of the bf16 step must not be fitted to one draw.  The same comparison over other images and
-    other seeded weights (3 further (data, weight) seed pairs in the suite; HTD_BF16_SEEDS=n extends the sweep) has to stay
+    other seeded weights (2 further (data, weight) seed pairs in the suite; HTD_BF16_SEEDS=n extends the sweep) has to stay
     inside the SAME bounds; the largest error per group is printed next to its bound.
     Measured on MI355X over 8 pairs per configuration (`HTD_BF16_SEEDS=8`, profiles/r03_bf16_bounds.log), largest relative
     L2 error, with the bound in brackets:
@@ -187,7 +187,7 @@ def test_bf16_gradient_bounds_hold_over_seeds(dcn):
     the same branch in fp32 agrees with the oracle to 1e-4, test_r101_fp32_train_step_against_the_oracle).  That group now
     has its own bound.  Every bound is 1.35 - 1.5x the worst of the 8 draws of its configuration."""
     import os
-    n = int(os.environ.get('HTD_BF16_SEEDS', '3'))
+    n = int(os.environ.get('HTD_BF16_SEEDS', '2'))
     worst = dict(trunk=0.0, heads=0.0, graph=0.0, small=0.0, feat=0.0, loss=0.0)
     failures = []
     for i in range(n):
