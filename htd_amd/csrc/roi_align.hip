@@ -414,16 +414,13 @@ __global__ __launch_bounds__(256) void roi_bbox_kernel(const float *__restrict__
 // Taller tiles share the gout loads of a bin row between the feature rows it reaches (a 4-row tile reads ~3.3x fewer
 // bytes per RoI than four 1-row strips: the kernel is bound by those L2 reads), at ROWS * GW_TILE * CPL accumulators.
 template <int CPL, int ROWS>
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ rois,
-                                                                   const RoiBox *__restrict__ box, float *__restrict__ gfeat,
-                                                                   int64_t n, int B, int C, int H, int W, int ph, int pw,
-                                                                   float scale, int sampling_ratio, int aligned, int accumulate,
-                                                                   int chunks, int segs, int hts, int64_t tasks)
+__device__ __forceinline__ void gather_tile(const float *__restrict__ gout, const float *__restrict__ rois,
+                                            const RoiBox *__restrict__ box, float *__restrict__ gfeat, int64_t n, int B, int C,
+                                            int H, int W, int ph, int pw, float scale, int sampling_ratio, int aligned,
+                                            int accumulate, int chunks, int segs, int hts, int64_t task)
 {
     static_assert(ROWS * MAXP <= 64, "one lane per (row, bin) weight");
     const int lane = threadIdx.x & 63;
-    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (task >= tasks) return;                          // whole wave exits together
     const int chunk = (int)(task % chunks);
     int64_t t2 = task / chunks;
     const int seg = (int)(t2 % segs);
@@ -530,6 +527,74 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *
             for (int k = 0; k < CPL; ++k) dst[k] = accumulate ? dst[k] + acc[r][xi][k] : acc[r][xi][k];
         }
     }
+}
+
+template <int CPL, int ROWS>
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ rois,
+                                                                   const RoiBox *__restrict__ box, float *__restrict__ gfeat,
+                                                                   int64_t n, int B, int C, int H, int W, int ph, int pw,
+                                                                   float scale, int sampling_ratio, int aligned, int accumulate,
+                                                                   int chunks, int segs, int hts, int64_t tasks)
+{
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= tasks) return;                          // whole wave exits together
+    gather_tile<CPL, ROWS>(gout, rois, box, gfeat, n, B, C, H, W, ph, pw, scale, sampling_ratio, aligned, accumulate, chunks, segs,
+                           hts, task);
+}
+
+// All pyramid levels of one extractor in ONE launch.  Launched level by level, the coarse maps set the time: P5 has 600
+// strips for 5 120 wavefront slots, and each of them walks ~50 large RoIs one after the other (a few microseconds of
+// dependent latency per RoI) while the rest of the chip idles; P2 then runs alone, 33 600 short strips.  With the levels in
+// one grid -- coarsest first, so the long chains start at once -- the fine levels' strips fill the idle slots.
+constexpr int GL_MAX = 6;
+struct GatherLevels {
+    float *gfeat[GL_MAX];
+    const RoiBox *box[GL_MAX];
+    int H[GL_MAX], W[GL_MAX], segs[GL_MAX], hts[GL_MAX], accumulate[GL_MAX], level[GL_MAX];
+    float scale[GL_MAX];
+    int64_t task0[GL_MAX + 1];       // first task of slot k (slots in launch order: coarsest level first)
+    int slots;
+};
+
+template <int CPL, int ROWS>
+__global__ __launch_bounds__(256) void roi_align_bwd_gather_levels_kernel(const float *__restrict__ gout,
+                                                                          const float *__restrict__ rois, GatherLevels t, int64_t n,
+                                                                          int B, int C, int ph, int pw, int sampling_ratio,
+                                                                          int aligned, int chunks)
+{
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (task >= t.task0[t.slots]) return;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < GL_MAX; ++i)
+        if (i < t.slots && task >= t.task0[i]) k = i;
+    gather_tile<CPL, ROWS>(gout, rois, t.box[k], t.gfeat[k], n, B, C, t.H[k], t.W[k], ph, pw, t.scale[k], sampling_ratio, aligned,
+                           t.accumulate[k], chunks, t.segs[k], t.hts[k], task - t.task0[k]);
+}
+
+// footprint boxes of every RoI on every level slot of the table (blockIdx.y = slot; b = -1 where the RoI is on another level)
+__global__ __launch_bounds__(256) void roi_bbox_levels_kernel(const float *__restrict__ rois, const int64_t *__restrict__ roi_level,
+                                                              GatherLevels t, int64_t n, int B, int ph, int pw, int sampling_ratio,
+                                                              int aligned)
+{
+    const int64_t ri = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ri >= n) return;
+    const int k = blockIdx.y;
+    const int H = t.H[k], W = t.W[k];
+    RoiBox o{};
+    o.b = -1;
+    if (roi_level[ri] == (int64_t)t.level[k]) {
+        const RoiGeom g = roi_geometry(rois + 5 * ri, t.scale[k], ph, pw, sampling_ratio, aligned);
+        int r_lo, r_hi, c_lo, c_hi, t0, t1;
+        axis_span(g.start_h, g.bin_h, 0, g.grid_h, H, r_lo, t0);
+        axis_span(g.start_h, g.bin_h, ph - 1, g.grid_h, H, t1, r_hi);
+        bool ok = g.batch >= 0 && g.batch < B && !(t0 < r_lo || r_hi < t1);
+        axis_span(g.start_w, g.bin_w, 0, g.grid_w, W, c_lo, t0);
+        axis_span(g.start_w, g.bin_w, pw - 1, g.grid_w, W, t1, c_hi);
+        ok = ok && !(t0 < c_lo || c_hi < t1);
+        if (ok) { o.b = (short)g.batch; o.r_lo = (short)r_lo; o.r_hi = (short)r_hi; o.c_lo = (short)c_lo; o.c_hi = (short)c_hi; }
+    }
+    const_cast<RoiBox *>(t.box[k])[ri] = o;
 }
 
 int launch(bool backward, const float *in, const float *rois, const int64_t *roi_level, int level, float *out,
@@ -644,6 +709,53 @@ extern "C" int htd_roi_align_bwd_gather(const float *grad_out, const float *rois
     hipLaunchKernelGGL((roi_align_bwd_gather_kernel<4, rows>), dim3((unsigned)blocks), dim3(256), 0, s, grad_out, rois, box, grad_feat,
                        n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, accumulate, chunks, segs, hts, tasks);
     return htd::check_launch("roi_align_bwd_gather");
+}
+
+// Gather-form backward of a multi-level extractor (SingleRoIExtractor: every RoI pooled on the level roi_level names), all
+// levels in one launch: grad_feats[l] = (accumulate[l] ? grad_feats[l] : 0) + RoIAlign_l^T(grad_out rows of level l).
+// grad_feats[l] == NULL skips level l.  workspace: L * htd_roi_align_bwd_gather_workspace_bytes(n).
+extern "C" int htd_roi_align_levels_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level,
+                                               float *const *grad_feats, const int *H, const int *W, const float *scales,
+                                               const int *accumulate, int L, int64_t n, int B, int C, int ph, int pw,
+                                               int sampling_ratio, int aligned, void *workspace, void *stream)
+{
+    HTD_REQUIRE(L > 0 && L <= GL_MAX && n >= 0 && B > 0 && C > 0 && ph > 0 && pw > 0 && ph <= MAXP && pw <= MAXP,
+                "roi_align_levels_bwd_gather: bad sizes L=%d n=%lld B=%d C=%d out=%dx%d", L, (long long)n, B, C, ph, pw);
+    HTD_REQUIRE(C % 4 == 0 && B < 32768 && grad_feats && H && W && scales && accumulate,
+                "roi_align_levels_bwd_gather: C=%d must be a multiple of 4, tables non-null", C);
+    HTD_REQUIRE(n == 0 || (grad_out && rois && roi_level && workspace), "roi_align_levels_bwd_gather: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    GatherLevels t{};
+    const int chunks = (C + 255) / 256;
+    int64_t tasks = 0;
+    for (int l = L - 1; l >= 0; --l) {                     // coarsest level first: its strips have the longest RoI lists
+        if (!grad_feats[l]) continue;
+        HTD_REQUIRE(H[l] > 0 && W[l] > 0 && H[l] < 32768 && W[l] < 32768, "roi_align_levels_bwd_gather: bad map size");
+        if (n == 0) {
+            if (!accumulate[l] && hipMemsetAsync(grad_feats[l], 0, (size_t)B * H[l] * W[l] * C * 4, s) != hipSuccess) {
+                htd::set_error("roi_align_levels_bwd_gather: memset failed");
+                return HTD_ERR_LAUNCH;
+            }
+            continue;
+        }
+        const int k = t.slots++;
+        t.gfeat[k] = grad_feats[l];
+        t.box[k] = (const RoiBox *)workspace + (int64_t)l * n;
+        t.H[k] = H[l]; t.W[k] = W[l]; t.scale[k] = scales[l]; t.accumulate[k] = accumulate[l]; t.level[k] = l;
+        t.segs[k] = (W[l] + GW_TILE - 1) / GW_TILE;
+        t.hts[k] = H[l];
+        t.task0[k] = tasks;
+        tasks += (int64_t)B * t.hts[k] * t.segs[k] * chunks;
+    }
+    if (t.slots == 0) return HTD_OK;
+    t.task0[t.slots] = tasks;
+    hipLaunchKernelGGL(roi_bbox_levels_kernel, dim3((unsigned)htd::ceil_div(n, 256), (unsigned)t.slots), dim3(256), 0, s, rois,
+                       roi_level, t, n, B, ph, pw, sampling_ratio, aligned);
+    const int64_t blocks = htd::ceil_div(tasks, 4);
+    HTD_REQUIRE(blocks < (1ll << 31), "roi_align_levels_bwd_gather: too many tiles");
+    hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, grad_out, rois, t, n, B, C,
+                       ph, pw, sampling_ratio, aligned, chunks);
+    return htd::check_launch("roi_align_levels_bwd_gather");
 }
 
 extern "C" int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *roi_level, int level,

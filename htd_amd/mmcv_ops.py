@@ -79,6 +79,7 @@ def _grad_buffer(galias, shape, device, dtype):
 # RoIAlign backward: 'gather' (default) -- a wavefront owns a strip of feature-map pixels and sums the RoIs covering it in
 # RoI order: no float atomics, bit-stable, every pixel written once (no memset); 'scatter' -- the atomic kernels.
 ROI_BWD = __import__('os').environ.get('HTD_ROI_BWD', 'gather')
+ROI_BWD_ONE_LAUNCH = True        # gather form: all levels of a SingleRoIExtractor in one launch (False: one launch per level)
 
 
 def _roi_align_bwd(g, rois, lvls, level, galias, shape, ph, pw, scale, sr, aligned):
@@ -105,6 +106,42 @@ def _roi_align_bwd(g, rois, lvls, level, galias, shape, ph, pw, scale, sr, align
     capi.call('htd_roi_align_bwd_gather', _P(g), _P(rois), _P(lvls), level if level is not None else 0, _P(gf), n, B, C, H, W,
               ph, pw, scale, sr, aligned, acc, _P(ws), _S(), work=work)
     return gf
+
+
+def _roi_align_levels_bwd(g, rois, lvls, handed, need, shapes, ph, pw, scales, sr, aligned):
+    """Gradient maps of every level that needs one, ONE launch (htd_roi_align_levels_bwd_gather): handed[i] (+)= RoIAlign_i^T(g),
+    or a fresh map where nothing was handed down."""
+    L, n = len(shapes), rois.size(0)
+    maps, accs = [], []
+    for i, shape in enumerate(shapes):
+        if not need[i]:
+            maps.append(None)
+            accs.append(0)
+            continue
+        ga = handed[i]
+        usable = ga is not None and ga.dtype == g.dtype and tuple(ga.shape) == tuple(shape) and ga.is_contiguous(memory_format=CL)
+        if usable:
+            maps.append(ga)
+            accs.append(1)
+        else:
+            gf = torch.empty(shape, device=g.device, dtype=g.dtype, memory_format=CL)
+            if ga is not None:
+                gf.copy_(ga)
+            maps.append(gf)
+            accs.append(1 if ga is not None else 0)
+    ws = torch.empty(L * capi.lib().htd_roi_align_bwd_gather_workspace_bytes(n), dtype=torch.uint8, device=g.device)
+    ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() if m is not None else None for m in maps])
+    Hs = (ctypes.c_int * L)(*[s_[2] for s_ in shapes])
+    Ws = (ctypes.c_int * L)(*[s_[3] for s_ in shapes])
+    sc = (ctypes.c_float * L)(*[float(v) for v in scales])
+    ac = (ctypes.c_int * L)(*accs)
+    B, C = shapes[0][0], shapes[0][1]
+    # algorithmic bytes: every map written once (+ read when accumulating) + every RoI's 7x7xC gradient read once
+    work = ('byte', 4.0 * (sum(s_[0] * s_[2] * s_[3] * C * (1 + a) for s_, a, m in zip(shapes, accs, maps) if m is not None) +
+                           n * ph * pw * C))
+    capi.call('htd_roi_align_levels_bwd_gather', _P(g), _P(rois), _P(lvls), ptrs, Hs, Ws, sc, ac, L, n, B, C, ph, pw, int(sr),
+              int(bool(aligned)), _P(ws), _S(), work=work)
+    return maps
 
 
 class RoIAlignFunction(Function):
@@ -228,13 +265,17 @@ class _RoIAlignLevels(Function):
         if g is None:                            # pooled features unused: hand the chained maps on unchanged
             return (None, ) * 7 + tuple(galias[i] if (ctx.chain and i < len(galias)) else None for i in range(len(shapes)))
         g = nhwc(g)
+        handed = [galias[i] if (ctx.chain and i < len(galias)) else None for i in range(len(shapes))]
+        need = [bool(ctx.needs_input_grad[7 + i]) for i in range(len(shapes))]
+        if ROI_BWD == 'gather' and ROI_BWD_ONE_LAUNCH and ph <= 8 and pw <= 8 and rois.size(0) > 0 and len(shapes) <= 6 and any(need):
+            grads = _roi_align_levels_bwd(g, rois, lvls, handed, need, shapes, ph, pw, scales, sr, aligned)
+            return (None, None, None, None, None, None, None, *grads)
         grads = []
         for i, (B, C, H, W) in enumerate(shapes):
-            if not ctx.needs_input_grad[7 + i]:
+            if not need[i]:
                 grads.append(None)
                 continue
-            grads.append(_roi_align_bwd(g, rois, lvls, i, galias[i] if (ctx.chain and i < len(galias)) else None,
-                                        (B, C, H, W), ph, pw, float(scales[i]), sr, aligned))
+            grads.append(_roi_align_bwd(g, rois, lvls, i, handed[i], (B, C, H, W), ph, pw, float(scales[i]), sr, aligned))
         return (None, None, None, None, None, None, None, *grads)
 
 

@@ -66,6 +66,15 @@ int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *r
 int htd_roi_align_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
                              const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph, int pw,
                              int sampling_ratio, int aligned, void *stream);
+/* Gather-form RoIAlign backward of all pyramid levels of a SingleRoIExtractor in one launch (coarsest level first, so the
+ * long per-strip RoI lists of the small maps overlap the many short strips of the large ones).  grad_feats[l] == NULL
+ * skips level l; accumulate[l] != 0 adds into a map another consumer has already written.
+ * Every map equals the per-level entry point's bit for bit.
+ * workspace: L * htd_roi_align_bwd_gather_workspace_bytes(n) bytes.  Bit-stable (no atomics). */
+int htd_roi_align_levels_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level,
+                                    float *const *grad_feats, const int *H, const int *W, const float *scales,
+                                    const int *accumulate, int L, int64_t n, int B, int C, int ph, int pw,
+                                    int sampling_ratio, int aligned, void *workspace, void *stream);
 int64_t htd_roi_align_bwd_gather_workspace_bytes(int64_t n);
 int htd_roi_align_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
                              float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,

@@ -87,6 +87,36 @@ def test_roi_align_levels_matches_per_level(dev):
         torch.testing.assert_close(a.grad.cpu(), ref_grad, rtol=1e-4, atol=1e-4)
 
 
+def test_roi_align_levels_backward_one_launch_equals_per_level(dev):
+    """htd_roi_align_levels_bwd_gather (all levels in one grid, coarsest first) against one htd_roi_align_bwd_gather launch per
+    level: the same strips sum the same RoIs in the same order, so the maps are equal BIT FOR BIT -- fresh maps, maps that
+    accumulate into a handed-down gradient (chain=True), a level without RoIs, a level that needs no gradient."""
+    from htd_amd import mmcv_ops as M
+    from oracle import boxes as B
+    gen = torch.Generator().manual_seed(5)
+    feats = [torch.randn(3, 64, 96 // s, 136 // s, generator=gen) for s in (1, 2, 4, 8)]
+    rois = rand_rois(gen, 400, 3, 96, 136, 4, big=True)
+    lv = B.map_roi_levels(rois, 4)
+    lv[lv == 1] = 2                                             # level 1 stays empty
+    go = torch.randn(400, 64, 7, 7, generator=gen).to(dev)
+    res = {}
+    try:
+        for one in (True, False):
+            M.ROI_BWD_ONE_LAUNCH = one
+            fd = [cl(f.to(dev)).requires_grad_(i != 3) for i, f in enumerate(feats)]      # the coarsest level needs no gradient
+            taps = M.PyramidTaps(fd)
+            a = M.roi_align_levels(taps, rois.to(dev), lv.to(dev), 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32])
+            b = M.roi_align_levels(taps, rois.to(dev).flip(0), lv.to(dev).flip(0), 7, [1 / 4, 1 / 8, 1 / 16, 1 / 32])   # second consumer
+            ((a * go).sum() + (b * go.flip(0) * 0.5).sum()).backward()
+            res[one] = [f.grad for f in fd]
+    finally:
+        M.ROI_BWD_ONE_LAUNCH = True
+    assert res[True][3] is None and res[False][3] is None
+    for x, y in zip(res[True][:3], res[False][:3]):
+        assert x is not None and torch.equal(x, y)
+    assert float(res[True][1].abs().max()) == 0.0               # the empty level: zeros, written not accumulated
+
+
 def clustered_boxes(gen, n, span=300.):
     k = max(1, n // 6)
     centers = torch.rand(k, 2, generator=gen) * span

@@ -47,8 +47,9 @@ def timed(fn, reps=10):
 
 t = timed(lambda: M.roi_align_levels(feats, rois, lv, 7, scales))
 print(f'forward  {n} RoIs: {t * 1e6:8.1f} us   (writes {roi_bytes / 1e6:.0f} MB)')
-for mode in ('scatter', 'gather'):
-    M.ROI_BWD = mode
+for mode in ('scatter', 'gather/level', 'gather'):
+    M.ROI_BWD = mode.split('/')[0]
+    M.ROI_BWD_ONE_LAUNCH = mode == 'gather'         # 'gather': all levels in one launch
 
     def bwd():
         for f in fd:
@@ -57,5 +58,5 @@ for mode in ('scatter', 'gather'):
         o.backward(go)
     tb = timed(bwd) - t
     nbytes = map_bytes + roi_bytes + (map_bytes if mode == 'scatter' else 0)        # scatter: memset + read-modify-write
-    print(f'backward {mode:8s}: {tb * 1e6:8.1f} us   {map_bytes / 1e6:.0f} MB of gradient maps + {roi_bytes / 1e6:.0f} MB read = '
+    print(f'backward {mode:14s}: {tb * 1e6:8.1f} us   {map_bytes / 1e6:.0f} MB of gradient maps + {roi_bytes / 1e6:.0f} MB read = '
           f'{(map_bytes + roi_bytes) / tb / 1e12:.2f} TB/s algorithmic')
