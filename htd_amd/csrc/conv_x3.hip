@@ -775,6 +775,10 @@ XPlan plan_x3p(int cfg, int64_t M, int Co, int total_steps, int kw, bool have_ws
     if (!have_ws || total_steps < 8 || tiles > 256 * kXOcc[cfg]) return pl;   // more than one resident round: dispatch balances
     const double tile_s = 2.0 * bm * bn * total_steps * XK * kw / (200e12 / 256);      // one tile on one CU at the large-layer rate
     const double ov = 8.0 / (double)(total_steps * kw);                               // prologue + partial epilogue, in tile times
+    // the reduce pass: one more dependent launch (~4 us in the queue) plus reading the partials back; HTD_X3P_PLAN_LAUNCH_US (tune
+    // mode) overrides the constant for experiments
+    const int forced_us = forced_splits("HTD_X3P_PLAN_LAUNCH_US");
+    const double launch_s = forced_us > 0 ? forced_us * 1e-6 : 4e-6;
     double best_t = 1e30;
     for (int base = 1; base <= 8; ++base) {
         if (fbase > 0 && base != fbase) continue;
@@ -794,7 +798,7 @@ XPlan plan_x3p(int cfg, int64_t M, int Co, int total_steps, int kw, bool have_ws
             const double latency = resident < 1.5 ? 1.45 : (resident < 2.5 ? 1.12 : 1.0);
             const int64_t pf = (base > 1 ? (int64_t)base * m0 * Co : 0) + (sb > 1 ? (int64_t)sb * (M - m0) * Co : 0);
             if (pf * 4 > (128ll << 20)) continue;
-            const double t = (t_a + t_b) * latency * tile_s + (double)pf * 8.0 / 4e12 + (pf ? 4e-6 : 0.0);
+            const double t = (t_a + t_b) * latency * tile_s + (double)pf * 8.0 / 4e12 + (pf ? launch_s : 0.0);
             if (t < best_t * 0.98) {
                 best_t = t;
                 const int spa = (int)htd::ceil_div(total_steps, base), spb = (int)htd::ceil_div(total_steps, sb);

@@ -24,6 +24,10 @@ if '--infer' in sys.argv:              # BASELINE configs[4]: R101, hard NMS, 51
         def train_step(d):
             with torch.no_grad():
                 return model.simple_test(d['img'], d['img_metas'])
+elif '--bf16' in sys.argv:           # BASELINE configs[2] per-GPU shape: HTD-R101, bf16 trunk / FC stacks
+    model = build_htd_detector(101, bf16=True).to(dev).train()
+    tr = Trainer(model, lr=0.015, comm_dtype=torch.bfloat16)
+    data = synthetic_batch(4, device=dev)
 else:
     model = build_htd_detector(50).to(dev).train()
     tr = Trainer(model)
