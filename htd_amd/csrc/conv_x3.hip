@@ -774,7 +774,12 @@ XPlan plan_x3p(int cfg, int64_t M, int Co, int total_steps, int kw, bool have_ws
     const int fbase = forced_splits("HTD_X3P_BASE_SPLITS"), frem = forced_splits("HTD_X3P_REM_SPLITS");
     if (!have_ws || total_steps < 8 || tiles > 256 * kXOcc[cfg]) return pl;   // more than one resident round: dispatch balances
     const double tile_s = 2.0 * bm * bn * total_steps * XK * kw / (200e12 / 256);      // one tile on one CU at the large-layer rate
-    const double ov = 8.0 / (double)(total_steps * kw);                               // prologue + partial epilogue, in tile times
+    // model constants; the HTD_X3P_PLAN_* variables (tune mode) override them for sweeps (tools/sweep_x3p_plan.sh)
+    const int f_ov = forced_splits("HTD_X3P_PLAN_OV"), f_l1 = forced_splits("HTD_X3P_PLAN_LAT1"), f_l2 = forced_splits("HTD_X3P_PLAN_LAT2");
+    const int f_mr = forced_splits("HTD_X3P_PLAN_MAXREM");
+    const double ov_taps = f_ov > 0 ? f_ov : 8.0, lat1 = f_l1 > 0 ? f_l1 * 0.01 : 1.45, lat2 = f_l2 > 0 ? f_l2 * 0.01 : 1.12;
+    const int max_rem = f_mr > 0 ? f_mr : 16;
+    const double ov = ov_taps / (double)(total_steps * kw);                           // prologue + partial epilogue, in tile times
     // the reduce pass: one more dependent launch (~4 us in the queue) plus reading the partials back; HTD_X3P_PLAN_LAUNCH_US (tune
     // mode) overrides the constant for experiments
     const int forced_us = forced_splits("HTD_X3P_PLAN_LAUNCH_US");
@@ -787,7 +792,7 @@ XPlan plan_x3p(int cfg, int64_t M, int Co, int total_steps, int kw, bool have_ws
         int64_t ua = (units / 256) * 256;
         ua -= ua % (nt * base);                                       // whole rows of tiles
         const int64_t ta = ua / base, r = tiles - ta, m0 = std::min<int64_t>((ta / nt) * bm, M);
-        for (int rem = 1; rem <= 16; ++rem) {
+        for (int rem = 1; rem <= max_rem; ++rem) {
             if (frem > 0 && rem != frem) continue;
             if (r == 0 && rem > 1) break;
             const int sb = base * rem;
@@ -795,7 +800,7 @@ XPlan plan_x3p(int cfg, int64_t M, int Co, int total_steps, int kw, bool have_ws
             const double t_a = (double)(ua / 256) * (1.0 / base + (base > 1 ? ov : 0.0));
             const double t_b = r ? (double)htd::ceil_div(r * sb, 256) * (1.0 / sb + (sb > 1 ? ov : 0.0)) : 0.0;
             const double resident = std::min<double>((double)(ua + r * sb) / 256.0, kXOcc[cfg]);
-            const double latency = resident < 1.5 ? 1.45 : (resident < 2.5 ? 1.12 : 1.0);
+            const double latency = resident < 1.5 ? lat1 : (resident < 2.5 ? lat2 : 1.0);
             const int64_t pf = (base > 1 ? (int64_t)base * m0 * Co : 0) + (sb > 1 ? (int64_t)sb * (M - m0) * Co : 0);
             if (pf * 4 > (128ll << 20)) continue;
             const double t = (t_a + t_b) * latency * tile_s + (double)pf * 8.0 / 4e12 + (pf ? launch_s : 0.0);
