@@ -36,6 +36,24 @@ __global__ __launch_bounds__(256) void fuse_global_fwd_kernel(const float *__res
     }
 }
 
+// both[0 .. n) = x, both[n .. 2n) = x + g[img(roi)]: the two batches the HTD classification FCs run on, one read of x
+__global__ __launch_bounds__(256) void plain_and_fused_kernel(const float *__restrict__ x, const float *__restrict__ rois,
+                                                              const float *__restrict__ g, float *__restrict__ both,
+                                                              int64_t total4, int P, int C4, int B)
+{
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const int64_t i = idx / ((int64_t)P * C4);
+        int b = (int)rois[5 * i];
+        b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+        float4 v = ld4(x + idx * 4);
+        st4(both + idx * 4, v);
+        const float4 gv = ld4(g + ((int64_t)b * C4 + c4) * 4);
+        v.x += gv.x; v.y += gv.y; v.z += gv.z; v.w += gv.w;
+        st4(both + (total4 + idx) * 4, v);
+    }
+}
+
 // grad_global[b][c] += sum_{i in image b} sum_p grad[i][p][c]; a block walks ROIS_PER_BLOCK
 // consecutive RoIs (RoIs arrive grouped by image, bbox2roi) and flushes once per image run.
 constexpr int ROIS_PER_BLOCK = 16;
@@ -565,6 +583,19 @@ extern "C" int htd_fuse_global_fwd(const float *roi_feats, const float *rois, co
     hipLaunchKernelGGL(fuse_global_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, roi_feats,
                        rois, global_feat, extra, alpha, out, total4, P, C / 4, B);
     return htd::check_launch("fuse_global_fwd");
+}
+
+// both [2n][P][C]: rows [0, n) = roi_feats, rows [n, 2n) = roi_feats + global_feat[image of the RoI] (htd_bbox_head.py:198,201)
+extern "C" int htd_plain_and_fused_fwd(const float *roi_feats, const float *rois, const float *global_feat, float *both,
+                                       int64_t n, int P, int C, int B, void *stream)
+{
+    HTD_REQUIRE(C % 4 == 0 && P > 0 && B > 0 && n >= 0, "plain_and_fused: bad sizes n=%lld P=%d C=%d B=%d", (long long)n, P, C, B);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(roi_feats && rois && global_feat && both, "plain_and_fused: null pointer");
+    const int64_t total4 = n * P * (C / 4);
+    hipLaunchKernelGGL(plain_and_fused_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, roi_feats, rois,
+                       global_feat, both, total4, P, C / 4, B);
+    return htd::check_launch("plain_and_fused_fwd");
 }
 
 extern "C" int htd_fuse_global_bwd_global(const float *grad, const float *rois, float *grad_global, int64_t n, int P,

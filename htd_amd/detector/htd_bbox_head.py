@@ -97,14 +97,14 @@ class HTDBBoxHead(BBoxHead):
         x_reg = M.global_avg_pool(x_reg).view(x_reg.size(0), x_reg.size(1))   # AvgPool2d(7) on a 7x7 map
         return dense.linear(x_reg, self.fc_reg.weight, self.fc_reg.bias) if self.with_reg else None
 
-    def forward_cls(self, x_cls, feat, rois, fc_cls_0, global_feat=None, rois_per_img=None, roi_valid=None):
+    def forward_cls(self, x_cls, feat, rois, fc_cls_0, global_feat=None, rois_per_img=None, roi_valid=None, row_stash=None):
         """Classification branch (:192-226): fcs (applied to the plain and to the global-fused tiles), semantic
         embedding from the stage-1 classifier, PGraph refinement, fc_cls."""
         from .pgraph import pgraph_refine
         prototype = torch.cat((fc_cls_0.weight, fc_cls_0.bias.unsqueeze(1)), 1).detach()
         if global_feat is not None:
             # the fcs run on the plain and on the global-fused tiles (:198,201): one batched pass over both
-            tiles = M.plain_and_fused(x_cls, rois, global_feat) if x_cls.is_cuda else \
+            tiles = M.plain_and_fused(x_cls, rois, global_feat, row_stash) if x_cls.is_cuda else \
                 torch.cat([x_cls, self._fuse_global(x_cls, global_feat, rois)], 0)
             both = self._cls_fcs(tiles)
             x_cls, x_cls_glb = both[:x_cls.size(0)], both[x_cls.size(0):]

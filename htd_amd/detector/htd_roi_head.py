@@ -293,8 +293,11 @@ class HTDRoIHead(nn.Module):
         npos_ready.record()
         head = self.bbox_head[1]
         gf = global_feat if self.with_global else None
+        # the positives' rows of bbox_feats are read after the classification branch is queued: through the alias that branch's
+        # first node leaves in the stash, so that their gradient joins its sum in place (mmcv_ops.PlainAndFusedFunction)
+        stash = M.RowStash() if (gf is not None and bbox_feats.is_cuda and torch.is_grad_enabled()) else None
         cls_score = head.forward_cls(bbox_feats, feats, rois, self.bbox_head[0].fc_cls, gf, rois_per_img=(n, ) * B,
-                                     roi_valid=S1.valid.view(-1))
+                                     roi_valid=S1.valid.view(-1), row_stash=stash)
         npos_ready.synchronize()
         npos = [int(v) for v in npos_host.tolist()]
         full = cls_score.new_zeros(cls_score.size(0), 4)
@@ -302,7 +305,9 @@ class HTDRoIHead(nn.Module):
             pos_rows = torch.cat([torch.arange(b * n, b * n + k, device=dev) for b, k in enumerate(npos)])
             pos_rois = torch.index_select(rois, 0, pos_rows)
             enhanced = enhanced_extractor(feats, pos_rois)
-            bbox_pred = head.forward_reg(torch.index_select(bbox_feats, 0, pos_rows), enhanced, pos_rois, gf)
+            pos_feats = M.select_rows_via(stash, pos_rows) if (stash is not None and stash.alias is not None) else \
+                torch.index_select(bbox_feats, 0, pos_rows)
+            bbox_pred = head.forward_reg(pos_feats, enhanced, pos_rois, gf)
             full = full.index_copy(0, pos_rows, bbox_pred)
         # no positive in the whole batch: the regression branch gets no gradient this step (zeros in the flat buffer)
         t1 = self._static_targets(1, S1)

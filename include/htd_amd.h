@@ -147,6 +147,10 @@ int htd_random_sample(const int64_t *assigned, const float *keys, int B, int64_t
 int htd_fuse_global_fwd(const float *roi_feats, const float *rois, const float *global_feat,
                         const float *extra, float alpha, float *out, int64_t n, int P, int C,
                         int B, void *stream);
+/* The two input batches of the HTD classification FCs in one pass over roi_feats (htd_bbox_head.py:198,201):
+ * both[0..n) = roi_feats, both[n..2n) = roi_feats + global_feat[image of the RoI].  both: [2n][P][C] floats. */
+int htd_plain_and_fused_fwd(const float *roi_feats, const float *rois, const float *global_feat, float *both,
+                            int64_t n, int P, int C, int B, void *stream);
 int htd_fuse_global_bwd_global(const float *grad, const float *rois, float *grad_global,
                                int64_t n, int P, int C, int B, void *stream);
 

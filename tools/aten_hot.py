@@ -42,12 +42,15 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 rows = []
 for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6 if STACK else 0):
     if e.key.startswith('aten::') and e.self_device_time_total > 0:
-        frames = [f for f in (getattr(e, 'stack', None) or []) if 'htd_amd' in f or 'bench' in f][:3]
-        rows.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:90], frames))
+        frames = [f for f in (getattr(e, 'stack', None) or []) if ('htd_amd' in f or 'bench' in f or 'tools/' in f) and 'aten_hot' not in f][:4]
+        rows.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:90], frames, e))
 rows.sort(reverse=True, key=lambda r: r[0])
 tot = sum(r[0] for r in rows)
 print('ATen self device time: %.3f ms in %d op groups, %d launches' % (tot / 1e3, len(rows), sum(r[1] for r in rows)))
-for t, n, k, sh, frames in rows[:int(os.environ.get('ATEN_TOP', '70'))]:
+for t, n, k, sh, frames, e in rows[:int(os.environ.get('ATEN_TOP', '70'))]:
     print('%8.1f us %4d  %-28s %s' % (t, n, k, sh))
     for f in frames:
         print('              ' + f.replace(os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + '/', '')[:150])
+    if STACK and not frames and t > 40:
+        for f in (getattr(e, 'stack', None) or [])[:4]:
+            print('              ? ' + f[:150])
