@@ -117,6 +117,59 @@ def test_roi_align_levels_backward_one_launch_equals_per_level(dev):
     assert float(res[True][1].abs().max()) == 0.0               # the empty level: zeros, written not accumulated
 
 
+def test_plain_and_fused_with_row_stash_matches_the_tensor_formulation(dev):
+    """mmcv_ops.plain_and_fused(+ RowStash) / select_rows_via against cat([x, x + g[img]]) and index_select: values, and the
+    gradients of x and g when (a) both outputs are used, (b) no row is selected (a batch without positives), (c) the batch
+    output is unused (only the selected rows feed the loss)."""
+    from htd_amd import mmcv_ops as M
+    gen = torch.Generator().manual_seed(9)
+    n, C, B = 37, 64, 3
+    x0 = torch.randn(n, C, 7, 7, generator=gen)
+    g0 = torch.randn(B, C, 1, 1, generator=gen)
+    img = torch.sort(torch.randint(0, B, (n, ), generator=gen))[0]
+    rois = torch.cat([img[:, None].float(), torch.rand(n, 4, generator=gen) * 50], 1)
+    rows = torch.tensor([0, 3, 4, 11, 36])
+    wb = torch.randn(2 * n, C, 7, 7, generator=gen)
+    wr = torch.randn(len(rows), C, 7, 7, generator=gen)
+    for case in ('both', 'no rows', 'rows only'):
+        xr, gr = x0.clone().requires_grad_(), g0.clone().requires_grad_()
+        both_r = torch.cat([xr, xr + gr[img]], 0)
+        loss_r = (both_r * wb).sum() if case != 'rows only' else xr.sum() * 0
+        if case != 'no rows':
+            loss_r = loss_r + (torch.index_select(xr, 0, rows) * wr).sum()
+        loss_r.backward()
+        xd, gd = cl(x0.to(dev)).requires_grad_(), g0.to(dev).requires_grad_()
+        stash = M.RowStash()
+        both = M.plain_and_fused(xd, rois.to(dev), gd, stash)
+        assert torch.equal(both.cpu(), both_r.detach())
+        loss = (both * wb.to(dev)).sum() if case != 'rows only' else xd.sum() * 0
+        if case != 'no rows':
+            sel = M.select_rows_via(stash, rows.to(dev))
+            assert torch.equal(sel.cpu(), x0[rows])
+            loss = loss + (sel * wr.to(dev)).sum()
+        loss.backward()
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-6, atol=1e-6)
+        if case != 'rows only':
+            torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-5, atol=1e-4)
+        assert stash.grad is None and not stash.pending            # handed over and cleared
+
+
+def test_roi_align_levels_backward_gather_without_rois(dev):
+    """htd_roi_align_levels_bwd_gather with n == 0: fresh maps are zero-filled, accumulated maps keep their contents."""
+    import ctypes
+    from htd_amd import capi
+    L, B, C = 3, 2, 8
+    maps = [torch.full((B, C, 16 >> i, 24 >> i), 3.0, device=dev).contiguous(memory_format=torch.channels_last) for i in range(L)]
+    ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in maps])
+    Hs, Ws = (ctypes.c_int * L)(16, 8, 4), (ctypes.c_int * L)(24, 12, 6)
+    sc, ac = (ctypes.c_float * L)(0.25, 0.125, 0.0625), (ctypes.c_int * L)(0, 1, 0)
+    capi.call('htd_roi_align_levels_bwd_gather', None, None, None, ptrs, Hs, Ws, sc, ac, L, 0, B, C, 7, 7, 0, 1, None,
+              capi.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert float(maps[0].abs().max()) == 0.0 and float(maps[2].abs().max()) == 0.0
+    assert float((maps[1] - 3.0).abs().max()) == 0.0
+
+
 def clustered_boxes(gen, n, span=300.):
     k = max(1, n // 6)
     centers = torch.rand(k, 2, generator=gen) * span
