@@ -424,13 +424,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradParams p)
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto put = [&](unsigned short *img, int row, int col, float4 v) {
         unsigned h0, m0_, l0, h1, m1, l1;
-#ifdef HTD_ABLATE_WGRAD_SPLIT       // timing experiment only (wrong results): what the kernel costs without the split arithmetic
-        h0 = m0_ = l0 = __float_as_uint(v.x) ^ __float_as_uint(v.y);
-        h1 = m1 = l1 = __float_as_uint(v.z) ^ __float_as_uint(v.w);
-#else
         split3x2w(v.x, v.y, h0, m0_, l0);
         split3x2w(v.z, v.w, h1, m1, l1);
-#endif
         unsigned short *d = img + row * X3_ROW + col;
         *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
         *reinterpret_cast<uint2 *>(d + X3_PLANE) = make_uint2(m0_, m1);
