@@ -642,6 +642,54 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
     }
 }
 
+// the same for Co % 4 == 0, four channels per thread: float4 loads of the partials (independent across the ranges), 32-bit
+// index arithmetic, one division per four outputs -- these launches are a few MB each and were latency, not bandwidth
+__global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_vec_kernel(X3Params p)
+{
+    const int C4 = p.Co >> 2;
+    const int64_t lo = p.splits_a > 1 ? 0 : p.m_rem0 * C4, hi = p.splits_b > 1 ? p.M * C4 : p.m_rem0 * C4;
+    const int64_t na = p.m_rem0 * C4, nb = (p.M - p.m_rem0) * C4;
+    const float4 *pa = reinterpret_cast<const float4 *>(p.partial);
+    const float4 *pb = pa + (p.splits_a > 1 ? (int64_t)p.splits_a * na : 0);
+    for (int64_t q = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < hi; q += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool in_a = q < na;
+        const float4 *src = in_a ? pa + q : pb + (q - na);
+        const int64_t stride = in_a ? na : nb;
+        const int splits = in_a ? p.splits_a : p.splits_b;
+#pragma unroll 4
+        for (int k = 0; k < splits; ++k) {
+            const float4 t = src[(int64_t)k * stride];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const unsigned m = (unsigned)(q / C4), n = (unsigned)(q - (int64_t)m * C4) * 4u;
+        const int64_t o = (int64_t)m * p.Co + n;
+        if (p.bias) {
+            const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        if (p.residual) {
+            int64_t ro = o;
+            if (p.res_H > 0) {
+                const unsigned wo = m % (unsigned)p.Wo, t = m / (unsigned)p.Wo;
+                const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
+            }
+            const float4 rv = *reinterpret_cast<const float4 *>(p.residual + ro);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.mask_src) {
+            const float4 mv = *reinterpret_cast<const float4 *>(p.mask_src + o);
+            v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+            v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(p.y + o) = v;
+    }
+}
+
 // ---- weight planes --------------------------------------------------------------------------------------------------
 // w [Co][taps][Ci] fp32 (KRSC) -> planes [taps][K/16][6][Np] x 16 B, chunk c = plane * 2 + half holds the bf16 piece `plane` of
 // the 8 reduction channels 16 cs + 8 half .. + 7 of output channel n (rows n >= N are zeros).
@@ -938,8 +986,13 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     }
     if (pl.partial_floats > 0) {
         const int64_t rows = (p.splits_a > 1 ? p.m_rem0 : 0) + (p.splits_b > 1 ? p.M - p.m_rem0 : 0);
-        const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * p.Co, 256), 4096);
-        hipLaunchKernelGGL(conv_x3p_splitk_epilogue_kernel, dim3(rb), dim3(256), 0, s, p);
+        if ((p.Co & 3) == 0) {      // (the main kernel writes its partial rows with float4 stores under the same condition)
+            const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * (p.Co >> 2), 256), 4096);
+            hipLaunchKernelGGL(conv_x3p_splitk_epilogue_vec_kernel, dim3(rb), dim3(256), 0, s, p);
+        } else {
+            const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * p.Co, 256), 4096);
+            hipLaunchKernelGGL(conv_x3p_splitk_epilogue_kernel, dim3(rb), dim3(256), 0, s, p);
+        }
     }
     return htd::check_launch("conv2d_x3p");
 }
