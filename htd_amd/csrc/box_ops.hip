@@ -349,6 +349,92 @@ __global__ __launch_bounds__(256) void rpn_loss_kernel(const float *__restrict__
 
 }  // namespace
 
+namespace {
+
+constexpr int ROI_LOSS_BLOCKS = 64;
+
+// The two losses of a RoI head stage over all its sample rows in one pass (bbox_heads/bbox_head.py:148-186 with
+// losses/cross_entropy_loss.py:9-39, smooth_l1_loss.py:8-26, the class-agnostic regression of the HTD heads):
+//   cls:  w_i * (logsumexp(x_i) - x_i[label_i])                                  -> partial[0], and  #(w_i > 0) -> partial[1]
+//   box:  sum_k bw_ik * [label_i is a foreground class] * SmoothL1_beta(pred_ik - target_ik)        -> partial[2]
+//   acc:  #(argmax x_i == label_i and w_i > 0) (first maximum, like torch.argmax)                  -> partial[3]
+// and d(sum)/dx, d(sum)/dpred in the same pass (the backward only scales them by loss weight / avg_factor).  One wavefront
+// per row, rows strided over a fixed grid; per-block partials, added in block order by the caller (bitwise reproducible).
+__global__ __launch_bounds__(256) void roi_head_loss_kernel(const float *__restrict__ cls, const int64_t *__restrict__ labels,
+                                                            const float *__restrict__ lw, const float *__restrict__ pred,
+                                                            const float *__restrict__ tgt, const float *__restrict__ bw,
+                                                            int64_t n, int NC, int num_fg, float beta,
+                                                            float *__restrict__ partial, float *__restrict__ gcls,
+                                                            float *__restrict__ gbox)
+{
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s_ce = 0.f, s_w = 0.f, s_box = 0.f, s_hit = 0.f;               // lane 0 of the wave keeps the running sums
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += (int64_t)gridDim.x * 4) {
+        const int64_t lab = labels[i];
+        const float w = lw[i];
+        const float *x = cls + i * NC;
+        // NC <= 128: two logits per lane
+        const int c0 = lane, c1 = lane + 64;
+        const float x0 = c0 < NC ? x[c0] : -INFINITY, x1 = c1 < NC ? x[c1] : -INFINITY;
+        const float m = htd::wave_max(fmaxf(x0, x1));
+        const float e0 = c0 < NC ? expf(x0 - m) : 0.f, e1 = c1 < NC ? expf(x1 - m) : 0.f;
+        const float lse = m + logf(htd::wave_sum(e0 + e1));
+        // first index of the maximum
+        int am = x0 == m ? c0 : (x1 == m ? c1 : 1 << 30);
+        for (int o = 32; o > 0; o >>= 1) am = min(am, __shfl_xor(am, o, 64));
+        const float xl = (lab >= 0 && lab < NC) ? x[lab] : 0.f;
+        if (lane == 0) {
+            s_ce += w * (lse - xl);
+            s_w += w > 0.f ? 1.f : 0.f;
+            s_hit += (w > 0.f && (int64_t)am == lab) ? 1.f : 0.f;
+        }
+        if (c0 < NC) gcls[i * NC + c0] = w * (expf(x0 - lse) - (c0 == lab ? 1.f : 0.f));
+        if (c1 < NC) gcls[i * NC + c1] = w * (expf(x1 - lse) - (c1 == lab ? 1.f : 0.f));
+        if (pred) {
+            const bool fg = lab >= 0 && lab < num_fg;
+            float l = 0.f, g = 0.f;
+            if (lane < 4) {
+                const float wk = fg ? bw[i * 4 + lane] : 0.f;
+                const float d = pred[i * 4 + lane] - tgt[i * 4 + lane], ad = fabsf(d);
+                if (ad < beta) { l = wk * (0.5f * ad * ad / beta); g = wk * (d / beta); }
+                else { l = wk * (ad - 0.5f * beta); g = wk * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
+                gbox[i * 4 + lane] = g;
+            }
+            l += __shfl_xor(l, 1, 64);
+            l += __shfl_xor(l, 2, 64);
+            if (lane == 0) s_box += l;
+        }
+    }
+    if (lane == 0) { red[0][wave] = s_ce; red[1][wave] = s_w; red[2][wave] = s_box; red[3][wave] = s_hit; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float *r = red[threadIdx.x];
+        partial[4 * blockIdx.x + threadIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int htd_roi_head_loss_partial_rows(void) { return ROI_LOSS_BLOCKS; }
+
+// cls_score [n][NC] (NC <= 128, last class = background), labels [n] int64, label_weights [n]; bbox_pred / bbox_targets /
+// bbox_weights [n][4] (class-agnostic regression; bbox_pred NULL: classification only), num_fg foreground classes.
+// -> partial [htd_roi_head_loss_partial_rows()][4] = per-block {sum w*CE, #(w > 0), sum bw*SmoothL1, #correct},
+//    grad_cls [n][NC], grad_box [n][4] = derivatives of the two sums.
+extern "C" int htd_roi_head_loss(const float *cls_score, const int64_t *labels, const float *label_weights,
+                                 const float *bbox_pred, const float *bbox_targets, const float *bbox_weights, int64_t n,
+                                 int NC, int num_fg, float beta, float *partial, float *grad_cls, float *grad_box,
+                                 void *stream)
+{
+    HTD_REQUIRE(n > 0 && NC > 0 && NC <= 128 && num_fg >= 0 && beta > 0.f, "roi_head_loss: bad sizes n=%lld NC=%d", (long long)n, NC);
+    HTD_REQUIRE(cls_score && labels && label_weights && partial && grad_cls, "roi_head_loss: null pointer");
+    HTD_REQUIRE(!bbox_pred || (bbox_targets && bbox_weights && grad_box), "roi_head_loss: null regression pointer");
+    hipLaunchKernelGGL(roi_head_loss_kernel, dim3(ROI_LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, cls_score, labels,
+                       label_weights, bbox_pred, bbox_targets, bbox_weights, n, NC, num_fg, beta, partial, grad_cls, grad_box);
+    return htd::check_launch("roi_head_loss");
+}
+
 extern "C" int htd_rpn_loss_partial_rows(void) { return RPN_LOSS_BLOCKS; }
 
 extern "C" int htd_rpn_loss(const float *cls, const float *reg, const float *anchors, const float *gts,

@@ -150,6 +150,11 @@ class BBoxHead(nn.Module):
              reduction_override=None, num_samples=None):
         """num_samples (device scalar, optional): number of real rows when the batch carries unused sample slots
         (static-shape training path); rows with label_weight 0 are then excluded from `acc` as well."""
+        if self._fused_loss_ok(cls_score, bbox_pred, reduction_override, num_samples):
+            loss_cls, acc, loss_bbox = _RoIHeadLoss.apply(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
+                                                          num_samples, self.num_classes, float(self.loss_bbox.beta),
+                                                          float(self.loss_cls.loss_weight), float(self.loss_bbox.loss_weight))
+            return dict(loss_cls=loss_cls, acc=acc, loss_bbox=loss_bbox)
         losses = dict()
         if cls_score is not None:
             # avg_factor stays on the device (the reference calls .item() here: one host sync per stage)
@@ -178,6 +183,20 @@ class BBoxHead(nn.Module):
                                                  avg_factor=bbox_targets.size(0) if num_samples is None else
                                                  num_samples.to(pred.dtype).clamp(min=1))
         return losses
+
+    fused_loss = True        # one kernel for cross-entropy + smooth-L1 + accuracy on the static-shape training path
+
+    def _fused_loss_ok(self, cls_score, bbox_pred, reduction_override, num_samples):
+        """The configuration of the HTD heads (softmax cross-entropy without class weights, class-agnostic smooth-L1 on
+        encoded deltas, mean reduction, static-shape batch): everything else keeps the tensor formulation below."""
+        from .losses import CrossEntropyLoss, SmoothL1Loss
+        lc, lb = self.loss_cls, self.loss_bbox
+        return (self.fused_loss and cls_score is not None and bbox_pred is not None and num_samples is not None and
+                reduction_override is None and cls_score.is_cuda and cls_score.dtype == torch.float32 and cls_score.dim() == 2 and
+                0 < cls_score.size(0) and cls_score.size(1) <= 128 and bbox_pred.dtype == torch.float32 and
+                self.reg_class_agnostic and not self.reg_decoded_bbox and tuple(bbox_pred.shape) == (cls_score.size(0), 4) and
+                type(lc) is CrossEntropyLoss and not lc.use_sigmoid and lc.class_weight is None and lc.reduction == 'mean' and
+                type(lb) is SmoothL1Loss and lb.reduction == 'mean')
 
     # ---------------------------------------------------------------- inference / refinement
     def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
@@ -224,6 +243,40 @@ class BBoxHead(nn.Module):
             return self.bbox_coder.decode(rois, bbox_pred, max_shape=img_meta['img_shape'])
         bboxes = self.bbox_coder.decode(rois[:, 1:], bbox_pred, max_shape=img_meta['img_shape'])
         return torch.cat((rois[:, [0]], bboxes), dim=1)
+
+
+class _RoIHeadLoss(torch.autograd.Function):
+    """BBoxHead.loss of the static-shape training path as one kernel (htd_roi_head_loss) plus a handful of scalar operations:
+    -> dict(loss_cls, acc, loss_bbox) with the values of the tensor formulation (sums in another fixed order)."""
+
+    @staticmethod
+    def forward(ctx, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, num_samples, num_fg, beta, lw_cls,
+                lw_box):
+        from .. import capi
+        n, NC = cls_score.shape
+        cls = cls_score.contiguous()
+        pred = bbox_pred.contiguous()
+        blocks = capi.lib().htd_roi_head_loss_partial_rows()
+        partial = torch.empty(blocks, 4, device=cls.device, dtype=torch.float32)
+        gcls, gbox = torch.empty_like(cls), torch.empty_like(pred)
+        capi.call('htd_roi_head_loss', capi.ptr(cls), capi.ptr(labels.contiguous()), capi.ptr(label_weights.float().contiguous()),
+                  capi.ptr(pred), capi.ptr(bbox_targets.float().contiguous()), capi.ptr(bbox_weights.float().contiguous()), n, NC,
+                  int(num_fg), float(beta), capi.ptr(partial), capi.ptr(gcls), capi.ptr(gbox), capi.current_stream_ptr())
+        sums = partial.sum(0)                                     # {sum w*CE, #(w > 0), sum bw*SmoothL1, #correct}
+        avg = torch.stack([sums[1], num_samples.to(torch.float32).reshape(())]).clamp(min=1.)       # avg_factor of cls, of box / acc
+        scale = torch.stack([lw_cls / avg[0], lw_box / avg[1], 100.0 / avg[1]])
+        vals = sums[[0, 2, 3]] * scale                            # loss_cls, loss_bbox, acc
+        loss_cls, loss_bbox, acc = vals[0], vals[1], vals[2:3]
+        ctx.save_for_backward(gcls, gbox, scale)
+        ctx.mark_non_differentiable(acc)
+        return loss_cls, acc, loss_bbox
+
+    @staticmethod
+    def backward(ctx, g_cls, g_acc, g_box):
+        gcls, gbox, scale = ctx.saved_tensors
+        gc = gcls * (g_cls * scale[0]) if g_cls is not None else None
+        gb = gbox * (g_box * scale[1]) if g_box is not None else None
+        return gc, gb, None, None, None, None, None, None, None, None, None
 
 
 @HEADS.register_module()

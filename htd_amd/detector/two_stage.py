@@ -55,15 +55,21 @@ class BaseDetector(nn.Module):
         return self.forward_test(img, img_metas, **kwargs)
 
     def _parse_losses(self, losses):
+        """detectors/base.py:196-223.  Values that already are scalars (every loss of this path) skip their `.mean()`, and the
+        total is ONE stacked sum whose backward hands the incoming gradient to every term as it is: the reference's chain of
+        `mean` and `+` nodes is ~25 element-wise launches on 0-dim tensors per step, forward and backward."""
+        def scalar(v):
+            return v.reshape(()) if v.numel() == 1 else v.mean()
         log_vars = OrderedDict()
         for name, value in losses.items():
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                log_vars[name] = scalar(value)
             elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
+                log_vars[name] = sum(scalar(v) for v in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        terms = [v for k, v in log_vars.items() if 'loss' in k]
+        loss = _SumScalars.apply(*terms) if len(terms) > 1 and all(t.dim() == 0 and t.is_cuda for t in terms) else sum(terms)
         log_vars['loss'] = loss
         packed = torch.stack([v.detach().reshape(()).float() for v in log_vars.values()])
         if dist.is_available() and dist.is_initialized():
@@ -79,6 +85,22 @@ class BaseDetector(nn.Module):
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
     val_step = train_step
+
+
+class _SumScalars(torch.autograd.Function):
+    """sum of 0-dim tensors, added left to right like Python's sum(); every input receives the output's gradient unchanged."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        ctx.n = len(terms)
+        total = terms[0] + terms[1]
+        for t in terms[2:]:
+            total = total + t
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g, ) * ctx.n
 
 
 class LazyLogVars(OrderedDict):

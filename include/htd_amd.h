@@ -391,6 +391,15 @@ int htd_delta2bbox_clip(const float *rois, const float *deltas, const float *lim
  * reg [B*A][4], anchors [A][4], gts [B][K][4], assigned [B][A] (MaxIoUAssigner output), pos / neg [B][A] sample masks.
  * partial [htd_rpn_loss_partial_rows()][2] = per-block (sum BCE, sum SmoothL1) -- reduce over rows in order;
  * grad_cls [B*A], grad_reg [B*A][4] = derivatives of those sums (scale by 1/avg_factor * loss_weight). */
+/* Both losses of a RoI head stage in one pass (BBoxHead.loss, bbox_heads/bbox_head.py:148-186: CrossEntropyLoss over the
+ * class logits with per-row weights, SmoothL1Loss over the class-agnostic box deltas of the foreground rows, accuracy):
+ * per-block partial sums partial[htd_roi_head_loss_partial_rows()][4] = {sum w*CE, #(w > 0), sum bw*SmoothL1, #correct} in a
+ * fixed grid (the caller adds them in row order: reproducible) and the derivatives of the two sums, grad_cls [n][NC] and
+ * grad_box [n][4].  NC <= 128; bbox_pred == NULL: classification part only. */
+int htd_roi_head_loss_partial_rows(void);
+int htd_roi_head_loss(const float *cls_score, const int64_t *labels, const float *label_weights, const float *bbox_pred,
+                      const float *bbox_targets, const float *bbox_weights, int64_t n, int NC, int num_fg, float beta,
+                      float *partial, float *grad_cls, float *grad_box, void *stream);
 int htd_rpn_loss_partial_rows(void);
 int htd_rpn_loss(const float *cls, const float *reg, const float *anchors, const float *gts, const int64_t *assigned,
                  const uint8_t *pos, const uint8_t *neg, int B, int A, int K, const float *means4, const float *stds4,

@@ -148,6 +148,49 @@ def test_batched_test_postprocessing_equals_the_per_image_loop(det, golden, scal
             assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b)
 
 
+def test_fused_roi_head_loss_matches_the_tensor_formulation():
+    """htd_roi_head_loss (cross-entropy + class-agnostic smooth-L1 + accuracy of BBoxHead.loss in one kernel) against the
+    tensor formulation of the same method (bbox_head.py:148-186): values to 1e-6 relative, gradients of both inputs to
+    1e-6 of their largest entry -- with unused sample slots (weight 0), background rows, an exact logit tie, large and
+    tiny box errors on both sides of beta, and a batch without a single positive."""
+    from htd_amd.detector.bbox_heads import Shared2FCBBoxHead
+    dev = torch.device('cuda:0')
+    head = Shared2FCBBoxHead(in_channels=8, fc_out_channels=16, roi_feat_size=2, num_classes=80, reg_class_agnostic=True,
+                             bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.1, 0.1, 0.2, 0.2]),
+                             loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                             loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=0.7))
+    g = torch.Generator().manual_seed(3)
+    n = 777
+    for case in ('mixed', 'no positives'):
+        cls = (torch.randn(n, 81, generator=g) * 3).to(dev)
+        cls[5, 7] = cls[5, 3] = cls[5].max() + 1.0                           # exact tie: argmax is the first maximum
+        labels = torch.randint(0, 81, (n, ), generator=g)
+        labels[torch.rand(n, generator=g) < 0.6] = 80                         # background
+        if case == 'no positives':
+            labels[:] = 80
+        lw = (torch.rand(n, generator=g) < 0.85).float()                      # unused slots: weight 0
+        pred = (torch.randn(n, 4, generator=g) * 2).to(dev)
+        tgt = torch.randn(n, 4, generator=g)
+        tgt[::7] = pred[::7].cpu() + 1e-3                                      # inside beta
+        bw = ((labels < 80) & (lw > 0)).float()[:, None].expand(n, 4).contiguous()
+        ns = lw.sum().to(dev)
+        out = {}
+        for fused in (True, False):
+            head.fused_loss = fused
+            c, p = cls.clone().requires_grad_(), pred.clone().requires_grad_()
+            losses = head.loss(c, p, None, labels.to(dev), lw.to(dev), tgt.to(dev), bw.to(dev), num_samples=ns)
+            (losses['loss_cls'] * 1.3 + losses['loss_bbox'] * 0.9).backward()
+            out[fused] = (losses, c.grad, p.grad)
+        for k in ('loss_cls', 'loss_bbox', 'acc'):
+            a, b = out[True][0][k], out[False][0][k]
+            assert a.shape == b.shape, (k, a.shape, b.shape)
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
+        for a, b in zip(out[True][1:], out[False][1:]):
+            torch.testing.assert_close(a, b, rtol=0, atol=1e-6 * max(float(b.abs().max()), 1e-30))
+        if case == 'no positives':
+            assert float(out[True][0]['loss_bbox'].detach()) == 0.0 and float(out[True][2].abs().max()) == 0.0
+
+
 def test_proposal_indices_and_stage_logits_match_reference_fixture(det, golden):
     """north_star's parity clause at path level.  (1) Fed the RPN logits of the reference run (detector.npz), the
     product's proposal stage -- per-level sort, decode, one batched NMS launch -- keeps the SAME candidates in the SAME
