@@ -521,6 +521,248 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradParams p)
         }
 }
 
+// ---- the same product with the split of slice s+1 in the shadow of the MFMAs of slice s (round 3) -----------------------------
+// conv_wgrad_x3_kernel alternates phases: 48 MFMAs per wave on the staged slice, barrier, ~250 vector instructions that split
+// the next slice into its planes, barrier -- the matrix pipe idles through every split phase (105-125 TF/s on the 1x1 layers,
+// where no tap shares a staged run).  Here a slice is 16 pixels, LDS holds TWO of them (the same 61 KB), and the loop body is
+// one basic block with one barrier: split + store of slice s+1 into the other buffer, the global loads of slice s+3 into the
+// registers just freed (slice s+2 is in flight in the second register set), 24 MFMAs per wave on slice s.  Vector and matrix
+// instructions of the same wave now interleave, and the loads have two slices of time to land.  Slices past the end of the
+// split's K range stage zeros (no branches in the body).  Same tiles, splits, partial layout and summation order as
+// conv_wgrad_x3_kernel: the results are bit-identical.
+constexpr int XD_KS = 16;                      // pixels per K slice
+constexpr int XD_PLANE = XD_KS * X3_ROW;       // half-words per plane image
+constexpr int XD_BUF = 6 * XD_PLANE;           // three gy planes + three x planes
+
+template <int PIX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
+{
+    constexpr int WGN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
+    constexpr int VA = BM / 4, VB = BN / 4, PA = XD_KS * VA / 256, PB = XD_KS * VB / 256;      // 2 float4 per thread, operand and slice
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * XD_BUF];
+
+    int tile, split;
+    {
+        const int tiles = p.mt * p.nt, L = blockIdx.x;
+        if (p.splits % 8 == 0) {
+            const int xcd = L % 8, idx = L / 8;
+            tile = idx % tiles;
+            split = (idx / tiles) * 8 + xcd;
+        } else {
+            tile = L % tiles;
+            split = L / tiles;
+        }
+    }
+    const int tile_m = tile % p.mt, tile_n = tile / p.mt;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    int a_row[PA], b_row[PB];
+    const int a_col = (tid % VA) * 4, b_col = (tid % VB) * 4;
+    const bool a_cok = m0 + a_col < p.Co;
+    const int nb = n0 + b_col;
+    const bool b_cok = nb < p.Ntot;
+    const int tap = b_cok ? nb / p.Ci : 0;
+    const int b_ci = b_cok ? nb - tap * p.Ci : 0;
+    const int b_dy = (tap / p.kw) * p.dil - p.pad, b_dx = (tap % p.kw) * p.dil - p.pad;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_row[i] = (tid + i * 256) / VA;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) b_row[i] = (tid + i * 256) / VB;
+
+    // the split's K range in pixels: [k_begin, k_end), the slice boundaries of conv_wgrad_x3_kernel (BKW pixels each)
+    const int64_t k_begin64 = (int64_t)split * p.slices_per_split * BKW;
+    const unsigned k_begin = (unsigned)k_begin64;
+    const unsigned k_end = (unsigned)min(p.K, k_begin64 + p.slices_per_split * BKW);
+    const int n_slices = k_begin64 < p.K ? (int)((k_end - k_begin + XD_KS - 1) / XD_KS) : 0;
+
+    // Operands come through buffer descriptors: a load whose byte offset lies past the descriptor's size returns zeros, so rows
+    // past the split's K range (the gy descriptor -- and for 1x1 layers the x descriptor -- ends at pixel k_end), columns past
+    // Co / Ntot and padding pixels (offset OOB) need no select on the data, no validity bits and no 64-bit address arithmetic:
+    // one vector add per load in the 1x1 form (4.5 vector instructions per MFMA instead of 6.8, PMC r03).
+    constexpr unsigned OOB = 0x80000000u;          // the host keeps both operands below 2^31 bytes
+    const __amdgpu_buffer_rsrc_t gy_desc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.gy), 0, (int)((unsigned)k_end * (unsigned)p.Co * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_desc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x), 0,
+        (int)(PIX == PIX_POINTWISE ? (unsigned)k_end * (unsigned)p.Ci * 4u : (unsigned)p.B * p.H * p.W * p.Ci * 4u), 0x00020000);
+    unsigned a_off[PA], b_k[PB], b_off[PB];
+    const unsigned a_step = a_cok ? XD_KS * (unsigned)p.Co * 4u : 0u, b_step = b_cok ? XD_KS * (unsigned)p.Ci * 4u : 0u;
+    int b_b[PB], b_ho[PB], b_wo[PB];
+    auto decode = [&](int i) {
+        const unsigned kk = b_k[i] < (unsigned)p.K ? b_k[i] : 0u;
+        b_wo[i] = (int)(kk % (unsigned)p.Wo);
+        const unsigned t = kk / (unsigned)p.Wo;
+        b_ho[i] = (int)(t % (unsigned)p.Ho);
+        b_b[i] = (int)(t / (unsigned)p.Ho);
+    };
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_off[i] = a_cok ? ((k_begin + a_row[i]) * (unsigned)p.Co + m0 + a_col) * 4u : OOB;
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        b_k[i] = k_begin + b_row[i];
+        b_off[i] = b_cok ? (b_k[i] * (unsigned)p.Ci + b_ci) * 4u : OOB;      // the 1x1 form; the others work from b_k
+        if constexpr (PIX != PIX_POINTWISE) decode(i);
+    }
+
+    float4 ra[2][PA], rb[2][PB];
+    using u32x4w = __attribute__((ext_vector_type(4))) unsigned;
+    auto load16 = [&](__amdgpu_buffer_rsrc_t d, unsigned off) {
+        union { u32x4w u; float4 f; } c;
+        c.u = __builtin_amdgcn_raw_buffer_load_b128(d, (int)off, 0, 0);
+        return c.f;
+    };
+    auto load_slice = [&](float4 (&qa)[PA], float4 (&qb)[PB]) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            qa[i] = load16(gy_desc, a_off[i]);
+            a_off[i] += a_step;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            if constexpr (PIX == PIX_POINTWISE) {
+                qb[i] = load16(x_desc, b_off[i]);
+                b_off[i] += b_step;
+            } else {
+                const int hi = b_ho[i] * p.stride + b_dy, wi = b_wo[i] * p.stride + b_dx;
+                const bool ok = b_cok && b_k[i] < k_end && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const unsigned off = ((((unsigned)b_b[i] * p.H + hi) * p.W + wi) * (unsigned)p.Ci + b_ci) * 4u;
+                qb[i] = load16(x_desc, off | (ok ? 0u : OOB));
+                b_k[i] += XD_KS;
+                if constexpr (PIX == PIX_WIDE) {            // Wo >= BKW > XD_KS: at most one carry
+                    const int wo = b_wo[i] + XD_KS;
+                    const bool c1 = wo >= p.Wo;
+                    b_wo[i] = c1 ? wo - p.Wo : wo;
+                    const int ho = b_ho[i] + (c1 ? 1 : 0);
+                    const bool c2 = ho == p.Ho;
+                    b_ho[i] = c2 ? 0 : ho;
+                    b_b[i] += c2 ? 1 : 0;
+                } else {
+                    decode(i);
+                }
+            }
+        }
+    };
+    const bool do_bias = p.bias_out != nullptr && tile_n == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto put = [&](unsigned short *img, int row, int col, float4 v) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3x2w(v.x, v.y, h0, m0_, l0);
+        split3x2w(v.z, v.w, h1, m1, l1);
+        unsigned short *d = img + row * X3_ROW + col;
+        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(m0_, m1);
+        *reinterpret_cast<uint2 *>(d + 2 * XD_PLANE) = make_uint2(l0, l1);
+    };
+    auto store_slice = [&](unsigned short *buf, const float4 (&qa)[PA], const float4 (&qb)[PB]) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const float4 v = qa[i];
+            put(buf, a_row[i], a_col, v);
+            bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;      // every tile (a branch would cut the loop body in two)
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) put(buf + 3 * XD_PLANE, b_row[i], b_col, qb[i]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one half of the loop body: the MFMAs of the slice in `rd` with the split of the staged registers (the next slice but
+    // one of that buffer's parity) into `wr` between them -- eight chunks of one split3x2w (two channels, ~12 vector
+    // instructions) and three MFMAs, pinned in this order by sched_barrier: left to itself hipcc moves all 24 MFMAs behind
+    // all of the vector work, and the matrix pipe idles through the split as it did in conv_wgrad_x3_kernel
+    auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[PA], float4 (&qb)[PB]) {
+        bf16x8w fa[TM][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag(rd + q * XD_PLANE, 0, wm * 64 + i * 32, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fb[j][q] = tr_frag(rd + (3 + q) * XD_PLANE, 0, wn * 64 + j * 32, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as conv_wgrad_x3_kernel
+        unsigned h[2], m[2], l[2];
+#pragma unroll
+        for (int c = 0; c < 2 * (PA + PB); ++c) {
+            const int u = c >> 1;                    // staged float4: gy rows first, then x rows
+            const bool is_a = u < PA;
+            const float4 v = is_a ? qa[u] : qb[u - PA];
+            if ((c & 1) == 0) {
+                split3x2w(v.x, v.y, h[0], m[0], l[0]);
+            } else {
+                split3x2w(v.z, v.w, h[1], m[1], l[1]);
+                unsigned short *d = (is_a ? wr + a_row[u] * X3_ROW + a_col : wr + 3 * XD_PLANE + b_row[u - PA] * X3_ROW + b_col);
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(m[0], m[1]);
+                *reinterpret_cast<uint2 *>(d + 2 * XD_PLANE) = make_uint2(l[0], l[1]);
+                if (is_a) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }     // every tile: no branch in the body
+            }
+#pragma unroll
+            for (int t = 3 * c; t < 3 * c + 3; ++t) {
+                const int q = t >> 2, i = (t >> 1) & 1, j = t & 1;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[q]], fb[j][QB[q]], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_slice(qa, qb);
+        __syncthreads();
+    };
+
+    // set 0: slices 0, 2, 4 ...; set 1: slices 1, 3, 5 ...  (loads past k_end return zeros)
+    unsigned short *buf0 = lds, *buf1 = lds + XD_BUF;
+    load_slice(ra[0], rb[0]);
+    load_slice(ra[1], rb[1]);
+    store_slice(buf0, ra[0], rb[0]);
+    load_slice(ra[0], rb[0]);
+    __syncthreads();
+    for (int s = 0; s < n_slices; s += 2) {
+        half(buf0, buf1, ra[1], rb[1]);           // MFMAs of slice s, slice s+1 staged, slice s+3 requested
+        half(buf1, buf0, ra[0], rb[0]);           // slice s+1 (zeros when n_slices is odd), s+2 staged, s+4 requested
+    }
+
+    if (do_bias) {          // threads sharing a column quad (tid % VA) fold their row partials in a fixed order
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < VA) {
+            float4 t = red[tid];
+            for (int r = 1; r < 256 / VA; ++r) {
+                const float4 v = red[r * VA + tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            float *dst = p.bias_out + (int64_t)split * p.Co;
+            const int m = m0 + tid * 4;
+            if (m < p.Co) dst[m] = t.x;
+            if (m + 1 < p.Co) dst[m + 1] = t.y;
+            if (m + 2 < p.Co) dst[m + 2] = t.z;
+            if (m + 3 < p.Co) dst[m + 3] = t.w;
+        }
+    }
+    float *out = p.out + (int64_t)split * p.Co * p.Ntot;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fcol;
+            if (n >= p.Ntot) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[i][j][r];
+            }
+        }
+}
+
 // ---- 3x3 layers: the three taps of a filter ROW in one workgroup (round 3) ------------------------------------------------------
 // conv_wgrad_x3_kernel gives every (128 co x 128 n) tile its own copy of the staging work: a gy element is loaded and split
 // once per N tile (18 times for a 3x3 256 -> 256 layer), an x element once per M tile and tap.  Here a workgroup owns
@@ -924,6 +1166,8 @@ Cfg choose(int Co, int Ntot, int64_t K)
     want = std::min<int64_t>(want, cap);
     c.splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 192));
     if (c.splits >= 6) c.splits = (c.splits + 7) / 8 * 8;            // multiples of 8: one split per XCD group
+    static const int forced = getenv("HTD_WGRAD_SPLITS") ? atoi(getenv("HTD_WGRAD_SPLITS")) : 0;       // tuning runs only
+    if (forced > 0) c.splits = (int)std::min<int64_t>(forced, slices);
     return c;
 }
 
@@ -1021,7 +1265,14 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
     static const int math_env = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
     const bool x3 = (g_wgrad_math < 0 ? math_env : g_wgrad_math) == 1 && c.bm == 128 && covec && (Ci & 3) == 0;
     if (x3) {
-        if (pix == PIX_POINTWISE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_POINTWISE>, grid, dim3(256), 0, s, p);
+        static const bool x3d_on = !(getenv("HTD_WGRAD_X3D") && atoi(getenv("HTD_WGRAD_X3D")) == 0);
+        // conv_wgrad_x3d_kernel addresses its operands with 32-bit BYTE offsets into buffer descriptors
+        const bool x3d = x3d_on && (int64_t)B * H * W * Ci * 4 < (1ll << 31) && p.K * Co * 4 < (1ll << 31);
+        if (x3d) {
+            if (pix == PIX_POINTWISE) hipLaunchKernelGGL(conv_wgrad_x3d_kernel<PIX_POINTWISE>, grid, dim3(256), 0, s, p);
+            else if (pix == PIX_WIDE) hipLaunchKernelGGL(conv_wgrad_x3d_kernel<PIX_WIDE>, grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(conv_wgrad_x3d_kernel<PIX_GENERAL>, grid, dim3(256), 0, s, p);
+        } else if (pix == PIX_POINTWISE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_POINTWISE>, grid, dim3(256), 0, s, p);
         else if (pix == PIX_WIDE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_WIDE>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_GENERAL>, grid, dim3(256), 0, s, p);
     } else if (c.bm == 32)

@@ -12,6 +12,7 @@ SETS=(
  "FETCH_SIZE"
  "WRITE_SIZE"
  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
+ "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA"
 )
 for s in "${SETS[@]}"; do python3 $R/tools/pmc_plan.py $s > /dev/null || { python3 $R/tools/pmc_plan.py $s; exit 2; }; done
 rm -rf /tmp/pk_$TAG; i=0; : > $R/gpurun_out/$TAG.progress
