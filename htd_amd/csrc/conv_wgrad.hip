@@ -983,6 +983,236 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3h_kernel(WgradParams p)
     }
 }
 
+// ---- the tap-fused 3x3 kernel with the split in the shadow of the MFMAs (round 3) -------------------------------------------------
+// conv_wgrad_x3h_kernel in the loop form of conv_wgrad_x3d_kernel: slices of 16 virtual pixels, two of them in LDS (51 KB), one
+// barrier per slice, the split of slice s+1 cut into chunks between the 36 MFMAs of slice s, operands through buffer
+// descriptors.  A gy row's byte offset advances by a constant per slice, less one pixel for every image row it crosses (the
+// virtual index has W + 1 columns, memory has W): no coordinates beyond the column are tracked for gy; the x run tracks the image
+// row as well (rows above / below the image are zeros).  The x run of a slice is 16 + 2 rows: 16 x 16 float4 for the 256 threads
+// and a ragged pass of 2 x 16 for the first 32.  Maps with W + 1 >= 16; same tiles, splits and summation order as
+// conv_wgrad_x3h_kernel: bit-identical results.
+constexpr int XHD_KS = 16;
+constexpr int XHD_RUN = XHD_KS + 2;
+constexpr int XHD_PLANE_A = XHD_KS * X3_ROW, XHD_PLANE_B = XHD_RUN * XH_ROWB;
+constexpr int XHD_BUF = 3 * XHD_PLANE_A + 3 * XHD_PLANE_B;
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
+{
+    constexpr int BM = 128, BNC = 64;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * XHD_BUF];
+    const int ntc = (p.Ci + BNC - 1) / BNC;
+    const int tiles = p.mt * ntc * 3;
+    int tile, split;
+    {
+        const int L = blockIdx.x;
+        if (p.splits % 8 == 0) {
+            const int xcd = L % 8, idx = L / 8;
+            tile = idx % tiles;
+            split = (idx / tiles) * 8 + xcd;
+        } else {
+            tile = L % tiles;
+            split = L / tiles;
+        }
+    }
+    const int tile_m = tile % p.mt, rest = tile / p.mt;
+    const int tile_nc = rest % ntc, ky = rest / ntc;
+    const int m0 = tile_m * BM, ci0 = tile_nc * BNC, dy = ky - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int Wv = p.W + 1;                                   // virtual row length
+    const int64_t V = (int64_t)p.B * p.H * Wv;
+    // the split's range of virtual pixels, on the slice boundaries of conv_wgrad_x3h_kernel (XH_KS pixels each)
+    const int64_t v_begin = (int64_t)split * p.slices_per_split * XH_KS;
+    const int64_t v_end = min((V + XH_KS - 1) / XH_KS * XH_KS, v_begin + p.slices_per_split * XH_KS);
+    const int n_slices = v_begin < v_end ? (int)((v_end - v_begin) / XHD_KS) : 0;
+
+    constexpr unsigned OOB = 0x80000000u;          // the host keeps both operands below 2^31 bytes
+    // the gy descriptor ends at the split's last pixel (v_end less one padding column per image row before it): the slice staged
+    // after the last one of the range is zeros, it must not reach the bias sums
+    const int64_t px_end = min((int64_t)p.B * p.H * p.W, v_end - v_end / Wv);
+    const __amdgpu_buffer_rsrc_t gy_desc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.gy), 0, (int)((unsigned)px_end * (unsigned)p.Co * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_desc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.x), 0, (int)((unsigned)p.B * p.H * p.W * p.Ci * 4u), 0x00020000);
+
+    const int a_col = (tid & 31) * 4, a_row0 = tid >> 5;      // gy rows a_row0, a_row0 + 8
+    const int b_col = (tid & 15) * 4, b_row0 = tid >> 4;      // x run row b_row0; threads 0..31 also row 16 + b_row0
+    const bool a_cok = m0 + a_col < p.Co, b_cok = ci0 + b_col < p.Ci;
+    const bool ragged = tid < 32;
+    // a staged row: column x in [0, Wv) of its image row, byte offset of the pixel it stands for (the padding column, x = W,
+    // stands for the first pixel of the next row and is masked); the x run also carries its image row y
+    auto decode = [&](int64_t v, int &x, int &y, int64_t &real) {
+        const int64_t vv = v < 0 ? 0 : v;
+        x = (int)(vv % Wv);
+        const int64_t t = vv / Wv;                  // image rows before this one (b * H + y)
+        y = (int)(t % p.H);
+        real = vv - t;
+        if (v < 0) { x = Wv - 1; y = -1; real = 0; }          // v = -1: the padding column of "row -1"
+    };
+    int ax[2], bx[2], by[2];
+    unsigned a_off[2], b_off[2];
+    const unsigned a_px = a_cok ? (unsigned)p.Co * 4u : 0u, b_px = b_cok ? (unsigned)p.Ci * 4u : 0u;       // bytes per pixel
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int y;
+        int64_t real;
+        decode(v_begin + a_row0 + 8 * i, ax[i], y, real);
+        a_off[i] = a_cok ? (unsigned)(real * p.Co + m0 + a_col) * 4u : OOB;
+        decode(v_begin - 1 + b_row0 + 16 * i, bx[i], by[i], real);
+        b_off[i] = b_cok && (i == 0 || ragged) ? (unsigned)((real + (int64_t)dy * p.W) * p.Ci + ci0 + b_col) * 4u : OOB;
+    }
+    const unsigned b_px1 = ragged ? b_px : 0u;
+
+    using u32x4w = __attribute__((ext_vector_type(4))) unsigned;
+    auto load16 = [&](__amdgpu_buffer_rsrc_t d, unsigned off) {
+        union { u32x4w u; float4 f; } c;
+        c.u = __builtin_amdgcn_raw_buffer_load_b128(d, (int)off, 0, 0);
+        return c.f;
+    };
+    float4 ra[2][2], rb[2][2];
+    auto load_slice = [&](float4 (&qa)[2], float4 (&qb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            qa[i] = load16(gy_desc, ax[i] < p.W ? a_off[i] : OOB);
+            ax[i] += XHD_KS;
+            const bool c1 = ax[i] >= Wv;
+            ax[i] -= c1 ? Wv : 0;
+            a_off[i] += XHD_KS * a_px - (c1 ? a_px : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned px = i == 0 ? b_px : b_px1;
+            qb[i] = load16(x_desc, bx[i] < p.W && (unsigned)(by[i] + dy) < (unsigned)p.H ? b_off[i] : OOB);
+            bx[i] += XHD_KS;
+            const bool c1 = bx[i] >= Wv;
+            bx[i] -= c1 ? Wv : 0;
+            by[i] += c1 ? 1 : 0;
+            by[i] -= by[i] >= p.H ? p.H : 0;
+            b_off[i] += XHD_KS * px - (c1 ? px : 0u);
+        }
+    };
+    const bool do_bias = p.bias_out != nullptr && tile_nc == 0 && ky == 1;       // the centre row sees every gy row once
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto put = [&](unsigned short *d, int plane, float4 v) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3x2w(v.x, v.y, h0, m0_, l0);
+        split3x2w(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m0_, m1);
+        *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l0, l1);
+    };
+    const int a_lds0 = a_row0 * X3_ROW + a_col, a_lds1 = (a_row0 + 8) * X3_ROW + a_col;
+    const int b_lds0 = 3 * XHD_PLANE_A + b_row0 * XH_ROWB + b_col, b_lds1 = 3 * XHD_PLANE_A + (16 + b_row0) * XH_ROWB + b_col;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+
+    // one half of the loop body (see conv_wgrad_x3d_kernel): 36 MFMAs on the slice in `rd`, the split of the staged registers
+    // into `wr` in six chunks of one split3x2w between them, the ragged rows of the x run last
+    auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[2], float4 (&qb)[2]) {
+        bf16x8w fa[2][3], fb[3][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag_row<X3_ROW>(rd + q * XHD_PLANE_A, 0, wm * 64 + i * 32, lane);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)            // tap kx = t reads the run one row further: gy row k meets x row k + t
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fb[t][q] = tr_frag_row<XH_ROWB>(rd + 3 * XHD_PLANE_A + q * XHD_PLANE_B, t, wn * 32, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as conv_wgrad_x3h_kernel
+        unsigned h[2], m[2], l[2];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int u = c >> 1;                    // staged float4: the two gy rows, then the x row
+            const float4 v = u < 2 ? qa[u] : qb[0];
+            if ((c & 1) == 0) {
+                split3x2w(v.x, v.y, h[0], m[0], l[0]);
+            } else {
+                split3x2w(v.z, v.w, h[1], m[1], l[1]);
+                unsigned short *d = wr + (u == 0 ? a_lds0 : u == 1 ? a_lds1 : b_lds0);
+                const int plane = u < 2 ? XHD_PLANE_A : XHD_PLANE_B;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m[0], m[1]);
+                *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l[0], l[1]);
+                if (u < 2) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }     // every tile: no branch in the body
+            }
+#pragma unroll
+            for (int e = 6 * c; e < 6 * c + 6; ++e) {          // MFMA e: product q = e / 6 of block (tap, i) = e % 6
+                const int q = e / 6, t = (e % 6) >> 1, i = e & 1;
+                acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[q]], fb[t][QB[q]], acc[t][i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (__builtin_amdgcn_readfirstlane(wave) == 0) {      // a scalar branch: the other three waves skip the instructions
+            if (ragged) put(wr + b_lds1, XHD_PLANE_B, qb[1]);
+        }
+        load_slice(qa, qb);
+        __syncthreads();
+    };
+    auto store_slice = [&](unsigned short *wr, const float4 (&qa)[2], const float4 (&qb)[2]) {
+        put(wr + a_lds0, XHD_PLANE_A, qa[0]);
+        put(wr + a_lds1, XHD_PLANE_A, qa[1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { bsum.x += qa[i].x; bsum.y += qa[i].y; bsum.z += qa[i].z; bsum.w += qa[i].w; }      // row by row
+        put(wr + b_lds0, XHD_PLANE_B, qb[0]);
+        if (ragged) put(wr + b_lds1, XHD_PLANE_B, qb[1]);
+    };
+
+    unsigned short *buf0 = lds, *buf1 = lds + XHD_BUF;
+    load_slice(ra[0], rb[0]);
+    load_slice(ra[1], rb[1]);
+    store_slice(buf0, ra[0], rb[0]);
+    load_slice(ra[0], rb[0]);
+    __syncthreads();
+    for (int s = 0; s < n_slices; s += 2) {          // n_slices is even: the split's range is whole XH_KS slices
+        half(buf0, buf1, ra[1], rb[1]);
+        half(buf1, buf0, ra[0], rb[0]);
+    }
+
+    if (do_bias) {          // threads sharing a column quad (tid & 31) fold their 8 row partials in a fixed order
+        float4 *red = reinterpret_cast<float4 *>(lds);
+        __syncthreads();
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float4 t = red[tid];
+            for (int r = 1; r < 8; ++r) {
+                const float4 v = red[r * 32 + tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            float *dst = p.bias_out + (int64_t)split * p.Co;
+            const int m = m0 + tid * 4;
+            if (m < p.Co) dst[m] = t.x;
+            if (m + 1 < p.Co) dst[m + 1] = t.y;
+            if (m + 2 < p.Co) dst[m + 2] = t.z;
+            if (m + 3 < p.Co) dst[m + 3] = t.w;
+        }
+    }
+    float *out = p.out + (int64_t)split * p.Co * p.Ntot;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+    const int ci = ci0 + wn * 32 + fcol;
+    if (ci < p.Ci) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int n = (ky * 3 + t) * p.Ci + ci;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[t][i][r];
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                             int64_t n, int splits, const float *__restrict__ ws2 = nullptr,
                                                             float *__restrict__ out2 = nullptr, int n2 = 0)
@@ -1240,7 +1470,11 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         p.bias_out = !gbias ? nullptr : (p.splits == 1 ? gbias : bias_part);
         hipStream_t s = (hipStream_t)stream;
         const dim3 grid((unsigned)(p.mt * p.nt * 3 * p.splits));
-        if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
+        static const bool x3hd_on = !(getenv("HTD_WGRAD_X3D") && atoi(getenv("HTD_WGRAD_X3D")) == 0);
+        // conv_wgrad_x3hd_kernel addresses its operands with 32-bit BYTE offsets into buffer descriptors
+        if (x3hd_on && W + 1 >= XHD_KS && (int64_t)B * H * W * Ci * 4 < (1ll << 31) && (int64_t)B * H * W * Co * 4 < (1ll << 31))
+            hipLaunchKernelGGL(conv_wgrad_x3hd_kernel, grid, dim3(256), 0, s, p);
+        else if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_x3h_kernel<false>, grid, dim3(256), 0, s, p);
         if (p.splits > 1) {
             const int64_t n = (int64_t)Co * p.Ntot;

@@ -40,6 +40,14 @@ OTHER = [
     ('reg 3x3 576 7x7 x24', 24, 576, 7, 7, 576, 3, 1, 1),
     ('l3.conv2 3x3 256', 4, 256, 50, 84, 256, 3, 1, 1),
     ('fpn P2 3x3 256', 4, 256, 200, 336, 256, 3, 1, 1),
+    ('fpn P3 3x3 256', 4, 256, 100, 168, 256, 3, 1, 1),
+    ('fpn P5 3x3 256', 4, 256, 25, 42, 256, 3, 1, 1),
+    ('fpn P6 3x3 256', 4, 256, 13, 21, 256, 3, 1, 1),
+    ('l1.conv2 3x3 64', 4, 64, 200, 336, 64, 3, 1, 1),
+    ('l2.conv2 3x3 128', 4, 128, 100, 168, 128, 3, 1, 1),
+    ('l4.conv2 3x3 512', 4, 512, 25, 42, 512, 3, 1, 1),
+    ('ragged 3x3 36-68 9x17 x2', 2, 36, 9, 17, 68, 3, 1, 1),
+    ('ragged 3x3 132-200 5x15 x3', 3, 132, 5, 15, 200, 3, 1, 1),
 ]
 
 
