@@ -1412,13 +1412,18 @@ int x3h_splits(int B, int H, int W, int Ci, int Co)
 {
     const int64_t tiles = htd::ceil_div(Co, 128) * htd::ceil_div(Ci, 64) * 3;
     const int64_t slices = htd::ceil_div((int64_t)B * H * (W + 1), XH_KS);
-    static const int target = getenv("HTD_WGRAD_X3H_UNITS") ? atoi(getenv("HTD_WGRAD_X3H_UNITS")) : 1536;
-    int64_t want = htd::ceil_div(target, tiles);                      // two workgroups per CU resident: ~3 rounds
-    int64_t cap = std::max<int64_t>(1, slices / 16);
+    // 768 workgroups (1.5 x the 512 resident ones), at least 8 slices each, at most 128 splits: measured over the splits of every
+    // 3x3 shape of the step with conv_wgrad_x3hd_kernel (profiles/r03_wgrad_x3h_splits_sweep.txt) -- beyond that the partial
+    // tiles (a workgroup writes 98 KB, the reduce kernel reads them back) cost more than the fuller chip gains
+    static const int target = getenv("HTD_WGRAD_X3H_UNITS") ? atoi(getenv("HTD_WGRAD_X3H_UNITS")) : 768;
+    int64_t want = htd::ceil_div(target, tiles);
+    int64_t cap = std::max<int64_t>(1, slices / 8);
     if (tiles * cap < 256) cap = std::max(cap, std::min<int64_t>(htd::ceil_div(256, tiles), std::max<int64_t>(1, slices / 4)));
     want = std::min<int64_t>(want, cap);
-    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 192));
+    int splits = (int)std::max<int64_t>(1, std::min<int64_t>(want, 128));
     if (splits >= 6) splits = (splits + 7) / 8 * 8;
+    static const int forced = getenv("HTD_WGRAD_X3H_SPLITS") ? atoi(getenv("HTD_WGRAD_X3H_SPLITS")) : 0;      // tuning runs only
+    if (forced > 0) splits = (int)std::min<int64_t>(forced, std::max<int64_t>(1, slices / 2));
     return splits;
 }
 
@@ -1530,7 +1535,8 @@ extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm
     HTD_REQUIRE(rows >= 0 && C > 0, "bias_grad: bad sizes");
     HTD_REQUIRE(g && (gbias || y) && (!gbias || workspace) && (!y || gm), "bias_grad: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(512, htd::ceil_div(rows, 64)));
+    // 8 rows per block at least: the FC stacks' 2048 x 1024 gradients used to run on 32 workgroups (23 us for 25 MB)
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(1024, htd::ceil_div(rows, 8)));
     const int64_t rpb = htd::ceil_div(std::max<int64_t>(rows, 1), nb);
     float *partial = gbias ? (float *)workspace : nullptr;          // gbias == NULL: ReLU mask only
     if ((C & 3) == 0 && (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gm | (uintptr_t)partial) & 15) == 0)
