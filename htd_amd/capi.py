@@ -11,7 +11,7 @@ import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_PKG), 'include', 'htd_amd.h')
-LIB_PATH = os.path.join(_PKG, 'libhtd_amd.so')
+LIB_PATH = os.environ.get('HTD_AMD_LIB') or os.path.join(_PKG, 'libhtd_amd.so')      # HTD_AMD_LIB: an experiment build, for A/B runs
 
 _PROTO = re.compile(r'^\s*(const char \*|int64_t|int)\s*(htd_\w+)\s*\(([^;]*?)\)\s*;', re.M | re.S)
 

@@ -57,6 +57,10 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned
 // order; landed() after the wait names the registers the inline-asm loads fill, so no use of them is scheduled above it and
 // the compiler has no reason to copy them earlier (a wait that took them as operands in two branches made hipcc insert
 // v_mov copies AHEAD of one of the waits: stale data).
+#ifndef HTD_X3P_EARLY
+#define HTD_X3P_EARLY 1
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm()
 {
@@ -268,6 +272,10 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
     // around the loop.  tools/x3p_check_isa.py (tests/test_build.py) checks the ISA of every instantiation for such moves.
     constexpr int NP = G::PASSES;
     constexpr int NPT = KW > 1 ? 1 : NP;                          // staging registers per set = A loads per tap
+    // 128x128 tiles (24 MFMAs per tap): the staged pass is waited for after ONE tap and split between this tap's MFMAs; the
+    // smaller tiles keep it in flight for two taps and split behind the MFMAs (their taps are too short to cover the load:
+    // -3 % on the 128x64 layers with the early form, +5..9 % on the 128x128 3x3 layers)
+    constexpr bool EARLY = HTD_X3P_EARLY && TM * TN >= 4;
     static_assert(KW == 1 || NP <= KW, "one pass per tap");
     f32x4 ra[2 * NPT];
 #pragma unroll
@@ -290,8 +298,15 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(ra[slot]) : "v"(p.x + (off & (0u - (unsigned)ok))) : "memory");
     };
     auto store_pass = [&](int buf, int i, int slot) __attribute__((always_inline)) {   // registers -> three bf16 planes, chunk-major
-        const int j = vrow + 64 * i;
-        if (G::RUN % 64 != 0 && j >= G::RUN) return;
+        int j = vrow + 64 * i;
+        if constexpr (EARLY) {
+            // rows past the run go to the spare row behind the zero row instead of skipping the stores: a predicated region
+            // (the branch over them) cannot take this tap's MFMAs
+            static_assert(G::PITCH >= G::RUN + 2, "a spare row behind the zero row");
+            j = (G::RUN % 64 == 0 || j < G::RUN) ? j : G::RUN + 1;
+        } else {
+            if (G::RUN % 64 != 0 && j >= G::RUN) return;
+        }
         bool ok;
         if constexpr (KW > 1) ok = (ra_ok >> i) & 1u;
         else ok = a_in[i];
@@ -480,18 +495,46 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
                 load_pass(last ? n2shift : n1shift, last ? n2koff : n1koff, last ? 0 : kx + 1, P, last ? more2 : more);
             }
         }
-        mma_tap(abuf, bbuf, kx, ky * KW);
-        // the other set (issued one tap ago) and the next tap's B tile have landed
-        if (TAIL) wait_vm<0>();
-        else wait_tap(issued);
+        if constexpr (EARLY) {
+            // the other set (issued one tap ago) has landed: only this tap's own B tile and A pass(es) may stay outstanding.  Its
+            // split then runs BETWEEN the MFMAs of this tap (group barriers below) instead of behind them -- the vector and the
+            // matrix work of one wave overlap (PMC r03: they co-executed in 9 % of the matrix cycles)
+            if (TAIL) wait_vm<0>();
+            else if (issued) wait_vm<NPT + NI_MIN>();
+            else wait_vm<NPT>();
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) landed(ra[(P ^ 1) * NPT + i]);
-        if (more) {
+            for (int i = 0; i < NPT; ++i) landed(ra[(P ^ 1) * NPT + i]);
+            mma_tap(abuf, bbuf, kx, ky * KW);
+            // (not under `if (more)`: a predicated region cannot take MFMAs; in the last step the stores put unused rows into the idle buffer)
             if constexpr (KW == 1) {
 #pragma unroll
                 for (int i = 0; i < NP; ++i) store_pass(abuf ^ 1, i, (P ^ 1) * NP + i);
             } else {
                 store_pass(abuf ^ 1, kx, P ^ 1);
+            }
+            constexpr int NM = RB * CB * (MF16 ? 3 : 6);              // MFMAs of the tap
+            constexpr int PER = (NPT * 36 + NM - 1) / NM;             // ~36 vector instructions per staged pass
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#pragma unroll
+            for (int e = 0; e < NM; ++e) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+            }
+            if (!TAIL) wait_vm<NPT>();   // the next tap's B tile has landed (this tap's A passes stay in flight)
+        } else {
+            mma_tap(abuf, bbuf, kx, ky * KW);
+            // the other set (issued one tap ago) and the next tap's B tile have landed
+            if (TAIL) wait_vm<0>();
+            else wait_tap(issued);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) landed(ra[(P ^ 1) * NPT + i]);
+            if (more) {
+                if constexpr (KW == 1) {
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) store_pass(abuf ^ 1, i, (P ^ 1) * NP + i);
+                } else {
+                    store_pass(abuf ^ 1, kx, P ^ 1);
+                }
             }
         }
         lds_barrier();               // every wave is done with this tap's buffers; the next tap's are complete
