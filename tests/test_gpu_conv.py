@@ -525,3 +525,67 @@ def test_step_flip_cache_never_serves_a_stale_or_misshapen_image():
     assert torch.allclose(dense._dgrad_raw(gy_conv, as_conv, (2, 32, 6, 6), 1, 1, 1), 2.0 * ref_conv, rtol=1e-6, atol=1e-6)
     dense.new_step()
     assert len(dense._STEP_FLIPS) == 0
+
+
+WGRAD_CASES = [
+    # B, Ci, H, W, Co, k, stride, pad: what conv_wgrad_x3d_kernel (1x1, strided, 7x7) and conv_wgrad_x3hd_kernel (3x3 stride 1,
+    # W + 1 >= 16) take -- ragged channel counts, K ranges that end inside a slice, maps one padding column wide of a slice,
+    # splits with an odd number of 16-pixel slices, a single image row
+    (2, 64, 20, 28, 128, 1, 1, 0), (3, 100, 9, 11, 132, 1, 1, 0), (1999, 36, 1, 1, 68, 1, 1, 0), (2, 256, 20, 28, 512, 1, 2, 0),
+    (2, 8, 64, 96, 64, 7, 2, 3), (2, 128, 40, 56, 128, 3, 2, 1), (2, 64, 20, 28, 128, 3, 1, 1), (2, 36, 9, 17, 68, 3, 1, 1),
+    (3, 132, 5, 15, 200, 3, 1, 1), (1, 64, 1, 40, 64, 3, 1, 1), (4, 256, 13, 21, 256, 3, 1, 1), (1, 32, 130, 130, 256, 3, 1, 1),
+]
+_WGRAD_CHILD = r'''
+import sys, zlib, torch
+sys.path.insert(0, sys.argv[1])
+from htd_amd import capi, dense
+cases = eval(sys.argv[2])
+dev = torch.device('cuda', 0)
+for B, Ci, H, W, Co, k, s, p in cases:
+    g = torch.Generator().manual_seed(B + Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    gy = torch.randn(B, Co, Ho, Wo, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = torch.empty(Co, Ci, k, k, device=dev).contiguous(memory_format=torch.channels_last)
+    gw, gb = dense._wgrad_launch(x, gy, w, s, p, 1, True)[:2]
+    print(zlib.crc32(gw.cpu().contiguous(memory_format=torch.channels_last).numpy().tobytes()), zlib.crc32(gb.cpu().numpy().tobytes()))
+'''
+
+
+def test_interleaved_weight_gradient_kernels_match_the_phased_ones_bit_for_bit():
+    """conv_wgrad_x3d_kernel / conv_wgrad_x3hd_kernel (csrc/conv_wgrad.hip: split of the next slice between the MFMAs of the
+    current one, buffer-descriptor loads) sum in the order of conv_wgrad_x3_kernel / conv_wgrad_x3h_kernel, which
+    HTD_WGRAD_X3D=0 selects: weight and bias gradients of both must be the same bits.  The switch is read once per
+    process, so each side runs in a child process (two GPU processes, one after the other)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for flag in ('1', '0'):
+        env = dict(os.environ, HTD_WGRAD_X3D=flag)
+        r = subprocess.run([sys.executable, '-c', _WGRAD_CHILD, root, repr(WGRAD_CASES)], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[flag] = [l for l in r.stdout.splitlines() if l and l[0].isdigit()]
+        assert len(out[flag]) == len(WGRAD_CASES), r.stdout
+    for case, a, b in zip(WGRAD_CASES, out['1'], out['0']):
+        assert a == b, (case, a, b)
+
+
+@pytest.mark.parametrize('B,Ci,H,W,Co,k,stride,pad', WGRAD_CASES)
+def test_weight_gradient_is_exact_on_integers(B, Ci, H, W, Co, k, stride, pad):
+    """Small-integer operands: every product and partial sum is exactly representable, so the split-bf16 weight gradient
+    (and the bias gradient of the same launch) must EQUAL the fp64 reference -- any dropped / doubled row, column or tap of
+    the staging (slice ends, padding column, ragged tiles, buffer-descriptor bounds) shows as a wrong integer."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7 * B + Ci)
+    x = torch.randint(-4, 5, (B, Ci, H, W), generator=g).float().to(dev).contiguous(memory_format=torch.channels_last)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = torch.randint(-4, 5, (B, Co, Ho, Wo), generator=g).float().to(dev).contiguous(memory_format=torch.channels_last)
+    w = torch.empty(Co, Ci, k, k, device=dev).contiguous(memory_format=torch.channels_last)
+    gw, gb = dense._wgrad_launch(x, gy, w, stride, pad, 1, True)[:2]
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), stride, pad)
+    assert torch.equal(gw.double(), ref)
+    assert torch.equal(gb.double(), gy.double().sum((0, 2, 3)))
