@@ -592,8 +592,65 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
         __syncthreads();
         const int c4 = tid % V;
         const int n = n0 + c4 * 4;
+        constexpr int NPASS = EPI_ROWS / RPP;
+        if (vec_ok && !part && p.res_H == 0) {
+            // The common form (16-byte columns, final values, residual / gradient sum at the output's own resolution): four passes
+            // at a time, every global load of the four issued before the first value is used.  The general loop below tests
+            // five kernel-uniform flags per pass and hipcc turns each into a branch around ONE load, i.e. 8 dependent memory
+            // round trips per thread and row block -- the whole run time of the short-K layers (layer1 conv3: 4 K steps)
+            const bool col_ok = n < p.Co;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            constexpr int UB = NPASS < 4 ? NPASS : 4;
 #pragma unroll
-        for (int pass = 0; pass < EPI_ROWS / RPP; ++pass) {
+            for (int pass0 = 0; pass0 < NPASS; pass0 += UB) {
+                float4 v[UB], rv[UB], mv[UB];
+                int64_t o[UB];
+                bool ok[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int row = tid / V + (pass0 + u) * RPP;
+                    const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+                    ok[u] = m < p.M && col_ok;
+                    o[u] = (m * p.Co + n) & -(int64_t)ok[u];          // rows / columns past the end: element 0, read and dropped
+                    v[u] = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
+                }
+                if (p.residual != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const float4 *>(p.residual + o[u]);
+                }
+                if (p.mask_src != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) mv[u] = *reinterpret_cast<const float4 *>(p.mask_src + o[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { v[u].x += bv.x; v[u].y += bv.y; v[u].z += bv.z; v[u].w += bv.w; }
+                if (p.residual != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { v[u].x += rv[u].x; v[u].y += rv[u].y; v[u].z += rv[u].z; v[u].w += rv[u].w; }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                    }
+                }
+                if (p.mask_src != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        v[u].x = mv[u].x > 0.f ? v[u].x : 0.f; v[u].y = mv[u].y > 0.f ? v[u].y : 0.f;
+                        v[u].z = mv[u].z > 0.f ? v[u].z : 0.f; v[u].w = mv[u].w > 0.f ? v[u].w : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (ok[u]) *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
+            }
+            if (i + 1 < TM) __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int row = tid / V + pass * RPP;
             const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
             if (m >= p.M || n >= p.Co) continue;
