@@ -196,34 +196,65 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 5)) void conv_bf16_kernel(
         __syncthreads();
         const int c4 = tid % V;
         const int n = n0 + c4 * 4;
+        // four row passes at a time, their residual / mask loads issued before the first value is used (one flag test per
+        // batch instead of a branch around every single load: conv_x3.hip, epilogue)
+        const bool col_ok = n < p.Co;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+        constexpr int NPASS = 64 / ROWS, UB = NPASS < 4 ? NPASS : 4;
 #pragma unroll
-        for (int pass = 0; pass < 64 / ROWS; ++pass) {
-            const int row = tid / V + pass * ROWS;
-            const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
-            if (m >= p.M || n >= p.Co) continue;
-            float4 v = *reinterpret_cast<const float4 *>(stage + row * EPI_STRIDE + c4 * 4);
-            const int64_t o = m * p.Co + n;
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        for (int pass0 = 0; pass0 < NPASS; pass0 += UB) {
+            float4 v[UB];
+            uint2 rv[UB], mv[UB];
+            int64_t o[UB];
+            bool ok[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int row = tid / V + (pass0 + u) * ROWS;
+                const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+                ok[u] = m < p.M && col_ok;
+                o[u] = (m * p.Co + n) & -(int64_t)ok[u];              // rows / columns past the end: element 0, read and dropped
+                v[u] = *reinterpret_cast<const float4 *>(stage + row * EPI_STRIDE + c4 * 4);
             }
-            if (p.residual) {
-                const uint2 rv = *reinterpret_cast<const uint2 *>(p.residual + o);
-                v.x += bf2f((unsigned short)(rv.x & 0xffffu)); v.y += bf2f((unsigned short)(rv.x >> 16));
-                v.z += bf2f((unsigned short)(rv.y & 0xffffu)); v.w += bf2f((unsigned short)(rv.y >> 16));
+            if (p.residual != nullptr) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const uint2 *>(p.residual + o[u]);
             }
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (p.mask) {                       // ReLU backward of the layer that produced this map: keep where it was > 0
-                const uint2 mv = *reinterpret_cast<const uint2 *>(p.mask + o);
-                if (!(bf2f((unsigned short)(mv.x & 0xffffu)) > 0.f)) v.x = 0.f;
-                if (!(bf2f((unsigned short)(mv.x >> 16)) > 0.f)) v.y = 0.f;
-                if (!(bf2f((unsigned short)(mv.y & 0xffffu)) > 0.f)) v.z = 0.f;
-                if (!(bf2f((unsigned short)(mv.y >> 16)) > 0.f)) v.w = 0.f;
+            if (p.mask != nullptr) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) mv[u] = *reinterpret_cast<const uint2 *>(p.mask + o[u]);
             }
-            uint2 ov;
-            ov.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-            ov.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-            *reinterpret_cast<uint2 *>(p.y + o) = ov;
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { v[u].x += bv.x; v[u].y += bv.y; v[u].z += bv.z; v[u].w += bv.w; }
+            if (p.residual != nullptr) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    v[u].x += bf2f((unsigned short)(rv[u].x & 0xffffu)); v[u].y += bf2f((unsigned short)(rv[u].x >> 16));
+                    v[u].z += bf2f((unsigned short)(rv[u].y & 0xffffu)); v[u].w += bf2f((unsigned short)(rv[u].y >> 16));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                }
+            }
+            if (p.mask != nullptr) {            // ReLU backward of the layer that produced this map: keep where it was > 0
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    v[u].x = bf2f((unsigned short)(mv[u].x & 0xffffu)) > 0.f ? v[u].x : 0.f;
+                    v[u].y = bf2f((unsigned short)(mv[u].x >> 16)) > 0.f ? v[u].y : 0.f;
+                    v[u].z = bf2f((unsigned short)(mv[u].y & 0xffffu)) > 0.f ? v[u].z : 0.f;
+                    v[u].w = bf2f((unsigned short)(mv[u].y >> 16)) > 0.f ? v[u].w : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                uint2 ov;
+                ov.x = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
+                ov.y = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+                if (ok[u]) *reinterpret_cast<uint2 *>(p.y + o[u]) = ov;
+            }
         }
         if (i + 1 < TM) __syncthreads();
     }

@@ -427,8 +427,70 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
         __syncthreads();
         const int c4 = tid % V;
         const int n = n0 + c4 * 4;
+        constexpr int NPASS = T::EPI_ROWS / RPP;
+        if (vec_ok && tail_split < 0 && p.splits <= 1 && p.res_H == 0) {
+            // the common form, four row passes at a time with all their residual / mask loads issued first (conv_x3.hip,
+            // epilogue: the general loop below is one dependent memory round trip per pass)
+            const bool col_ok = n < p.Co;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            constexpr int UB = NPASS < 4 ? NPASS : 4;
 #pragma unroll
-        for (int pass = 0; pass < T::EPI_ROWS / RPP; ++pass) {
+            for (int pass0 = 0; pass0 < NPASS; pass0 += UB) {
+                float4 v[UB], rv[UB], mv[UB];
+                int64_t o[UB];
+                bool ok[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int row = tid / V + (pass0 + u) * RPP;
+                    const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+                    ok[u] = m < p.M && col_ok;
+                    int64_t oo;
+                    if constexpr (TAPS) {
+                        const unsigned mm = ok[u] ? (unsigned)m : 0u, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                        oo = (((int64_t)b * p.oH + p.o_h0 + p.o_step * (int)ho) * p.oW + p.o_w0 + p.o_step * (int)wo) * p.Co + n;
+                    } else
+                        oo = m * p.Co + n;
+                    o[u] = oo & -(int64_t)ok[u];                      // rows / columns past the end: element 0, read and dropped
+                    v[u] = *reinterpret_cast<const float4 *>(lds + row * T::EPI_STRIDE + c4 * 4);
+                }
+                if (p.residual != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const float4 *>(p.residual + o[u]);
+                }
+                if (p.mask_src != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) mv[u] = *reinterpret_cast<const float4 *>(p.mask_src + o[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { v[u].x += bv.x; v[u].y += bv.y; v[u].z += bv.z; v[u].w += bv.w; }
+                if (p.residual != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { v[u].x += rv[u].x; v[u].y += rv[u].y; v[u].z += rv[u].z; v[u].w += rv[u].w; }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                    }
+                }
+                if (p.mask_src != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        v[u].x = mv[u].x > 0.f ? v[u].x : 0.f; v[u].y = mv[u].y > 0.f ? v[u].y : 0.f;
+                        v[u].z = mv[u].z > 0.f ? v[u].z : 0.f; v[u].w = mv[u].w > 0.f ? v[u].w : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (ok[u]) *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
+            }
+            if (i + 1 < TM) __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int row = tid / V + pass * RPP;                    // staged row: wave-row (row >> 5), line (row & 31)
             const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
             if (m >= p.M || n >= p.Co) continue;
