@@ -547,6 +547,10 @@ __device__ __forceinline__ bf16x8 tr_operand(const unsigned short *img, int k0, 
     return u.v;
 }
 
+// PIX: how a staged pixel row finds its x address (as in conv_wgrad.hip): 0 = 1x1 stride 1 (the pixel index IS the row of x),
+// 1 = Wo >= 64 (coordinates advance by one slice with at most one carry), 2 = decoded every slice (two divisions per row --
+// they were ~2/3 of the vector instructions of the loop for every layer before this parameter existed)
+template <int PIX>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(BfWgradParams p)
 {
     constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WGN = 2;
@@ -572,21 +576,54 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_bf16_kernel(BfWgradParams p
 
     uint4 ra[4], rb[4];
     unsigned ok_a = 0u, ok_b = 0u;
-    auto load_slice = [&](int64_t s) {
+    int c_wo[4], c_ho[4], c_b[4];                                  // PIX 1: (b, ho, wo) of the row's pixel in the slice to load next
+    if constexpr (PIX == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned k = (unsigned)(s_begin * WB_K) + row0 + 16 * i;
+            const unsigned kk = k < (unsigned)p.K ? k : 0u;
+            c_wo[i] = (int)(kk % (unsigned)p.Wo);
+            const unsigned t = kk / (unsigned)p.Wo;
+            c_ho[i] = (int)(t % (unsigned)p.Ho);
+            c_b[i] = (int)(t / (unsigned)p.Ho);
+        }
+    }
+    auto load_slice = [&](int64_t s) {              // called for consecutive slices s_begin, s_begin + 1, ...
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned k = (unsigned)(s * WB_K) + row0 + 16 * i;
             const bool kin = k < (unsigned)p.K;
             const bool oa = a_cok && kin;
-            ra[i] = *reinterpret_cast<const uint4 *>(p.gy + (oa ? k * (unsigned)p.Co + m0 + chunk * 8 : 0u));
+            ra[i] = *reinterpret_cast<const uint4 *>(p.gy + ((k * (unsigned)p.Co + m0 + chunk * 8) & (0u - (unsigned)oa)));
             ok_a = oa ? (ok_a | (1u << i)) : (ok_a & ~(1u << i));
-            const unsigned kk = kin ? k : 0u;
-            const unsigned wo = kk % (unsigned)p.Wo, t = kk / (unsigned)p.Wo;
-            const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
-            const int hi = (int)ho * p.stride + b_dy, wi = (int)wo * p.stride + b_dx;
-            const bool ob = b_cok && kin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned off = ((b * (unsigned)p.H + (unsigned)hi) * (unsigned)p.W + (unsigned)wi) * (unsigned)p.Ci + b_ci;
-            rb[i] = *reinterpret_cast<const uint4 *>(p.x + (ob ? off : 0u));
+            bool ob;
+            unsigned off;
+            if constexpr (PIX == 0) {
+                ob = b_cok && kin;
+                off = k * (unsigned)p.Ci + b_ci;
+            } else {
+                unsigned wo, ho, b;
+                if constexpr (PIX == 1) {
+                    wo = (unsigned)c_wo[i]; ho = (unsigned)c_ho[i]; b = (unsigned)c_b[i];
+                    const int w2 = c_wo[i] + WB_K;                 // Wo >= WB_K: at most one carry
+                    const bool c1 = w2 >= p.Wo;
+                    c_wo[i] = c1 ? w2 - p.Wo : w2;
+                    const int h2 = c_ho[i] + (c1 ? 1 : 0);
+                    const bool c2 = h2 == p.Ho;
+                    c_ho[i] = c2 ? 0 : h2;
+                    c_b[i] += c2 ? 1 : 0;
+                } else {
+                    const unsigned kk = kin ? k : 0u;
+                    wo = kk % (unsigned)p.Wo;
+                    const unsigned t = kk / (unsigned)p.Wo;
+                    ho = t % (unsigned)p.Ho;
+                    b = t / (unsigned)p.Ho;
+                }
+                const int hi = (int)ho * p.stride + b_dy, wi = (int)wo * p.stride + b_dx;
+                ob = b_cok && kin && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                off = ((b * (unsigned)p.H + (unsigned)hi) * (unsigned)p.W + (unsigned)wi) * (unsigned)p.Ci + b_ci;
+            }
+            rb[i] = *reinterpret_cast<const uint4 *>(p.x + (off & (0u - (unsigned)ob)));
             ok_b = ob ? (ok_b | (1u << i)) : (ok_b & ~(1u << i));
         }
     };
@@ -748,7 +785,10 @@ static int bwd_weight_bf16_impl(const void *x, const void *gy, float *gw, float 
     float *bias_partial = (float *)workspace + (int64_t)p.splits * Co * p.Ntot;
     p.bias_out = !gbias ? nullptr : (p.splits == 1 ? gbias : bias_partial);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3((unsigned)(p.mt * p.nt * p.splits)), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)(p.mt * p.nt * p.splits));
+    if (kh == 1 && kw == 1 && stride == 1 && pad == 0) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<0>, grid, dim3(256), 0, s, p);
+    else if (p.Wo >= WB_K) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, s, p);
     if (p.splits > 1) {
         const int64_t n = (int64_t)Co * p.Ntot;
         const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n / 4, 256), 2048);
