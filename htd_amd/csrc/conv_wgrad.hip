@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3h_kernel(WgradParams p)
 // descriptors.  A gy row's byte offset advances by a constant per slice, less one pixel for every image row it crosses (the
 // virtual index has W + 1 columns, memory has W): no coordinates beyond the column are tracked for gy; the x run tracks the image
 // row as well (rows above / below the image are zeros).  The x run of a slice is 16 + 2 rows: 16 x 16 float4 for the 256 threads
-// and a ragged pass of 2 x 16 for the first 32.  Maps with W + 1 >= 16; same tiles, splits and summation order as
+// and a ragged pass of 2 x 16 for the first 32.  Any map on which a slice spans at most H image rows; same tiles, splits and summation order as
 // conv_wgrad_x3h_kernel: bit-identical results.
 constexpr int XHD_KS = 16;
 constexpr int XHD_RUN = XHD_KS + 2;
@@ -1063,6 +1063,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         b_off[i] = b_cok && (i == 0 || ragged) ? (unsigned)((real + (int64_t)dy * p.W) * p.Ci + ci0 + b_col) * 4u : OOB;
     }
     const unsigned b_px1 = ragged ? b_px : 0u;
+    const int adv_rows = XHD_KS / Wv, adv_x = XHD_KS - adv_rows * Wv;      // narrow maps: a slice spans several image rows
 
     using u32x4w = __attribute__((ext_vector_type(4))) unsigned;
     auto load16 = [&](__amdgpu_buffer_rsrc_t d, unsigned off) {
@@ -1075,21 +1076,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             qa[i] = load16(gy_desc, ax[i] < p.W ? a_off[i] : OOB);
-            ax[i] += XHD_KS;
+            ax[i] += adv_x;                                   // + 16 virtual pixels = adv_rows image rows + adv_x columns (+ a carry)
             const bool c1 = ax[i] >= Wv;
             ax[i] -= c1 ? Wv : 0;
-            a_off[i] += XHD_KS * a_px - (c1 ? a_px : 0u);
+            a_off[i] += XHD_KS * a_px - (unsigned)(adv_rows + (c1 ? 1 : 0)) * a_px;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned px = i == 0 ? b_px : b_px1;
             qb[i] = load16(x_desc, bx[i] < p.W && (unsigned)(by[i] + dy) < (unsigned)p.H ? b_off[i] : OOB);
-            bx[i] += XHD_KS;
+            bx[i] += adv_x;
             const bool c1 = bx[i] >= Wv;
             bx[i] -= c1 ? Wv : 0;
-            by[i] += c1 ? 1 : 0;
+            const int rows = adv_rows + (c1 ? 1 : 0);         // <= H (the host's condition for this kernel)
+            by[i] += rows;
             by[i] -= by[i] >= p.H ? p.H : 0;
-            b_off[i] += XHD_KS * px - (c1 ? px : 0u);
+            b_off[i] += XHD_KS * px - (unsigned)rows * px;
         }
     };
     const bool do_bias = p.bias_out != nullptr && tile_nc == 0 && ky == 1;       // the centre row sees every gy row once
@@ -1477,7 +1479,9 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         const dim3 grid((unsigned)(p.mt * p.nt * 3 * p.splits));
         static const bool x3hd_on = !(getenv("HTD_WGRAD_X3D") && atoi(getenv("HTD_WGRAD_X3D")) == 0);
         // conv_wgrad_x3hd_kernel addresses its operands with 32-bit BYTE offsets into buffer descriptors
-        if (x3hd_on && W + 1 >= XHD_KS && (int64_t)B * H * W * Ci * 4 < (1ll << 31) && (int64_t)B * H * W * Co * 4 < (1ll << 31))
+        // (a slice of 16 virtual pixels must not span more than H image rows: the row index wraps once per slice at most)
+        if (x3hd_on && XHD_KS / (W + 1) + 1 <= H && (int64_t)B * H * W * Ci * 4 < (1ll << 31) &&
+            (int64_t)B * H * W * Co * 4 < (1ll << 31))
             hipLaunchKernelGGL(conv_wgrad_x3hd_kernel, grid, dim3(256), 0, s, p);
         else if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_x3h_kernel<false>, grid, dim3(256), 0, s, p);

@@ -534,6 +534,10 @@ WGRAD_CASES = [
     (2, 64, 20, 28, 128, 1, 1, 0), (3, 100, 9, 11, 132, 1, 1, 0), (1999, 36, 1, 1, 68, 1, 1, 0), (2, 256, 20, 28, 512, 1, 2, 0),
     (2, 8, 64, 96, 64, 7, 2, 3), (2, 128, 40, 56, 128, 3, 2, 1), (2, 64, 20, 28, 128, 3, 1, 1), (2, 36, 9, 17, 68, 3, 1, 1),
     (3, 132, 5, 15, 200, 3, 1, 1), (1, 64, 1, 40, 64, 3, 1, 1), (4, 256, 13, 21, 256, 3, 1, 1), (1, 32, 130, 130, 256, 3, 1, 1),
+    # narrow maps, where a 16-pixel slice spans several image rows (the RoI regression branch: 7x7), down to maps too small for
+    # the interleaved kernel (2x3: the phased one takes them)
+    (24, 576, 7, 7, 576, 3, 1, 1), (37, 32, 7, 7, 96, 3, 1, 1), (2, 48, 5, 3, 64, 3, 1, 1), (5, 64, 2, 3, 64, 3, 1, 1),
+    (3, 64, 9, 13, 128, 3, 1, 1),
 ]
 _WGRAD_CHILD = r'''
 import sys, zlib, torch
