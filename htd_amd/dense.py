@@ -8,6 +8,8 @@ joins live in the data-gradient epilogues (ResStageFunction), bias gradients com
 and parameter gradients are written straight into the flat gradient buffer (gradient sinks).
 GPU tensors only -- there is no other path.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -1028,6 +1030,9 @@ def linear(x, weight, bias=None, relu=False):
     return y.permute(0, 2, 3, 1).reshape(M, N)                         # (M, N, 1, 1) channels_last -> (M, N)
 
 
+BGEMM_BWD_LIMITS = os.environ.get('HTD_BGEMM_BWD_LIMITS', '1') != '0'      # 0: full padded gradient products (A/B runs)
+
+
 class BatchedGemmNT(Function):
     """c[g] = a[g] @ b[g]^T on the MFMA kernel (htd_bgemm_nt).  a (G,M,K), b (G,N,K) -> (G,M,N).
     Backward is two more NT products on transposed copies: ga = gc @ b, gb = gc^T @ a."""
@@ -1051,6 +1056,7 @@ class BatchedGemmNT(Function):
         ctx.gram = a is b                       # a @ a^T (PGraph's similarity): one gradient product instead of two
         a, b = a.contiguous(), b.contiguous()
         ctx.save_for_backward(a, b)
+        ctx.counts, ctx.limit = counts, int(limit)
         return BatchedGemmNT._run(a, b, counts, limit)
 
     @staticmethod
@@ -1059,13 +1065,18 @@ class BatchedGemmNT(Function):
         a, b = ctx.saved_tensors
         gc = gc.contiguous()
         ga = gb = None
+        # the gradient products skip the padding as the forward product did: an axis that was limited to the group's size keeps
+        # its limit in the role it plays now (bits: 1 rows of the first operand, 2 rows of the second, 4 reduction)
+        counts, lim = (ctx.counts, ctx.limit) if BGEMM_BWD_LIMITS else (None, 0)
+        lim_a = (lim & 1) | ((lim & 4) >> 1) | ((lim & 2) << 1)      # ga = gc @ b: rows M, columns K (was the reduction), reduction N
+        lim_b = ((lim & 2) >> 1) | ((lim & 4) >> 1) | ((lim & 1) << 2)     # gb = gc^T @ a: rows N, columns K, reduction M
         if ctx.gram and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             # d(a a^T): gc @ a + gc^T @ a = (gc + gc^T) @ a, handed back through the first argument
-            return BatchedGemmNT._run(gc + gc.transpose(1, 2), a.transpose(1, 2).contiguous()), None, None, None
+            return BatchedGemmNT._run(gc + gc.transpose(1, 2), a.transpose(1, 2).contiguous(), counts, lim_a), None, None, None
         if ctx.needs_input_grad[0]:
-            ga = BatchedGemmNT._run(gc, b.transpose(1, 2).contiguous())                 # (G,M,N) x (G,K,N)^T
+            ga = BatchedGemmNT._run(gc, b.transpose(1, 2).contiguous(), counts, lim_a)   # (G,M,N) x (G,K,N)^T
         if ctx.needs_input_grad[1]:
-            gb = BatchedGemmNT._run(gc.transpose(1, 2).contiguous(), a.transpose(1, 2).contiguous())   # (G,N,M) x (G,K,M)^T
+            gb = BatchedGemmNT._run(gc.transpose(1, 2).contiguous(), a.transpose(1, 2).contiguous(), counts, lim_b)   # (G,N,M) x (G,K,M)^T
         return ga, gb, None, None
 
 
