@@ -534,11 +534,15 @@ constexpr int XD_KS = 16;                      // pixels per K slice
 constexpr int XD_PLANE = XD_KS * X3_ROW;       // half-words per plane image
 constexpr int XD_BUF = 6 * XD_PLANE;           // three gy planes + three x planes
 
-template <int PIX>
+// TM x TN 32x32 blocks per wave (2 x 2 waves): 128x128 tiles, or 64x128 / 128x64 for layers with 64 output or 64 reduction-side
+// channels (layer1, the stem), where half of a 128-wide tile would multiply zeros.  p.mt / p.nt count tiles of THIS shape; the
+// split count and the K ranges are those of the 128x128 form (same summation order, same bits).
+template <int PIX, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
 {
-    constexpr int WGN = 2, TM = 2, TN = 2, BM = 128, BN = 128;
-    constexpr int VA = BM / 4, VB = BN / 4, PA = XD_KS * VA / 256, PB = XD_KS * VB / 256;      // 2 float4 per thread, operand and slice
+    constexpr int WGN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32;
+    constexpr int VA = BM / 4, VB = BN / 4, PA = XD_KS * VA / 256, PB = XD_KS * VB / 256;      // float4 per thread, operand and slice
+    static_assert(PA >= 1 && PB >= 1 && (6 * TM * TN) % (2 * (PA + PB)) == 0, "whole MFMAs per split chunk");
     __shared__ __attribute__((aligned(16))) unsigned short lds[2 * XD_BUF];
 
     // Workgroup -> (tile, split).  Consecutive workgroups go to consecutive XCDs, each with its own L2:
@@ -686,19 +690,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // one half of the loop body: the MFMAs of the slice in `rd` with the split of the staged registers (the next slice but
-    // one of that buffer's parity) into `wr` between them -- eight chunks of one split3x2w (two channels, ~12 vector
-    // instructions) and three MFMAs, pinned in this order by sched_barrier: left to itself hipcc moves all 24 MFMAs behind
+    // one of that buffer's parity) into `wr` between them -- chunks of one split3x2w (two channels, ~12 vector
+    // instructions) and MPC MFMAs (eight chunks of three for the 128x128 tile), pinned in this order by sched_barrier: left to itself hipcc moves all MFMAs behind
     // all of the vector work, and the matrix pipe idles through the split as it did in conv_wgrad_x3_kernel
     auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[PA], float4 (&qb)[PB]) {
         bf16x8w fa[TM][3], fb[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag(rd + q * XD_PLANE, 0, wm * 64 + i * 32, lane);
+            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag(rd + q * XD_PLANE, 0, wm * TM * 32 + i * 32, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fb[j][q] = tr_frag(rd + (3 + q) * XD_PLANE, 0, wn * 64 + j * 32, lane);
+            for (int q = 0; q < 3; ++q) fb[j][q] = tr_frag(rd + (3 + q) * XD_PLANE, 0, wn * TN * 32 + j * 32, lane);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as conv_wgrad_x3_kernel
         unsigned h[2], m[2], l[2];
@@ -717,9 +721,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
                 *reinterpret_cast<uint2 *>(d + 2 * XD_PLANE) = make_uint2(l[0], l[1]);
                 if (is_a) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }     // every tile: no branch in the body
             }
+            constexpr int MPC = 6 * TM * TN / (2 * (PA + PB));       // MFMAs per chunk
 #pragma unroll
-            for (int t = 3 * c; t < 3 * c + 3; ++t) {
-                const int q = t >> 2, i = (t >> 1) & 1, j = t & 1;
+            for (int t = MPC * c; t < MPC * c + MPC; ++t) {          // MFMA t: product q of block (i, j)
+                const int q = t / (TM * TN), i = (t % (TM * TN)) / TN, j = t % TN;
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[q]], fb[j][QB[q]], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -764,11 +769,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + fcol;
+            const int n = n0 + wn * TN * 32 + j * 32 + fcol;
             if (n >= p.Ntot) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                 if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[i][j][r];
             }
         }
@@ -1523,11 +1528,20 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         // conv_wgrad_x3d_kernel addresses its operands with 32-bit BYTE offsets into buffer descriptors
         const bool x3d = x3d_on && (int64_t)B * H * W * Ci * 4 < (1ll << 31) && p.K * Co * 4 < (1ll << 31);
         if (x3d) {
+            // 64-wide tiles where a 128-wide one would be half zeros (the split count stays that of the 128x128 form)
+            static const bool tile64 = !(getenv("HTD_WGRAD_TILE64") && atoi(getenv("HTD_WGRAD_TILE64")) == 0);
+            const bool m64 = tile64 && Co <= 64 && pix != PIX_GENERAL, n64 = tile64 && !m64 && p.Ntot <= 64 && pix == PIX_POINTWISE;
+            p.mt = (int)htd::ceil_div(Co, m64 ? 64 : 128);
+            p.nt = (int)htd::ceil_div(p.Ntot, n64 ? 64 : 128);
             // splits % 8 != 0: (split, N tile) groups dealt over the 8 XCDs, mt workgroups each (see the kernel)
-            const dim3 gd = c.splits % 8 == 0 ? grid : dim3((unsigned)(8 * htd::ceil_div(c.nt * c.splits, 8) * c.mt));
-            if (pix == PIX_POINTWISE) hipLaunchKernelGGL(conv_wgrad_x3d_kernel<PIX_POINTWISE>, gd, dim3(256), 0, s, p);
-            else if (pix == PIX_WIDE) hipLaunchKernelGGL(conv_wgrad_x3d_kernel<PIX_WIDE>, gd, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(conv_wgrad_x3d_kernel<PIX_GENERAL>, gd, dim3(256), 0, s, p);
+            const dim3 gd = c.splits % 8 == 0 ? dim3((unsigned)(p.mt * p.nt * c.splits))
+                                              : dim3((unsigned)(8 * htd::ceil_div(p.nt * c.splits, 8) * p.mt));
+            if (m64 && pix == PIX_POINTWISE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 1, 2>), gd, dim3(256), 0, s, p);
+            else if (m64) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_WIDE, 1, 2>), gd, dim3(256), 0, s, p);
+            else if (n64) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 2, 1>), gd, dim3(256), 0, s, p);
+            else if (pix == PIX_POINTWISE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 2, 2>), gd, dim3(256), 0, s, p);
+            else if (pix == PIX_WIDE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_WIDE, 2, 2>), gd, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_GENERAL, 2, 2>), gd, dim3(256), 0, s, p);
         } else if (pix == PIX_POINTWISE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_POINTWISE>, grid, dim3(256), 0, s, p);
         else if (pix == PIX_WIDE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_WIDE>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_GENERAL>, grid, dim3(256), 0, s, p);

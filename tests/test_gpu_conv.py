@@ -538,6 +538,9 @@ WGRAD_CASES = [
     # the interleaved kernel (2x3: the phased one takes them)
     (24, 576, 7, 7, 576, 3, 1, 1), (37, 32, 7, 7, 96, 3, 1, 1), (2, 48, 5, 3, 64, 3, 1, 1), (5, 64, 2, 3, 64, 3, 1, 1),
     (3, 64, 9, 13, 128, 3, 1, 1),
+    # 64-wide tiles of conv_wgrad_x3d_kernel: Co <= 64 (64 x 128), Ci <= 64 on a 1x1 layer (128 x 64), ragged forms of both
+    (2, 256, 20, 28, 64, 1, 1, 0), (2, 64, 20, 28, 256, 1, 1, 0), (3, 36, 9, 11, 40, 1, 1, 0), (3, 40, 9, 11, 132, 1, 1, 0),
+    (2, 16, 33, 47, 48, 3, 2, 1),
 ]
 _WGRAD_CHILD = r'''
 import sys, zlib, torch
@@ -552,15 +555,18 @@ for B, Ci, H, W, Co, k, s, p in cases:
     gy = torch.randn(B, Co, Ho, Wo, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     w = torch.empty(Co, Ci, k, k, device=dev).contiguous(memory_format=torch.channels_last)
     gw, gb = dense._wgrad_launch(x, gy, w, s, p, 1, True)[:2]
-    print(zlib.crc32(gw.cpu().contiguous(memory_format=torch.channels_last).numpy().tobytes()), zlib.crc32(gb.cpu().numpy().tobytes()))
+    print(zlib.crc32(gw.cpu().contiguous(memory_format=torch.channels_last).numpy().tobytes()), zlib.crc32(gb.cpu().numpy().tobytes()),
+          ','.join(v.hex() for v in gb.cpu().double().tolist()))
 '''
 
 
 def test_interleaved_weight_gradient_kernels_match_the_phased_ones_bit_for_bit():
     """conv_wgrad_x3d_kernel / conv_wgrad_x3hd_kernel (csrc/conv_wgrad.hip: split of the next slice between the MFMAs of the
     current one, buffer-descriptor loads) sum in the order of conv_wgrad_x3_kernel / conv_wgrad_x3h_kernel, which
-    HTD_WGRAD_X3D=0 selects: weight and bias gradients of both must be the same bits.  The switch is read once per
-    process, so each side runs in a child process (two GPU processes, one after the other)."""
+    HTD_WGRAD_X3D=0 selects: weight and bias gradients of both must be the same bits.  One exception: layers with Co <= 64 run
+    on 64-row tiles, whose 16 staging rows per slice (instead of 2 x 8) associate the bias-gradient partial sums differently --
+    there the weight gradient is still the same bits and the bias gradient agrees to fp32 rounding.  The switch is read once
+    per process, so each side runs in a child process (two GPU processes, one after the other)."""
     import os
     import subprocess
     import sys
@@ -574,7 +580,14 @@ def test_interleaved_weight_gradient_kernels_match_the_phased_ones_bit_for_bit()
         out[flag] = [l for l in r.stdout.splitlines() if l and l[0].isdigit()]
         assert len(out[flag]) == len(WGRAD_CASES), r.stdout
     for case, a, b in zip(WGRAD_CASES, out['1'], out['0']):
-        assert a == b, (case, a, b)
+        (wa, ba, va), (wb, bb, vb) = a.split(), b.split()
+        assert wa == wb, (case, wa, wb)
+        if case[4] > 64 or (case[5] == 3 and case[6] == 1):            # Co > 64, or the 3x3 stride-1 kernel (always 128-row tiles)
+            assert ba == bb, (case, ba, bb)
+        else:
+            ga = torch.tensor([float.fromhex(v) for v in va.split(',')], dtype=torch.float64)
+            gb = torch.tensor([float.fromhex(v) for v in vb.split(',')], dtype=torch.float64)
+            assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max()), (case, float((ga - gb).abs().max()))
 
 
 @pytest.mark.parametrize('B,Ci,H,W,Co,k,stride,pad', WGRAD_CASES)
