@@ -1011,10 +1011,13 @@ constexpr int XHD_KS = 16;
 constexpr int XHD_RUN = XHD_KS + 2;
 constexpr int XHD_PLANE_A = XHD_KS * X3_ROW, XHD_PLANE_B = XHD_RUN * XH_ROWB;
 constexpr int XHD_BUF = 3 * XHD_PLANE_A + 3 * XHD_PLANE_B;
-
+template <int TM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
 {
-    constexpr int BM = 128, BNC = 64;
+    // TM 32-row blocks of output channels per wave: 128 co per workgroup, or 64 for the 64-channel layers (layer1), where half of
+    // a 128-row tile would multiply zeros; p.mt counts tiles of this height, the splits are those of the 128-row form
+    constexpr int BM = 2 * TM * 32, BNC = 64;
+    constexpr int VA = BM / 4, RA = 256 / VA, PA = XHD_KS / RA;          // gy staging: VA threads per row, PA rows per thread
     __shared__ __attribute__((aligned(16))) unsigned short lds[2 * XHD_BUF];
     const int ntc = (p.Ci + BNC - 1) / BNC;
     const int tiles = p.mt * ntc * 3;
@@ -1052,7 +1055,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
     const __amdgpu_buffer_rsrc_t x_desc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.x), 0, (int)((unsigned)p.B * p.H * p.W * p.Ci * 4u), 0x00020000);
 
-    const int a_col = (tid & 31) * 4, a_row0 = tid >> 5;      // gy rows a_row0, a_row0 + 8
+    const int a_col = (tid % VA) * 4, a_row0 = tid / VA;      // gy rows a_row0 (+ RA)
     const int b_col = (tid & 15) * 4, b_row0 = tid >> 4;      // x run row b_row0; threads 0..31 also row 16 + b_row0
     const bool a_cok = m0 + a_col < p.Co, b_cok = ci0 + b_col < p.Ci;
     const bool ragged = tid < 32;
@@ -1066,15 +1069,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         real = vv - t;
         if (v < 0) { x = Wv - 1; y = -1; real = 0; }          // v = -1: the padding column of "row -1"
     };
-    int ax[2], bx[2], by[2];
-    unsigned a_off[2], b_off[2];
+    int ax[PA], bx[2], by[2];
+    unsigned a_off[PA], b_off[2];
     const unsigned a_px = a_cok ? (unsigned)p.Co * 4u : 0u, b_px = b_cok ? (unsigned)p.Ci * 4u : 0u;       // bytes per pixel
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PA; ++i) {
         int y;
         int64_t real;
-        decode(v_begin + a_row0 + 8 * i, ax[i], y, real);
+        decode(v_begin + a_row0 + RA * i, ax[i], y, real);
         a_off[i] = a_cok ? (unsigned)(real * p.Co + m0 + a_col) * 4u : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t real;
         decode(v_begin - 1 + b_row0 + 16 * i, bx[i], by[i], real);
         b_off[i] = b_cok && (i == 0 || ragged) ? (unsigned)((real + (int64_t)dy * p.W) * p.Ci + ci0 + b_col) * 4u : OOB;
     }
@@ -1087,10 +1094,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         c.u = __builtin_amdgcn_raw_buffer_load_b128(d, (int)off, 0, 0);
         return c.f;
     };
-    float4 ra[2][2], rb[2][2];
-    auto load_slice = [&](float4 (&qa)[2], float4 (&qb)[2]) {
+    float4 ra[2][PA], rb[2][2];
+    auto load_slice = [&](float4 (&qa)[PA], float4 (&qb)[2]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PA; ++i) {
             qa[i] = load16(gy_desc, ax[i] < p.W ? a_off[i] : OOB);
             ax[i] += adv_x;                                   // + 16 virtual pixels = adv_rows image rows + adv_x columns (+ a carry)
             const bool c1 = ax[i] >= Wv;
@@ -1120,25 +1127,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m0_, m1);
         *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l0, l1);
     };
-    const int a_lds0 = a_row0 * X3_ROW + a_col, a_lds1 = (a_row0 + 8) * X3_ROW + a_col;
+    const int a_lds0 = a_row0 * X3_ROW + a_col, a_lds1 = (a_row0 + RA) * X3_ROW + a_col;
     const int b_lds0 = 3 * XHD_PLANE_A + b_row0 * XH_ROWB + b_col, b_lds1 = 3 * XHD_PLANE_A + (16 + b_row0) * XH_ROWB + b_col;
 
-    f32x16 acc[3][2];
+    f32x16 acc[3][TM];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
 
     // one half of the loop body (see conv_wgrad_x3d_kernel): 36 MFMAs on the slice in `rd`, the split of the staged registers
     // into `wr` in six chunks of one split3x2w between them, the ragged rows of the x run last
-    auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[2], float4 (&qb)[2]) {
-        bf16x8w fa[2][3], fb[3][3];
+    auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[PA], float4 (&qb)[2]) {
+        bf16x8w fa[TM][3], fb[3][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag_row<X3_ROW>(rd + q * XHD_PLANE_A, 0, wm * 64 + i * 32, lane);
+            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag_row<X3_ROW>(rd + q * XHD_PLANE_A, 0, wm * TM * 32 + i * 32, lane);
 #pragma unroll
         for (int t = 0; t < 3; ++t)            // tap kx = t reads the run one row further: gy row k meets x row k + t
 #pragma unroll
@@ -1146,24 +1153,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         __builtin_amdgcn_sched_barrier(0);
         constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as conv_wgrad_x3h_kernel
         unsigned h[2], m[2], l[2];
+        constexpr int NC = 2 * (PA + 1), NM = 18 * TM;       // split chunks; MFMAs of the slice (6 products x 3 taps x TM blocks)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const int u = c >> 1;                    // staged float4: the two gy rows, then the x row
-            const float4 v = u < 2 ? qa[u] : qb[0];
+        for (int c = 0; c < NC; ++c) {
+            const int u = c >> 1;                    // staged float4: the gy row(s), then the x row
+            const float4 v = u < PA ? qa[u < PA ? u : 0] : qb[0];
             if ((c & 1) == 0) {
                 split3x2w(v.x, v.y, h[0], m[0], l[0]);
             } else {
                 split3x2w(v.z, v.w, h[1], m[1], l[1]);
-                unsigned short *d = wr + (u == 0 ? a_lds0 : u == 1 ? a_lds1 : b_lds0);
-                const int plane = u < 2 ? XHD_PLANE_A : XHD_PLANE_B;
+                unsigned short *d = wr + (u >= PA ? b_lds0 : u == 0 ? a_lds0 : a_lds1);
+                const int plane = u < PA ? XHD_PLANE_A : XHD_PLANE_B;
                 *reinterpret_cast<uint2 *>(d) = make_uint2(h[0], h[1]);
                 *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m[0], m[1]);
                 *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l[0], l[1]);
-                if (u < 2) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }     // every tile: no branch in the body
+                if (u < PA) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }    // every tile: no branch in the body
             }
 #pragma unroll
-            for (int e = 6 * c; e < 6 * c + 6; ++e) {          // MFMA e: product q = e / 6 of block (tap, i) = e % 6
-                const int q = e / 6, t = (e % 6) >> 1, i = e & 1;
+            for (int e = c * NM / NC; e < (c + 1) * NM / NC; ++e) {          // MFMA e: product q of block (tap t, row block i)
+                const int q = e / (3 * TM), t = (e % (3 * TM)) / TM, i = e % TM;
                 acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[q]], fb[t][QB[q]], acc[t][i], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1174,11 +1182,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         load_slice(qa, qb);
         __syncthreads();
     };
-    auto store_slice = [&](unsigned short *wr, const float4 (&qa)[2], const float4 (&qb)[2]) {
+    auto store_slice = [&](unsigned short *wr, const float4 (&qa)[PA], const float4 (&qb)[2]) {
         put(wr + a_lds0, XHD_PLANE_A, qa[0]);
-        put(wr + a_lds1, XHD_PLANE_A, qa[1]);
+        if constexpr (PA > 1) put(wr + a_lds1, XHD_PLANE_A, qa[PA - 1]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { bsum.x += qa[i].x; bsum.y += qa[i].y; bsum.z += qa[i].z; bsum.w += qa[i].w; }      // row by row
+        for (int i = 0; i < PA; ++i) { bsum.x += qa[i].x; bsum.y += qa[i].y; bsum.z += qa[i].z; bsum.w += qa[i].w; }     // row by row
         put(wr + b_lds0, XHD_PLANE_B, qb[0]);
         if (ragged) put(wr + b_lds1, XHD_PLANE_B, qb[1]);
     };
@@ -1194,15 +1202,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         half(buf1, buf0, ra[0], rb[0]);
     }
 
-    if (do_bias) {          // threads sharing a column quad (tid & 31) fold their 8 row partials in a fixed order
+    if (do_bias) {          // threads sharing a column quad (tid % VA) fold their RA row partials in a fixed order
         float4 *red = reinterpret_cast<float4 *>(lds);
         __syncthreads();
         red[tid] = bsum;
         __syncthreads();
-        if (tid < 32) {
+        if (tid < VA) {
             float4 t = red[tid];
-            for (int r = 1; r < 8; ++r) {
-                const float4 v = red[r * 32 + tid];
+            for (int r = 1; r < RA; ++r) {
+                const float4 v = red[r * VA + tid];
                 t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
             }
             float *dst = p.bias_out + (int64_t)split * p.Co;
@@ -1221,10 +1229,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
         for (int t = 0; t < 3; ++t) {
             const int n = (ky * 3 + t) * p.Ci + ci;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
                     if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[t][i][r];
                 }
         }
@@ -1498,7 +1506,15 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         // (a slice of 16 virtual pixels must not span more than H image rows: the row index wraps once per slice at most)
         if (x3hd_on && XHD_KS / (W + 1) + 1 <= H && (int64_t)B * H * W * Ci * 4 < (1ll << 31) &&
             (int64_t)B * H * W * Co * 4 < (1ll << 31))
-            hipLaunchKernelGGL(conv_wgrad_x3hd_kernel, grid, dim3(256), 0, s, p);
+        {
+            static const bool tile64 = !(getenv("HTD_WGRAD_TILE64") && atoi(getenv("HTD_WGRAD_TILE64")) == 0);
+            if (tile64 && Co <= 64) {                 // 64 output channels: 64-row tiles (same tile count, no rows of zeros)
+                p.mt = (int)htd::ceil_div(Co, 64);
+                hipLaunchKernelGGL(conv_wgrad_x3hd_kernel<1>, dim3((unsigned)(p.mt * p.nt * 3 * p.splits)), dim3(256), 0, s, p);
+            } else {
+                hipLaunchKernelGGL(conv_wgrad_x3hd_kernel<2>, grid, dim3(256), 0, s, p);
+            }
+        }
         else if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_x3h_kernel<false>, grid, dim3(256), 0, s, p);
         if (p.splits > 1) {
