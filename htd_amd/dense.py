@@ -728,20 +728,29 @@ def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=Fals
     return y
 
 
-def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1, with_bias=False):
+def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1, with_bias=False, weight=None, bias=None):
     """fp32 weight gradient of a convolution from bf16 activations x (B,Ci,H,W) and bf16 output gradient gy
     (htd_conv2d_bwd_weight_bf16) -> (Co,Ci,kh,kw) fp32 channels_last.  with_bias: -> (gw, gbias), the column sums of gy
-    (fp32) from the same launch (htd_conv2d_bwd_weight_bf16_bias)."""
+    (fp32) from the same launch (htd_conv2d_bwd_weight_bf16_bias).  weight / bias (the fp32 master parameters, optional):
+    their slices of the flat gradient buffer are written in place when they are registered as gradient sinks (grad_out2),
+    as the fp32 path does -- no copy into the buffer afterwards."""
     _need_gpu(x, 'conv2d_wgrad_bf16')
     x = x.contiguous(memory_format=CL)
     gy = gy.contiguous(memory_format=CL)
     B, Ci, H, W = x.shape
     Co, _, kh, kw = weight_shape
-    gw = torch.empty((Co, Ci, kh, kw), device=x.device, dtype=torch.float32, memory_format=CL)
+    gw = None
+    if weight is not None and weight.dtype == torch.float32 and tuple(weight.shape) == tuple(weight_shape):
+        gw = grad_out2(weight)[0]
+        if not (gw.dim() == 4 and gw.is_contiguous(memory_format=CL)):
+            gw = None
+    if gw is None:
+        gw = torch.empty((Co, Ci, kh, kw), device=x.device, dtype=torch.float32, memory_format=CL)
     nbytes = capi.lib().htd_conv2d_wgrad_bf16_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
     ws = torch.empty(nbytes // 4 + 1, device=x.device, dtype=torch.float32)
     if with_bias:
-        gb = torch.empty(Co, device=x.device, dtype=torch.float32)
+        gb = grad_out2(bias)[0] if (bias is not None and bias.dtype == torch.float32 and bias.numel() == Co) else \
+            torch.empty(Co, device=x.device, dtype=torch.float32)
         capi.call('htd_conv2d_bwd_weight_bf16_bias', _P(x), _P(gy), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, int(stride),
                   int(padding), int(dilation), _P(ws), _S(), work=('flop', 2.0 * gy.numel() * kh * kw * Ci))
         return gw, gb
@@ -843,6 +852,7 @@ class Conv2dBf16Function(Function):
         y = conv2d_bf16(x, wb, bias, stride, padding, dilation, relu, residual)
         ctx.save_for_backward(x, wT if need_wT else wb, y if relu else None)
         ctx.cfg = (stride, padding, dilation, bias is not None, residual is not None, tuple(weight.shape), need_wT)
+        ctx.master = (weight, bias)                 # the parameters themselves: their gradient sinks are looked up in backward
         return y
 
     @staticmethod
@@ -850,6 +860,7 @@ class Conv2dBf16Function(Function):
     def backward(ctx, g):
         x, wsaved, y = ctx.saved_tensors
         stride, padding, dilation, has_bias, has_res, wshape, have_wT = ctx.cfg
+        w_master, b_master = ctx.master
         g = g.contiguous(memory_format=CL)
         if y is not None:
             g = torch.ops.aten.threshold_backward(g, y, 0)          # ReLU backward: one launch
@@ -863,10 +874,11 @@ class Conv2dBf16Function(Function):
                 gx = _dgrad_raw(g.float().contiguous(memory_format=CL), wsaved.float().contiguous(memory_format=CL),
                                 x.shape, stride, padding, dilation).to(torch.bfloat16)
         if need_w and has_bias and need_b:
-            gw, gb = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation, with_bias=True)      # one launch for both
+            gw, gb = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation, with_bias=True, weight=w_master,
+                                       bias=b_master)      # one launch for both
         else:
             if need_w:
-                gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation)
+                gw = conv2d_wgrad_bf16(x, g, wshape, stride, padding, dilation, weight=w_master)
             if has_bias and need_b:
                 gb = _colsum_bf16_raw(g) if g.size(1) % 4 == 0 else \
                     torch.sum(g.permute(0, 2, 3, 1).reshape(-1, g.size(1)), dim=0, dtype=torch.float32)
