@@ -44,8 +44,8 @@ def timeit(fn, n=5):
 def device_rates(x, w, g, s, p, flop, n=8):
     """TF/s of the three C-ABI entry points from device events around each call (capi profile)."""
     xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
-    for it in range(n + 2):
-        if it == 2:
+    for it in range(n + 20):                 # 20 untimed iterations first: an idle device needs milliseconds to raise its clocks
+        if it == 20:
             capi.profile_begin()
         dense.conv2d(xg, wg, None, s, p, 1).backward(g)
     prof = capi.profile_end()
