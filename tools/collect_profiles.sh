@@ -47,7 +47,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_$TAG/w -
 python3 $R/tools/pmc_traffic.py /tmp/p_$TAG/f/*counter_collection.csv /tmp/p_$TAG/w/*counter_collection.csv $OUT/hbm_traffic.json > /dev/null
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d /tmp/p_$TAG/m -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python3 $R/tools/pmc_mfma.py /tmp/p_$TAG/m/*counter_collection.csv $OUT/mfma_busy.json > /dev/null
+echo "== per-layer convolution tables (stand-alone, warm device)"
+python3 $R/tools/bench_conv.py > $OUT/bench_conv_new.log 2>&1
+HTD_X3P=0 HTD_WGRAD_X3H=0 HTD_WGRAD_X3D=0 python3 $R/tools/bench_conv.py > $OUT/bench_conv_r02_kernels.log 2>&1
+python3 $R/tools/bench_wgrad.py --all > $OUT/wgrad_new.txt 2>&1
+HTD_WGRAD_X3D=0 python3 $R/tools/bench_wgrad.py --all > $OUT/wgrad_phased.txt 2>&1
 echo "== RoIAlign"
 python3 $R/tools/bench_roi_align.py 2048 4 > $OUT/roi_align_2048.log 2>&1
 python3 $R/tools/bench_roi_align.py 32768 4 > $OUT/roi_align_32768.log 2>&1
+python3 $R/tools/summarize_collection.py $OUT > $OUT/summary.txt 2>&1
 ls -la $OUT
