@@ -324,6 +324,10 @@ __global__ __launch_bounds__(256) void chunk_sums_kernel(const float *__restrict
 // ------------------------------------------------------------------ GroupNorm (+ReLU)
 // One block per RoI tile; thread = channel, so a group's `cpg` channels sit on adjacent
 // lanes and the group statistics are a segmented wave reduction (cpg must divide 64).
+// PREG > 0: the P <= PREG positions of a channel are read ONCE into registers (all loads in flight together) and the three
+// passes -- sum, squared deviations, normalise -- run on them in the same order as the memory form: same bits, a third of
+// the reads and no chain of dependent loads (the 7x7 tiles of the RoI regression branch: 3.2 -> 1.x ms for 32 768 RoIs).
+template <int PREG>
 __global__ void gn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                               const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ mean,
                               float *__restrict__ rstd, int P, int C, int G, float eps, int relu)
@@ -333,25 +337,54 @@ __global__ void gn_fwd_kernel(const float *__restrict__ x, const float *__restri
     const int cpg = C / G;
     const bool act = c < C;
     const float *xp = x + i * P * C + c;
+    float xr[PREG > 0 ? PREG : 1];
+    if constexpr (PREG > 0) {
+#pragma unroll
+        for (int q = 0; q < PREG; ++q) xr[q] = (act && q < P) ? xp[(int64_t)q * C] : 0.f;
+    }
     float s = 0.f;
-    if (act) for (int q = 0; q < P; ++q) s += xp[(int64_t)q * C];
+    if constexpr (PREG > 0) {
+#pragma unroll
+        for (int q = 0; q < PREG; ++q) if (q < P) s += xr[q];
+    } else {
+        if (act) for (int q = 0; q < P; ++q) s += xp[(int64_t)q * C];
+    }
     for (int o = 1; o < cpg; o <<= 1) s += __shfl_xor(s, o, 64);
     const float mu = s / (float)(P * cpg);
     float v = 0.f;
-    if (act) for (int q = 0; q < P; ++q) { const float d = xp[(int64_t)q * C] - mu; v += d * d; }
+    if constexpr (PREG > 0) {
+#pragma unroll
+        for (int q = 0; q < PREG; ++q) if (q < P) { const float d = xr[q] - mu; v += d * d; }
+        if (!act) v = 0.f;
+    } else {
+        if (act) for (int q = 0; q < P; ++q) { const float d = xp[(int64_t)q * C] - mu; v += d * d; }
+    }
     for (int o = 1; o < cpg; o <<= 1) v += __shfl_xor(v, o, 64);
     const float rs = rsqrtf(v / (float)(P * cpg) + eps);
     if (!act) return;
     if (c % cpg == 0) { mean[i * G + c / cpg] = mu; rstd[i * G + c / cpg] = rs; }
     const float ga = gamma[c] * rs, be = beta[c] - mu * gamma[c] * rs;
     float *yp = y + i * P * C + c;
-    for (int q = 0; q < P; ++q) {
-        float t = xp[(int64_t)q * C] * ga + be;
-        if (relu) t = fmaxf(t, 0.f);
-        yp[(int64_t)q * C] = t;
+    if constexpr (PREG > 0) {
+#pragma unroll
+        for (int q = 0; q < PREG; ++q)
+            if (q < P) {
+                float t = xr[q] * ga + be;
+                if (relu) t = fmaxf(t, 0.f);
+                yp[(int64_t)q * C] = t;
+            }
+    } else {
+        for (int q = 0; q < P; ++q) {
+            float t = xp[(int64_t)q * C] * ga + be;
+            if (relu) t = fmaxf(t, 0.f);
+            yp[(int64_t)q * C] = t;
+        }
     }
 }
 
+// PREG > 0 (P <= PREG): the masked gradient and the centred input of a channel are read once and kept in registers for the
+// second pass (same expressions in the same order: same bits)
+template <int PREG>
 __global__ void gn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
                               const float *__restrict__ gamma, const float *__restrict__ mean,
                               const float *__restrict__ rstd, const float *__restrict__ gy, float *__restrict__ gx,
@@ -367,7 +400,26 @@ __global__ void gn_bwd_kernel(const float *__restrict__ x, const float *__restri
     const float ga = act ? gamma[c] : 0.f;
     const float *xp = x + i * P * C + c, *yp = y + i * P * C + c, *gp = gy + i * P * C + c;
     float sg = 0.f, sgx = 0.f;  // sum dy, sum dy*xhat for this channel
-    if (act)
+    float dr[PREG > 0 ? PREG : 1], xc[PREG > 0 ? PREG : 1];
+    if constexpr (PREG > 0) {
+        float yv[PREG];
+#pragma unroll
+        for (int q = 0; q < PREG; ++q) {
+            const bool in = act && q < P;
+            dr[q] = in ? gp[(int64_t)q * C] : 0.f;
+            yv[q] = in ? yp[(int64_t)q * C] : 1.f;
+            xc[q] = in ? xp[(int64_t)q * C] : mu;
+        }
+#pragma unroll
+        for (int q = 0; q < PREG; ++q) {
+            if (relu && !(yv[q] > 0.f)) dr[q] = 0.f;
+            xc[q] = xc[q] - mu;
+            if (act && q < P) {
+                sg += dr[q];
+                sgx += dr[q] * xc[q] * rs;
+            }
+        }
+    } else if (act)
         for (int q = 0; q < P; ++q) {
             float d = gp[(int64_t)q * C];
             if (relu && !(yp[(int64_t)q * C] > 0.f)) d = 0.f;
@@ -391,11 +443,20 @@ __global__ void gn_bwd_kernel(const float *__restrict__ x, const float *__restri
     a *= m; b *= m;
     if (!act) return;
     float *gxp = gx + i * P * C + c;
-    for (int q = 0; q < P; ++q) {
-        float d = gp[(int64_t)q * C];
-        if (relu && !(yp[(int64_t)q * C] > 0.f)) d = 0.f;
-        const float xh = (xp[(int64_t)q * C] - mu) * rs;
-        gxp[(int64_t)q * C] = rs * (d * ga - a - xh * b);
+    if constexpr (PREG > 0) {
+#pragma unroll
+        for (int q = 0; q < PREG; ++q)
+            if (q < P) {
+                const float xh = xc[q] * rs;
+                gxp[(int64_t)q * C] = rs * (dr[q] * ga - a - xh * b);
+            }
+    } else {
+        for (int q = 0; q < P; ++q) {
+            float d = gp[(int64_t)q * C];
+            if (relu && !(yp[(int64_t)q * C] > 0.f)) d = 0.f;
+            const float xh = (xp[(int64_t)q * C] - mu) * rs;
+            gxp[(int64_t)q * C] = rs * (d * ga - a - xh * b);
+        }
     }
 }
 
@@ -700,8 +761,12 @@ extern "C" int htd_group_norm_relu_fwd(const float *x, const float *gamma, const
     if (n == 0) return HTD_OK;
     HTD_REQUIRE(x && gamma && beta && y && mean && rstd, "group_norm: null pointer");
     const int threads = (int)htd::ceil_div(C, 64) * 64;
-    hipLaunchKernelGGL(gn_fwd_kernel, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y,
-                       mean, rstd, P, C, G, eps, relu);
+    if (P <= 49)
+        hipLaunchKernelGGL(gn_fwd_kernel<49>, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y,
+                           mean, rstd, P, C, G, eps, relu);
+    else
+        hipLaunchKernelGGL(gn_fwd_kernel<0>, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y,
+                           mean, rstd, P, C, G, eps, relu);
     return htd::check_launch("group_norm_fwd");
 }
 
@@ -716,7 +781,7 @@ extern "C" int htd_group_norm_relu_bwd(const float *x, const float *y, const flo
     if (n == 0) return HTD_OK;
     HTD_REQUIRE(x && y && gamma && mean && rstd && gy && gx && ggamma && gbeta, "group_norm_bwd: null pointer");
     const int threads = (int)htd::ceil_div(C, 64) * 64;
-    hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, y, gamma, mean,
+    hipLaunchKernelGGL((P <= 49 ? gn_bwd_kernel<49> : gn_bwd_kernel<0>), dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, y, gamma, mean,
                        rstd, gy, gx, ggamma, gbeta, P, C, G, relu, (float *)nullptr);
     return htd::check_launch("group_norm_bwd");
 }
@@ -741,7 +806,7 @@ extern "C" int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const 
     HTD_REQUIRE(x && y && gamma && mean && rstd && gy && gx && workspace, "group_norm_bwd: null pointer");
     const int threads = (int)htd::ceil_div(C, 64) * 64;
     float *ws = (float *)workspace;
-    hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)n), dim3(threads), 0, s, x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta,
+    hipLaunchKernelGGL((P <= 49 ? gn_bwd_kernel<49> : gn_bwd_kernel<0>), dim3((unsigned)n), dim3(threads), 0, s, x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta,
                        P, C, G, relu, ws);
     hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)htd::ceil_div(C, 16), 2), dim3(256), 0, s, (const float *)ws, ggamma,
                        gbeta, C, (int)n);
