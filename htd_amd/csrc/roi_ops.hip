@@ -221,7 +221,15 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float *__restrict__ 
     if (c >= C) return;
     const float *p = x + b * P * C + c;
     float acc = 0.f;
-    for (int q = 0; q < P; ++q) acc += p[(int64_t)q * C];
+    int q = 0;
+    for (; q + 7 < P; q += 8) {              // eight loads in flight, added in position order (same sum, no chain of dependent loads)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(q + u) * C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; q < P; ++q) acc += p[(int64_t)q * C];
     out[b * C + c] = acc / (float)P;
 }
 
