@@ -279,6 +279,16 @@ def join_side_stream():
 
 # ---- raw launches (no autograd): the building blocks of Conv2dFunction and ResStageFunction -------------------
 
+STEM7 = os.environ.get('HTD_STEM7', '1') != '0'       # 0: the stem on the generic kernels with an 8-channel image (A/B runs)
+
+
+def _stem7_ok(x, weight, stride, padding, dilation, residual=None):
+    """The ResNet stem in the form htd_conv2d_stem7_fwd takes: 7x7 / stride 2 / padding 3, 4 input channels (RGB + zero), 64
+    output channels, fp32 with the split-bf16 arithmetic selected."""
+    return (STEM7 and x.dtype == torch.float32 and tuple(weight.shape) == (64, 4, 7, 7) and x.size(1) == 4 and stride == 2 and
+            padding == 3 and dilation == 1 and residual is None and capi.lib().htd_conv2d_set_math(-1) == 1)
+
+
 def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu, res_up=False):
     B, Ci, H, W = x.shape
     Co, Ci_w, kh, kw = weight.shape
@@ -290,6 +300,11 @@ def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu, res_up=
         return y
     flops = 2.0 * B * Ho * Wo * Co * kh * kw * Ci
     rh, rw = (residual.size(2), residual.size(3)) if (res_up and residual is not None) else (0, 0)
+    if _stem7_ok(x, weight, stride, padding, dilation, residual):
+        ws = torch.empty(capi.lib().htd_conv2d_stem7_workspace_bytes() // 4, device=x.device, dtype=torch.float32)
+        capi.call('htd_conv2d_stem7_fwd', _P(x), _P(weight), _P(bias), _P(y), B, H, W, int(bool(relu)), _P(ws), _S(),
+                  work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel())))
+        return y
     if _x3p_ok(Ci, Co, kh, kw, stride, padding, dilation, x.dtype):
         nb = capi.lib().htd_conv2d_x3p_workspace_bytes(B * Ho * Wo, Co, Ci, kh, kw)
         ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32) if nb > 0 else None
@@ -1017,7 +1032,12 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, re
         stride, padding, dilation = stride[0], padding[0], dilation[0]
     if x.size(1) % 8 != 0:
         assert not chain
-        x, weight = _pad_channels(x, weight)
+        # the ResNet stem on an image nobody differentiates: RGB + ONE zero channel, htd_conv2d_stem7_fwd / a 4-channel weight
+        # gradient (half the reduction-side work of the 8-channel form); everything else: channels padded to a multiple of 8
+        stem = (STEM7 and x.size(1) == 3 and tuple(weight.shape) == (64, 3, 7, 7) and int(stride) == 2 and int(padding) == 3 and
+                int(dilation) == 1 and residual is None and not x.requires_grad and x.dtype == torch.float32 and x.is_cuda and
+                capi.lib().htd_conv2d_set_math(-1) == 1)
+        x, weight = _pad_channels(x, weight, 4 if stem else 8)
     return Conv2dFunction.apply(x, weight, bias, residual, int(stride), int(padding), int(dilation), relu,
                                 bool(residual_up), bool(chain))
 

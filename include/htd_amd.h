@@ -239,6 +239,15 @@ int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbi
                           void *stream);
 int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows,
                             int C, void *workspace, void *stream);
+/* The ResNet stem (backbones/resnet.py:596-607 `conv1`: 7x7, stride 2, padding 3, 3 -> 64 channels; what cuDNN's
+ * small-channel first-layer algorithm is to the reference): x [B][H][W][4] fp32 NHWC with the fourth channel zero,
+ * w [64][7][7][4] fp32 KRSC, bias [64] or NULL, y [B][Ho][Wo][64], Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1; relu != 0 applies
+ * max(., 0).  The reduction runs over filter rows of 7 pixels x 4 channels (224 k per output pixel instead of the 784 the
+ * generic kernel spends on an 8-channel image), same split-bf16 arithmetic as the other fp32 convolutions
+ * (csrc/conv_stem.hip).  workspace >= htd_conv2d_stem7_workspace_bytes() bytes, 16-byte aligned like the tensors. */
+int64_t htd_conv2d_stem7_workspace_bytes(void);
+int htd_conv2d_stem7_fwd(const float *x, const float *w, const float *bias, float *y, int B, int H, int W, int relu,
+                         void *workspace, void *stream);
 /* The same convolutions with the weight operand split into its three bf16 planes ONCE PER OPTIMIZER STEP instead of once per
  * tile and filter tap inside the kernel (csrc/conv_x3.hip; the role cuDNN's pre-transformed filters play behind
  * backbones/resnet.py:260-300, necks/fpn.py:190-192, dense_heads/rpn_head.py:37-43, htd_bbox_head.py:77-113).

@@ -606,3 +606,38 @@ def test_weight_gradient_is_exact_on_integers(B, Ci, H, W, Co, k, stride, pad):
     ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), stride, pad)
     assert torch.equal(gw.double(), ref)
     assert torch.equal(gb.double(), gy.double().sum((0, 2, 3)))
+
+
+@pytest.mark.parametrize('B,H,W,relu', [(2, 64, 96, True), (1, 33, 47, False), (3, 7, 301, True), (1, 1, 1, False), (2, 130, 258, True)])
+def test_stem7_kernel_matches_fp64_and_is_exact_on_integers(B, H, W, relu):
+    """htd_conv2d_stem7_fwd (csrc/conv_stem.hip: the 7x7 / stride 2 / padding 3 stem on a 4-channel image, reduction over
+    filter rows) against an fp64 convolution: odd sizes (output rows that end inside a 128-pixel tile, maps narrower than the
+    filter), borders on every side; integer operands must give the exact integers; random operands stay within fp32
+    rounding of the accumulated magnitude (the bound of test_split_bf16_products_are_fp32_accurate).  Through dense.conv2d the
+    3-channel image takes this path and the weight gradient the 4-channel form of conv_wgrad_x3d_kernel."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    xi = torch.randint(-3, 4, (B, 3, H, W), generator=g).float().to(dev).contiguous(memory_format=torch.channels_last)
+    wi = torch.randint(-3, 4, (64, 3, 7, 7), generator=g).float().to(dev).contiguous(memory_format=torch.channels_last)
+    bi = torch.randint(-3, 4, (64, ), generator=g).float().to(dev)
+    y = dense.conv2d(xi, wi, bi, 2, 3, 1, relu=relu)
+    ref = F.conv2d(xi.double(), wi.double(), bi.double(), 2, 3)
+    ref = ref.clamp(min=0) if relu else ref
+    assert torch.equal(y.double(), ref)
+    x = torch.randn(B, 3, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    b = torch.randn(64, generator=g).to(dev).requires_grad_()
+    y = dense.conv2d(x, w, b, 2, 3, 1, relu=relu)
+    ref = F.conv2d(x.double(), w.detach().double(), b.detach().double(), 2, 3)
+    scale = F.conv2d(x.double().abs(), w.detach().double().abs(), b.detach().double().abs(), 2, 3)
+    ref = ref.clamp(min=0) if relu else ref
+    assert float(((y.detach().double() - ref).abs() / scale).max()) < 1.5e-7 * 148 ** 0.5
+    gy = torch.randn(y.shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    y.backward(gy)
+    gm = gy.double() * (ref > 0) if relu else gy.double()
+    wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gm, 2, 3)
+    wscale = torch.nn.grad.conv2d_weight(x.double().abs(), w.shape, gm.abs(), 2, 3) + 1e-30
+    npix = y.shape[0] * y.shape[2] * y.shape[3]
+    assert float(((w.grad.double() - wref).abs() / wscale).max()) < 1.5e-7 * max(npix, 1) ** 0.5 + 1e-12
+    assert float((b.grad.double() - gm.sum((0, 2, 3))).abs().max()) <= 1e-5 * float(gm.abs().sum((0, 2, 3)).max()) + 1e-12
