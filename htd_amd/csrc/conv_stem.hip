@@ -18,6 +18,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int ST_BM = 128;                      // output pixels per workgroup
 constexpr int ST_PIX = 2 * ST_BM + 6;           // input pixels per filter row (the last one only meets zero weights)
@@ -102,10 +103,8 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
         v[i] = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
     }
     // the first filter row of weights
-    const uint4 *wsrc = reinterpret_cast<const uint4 *>(p.planes);
-    uint4 wb[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) wb[i] = wsrc[tid + i * 256];
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(p.planes);
+    u32x4 w0 = wsrc[tid], w1 = wsrc[tid + 256], w2 = wsrc[tid + 512];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int it = tid + i * 256;
@@ -120,8 +119,9 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
             *reinterpret_cast<uint2 *>(d + 2 * ST_APLANE) = make_uint2(l0, l1);
         }
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) reinterpret_cast<uint4 *>(lb)[tid + i * 256] = wb[i];
+    reinterpret_cast<u32x4 *>(lb)[tid] = w0;
+    reinterpret_cast<u32x4 *>(lb)[tid + 256] = w1;
+    reinterpret_cast<u32x4 *>(lb)[tid + 512] = w2;
     __syncthreads();
 
     f32x16 acc[2];
@@ -135,9 +135,10 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
     constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
     for (int ky = 0; ky < 7; ++ky) {
         if (ky + 1 < 7) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) wb[i] = wsrc[(ky + 1) * (ST_BT / 8) + tid + i * 256];
+            const u32x4 *src = wsrc + (ky + 1) * (ST_BT / 8) + tid;
+            w0 = src[0]; w1 = src[256]; w2 = src[512];
         }
+        __builtin_amdgcn_sched_barrier(0);      // (hipcc sinks these loads behind the MFMAs and waits for them at once otherwise)
         const unsigned short *bt = lb + (ky & 1) * ST_BT;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -156,10 +157,14 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
                 for (int j = 0; j < 2; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QA[q]], fb[j][QB[q]], acc[j], 0, 0, 0);
         }
+        // (... and hoists their LDS stores, with the wait for the loads, in front of the MFMAs.  The stores are therefore made to
+        // depend on the accumulators: an empty asm that "produces" one register of each staged vector from them)
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2) : "v"(acc[0][0]), "v"(acc[1][0]));
         if (ky + 1 < 7) {
             unsigned short *nb = lb + ((ky + 1) & 1) * ST_BT;       // last read in iteration ky - 1, before its closing barrier
-#pragma unroll
-            for (int i = 0; i < 3; ++i) reinterpret_cast<uint4 *>(nb)[tid + i * 256] = wb[i];
+            reinterpret_cast<u32x4 *>(nb)[tid] = w0;
+            reinterpret_cast<u32x4 *>(nb)[tid + 256] = w1;
+            reinterpret_cast<u32x4 *>(nb)[tid + 512] = w2;
         }
         __syncthreads();
     }
