@@ -641,3 +641,18 @@ def test_stem7_kernel_matches_fp64_and_is_exact_on_integers(B, H, W, relu):
     npix = y.shape[0] * y.shape[2] * y.shape[3]
     assert float(((w.grad.double() - wref).abs() / wscale).max()) < 1.5e-7 * max(npix, 1) ** 0.5 + 1e-12
     assert float((b.grad.double() - gm.sum((0, 2, 3))).abs().max()) <= 1e-5 * float(gm.abs().sum((0, 2, 3)).max()) + 1e-12
+
+
+@pytest.mark.parametrize('tool,n', [('fuzz_conv.py', 40), ('fuzz_wgrad.py', 40)])
+def test_random_convolution_shapes_are_exact_on_integers(tool, n):
+    """tools/fuzz_conv.py: random problems through dense.conv2d and its backward (forward / data-gradient kernels with their
+    epilogues, ReLU masks, weight gradients) on small-integer operands must equal the fp64 reference; tools/fuzz_wgrad.py: random
+    weight-gradient problems, interleaved kernels = phased kernels bit for bit (its own child process), and random image sizes
+    through the stem kernel.  A fixed seed here; profiles/r03_fuzz_*.log hold the longer runs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', tool), str(n), '11'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert '0 mismatches' in r.stdout, r.stdout[-2000:]
