@@ -5,8 +5,9 @@
 // 784 k per output pixel for 147 real ones.  Here the reduction runs over FILTER ROWS: for filter row ky an output pixel
 // (ho, wo) meets the 7 input pixels 2 wo - 3 .. 2 wo + 3 of image row 2 ho - 3 + ky -- with 4 channels per pixel that is 28
 // CONSECUTIVE values of the NHWC input, 32 with the next pixel (whose weights are zeros): two 16-k steps per filter row, 224 k
-// in all.  A workgroup owns 128 consecutive output pixels of one output row and all 64 output channels; it splits the
-// 7 x 262 input pixels it needs ONCE into bf16 planes in LDS, in their memory order.  The A fragment of output pixel wo is the
+// in all.  A workgroup owns 64 consecutive output pixels of one output row (128 with -DHTD_STEM_BM=128: 246 against 216 us at
+// B = 4, two resident workgroups instead of three) and all 64 output channels; it splits the 7 x 134 input pixels it needs
+// ONCE into bf16 planes in LDS, in their memory order.  The A fragment of output pixel wo is the
 // 16-byte window that starts at pixel 2 (wo - wo0) + 4 kk + 2 half of that image: neighbouring lanes read neighbouring
 // 16-byte chunks (conflict-free), and no im2col image exists anywhere.  Weight planes ([ky][k / 8][plane][co][8]) are made
 // per call by a small kernel and stream through a double-buffered 12 KB LDS tile per filter row.
@@ -20,11 +21,15 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int ST_BM = 128;                      // output pixels per workgroup
+#ifndef HTD_STEM_BM
+#define HTD_STEM_BM 64
+#endif
+constexpr int ST_BM = HTD_STEM_BM;              // output pixels per workgroup: 128 (4 waves x 32 pixels x 64 channels) or 64 (2 x 2 waves)
 constexpr int ST_PIX = 2 * ST_BM + 6;           // input pixels per filter row (the last one only meets zero weights)
-constexpr int ST_PIXP = 264;                    // row pitch in pixels
+constexpr int ST_PIXP = (ST_PIX + 7) / 8 * 8;   // row pitch in pixels
 constexpr int ST_APLANE = ST_PIXP * 4;          // half-words per (filter row, plane): 4 channels per pixel
-constexpr int ST_A = 7 * 3 * ST_APLANE;         // 44 352 bytes
+constexpr int ST_A = 7 * 3 * ST_APLANE;         // 44 352 bytes at 128 pixels
+constexpr int ST_NJ = ST_BM == 128 ? 2 : 1;     // 32-column blocks per wave
 constexpr int ST_BT = 4 * 3 * 64 * 8;           // half-words per filter row of weights: [k chunk][plane][co][8]
 constexpr int ST_WPLANES = 7 * ST_BT;           // half-words of the whole plane image
 
@@ -71,7 +76,7 @@ struct StemParams {
     int B, H, W, Ho, Wo, segs, relu;
 };
 
-__global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
+__global__ __launch_bounds__(256, (ST_BM == 128 ? 2 : 3)) void stem7_fwd_kernel(StemParams p)
 {
     __shared__ __attribute__((aligned(16))) unsigned short lds[ST_A + 2 * ST_BT];
     unsigned short *la = lds, *lb = lds + ST_A;
@@ -124,14 +129,15 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
     reinterpret_cast<u32x4 *>(lb)[tid + 512] = w2;
     __syncthreads();
 
-    f32x16 acc[2];
+    f32x16 acc[ST_NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < ST_NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // wave w: output pixels wo0 + 32 w .. + 31, all 64 channels (two 32-column blocks)
-    const int a_px = 2 * (wave * 32 + frow) + 2 * fhalf;       // first pixel of the lane's 16-byte window at kk = 0
+    // 128 pixels: wave w takes output pixels wo0 + 32 w .. + 31 and all 64 channels; 64 pixels: 2 x 2 waves of 32 x 32
+    const int wrow = (ST_BM == 128 ? wave : (wave & 1)) * 32, wcol = ST_BM == 128 ? 0 : (wave >> 1) * 32;
+    const int a_px = 2 * (wrow + frow) + 2 * fhalf;            // first pixel of the lane's 16-byte window at kk = 0
     constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
     for (int ky = 0; ky < 7; ++ky) {
         if (ky + 1 < 7) {
@@ -142,24 +148,24 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
         const unsigned short *bt = lb + (ky & 1) * ST_BT;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[3], fb[2][3];
+            bf16x8 fa[3], fb[ST_NJ][3];
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 fa[q] = *reinterpret_cast<const bf16x8 *>(la + (ky * 3 + q) * ST_APLANE + (a_px + 4 * kk) * 4);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < ST_NJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    fb[j][q] = *reinterpret_cast<const bf16x8 *>(bt + (((2 * kk + fhalf) * 3 + q) * 64 + j * 32 + frow) * 8);
+                    fb[j][q] = *reinterpret_cast<const bf16x8 *>(bt + (((2 * kk + fhalf) * 3 + q) * 64 + wcol + j * 32 + frow) * 8);
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < ST_NJ; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QA[q]], fb[j][QB[q]], acc[j], 0, 0, 0);
         }
         // (... and hoists their LDS stores, with the wait for the loads, in front of the MFMAs.  The stores are therefore made to
         // depend on the accumulators: an empty asm that "produces" one register of each staged vector from them)
-        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2) : "v"(acc[0][0]), "v"(acc[1][0]));
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2) : "v"(acc[0][0]), "v"(acc[ST_NJ - 1][0]));
         if (ky + 1 < 7) {
             unsigned short *nb = lb + ((ky + 1) & 1) * ST_BT;       // last read in iteration ky - 1, before its closing barrier
             reinterpret_cast<u32x4 *>(nb)[tid] = w0;
@@ -172,12 +178,12 @@ __global__ __launch_bounds__(256, 2) void stem7_fwd_kernel(StemParams p)
     // ---- epilogue straight from the accumulators: D layout col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); a
     // store instruction covers two output pixels x 32 channels = two full 128-byte lines
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = j * 32 + frow;
+    for (int j = 0; j < ST_NJ; ++j) {
+        const int col = wcol + j * 32 + frow;
         const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int wo = wo0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            const int wo = wo0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
             if (wo < p.Wo) {
                 float t = acc[j][r] + bv;
                 if (p.relu) t = fmaxf(t, 0.f);
