@@ -28,6 +28,8 @@ struct BfParams {
     int64_t M;
     int mt, nt;
     int cmajor;             // K order: 1 = channel-major (taps of a channel slice back to back), 0 = tap-major
+    int res_H, res_W;       // > 0: residual is a coarser map read through nearest up-sampling (FPN top-down, as conv_x3.hip)
+    float res_sh, res_sw;
 };
 
 __device__ __forceinline__ uint4 keep16(bool ok, uint4 v)
@@ -217,8 +219,23 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 5)) void conv_bf16_kernel(
                 v[u] = *reinterpret_cast<const float4 *>(stage + row * EPI_STRIDE + c4 * 4);
             }
             if (p.residual != nullptr) {
+                int64_t ro[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const uint2 *>(p.residual + o[u]);
+                for (int u = 0; u < UB; ++u) ro[u] = o[u];
+                if (p.res_H > 0) {              // ATen's nearest rule: source = min(floor(dst * in / out), in - 1)
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int row = tid / V + (pass0 + u) * ROWS;
+                        const unsigned mm = (unsigned)(m0 + ((row >> 5) * TM + i) * 32 + (row & 31));
+                        const unsigned wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                        const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                        const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                        ro[u] = ((((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n) & -(int64_t)ok[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const uint2 *>(p.residual + ro[u]);
             }
             if (p.mask != nullptr) {
 #pragma unroll
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 5)) void conv_bf16_kernel(
 // mask [B][Ho][Wo][Co] bf16 or NULL, y [B][Ho][Wo][Co] bf16.  Ci % 32 == 0, Co % 4 == 0.
 static int launch_conv_bf16(const char *what, const void *x, const void *w, const float *bias, const void *residual,
                             const void *mask, void *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
-                            int pad, int dil, int relu, void *stream)
+                            int pad, int dil, int relu, void *stream, int res_h = 0, int res_w = 0)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "%s: bad sizes", what);
@@ -284,6 +301,12 @@ static int launch_conv_bf16(const char *what, const void *x, const void *w, cons
     p.M = (int64_t)B * p.Ho * p.Wo;
     HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && (int64_t)Co * kh * kw * Ci < (1ll << 31) && p.M < (1ll << 31),
                 "%s: operand larger than 2^31 elements", what);
+    if (residual != nullptr && res_h > 0) {
+        HTD_REQUIRE(res_w > 0 && res_h <= p.Ho && res_w <= p.Wo, "%s: up-sampled residual %dx%d larger than the output", what,
+                    res_h, res_w);
+        p.res_H = res_h; p.res_W = res_w;
+        p.res_sh = (float)res_h / (float)p.Ho; p.res_sw = (float)res_w / (float)p.Wo;
+    }
     // 64x64 tiles: below three 128x128 tiles per CU, and for 1x1 layers (a handful of K slices per tile: the wave count,
     // not the tile's arithmetic intensity, decides) up to ~20 per CU.  Measured on the R101 layer set at B = 4:
     // 1x1 256->1024 at 50x84 209 -> 296 TFLOP/s, 1x1 128->512 at 100x168 154 -> 199, 3x3 256 at 50x84 408 -> 427, while
@@ -318,6 +341,16 @@ extern "C" int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bi
 {
     return launch_conv_bf16("conv2d_fwd_bf16", x, w, bias, residual, nullptr, y, B, H, W, Ci, Co, kh, kw, stride, pad, dil,
                             relu, stream);
+}
+
+// The same with the residual read through nearest up-sampling from a coarser map [B][res_h][res_w][Co] (res_h = 0: same
+// size): the FPN top-down sum (necks/fpn.py:177-186) in the lateral convolution's epilogue, one rounding to bf16.
+extern "C" int htd_conv2d_fwd_bf16_up(const void *x, const void *w, const float *bias, const void *residual, int res_h,
+                                      int res_w, void *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+                                      int pad, int dil, int relu, void *stream)
+{
+    return launch_conv_bf16("conv2d_fwd_bf16_up", x, w, bias, residual, nullptr, y, B, H, W, Ci, Co, kh, kw, stride, pad, dil,
+                            relu, stream, res_h, res_w);
 }
 
 // The data-gradient form: gx = (conv(gy, wT) + accum) * (mask_src > 0), all maps bf16; (H, W) are gy's, the conv is

@@ -981,6 +981,52 @@ __global__ __launch_bounds__(256) void upsample_nearest_bwd_kernel(const float4 
 }
 }  // namespace
 
+namespace {
+// The same on bf16 maps (four channels per thread, fp32 sums in the order of the fp32 kernel, one rounding at the end).
+__global__ __launch_bounds__(256) void upsample_nearest_bwd_bf16_kernel(const uint2 *__restrict__ g, uint2 *__restrict__ out, int B,
+                                                                        int H, int W, int h, int w, int C4, float sh, float sw)
+{
+    const int64_t total = (int64_t)B * h * w * C4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        int64_t t = e / C4;
+        const int rw = (int)(t % w);
+        t /= w;
+        const int rh = (int)(t % h), b = (int)(t / h);
+        const int ho0 = max(0, (int)floorf(rh / sh) - 1), ho1 = min(H - 1, (int)ceilf((rh + 1) / sh) + 1);
+        const int wo0 = max(0, (int)floorf(rw / sw) - 1), wo1 = min(W - 1, (int)ceilf((rw + 1) / sw) + 1);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ho = ho0; ho <= ho1; ++ho) {
+            if (min((int)floorf(ho * sh), h - 1) != rh) continue;
+            for (int wo = wo0; wo <= wo1; ++wo) {
+                if (min((int)floorf(wo * sw), w - 1) != rw) continue;
+                const uint2 v = g[(((int64_t)b * H + ho) * W + wo) * C4 + c];
+                acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+                acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+            }
+        }
+        unsigned r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {             // round to nearest even; NaN stays NaN
+            const unsigned u = __float_as_uint(acc[k]);
+            r[k] = (u & 0x7fffffffu) > 0x7f800000u ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        out[e] = make_uint2(r[0] | (r[1] << 16), r[2] | (r[3] << 16));
+    }
+}
+}  // namespace
+
+extern "C" int htd_upsample_nearest_bwd_bf16(const void *g, void *out, int B, int H, int W, int h, int w, int C, void *stream)
+{
+    HTD_REQUIRE(g && out && B > 0 && H > 0 && W > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0,
+                "upsample_nearest_bwd_bf16: bad arguments");
+    const int64_t total = (int64_t)B * h * w * (C / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 65536);
+    hipLaunchKernelGGL(upsample_nearest_bwd_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint2 *)g,
+                       (uint2 *)out, B, H, W, h, w, C / 4, (float)h / (float)H, (float)w / (float)W);
+    return htd::check_launch("upsample_nearest_bwd_bf16");
+}
+
 // g [B][H][W][C] (fine) -> out [B][h][w][C] (coarse); replaces aten::upsample_nearest2d_backward on the FPN top-down path
 extern "C" int htd_upsample_nearest_bwd(const float *g, float *out, int B, int H, int W, int h, int w, int C, void *stream)
 {

@@ -723,7 +723,7 @@ class ResStageFunction(Function):
         return (g, None, None, None, *grads)
 
 
-def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
+def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, res_up=False):
     """Forward-only bf16 convolution (fp32 accumulate, htd_conv2d_fwd_bf16): x (B,Ci,H,W) and weight (Co,Ci,kh,kw)
     bf16 channels_last, bias fp32, residual bf16 -> bf16.  Groundwork for the bf16 configurations; not yet wired into
     the detector (no gradient kernels)."""
@@ -738,6 +738,13 @@ def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=Fals
     y = torch.empty((B, Co, Ho, Wo), device=x.device, dtype=torch.bfloat16, memory_format=CL)
     b = bias.float().contiguous() if bias is not None else None
     res = residual.to(torch.bfloat16).contiguous(memory_format=CL) if residual is not None else None
+    if res_up and res is not None:          # a coarser map added through nearest up-sampling (FPN top-down)
+        if res.size(0) != B or res.size(1) != Co or res.size(2) > Ho or res.size(3) > Wo:
+            raise ValueError('conv2d_bf16: up-sampled residual %s does not fit the output %s' % (tuple(res.shape), tuple(y.shape)))
+        capi.call('htd_conv2d_fwd_bf16_up', _P(x), _P(weight), _P(b), _P(res), res.size(2), res.size(3), _P(y), B, H, W, Ci,
+                  Co, kh, kw, int(stride), int(padding), int(dilation), int(bool(relu)), _S(),
+                  work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
+        return y
     capi.call('htd_conv2d_fwd_bf16', _P(x), _P(weight), _P(b), _P(res), _P(y), B, H, W, Ci, Co, kh, kw, int(stride),
               int(padding), int(dilation), int(bool(relu)), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
     return y
@@ -861,12 +868,13 @@ class Conv2dBf16Function(Function):
     Gradients w.r.t. weight and bias come out in fp32, ready for the flat fp32 gradient buffer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu):
+    def forward(ctx, x, weight, bias, residual, stride, padding, dilation, relu, res_up=False):
         need_wT = ctx.needs_input_grad[0] and stride == 1
         wb, wT = _prep_bf16(weight, need_wT)
-        y = conv2d_bf16(x, wb, bias, stride, padding, dilation, relu, residual)
+        y = conv2d_bf16(x, wb, bias, stride, padding, dilation, relu, residual, res_up)
         ctx.save_for_backward(x, wT if need_wT else wb, y if relu else None)
         ctx.cfg = (stride, padding, dilation, bias is not None, residual is not None, tuple(weight.shape), need_wT)
+        ctx.res_up = tuple(residual.shape) if (res_up and residual is not None) else None
         ctx.master = (weight, bias)                 # the parameters themselves: their gradient sinks are looked up in backward
         return y
 
@@ -897,7 +905,15 @@ class Conv2dBf16Function(Function):
             if has_bias and need_b:
                 gb = _colsum_bf16_raw(g) if g.size(1) % 4 == 0 else \
                     torch.sum(g.permute(0, 2, 3, 1).reshape(-1, g.size(1)), dim=0, dtype=torch.float32)
-        return gx, gw, gb, (g if (has_res and need_r) else None), None, None, None, None
+        gr = None
+        if has_res and need_r:
+            gr = g
+            if ctx.res_up is not None:      # the residual came in through nearest up-sampling: sum the gradient back down
+                rB, rC, rh, rw = ctx.res_up
+                gr = torch.empty((rB, rC, rh, rw), device=g.device, dtype=g.dtype, memory_format=CL)
+                capi.call('htd_upsample_nearest_bwd_bf16', _P(g), _P(gr), rB, g.size(2), g.size(3), rh, rw, rC, _S(),
+                          work=('byte', 2.0 * (g.numel() + gr.numel())))
+        return gx, gw, gb, gr, None, None, None, None, None
 
 
 class ResStageBf16Function(Function):
@@ -1008,9 +1024,11 @@ class ResStageBf16Function(Function):
         return (g, None, None, None, *grads)
 
 
-def conv2d_bf16_autograd(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
-    """Differentiable bf16 convolution with fp32 master parameters (see Conv2dBf16Function)."""
-    return Conv2dBf16Function.apply(x, weight, bias, residual, int(stride), int(padding), int(dilation), bool(relu))
+def conv2d_bf16_autograd(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, residual_up=False):
+    """Differentiable bf16 convolution with fp32 master parameters (see Conv2dBf16Function).  residual_up: the residual is a
+    coarser bf16 map, added through nearest-neighbour up-sampling to the output size."""
+    return Conv2dBf16Function.apply(x, weight, bias, residual, int(stride), int(padding), int(dilation), bool(relu),
+                                    bool(residual_up))
 
 
 def _pad_channels(x, weight, mult=8):

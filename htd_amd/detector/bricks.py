@@ -20,8 +20,7 @@ def dense_conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=Fal
     mixed-precision kernels (bf16 operands, fp32 accumulate, fp32 master parameters and parameter gradients)."""
     from .. import dense
     if x.dtype == torch.bfloat16:
-        assert not residual_up, 'the bf16 kernels take same-size residuals only'
-        y = dense.conv2d_bf16_autograd(x, weight, bias, stride, padding, dilation, relu, residual)
+        y = dense.conv2d_bf16_autograd(x, weight, bias, stride, padding, dilation, relu, residual, residual_up)
         return (y, x) if chain else y                 # no chaining in the bf16 path: the alias is the tensor itself
     return dense.conv2d(x, weight, bias, stride, padding, dilation, relu, residual, residual_up, chain)
 

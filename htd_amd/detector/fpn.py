@@ -1,11 +1,16 @@
 """FPN neck (mmdet/models/necks/fpn.py:9-216): 1x1 laterals, nearest top-down add, 3x3 output convs,
 P6 = stride-2 subsample of P5.  The HTD configs use the plain variant (no extra convs, no norm)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import NECKS
 from .bricks import ConvModule, xavier_init
+
+
+FUSED_TOP_DOWN = os.environ.get('HTD_FPN_FUSED', '1') != '0'      # 0: interpolate + add (A/B runs)
 
 
 @NECKS.register_module()
@@ -42,9 +47,10 @@ class FPN(nn.Module):
 
     def _fused_top_down(self, inputs):
         """Plain lateral convs (no norm / activation) on GPU tensors, nearest up-sampling to the finer level's size."""
-        if not inputs[0].is_cuda or inputs[0].dtype != torch.float32 or \
+        if not inputs[0].is_cuda or inputs[0].dtype not in (torch.float32, torch.bfloat16) or \
+                any(t.dtype != inputs[0].dtype for t in inputs) or \
                 self.upsample_cfg.get('mode', 'nearest') != 'nearest' or \
-                self.out_channels % 4 != 0 or not getattr(self, 'fused_top_down', True):
+                self.out_channels % 4 != 0 or not getattr(self, 'fused_top_down', FUSED_TOP_DOWN):
             return False
         if 'scale_factor' in self.upsample_cfg:      # must land exactly on the finer level's size
             sf = self.upsample_cfg['scale_factor']

@@ -432,6 +432,14 @@ int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, 
  * fp32.  Ci % 32 == 0, Co % 4 == 0. */
 int htd_conv2d_fwd_bf16(const void *x, const void *w, const float *bias, const void *residual, void *y, int B, int H,
                         int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu, void *stream);
+/* htd_conv2d_fwd_bf16 with the residual [B][res_h][res_w][Co] read through nearest up-sampling to the output size
+ * (res_h = 0: a same-size residual): the FPN top-down sum inside the lateral convolution, mmdet necks/fpn.py:177-186
+ * (F.interpolate(..., mode='nearest') + add), for bf16 maps. */
+int htd_conv2d_fwd_bf16_up(const void *x, const void *w, const float *bias, const void *residual, int res_h, int res_w,
+                           void *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                           int relu, void *stream);
+/* htd_upsample_nearest_bwd on bf16 maps (fp32 sums, one rounding). */
+int htd_upsample_nearest_bwd_bf16(const void *g, void *out, int B, int H, int W, int h, int w, int C, void *stream);
 /* The data-gradient form of the bf16 convolution: gx = (conv(gy, wT) + accum) * (mask_src > 0), every map bf16;
  * (H, W) are gy's; stride-1 layers only; wT = the transposed, tap-flipped weights [Ci'][kh][kw][Co'] of
  * htd_weights_prep_bf16 (Ci = channels of gy, Co = channels of gx); pad = dil*(k-1) - layer padding.  mask_src (the

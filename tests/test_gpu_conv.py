@@ -160,6 +160,62 @@ def test_fpn_fused_top_down_matches_interpolate_add():
 
 
 @pytest.mark.gpu
+def test_bf16_fpn_top_down_runs_inside_the_lateral_convolutions():
+    """bf16 maps: the up-sampled residual of htd_conv2d_fwd_bf16_up and htd_upsample_nearest_bwd_bf16 (odd sizes 25 -> 13 ->
+    7) are EXACT on small integers (every sum is representable), and the fused FPN agrees with interpolate + add to the one
+    bf16 rounding the fused form saves."""
+    from htd_amd import capi, dense
+    from htd_amd.detector.fpn import FPN
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    CL = torch.channels_last
+    for (H, W), (h, w) in (((25, 42), (13, 21)), ((13, 21), (7, 11)), ((50, 84), (25, 42))):
+        x = torch.randint(-2, 3, (2, 64, H, W), generator=g).to(dev, torch.bfloat16).contiguous(memory_format=CL)
+        wt = torch.randint(-1, 2, (72, 64, 1, 1), generator=g).to(dev, torch.bfloat16).contiguous(memory_format=CL)
+        b = torch.randint(-3, 4, (72, ), generator=g).float().to(dev)
+        r = torch.randint(-9, 10, (2, 72, h, w), generator=g).to(dev, torch.bfloat16).contiguous(memory_format=CL)
+        y = dense.conv2d_bf16(x, wt, b, 1, 0, 1, False, r, res_up=True)
+        ref = F.conv2d(x.float(), wt.float(), b) + F.interpolate(r.float(), size=(H, W), mode='nearest')
+        assert torch.equal(y.float(), ref)
+        gy = torch.randint(-4, 5, (2, 72, H, W), generator=g).to(dev, torch.bfloat16).contiguous(memory_format=CL)
+        gr = torch.empty((2, 72, h, w), device=dev, dtype=torch.bfloat16).contiguous(memory_format=CL)
+        capi.call('htd_upsample_nearest_bwd_bf16', dense._P(gy), dense._P(gr), 2, H, W, h, w, 72, dense._S())
+        rf = r.float().requires_grad_()
+        F.interpolate(rf, size=(H, W), mode='nearest').backward(gy.float())
+        assert torch.equal(gr.float(), rf.grad)
+    torch.manual_seed(4)
+    fpn = FPN([32, 64, 128, 256], 64, 5).to(dev)
+    fpn.init_weights()
+    sizes = [(50, 84), (25, 42), (13, 21), (7, 11)]
+    xs = [torch.randn(2, c, hh, ww, device=dev).to(torch.bfloat16).contiguous(memory_format=CL).requires_grad_()
+          for c, (hh, ww) in zip([32, 64, 128, 256], sizes)]
+    res = []
+    for fused in (True, False):
+        fpn.fused_top_down = fused
+        fpn.zero_grad()
+        for t in xs:
+            t.grad = None
+        keep = F.interpolate
+        if fused:                       # the fused form must not up-sample anything
+            F.interpolate = None
+        try:
+            outs = fpn(xs)
+        finally:
+            F.interpolate = keep
+        assert all(o.dtype == torch.bfloat16 for o in outs)
+        sum((o.float() * torch.linspace(0.5, 1.5, o.numel(), device=dev).view_as(o)).sum() for o in outs).backward()
+        res.append(([o.detach().float() for o in outs], [t.grad.float() for t in xs],
+                    {n: q.grad.clone() for n, q in fpn.named_parameters()}))
+    (o1, g1, p1), (o2, g2, p2) = res
+    for a, b in zip(o1, o2):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+    for n in p2:
+        torch.testing.assert_close(p1[n], p2[n], rtol=2e-2, atol=2e-2 * float(p2[n].abs().max()), msg=n)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,Ci,H,W,Co,k,stride,pad,relu,with_res', [
     (2, 64, 20, 28, 128, 3, 1, 1, True, False), (1, 256, 13, 17, 256, 1, 1, 0, False, True),
     (2, 96, 15, 15, 72, 3, 2, 1, True, True), (1, 128, 9, 40, 300, 3, 1, 2, False, False)])
