@@ -154,9 +154,21 @@ def call(name, *args, work=None):
     check(status, name)
 
 
+_RAW_STREAM = None
+
+
 def current_stream_ptr():
-    import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The HIP stream torch is issuing on for the current device, as a pointer argument (a few hundred calls per step: the raw
+    query, not a torch.cuda.Stream object per call)."""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+        raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+        if raw is not None:
+            _RAW_STREAM = lambda: raw(torch.cuda.current_device())
+        else:
+            _RAW_STREAM = lambda: torch.cuda.current_stream().cuda_stream
+    return ctypes.c_void_p(_RAW_STREAM())
 
 
 def ptr(t):

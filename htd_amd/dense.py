@@ -157,10 +157,16 @@ def take_flipped(weight):
 _STEP_FLIPS = {}
 
 
+_M = None
+
+
 def _flip_key(w):
     # mmcv_ops.PARAM_EPOCH: the optimizer kernel and the rank-0 broadcast rewrite weights without touching tensor._version
-    from . import mmcv_ops as M
-    return (w.data_ptr(), w._version, tuple(w.shape), M.PARAM_EPOCH)
+    global _M
+    if _M is None:
+        from . import mmcv_ops
+        _M = mmcv_ops
+    return (w.data_ptr(), w._version, tuple(w.shape), _M.PARAM_EPOCH)
 
 
 def new_step():
@@ -206,11 +212,15 @@ def planes_many(items):
     """items: [(weight (Co,Ci,kh,kw) channels_last fp32, transposed)] -> their plane images in ONE launch
     (htd_conv2d_x3_planes_many), registered for x3_planes() to find.  Entries already made this step are skipped."""
     import numpy as np
-    todo = []
+    todo, seen = [], set()
     for w, tr in items:
         w4 = w if w.dim() == 4 else w.view(w.size(0), w.size(1), 1, 1)
-        if _planes_wanted(w4, tr) and _planes_key(w4, tr) not in _STEP_PLANES and not any(_planes_key(w4, tr) == k for k, _, _ in todo):
-            todo.append((_planes_key(w4, tr), w4, tr))
+        if not _planes_wanted(w4, tr):
+            continue
+        key = _planes_key(w4, tr)
+        if key not in _STEP_PLANES and key not in seen:
+            seen.add(key)
+            todo.append((key, w4, tr))
     if not todo:
         return
     L = capi.lib()

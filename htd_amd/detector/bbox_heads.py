@@ -265,7 +265,7 @@ class _RoIHeadLoss(torch.autograd.Function):
         sums = partial.sum(0)                                     # {sum w*CE, #(w > 0), sum bw*SmoothL1, #correct}
         avg = torch.stack([sums[1], num_samples.to(torch.float32).reshape(())]).clamp(min=1.)       # avg_factor of cls, of box / acc
         scale = torch.stack([lw_cls / avg[0], lw_box / avg[1], 100.0 / avg[1]])
-        vals = sums[[0, 2, 3]] * scale                            # loss_cls, loss_bbox, acc
+        vals = torch.stack([sums[0], sums[2], sums[3]]) * scale   # loss_cls, loss_bbox, acc (no index upload: that copy waits)
         loss_cls, loss_bbox, acc = vals[0], vals[1], vals[2:3]
         ctx.save_for_backward(gcls, gbox, scale)
         ctx.mark_non_differentiable(acc)
