@@ -298,9 +298,11 @@ class HTDRoIHead(nn.Module):
         stash = M.RowStash() if (gf is not None and bbox_feats.is_cuda and torch.is_grad_enabled()) else None
         cls_score = head.forward_cls(bbox_feats, feats, rois, self.bbox_head[0].fc_cls, gf, rois_per_img=(n, ) * B,
                                      roi_valid=S1.valid.view(-1), row_stash=stash)
+        t1 = self._static_targets(1, S1)          # needs no count: queued before the host stops for it
+        full = cls_score.new_zeros(cls_score.size(0), 4)
+        nvalid1 = S1.valid.sum()
         npos_ready.synchronize()
         npos = [int(v) for v in npos_host.tolist()]
-        full = cls_score.new_zeros(cls_score.size(0), 4)
         if sum(npos) > 0:
             pos_rows = torch.cat([torch.arange(b * n, b * n + k, device=dev) for b, k in enumerate(npos)])
             pos_rois = torch.index_select(rois, 0, pos_rows)
@@ -310,8 +312,7 @@ class HTDRoIHead(nn.Module):
             bbox_pred = head.forward_reg(pos_feats, enhanced, pos_rois, gf)
             full = full.index_copy(0, pos_rows, bbox_pred)
         # no positive in the whole batch: the regression branch gets no gradient this step (zeros in the flat buffer)
-        t1 = self._static_targets(1, S1)
-        loss1 = self.bbox_head[1].loss(cls_score, full, rois, *t1, num_samples=S1.valid.sum())
+        loss1 = self.bbox_head[1].loss(cls_score, full, rois, *t1, num_samples=nvalid1)
         lw = self.stage_loss_weights[1]
         for name, value in loss1.items():
             losses[f's1.{name}'] = value * lw if 'loss' in name else value
