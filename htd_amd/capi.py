@@ -129,13 +129,15 @@ def profile_end():
     return out
 
 
-def call(name, *args, work=None):
+def call(name, *args, work=None, key=None):
+    """key: the entry point this call is accounted under in the live timing (a variant of an entry point that belongs to the
+    same kernel class, e.g. htd_conv2d_fwd_x3q under htd_conv2d_fwd_x3p); default: its own name."""
     fn = getattr(lib(), name)
-    if _PROFILE is None or _PAUSED or (_ONLY is not None and name not in _ONLY):
+    key = key or name
+    if _PROFILE is None or _PAUSED or (_ONLY is not None and key not in _ONLY):
         check(fn(*args), name)
         return
     import torch
-    key = name
     if _DETAIL:
         key = name + '(' + ','.join(str(a) for a in args if isinstance(a, int) and not isinstance(a, bool)) + ')'
         # which pointer operands are present (residual / mask / accum select epilogue variants): 1 = given, 0 = NULL

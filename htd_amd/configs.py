@@ -101,11 +101,11 @@ def build_htd_detector(depth=50, dcn=False, cfg=None, bf16=False, resnext=False)
     if bf16:
         import os
         import torch
-        from . import dense
         if 'HTD_OVERLAP_WGRAD' not in os.environ:
             # weight gradients on a second stream: +2 % on the fp32 step, -6 % on the bf16 one (R101: 33.3 -> 35.4 ms; its
-            # hundreds of 10-40 us kernels gain nothing from sharing the chip and pay for the cross-stream waits)
-            dense.OVERLAP_WGRAD = False
+            # hundreds of 10-40 us kernels gain nothing from sharing the chip and pay for the cross-stream waits).  A
+            # property of THIS model (runner.Trainer applies it around its steps), not of the process.
+            model.overlap_wgrad = False
         model.backbone.compute_dtype = torch.bfloat16
         for head in model.roi_head.bbox_head:          # the 12544->1024->1024 FC stacks of both stages
             head.compute_dtype = torch.bfloat16

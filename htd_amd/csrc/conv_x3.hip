@@ -114,7 +114,27 @@ struct X3Params {
     int tiles_a, splits_a, sps_a, splits_b, sps_b;
     int64_t m_rem0;
     float *partial;
+    // Activation planes (round 4).  xp: the A operand ALREADY split -- [Ci/16][6][xp_rows] x 16 B, chunk = plane * 2 + half as in
+    // the weight image, row = pixel -- read by conv_x3q_kernel with LDS-DMA (1x1, stride 1 only).  yp: the epilogue also
+    // writes the planes of the final values it stores to y, in the same layout with yp_rows rows per chunk array, for a 1x1
+    // consumer of y (Co % 16 == 0).  Rows >= M of an image are never written and never matter: a 1x1 output row depends on its
+    // own input row only.
+    const uint4 *xp;
+    uint4 *yp;
+    int64_t xp_rows, yp_rows;
 };
+
+// planes of four consecutive channels n .. n + 3 (n % 4 == 0) of row m: 8 bytes into each of the three plane chunks
+__device__ __forceinline__ void emit_planes4(uint4 *yp, int64_t rows, int64_t m, int n, float4 v)
+{
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3x2(v.x, v.y, h0, m0, l0);
+    split3x2(v.z, v.w, h1, m1, l1);
+    char *d = reinterpret_cast<char *>(yp + ((int64_t)(n >> 4) * NCH + ((n >> 3) & 1)) * rows + m) + ((n >> 2) & 1) * 8;
+    *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(d + 2 * rows * 16) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2 *>(d + 4 * rows * 16) = make_uint2(l0, l1);
+}
 
 template <int BM, int KW>
 struct Geo {
@@ -122,6 +142,172 @@ struct Geo {
     static constexpr int PITCH = ((RUN + 1 + 3) / 8) * 8 + 4;     // rows per chunk array: >= RUN + 1 (zero row), = 4 mod 8
     static constexpr int PASSES = (RUN + 63) / 64;                // 64 rows x 4 float4 per pass of the 256 threads
 };
+
+// ---- epilogue (conv_fwd.hip): accumulators through LDS, 16-byte stores along output rows, fused bias / residual / ReLU /
+// producer's ReLU mask (+ the bf16 planes of the stored values for a 1x1 consumer, X3Params::yp).  Shared by conv_x3p_kernel and
+// conv_x3q_kernel.  D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+template <int WGM, int WGN, int TM, int TN, bool MF16, typename Acc>
+__device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *lds, int64_t m0, int n0, bool part, bool region_b,
+                                            int split)
+{
+    constexpr int BN = WGN * TN * 32;
+    constexpr int EPI_STRIDE = BN + 4, EPI_ROWS = WGM * 32;
+    constexpr int RBLK = MF16 ? 16 : 32;
+    constexpr int CB = TN * 32 / RBLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int lrow = MF16 ? (lane & 15) : frow;
+    const int kg = lane >> 4;
+    float *le = reinterpret_cast<float *>(lds);
+    const bool vec_ok = (p.Co & 3) == 0;
+    constexpr int V = BN / 4, RPP = 256 / V;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if constexpr (MF16) {       // D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        le[(wm * 32 + ib * 16 + 4 * kg + r) * EPI_STRIDE + wn * TN * 32 + j * 16 + lrow] = acc[2 * i + ib][j][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    le[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
+                }
+        }
+        __syncthreads();
+        const int c4 = tid % V;
+        const int n = n0 + c4 * 4;
+        constexpr int NPASS = EPI_ROWS / RPP;
+        if (vec_ok && !part && p.res_H == 0) {
+            // The common form (16-byte columns, final values, residual / gradient sum at the output's own resolution): four passes
+            // at a time, every global load of the four issued before the first value is used.  The general loop below tests
+            // five kernel-uniform flags per pass and hipcc turns each into a branch around ONE load, i.e. 8 dependent memory
+            // round trips per thread and row block -- the whole run time of the short-K layers (layer1 conv3: 4 K steps)
+            const bool col_ok = n < p.Co;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+            constexpr int UB = NPASS < 4 ? NPASS : 4;
+#pragma unroll
+            for (int pass0 = 0; pass0 < NPASS; pass0 += UB) {
+                float4 v[UB], rv[UB], mv[UB];
+                int64_t o[UB];
+                bool ok[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int row = tid / V + (pass0 + u) * RPP;
+                    const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+                    ok[u] = m < p.M && col_ok;
+                    o[u] = (m * p.Co + n) & -(int64_t)ok[u];          // rows / columns past the end: element 0, read and dropped
+                    v[u] = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
+                }
+                if (p.residual != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const float4 *>(p.residual + o[u]);
+                }
+                if (p.mask_src != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) mv[u] = *reinterpret_cast<const float4 *>(p.mask_src + o[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { v[u].x += bv.x; v[u].y += bv.y; v[u].z += bv.z; v[u].w += bv.w; }
+                if (p.residual != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) { v[u].x += rv[u].x; v[u].y += rv[u].y; v[u].z += rv[u].z; v[u].w += rv[u].w; }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                    }
+                }
+                if (p.mask_src != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        v[u].x = mv[u].x > 0.f ? v[u].x : 0.f; v[u].y = mv[u].y > 0.f ? v[u].y : 0.f;
+                        v[u].z = mv[u].z > 0.f ? v[u].z : 0.f; v[u].w = mv[u].w > 0.f ? v[u].w : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (ok[u]) *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
+                if (p.yp != nullptr) {           // bf16 planes of the same values for a 1x1 consumer
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int row = tid / V + (pass0 + u) * RPP;
+                        if (ok[u]) emit_planes4(p.yp, p.yp_rows, m0 + ((row >> 5) * TM + i) * 32 + (row & 31), n, v[u]);
+                    }
+                }
+            }
+            if (i + 1 < TM) __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int row = tid / V + pass * RPP;
+            const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+            if (m >= p.M || n >= p.Co) continue;
+            float4 v = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
+            const int64_t o = m * p.Co + n;
+            if (part) {
+                float *dst = region_b ? p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * p.m_rem0 * p.Co : 0) +
+                                            ((int64_t)split * (p.M - p.m_rem0) + (m - p.m_rem0)) * p.Co + n
+                                      : p.partial + ((int64_t)split * p.m_rem0 + m) * p.Co + n;
+                if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
+                else {
+                    dst[0] = v.x;
+                    if (n + 1 < p.Co) dst[1] = v.y;
+                    if (n + 2 < p.Co) dst[2] = v.z;
+                    if (n + 3 < p.Co) dst[3] = v.w;
+                }
+                continue;
+            }
+            if (vec_ok) {
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                }
+                if (p.residual) {
+                    int64_t ro = o;
+                    if (p.res_H > 0) {
+                        const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                        const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                        const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                        ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
+                    }
+                    const float4 rv = *reinterpret_cast<const float4 *>(p.residual + ro);
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.mask_src) {
+                    const float4 mv = *reinterpret_cast<const float4 *>(p.mask_src + o);
+                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
+                    v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(p.y + o) = v;
+                if (p.yp != nullptr) emit_planes4(p.yp, p.yp_rows, m, n, v);
+            } else {
+                auto put = [&](int e, float t) {
+                    if (n + e >= p.Co) return;
+                    t += p.bias ? p.bias[n + e] : 0.f;
+                    if (p.residual) t += p.residual[o + e];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if (p.mask_src) t = p.mask_src[o + e] > 0.f ? t : 0.f;
+                    p.y[o + e] = t;
+                };
+                put(0, v.x); put(1, v.y); put(2, v.z); put(3, v.w);
+            }
+        }
+        if (i + 1 < TM) __syncthreads();
+    }
+}
 
 // MF16: the products run on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  Its 32 k per instruction carry TWO of
 // the six plane products at once -- the lane groups k = 0..15 and k = 16..31 read different planes: [a0|a1].[b0|b1] = a0 b0 +
@@ -565,148 +751,202 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
 #pragma unroll
     for (int i = 0; i < 2 * NPT; ++i) landed(ra[i]);
 
-    // ---- epilogue (conv_fwd.hip): accumulators through LDS, 16-byte stores along output rows, fused bias / residual /
-    // ReLU / producer's ReLU mask.  D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-    float *le = reinterpret_cast<float *>(lds);
-    const bool vec_ok = (p.Co & 3) == 0;
-    constexpr int V = BN / 4, RPP = 256 / V;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        if constexpr (MF16) {       // D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-                for (int j = 0; j < CB; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        le[(wm * 32 + ib * 16 + 4 * kg + r) * EPI_STRIDE + wn * TN * 32 + j * 16 + lrow] = acc[2 * i + ib][j][r];
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    le[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
-                }
-        }
-        __syncthreads();
-        const int c4 = tid % V;
-        const int n = n0 + c4 * 4;
-        constexpr int NPASS = EPI_ROWS / RPP;
-        if (vec_ok && !part && p.res_H == 0) {
-            // The common form (16-byte columns, final values, residual / gradient sum at the output's own resolution): four passes
-            // at a time, every global load of the four issued before the first value is used.  The general loop below tests
-            // five kernel-uniform flags per pass and hipcc turns each into a branch around ONE load, i.e. 8 dependent memory
-            // round trips per thread and row block -- the whole run time of the short-K layers (layer1 conv3: 4 K steps)
-            const bool col_ok = n < p.Co;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(p.bias + n);
-            constexpr int UB = NPASS < 4 ? NPASS : 4;
-#pragma unroll
-            for (int pass0 = 0; pass0 < NPASS; pass0 += UB) {
-                float4 v[UB], rv[UB], mv[UB];
-                int64_t o[UB];
-                bool ok[UB];
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int row = tid / V + (pass0 + u) * RPP;
-                    const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
-                    ok[u] = m < p.M && col_ok;
-                    o[u] = (m * p.Co + n) & -(int64_t)ok[u];          // rows / columns past the end: element 0, read and dropped
-                    v[u] = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
-                }
-                if (p.residual != nullptr) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const float4 *>(p.residual + o[u]);
-                }
-                if (p.mask_src != nullptr) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) mv[u] = *reinterpret_cast<const float4 *>(p.mask_src + o[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u) { v[u].x += bv.x; v[u].y += bv.y; v[u].z += bv.z; v[u].w += bv.w; }
-                if (p.residual != nullptr) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) { v[u].x += rv[u].x; v[u].y += rv[u].y; v[u].z += rv[u].z; v[u].w += rv[u].w; }
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
-                    }
-                }
-                if (p.mask_src != nullptr) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        v[u].x = mv[u].x > 0.f ? v[u].x : 0.f; v[u].y = mv[u].y > 0.f ? v[u].y : 0.f;
-                        v[u].z = mv[u].z > 0.f ? v[u].z : 0.f; v[u].w = mv[u].w > 0.f ? v[u].w : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u)
-                    if (ok[u]) *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
-            }
-            if (i + 1 < TM) __syncthreads();
-            continue;
-        }
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int row = tid / V + pass * RPP;
-            const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
-            if (m >= p.M || n >= p.Co) continue;
-            float4 v = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
-            const int64_t o = m * p.Co + n;
-            if (part) {
-                float *dst = region_b ? p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * p.m_rem0 * p.Co : 0) +
-                                            ((int64_t)split * (p.M - p.m_rem0) + (m - p.m_rem0)) * p.Co + n
-                                      : p.partial + ((int64_t)split * p.m_rem0 + m) * p.Co + n;
-                if (vec_ok) *reinterpret_cast<float4 *>(dst) = v;
-                else {
-                    dst[0] = v.x;
-                    if (n + 1 < p.Co) dst[1] = v.y;
-                    if (n + 2 < p.Co) dst[2] = v.z;
-                    if (n + 3 < p.Co) dst[3] = v.w;
-                }
-                continue;
-            }
-            if (vec_ok) {
-                if (p.bias) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                }
-                if (p.residual) {
-                    int64_t ro = o;
-                    if (p.res_H > 0) {
-                        const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
-                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
-                        const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
-                        const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
-                        ro = (((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n;
-                    }
-                    const float4 rv = *reinterpret_cast<const float4 *>(p.residual + ro);
-                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (p.mask_src) {
-                    const float4 mv = *reinterpret_cast<const float4 *>(p.mask_src + o);
-                    v.x = mv.x > 0.f ? v.x : 0.f; v.y = mv.y > 0.f ? v.y : 0.f;
-                    v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
-                }
-                *reinterpret_cast<float4 *>(p.y + o) = v;
-            } else {
-                auto put = [&](int e, float t) {
-                    if (n + e >= p.Co) return;
-                    t += p.bias ? p.bias[n + e] : 0.f;
-                    if (p.residual) t += p.residual[o + e];
-                    if (p.relu) t = fmaxf(t, 0.f);
-                    if (p.mask_src) t = p.mask_src[o + e] > 0.f ? t : 0.f;
-                    p.y[o + e] = t;
-                };
-                put(0, v.x); put(1, v.y); put(2, v.z); put(3, v.w);
-            }
-        }
-        if (i + 1 < TM) __syncthreads();
+    x3_epilogue<WGM, WGN, TM, TN, MF16>(p, acc, lds, m0, n0, part, region_b, split);
+}
+
+// ---- conv_x3q_kernel (round 4): the 1x1 / stride-1 form with BOTH operands pre-split ------------------------------------
+// conv_x3p_kernel splits its A slices inside the K loop: global -> registers -> three bf16 planes -> ds_write, once per (M tile,
+// N tile) -- an activation of layer3's conv3 (256 -> 1024) is split Co / BN = 8 times, and the loop carries 3.4 vector + 2.3
+// scalar instructions per MFMA and the split's ds_writes next to the fragment reads (matrix pipe 39 % busy on
+// that layer).  Here the producer of the activation map has already written its planes (X3Params::yp of ITS epilogue, or
+// act_planes_kernel): [Ci/16][6][rows] x 16 B, the weight image's layout with pixels for output channels.  A K step then
+// is 6 * (BM + BN) / 64 LDS-DMA instructions dealt round-robin to the four waves, one barrier, the fragment reads and the
+// MFMAs: no vector arithmetic, no staging register, no ds_write in the loop.  NS stages of (A, B) tiles in LDS; the tiles of
+// step s + NS - 1 are issued at the start of step s.  Work plan, tile order, fragment addressing, MFMA order and epilogue are
+// conv_x3p_kernel's (the products and their summation order are the same: the results are bit-identical).
+template <int WGM, int WGN, int TM, int TN, int NS>
+constexpr int x3q_occupancy()
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int main_bytes = NS * NCH * (BM + BN) * 16;
+    constexpr int epi_bytes = WGM * 32 * (BN + 4) * 4;
+    constexpr int by_lds = 163840 / (main_bytes > epi_bytes ? main_bytes : epi_bytes);
+    constexpr int by_regs = TM * TN >= 4 ? 3 : 4;
+    return by_lds < by_regs ? by_lds : by_regs;
+}
+
+template <int WGM, int WGN, int TM, int TN, bool MF16, int NS>
+__global__ __launch_bounds__(256, (x3q_occupancy<WGM, WGN, TM, TN, NS>())) void conv_x3q_kernel(X3Params p)
+{
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int A_VEC = NCH * BM, B_VEC = NCH * BN;             // uint4 per A / B tile: [chunk][row]
+    constexpr int MAIN_VEC = NS * (A_VEC + B_VEC);
+    constexpr int EPI_VEC = WGM * 32 * (BN + 4) / 4;
+    constexpr int LDS_VEC = MAIN_VEC > EPI_VEC ? MAIN_VEC : EPI_VEC;
+    __shared__ uint4 lds[LDS_VEC];
+    uint4 *const lA = lds, *const lB = lds + NS * A_VEC;
+    const unsigned lds_a0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lA;
+    const unsigned lds_b0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lB;
+
+    // tile / K-range of this workgroup: conv_x3p_kernel's decomposition (plan_x3p)
+    int bid = blockIdx.x, split = 0, sps = 0;
+    bool part = false;
+    const bool region_b = bid >= p.tiles_a * p.splits_a;
+    if (region_b) {
+        const int r = bid - p.tiles_a * p.splits_a;
+        bid = p.tiles_a + r / p.splits_b;
+        split = r % p.splits_b;
+        part = p.splits_b > 1;
+        sps = p.sps_b;
+    } else if (p.splits_a > 1) {
+        split = bid % p.splits_a;
+        bid = bid / p.splits_a;
+        part = true;
+        sps = p.sps_a;
+    } else {
+        const int q = p.tiles_a / 8, r = p.tiles_a % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int tile_m = bid / p.nt, tile_n = bid % p.nt;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    constexpr int RBLK = MF16 ? 16 : 32;
+    constexpr int RB = TM * 32 / RBLK, CB = TN * 32 / RBLK;
+    const int lrow = MF16 ? (lane & 15) : frow;
+    const int kg = lane >> 4;
+    // fragment addressing as in conv_x3p_kernel, with BM rows per A chunk array
+    const int a_row = (wm * TM * 32 + lrow) * 16;
+    const int a_c0 = (MF16 ? kg * BM * 16 : fhalf * BM * 16) + a_row;                                  // [a0|a1] / a0
+    const int a_c1 = MF16 ? ((kg >> 1) * 4 + (kg & 1)) * BM * 16 + a_row : 0;                          // [a0|a2]
+    const int b_row = (wn * TN * 32 + lrow) * 16;
+    const int b_c0 = (MF16 ? kg * BN * 16 : fhalf * BN * 16) + b_row;                                  // [b0|b1] / b0
+    const int b_c1 = MF16 ? ((1 - (kg >> 1)) * 2 + (kg & 1)) * BN * 16 + b_row : 0;                    // [b1|b0]
+    const int b_c2 = MF16 ? (((kg >> 1) ? 0 : 4) + (kg & 1)) * BN * 16 + b_row : 0;                    // [b2|b0]
+
+    const int total_steps = p.ncs;                                // kh = kw = 1
+    const int s_begin = part ? split * sps : 0;
+    const int s_end = part ? min(total_steps, s_begin + sps) : total_steps;
+
+    // LDS-DMA instructions of one stage: A tile first (NIA), then the B tile (NIB); instruction idx covers 64 rows of one chunk
+    // array = 1 KiB of LDS; wave w issues idx = w, w + 4, ...
+    constexpr int NIA = NCH * BM / 64, NIB = NCH * BN / 64, NI = NIA + NIB, NIW = (NI + 3) / 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint4 *src[NIW];                                        // the lane's source of the wave's k-th instruction at slice 0
+    unsigned dst[NIW], adv[NIW];                                  // LDS byte offset inside stage 0; source advance per slice
+#pragma unroll
+    for (int k = 0; k < NIW; ++k) {
+        const int idx = wave_u + 4 * k;
+        if (idx < NIA) {
+            const int chunk = idx / (BM / 64), half = idx % (BM / 64);
+            src[k] = p.xp + (int64_t)chunk * p.xp_rows + m0 + half * 64 + lane;
+            dst[k] = lds_a0 + (unsigned)((chunk * BM + half * 64) * 16);
+            adv[k] = (unsigned)(NCH * p.xp_rows);
+        } else {
+            const int j = (idx < NI ? idx : NIA) - NIA, chunk = j / (BN / 64), half = j % (BN / 64);
+            src[k] = p.wp + (int64_t)chunk * p.Cop + n0 + half * 64 + lane;
+            dst[k] = lds_b0 + (unsigned)((chunk * BN + half * 64) * 16);
+            adv[k] = (unsigned)(NCH * p.Cop);
+        }
+    }
+    auto issue = [&](int s, int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NIW; ++k) {
+            const int idx = wave_u + 4 * k;
+            if (NI % 4 != 0 && idx >= NI) continue;
+            const unsigned st = (unsigned)stage * (unsigned)((idx < NIA ? A_VEC : B_VEC) * 16);
+            lds_dma16(src[k] + (int64_t)s * adv[k], dst[k] + st);
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    using acc_t = typename std::conditional<MF16, f32x4, f32x16>::type;
+    acc_t acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < (MF16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+
+    auto mma = [&](int stage) __attribute__((always_inline)) {
+        const char *la = reinterpret_cast<const char *>(lA + stage * A_VEC);
+        const char *lb = reinterpret_cast<const char *>(lB + stage * B_VEC);
+        if constexpr (MF16) {
+            bf16x8 fa01[RB], fa02[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                fa01[i] = *reinterpret_cast<const bf16x8 *>(la + a_c0 + i * 16 * 16);
+                fa02[i] = *reinterpret_cast<const bf16x8 *>(la + a_c1 + i * 16 * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const bf16x8 fb01 = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 16 * 16);
+                const bf16x8 fb10 = *reinterpret_cast<const bf16x8 *>(lb + b_c1 + j * 16 * 16);
+                const bf16x8 fb20 = *reinterpret_cast<const bf16x8 *>(lb + b_c2 + j * 16 * 16);
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {      // smallest terms first (conv_x3p_kernel's order)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa02[i], fb20, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb10, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb01, acc[i][j], 0, 0, 0);
+                }
+            }
+        } else {
+            bf16x8 fa[RB][3], fb[CB][3];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fa[i][q] = *reinterpret_cast<const bf16x8 *>(la + a_c0 + i * 32 * 16 + q * 2 * BM * 16);
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fb[j][q] = *reinterpret_cast<const bf16x8 *>(lb + b_c0 + j * 32 * 16 + q * 2 * BN * 16);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // The tiles of step s + NS - 1 are issued at the start of step s into the stage that step s - 1 read (the barrier at the end
+    // of s - 1 ordered those reads first) and must have landed at the end of step s + NS - 2.  Vector-memory operations retire
+    // in order, so at the end of step s all but this wave's youngest NS - 2 stages must be done: NI / 4 is the least any wave
+    // issues per stage (a wave with one instruction more waits for part of a younger stage too); in the tail, where fewer
+    // stages are outstanding, everything is waited for.  ONE barrier per step.
+    constexpr int KEEP = (NS - 2) * (NI / 4);
+#pragma unroll
+    for (int d = 0; d < NS - 1; ++d)
+        if (s_begin + d < s_end) issue(s_begin + d, d);
+    if (s_begin + NS - 2 < s_end) wait_vm<KEEP>();
+    else wait_vm<0>();
+    lds_barrier();
+    int stage = 0, pstage = NS - 1;
+#pragma unroll 1
+    for (int s = s_begin; s < s_end; ++s) {
+        const bool more = s + NS - 1 < s_end;
+        if (more) issue(s + NS - 1, pstage);
+        mma(stage);
+        if (more) wait_vm<KEEP>();
+        else wait_vm<0>();
+        lds_barrier();               // every wave is done with this step's stage; the next step's is complete
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        pstage = pstage + 1 == NS ? 0 : pstage + 1;
+    }
+    x3_epilogue<WGM, WGN, TM, TN, MF16>(p, acc, lds, m0, n0, part, region_b, split);
 }
 
 // sums the K-range partials of the regions that have them, in range order, and applies the epilogue
@@ -787,6 +1027,7 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_vec_kernel(X3Par
             v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
         }
         *reinterpret_cast<float4 *>(p.y + o) = v;
+        if (p.yp != nullptr) emit_planes4(p.yp, p.yp_rows, (int64_t)m, (int)n, v);
     }
 }
 
@@ -868,6 +1109,33 @@ __global__ __launch_bounds__(256) void x3_planes_many_kernel(const PlanesDesc *_
 }
 
 inline int planes_np(int N) { return (int)htd::ceil_div(N, 128) * 128; }
+
+// fp32 map x [M][C] (NHWC pixels x channels, C % 16 == 0) -> activation planes [C/16][6][rows] x 16 B (X3Params::xp): what a
+// producer's epilogue writes through X3Params::yp, as a pass of its own for maps whose producer is not one of these kernels.
+// One thread per (pixel, 8 channels): two float4 in, three 16-byte chunks out, consecutive lanes = consecutive pixels.
+__global__ __launch_bounds__(256) void act_planes_kernel(const float *__restrict__ x, uint4 *__restrict__ out, int64_t M, int C,
+                                                         int64_t rows)
+{
+    const int c8n = C >> 3;
+    const int64_t total = M * c8n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t m = e % M;
+        const int c8 = (int)(e / M);
+        const float4 a = *reinterpret_cast<const float4 *>(x + m * C + c8 * 8);
+        const float4 b = *reinterpret_cast<const float4 *>(x + m * C + c8 * 8 + 4);
+        unsigned h[4], md[4], l[4];
+        split3x2(a.x, a.y, h[0], md[0], l[0]);
+        split3x2(a.z, a.w, h[1], md[1], l[1]);
+        split3x2(b.x, b.y, h[2], md[2], l[2]);
+        split3x2(b.z, b.w, h[3], md[3], l[3]);
+        uint4 *d = out + ((int64_t)(c8 >> 1) * NCH + (c8 & 1)) * rows + m;
+        d[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        d[2 * rows] = make_uint4(md[0], md[1], md[2], md[3]);
+        d[4 * rows] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+inline int64_t act_rows(int64_t M) { return htd::ceil_div(M, (int64_t)128) * 128; }
 
 // Tile configurations (BM x BN): 0 64x64, 1 128x128, 2 128x64, 3 64x128 -- all 2x2 waves
 struct XCfg { int bm, bn; };
@@ -1065,6 +1333,31 @@ void launch_tile(const X3Params &p, int kw, dim3 grid, hipStream_t s)
     launch_tile_nb<TM, TN, 2>(p, kw, grid, s);
 }
 
+// HTD_X3Q_MFMA=16 / 32, HTD_X3Q_NS=2 / 3 (tune mode re-reads them per call): instruction shape and LDS stages of conv_x3q_kernel
+static const int g_x3q_mfma = getenv("HTD_X3Q_MFMA") ? atoi(getenv("HTD_X3Q_MFMA")) : 0;
+static const int g_x3q_ns = getenv("HTD_X3Q_NS") ? atoi(getenv("HTD_X3Q_NS")) : 0;
+int x3q_env(const char *name, int at_load)
+{
+    if (!g_x3p_tune) return at_load;
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
+template <int TM, int TN>
+void launch_tile_q(const X3Params &p, dim3 grid, hipStream_t s)
+{
+    // defaults: 16x16x32 (the shape conv_x3p_kernel runs its 1x1 layers on, so a plane-fed layer returns the bits of the
+    // fp32-fed one; also the fastest, tools/bench_planes.py) and two LDS stages (three cost a resident workgroup)
+    const int mf = x3q_env("HTD_X3Q_MFMA", g_x3q_mfma), ns = x3q_env("HTD_X3Q_NS", g_x3q_ns);
+    if (mf != 32) {
+        if (ns == 3) hipLaunchKernelGGL((conv_x3q_kernel<2, 2, TM, TN, true, 3>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_x3q_kernel<2, 2, TM, TN, true, 2>), grid, dim3(256), 0, s, p);
+    } else {
+        if (ns == 3) hipLaunchKernelGGL((conv_x3q_kernel<2, 2, TM, TN, false, 3>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_x3q_kernel<2, 2, TM, TN, false, 2>), grid, dim3(256), 0, s, p);
+    }
+}
+
 int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
 {
     const int total_steps = p.ncs * p.kh;
@@ -1078,11 +1371,20 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     p.nt = (int)htd::ceil_div(p.Co, kXCfg[cfg].bn);
     HTD_REQUIRE(pl.grid > 0 && pl.grid < (1ll << 31), "conv2d_x3p: bad grid");
     const dim3 grid((unsigned)pl.grid);
-    switch (cfg) {
-    case 0: launch_tile<1, 1>(p, kw, grid, s); break;
-    case 1: launch_tile<2, 2>(p, kw, grid, s); break;
-    case 2: launch_tile<2, 1>(p, kw, grid, s); break;
-    default: launch_tile<1, 2>(p, kw, grid, s); break;
+    if (p.xp != nullptr) {          // A operand pre-split: conv_x3q_kernel (1x1, stride 1)
+        switch (cfg) {
+        case 0: launch_tile_q<1, 1>(p, grid, s); break;
+        case 1: launch_tile_q<2, 2>(p, grid, s); break;
+        case 2: launch_tile_q<2, 1>(p, grid, s); break;
+        default: launch_tile_q<1, 2>(p, grid, s); break;
+        }
+    } else {
+        switch (cfg) {
+        case 0: launch_tile<1, 1>(p, kw, grid, s); break;
+        case 1: launch_tile<2, 2>(p, kw, grid, s); break;
+        case 2: launch_tile<2, 1>(p, kw, grid, s); break;
+        default: launch_tile<1, 2>(p, kw, grid, s); break;
+        }
     }
     if (pl.partial_floats > 0) {
         const int64_t rows = (p.splits_a > 1 ? p.m_rem0 : 0) + (p.splits_b > 1 ? p.M - p.m_rem0 : 0);
@@ -1190,15 +1492,39 @@ extern "C" int64_t htd_conv2d_x3p_workspace_bytes(int64_t M, int Co, int Ci, int
     return need;
 }
 
-extern "C" int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const float *bias, const float *residual, int res_h,
-                                  int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
-                                  int relu, void *workspace, void *stream)
+// rows per chunk array / bytes of the activation planes of a map with M pixels and C channels (C % 16 == 0)
+extern "C" int64_t htd_act_planes_rows(int64_t M) { return M > 0 ? act_rows(M) : 0; }
+
+extern "C" int64_t htd_act_planes_bytes(int64_t M, int C)
 {
-    HTD_REQUIRE(x && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3p: bad arguments");
-    HTD_REQUIRE(x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3p: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d", Ci,
+    if (M <= 0 || C <= 0 || C % XK != 0) return 0;
+    return (int64_t)(C / XK) * NCH * act_rows(M) * 16;
+}
+
+// planes of the fp32 map x [M][C]: what the convolutions below write through `yplanes` for the values they store to y
+extern "C" int htd_act_planes(const float *x, void *planes, int64_t M, int C, void *stream)
+{
+    HTD_REQUIRE(x && planes && M > 0 && C > 0 && C % XK == 0, "act_planes: bad arguments (C %% 16)");
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(M * (C >> 3), (int64_t)256), 65536);
+    hipLaunchKernelGGL(act_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (uint4 *)planes, M, C, act_rows(M));
+    return htd::check_launch("act_planes");
+}
+
+// htd_conv2d_fwd_x3p with the activation planes of round 4:
+//   xplanes  != NULL: the input map's planes (htd_act_planes layout, M = B*H*W pixels); 1x1 / stride 1 / pad 0 layers only;
+//                     x is then not read and may be NULL (conv_x3q_kernel: both operands by LDS-DMA)
+//   yplanes  != NULL: the planes of y (Co % 16 == 0), written next to y by the same epilogue
+extern "C" int htd_conv2d_fwd_x3q(const float *x, const void *xplanes, const void *wplanes, const float *bias,
+                                  const float *residual, int res_h, int res_w, float *y, void *yplanes, int B, int H, int W, int Ci,
+                                  int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream)
+{
+    HTD_REQUIRE((x || xplanes) && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3q: bad arguments");
+    HTD_REQUIRE(x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3q: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d", Ci,
                 Co, kh, kw, stride, pad);
+    HTD_REQUIRE(!xplanes || (kh == 1 && stride == 1), "conv2d_fwd_x3q: input planes serve 1x1 / stride-1 layers only");
+    HTD_REQUIRE(!yplanes || Co % XK == 0, "conv2d_fwd_x3q: output planes need Co %% 16 == 0 (Co=%d)", Co);
     HTD_REQUIRE((res_h > 0) == (res_w > 0) && res_h >= 0 && (res_h == 0 || ((Co & 3) == 0 && residual)),
-                "conv2d_fwd_x3p: bad residual up-sampling arguments");
+                "conv2d_fwd_x3q: bad residual up-sampling arguments");
     X3Params p{};
     p.x = x; p.wp = (const uint4 *)wplanes; p.bias = bias; p.residual = residual; p.y = y;
     p.Hx = H; p.Wx = W;
@@ -1207,7 +1533,9 @@ extern "C" int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const flo
     p.Ci = Ci; p.Co = Co; p.Cop = planes_np(Co); p.kh = kh; p.stride = stride; p.relu = relu;
     p.M = (int64_t)B * p.Ho * p.Wo;
     p.ncs = Ci / XK;
-    HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.M * Co < (1ll << 40), "conv2d_fwd_x3p: operand too large");
+    p.xp = (const uint4 *)xplanes; p.xp_rows = act_rows(p.M);
+    p.yp = (uint4 *)yplanes; p.yp_rows = act_rows(p.M);
+    HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.M * Co < (1ll << 40), "conv2d_fwd_x3q: operand too large");
     if (res_h > 0) {
         p.res_H = res_h; p.res_W = res_w;
         p.res_sh = (float)res_h / (float)p.Ho; p.res_sw = (float)res_w / (float)p.Wo;
@@ -1215,21 +1543,44 @@ extern "C" int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const flo
     return launch_x3p(p, kw, (hipStream_t)stream, workspace);
 }
 
+extern "C" int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const float *bias, const float *residual, int res_h,
+                                  int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                                  int relu, void *workspace, void *stream)
+{
+    HTD_REQUIRE(x, "conv2d_fwd_x3p: bad arguments");
+    return htd_conv2d_fwd_x3q(x, nullptr, wplanes, bias, residual, res_h, res_w, y, nullptr, B, H, W, Ci, Co, kh, kw, stride, pad,
+                              relu, workspace, stream);
+}
+
 // gx[B][H][W][Ci] from gy[B][Ho][Wo][Co] and the transposed planes of the layer's weights (htd_conv2d_x3_planes(...,
 // transposed = 1)); stride 1 only (kh = 1: pad 0; kh = 3: pad 1).  mask_src / accum as htd_conv2d_bwd_data.
-extern "C" int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, const float *mask_src, const float *accum,
-                                       float *gx, int B, int H, int W, int Ci, int Co, int kh, int kw, int pad, void *workspace,
-                                       void *stream)
+// gyplanes != NULL (1x1 layers): the planes of gy, gy itself is then not read; gxplanes != NULL: the planes of gx (Ci % 16 == 0).
+extern "C" int htd_conv2d_bwd_data_x3q(const float *gy, const void *gyplanes, const void *wplanesT, const float *mask_src,
+                                       const float *accum, float *gx, void *gxplanes, int B, int H, int W, int Ci, int Co, int kh,
+                                       int kw, int pad, void *workspace, void *stream)
 {
-    HTD_REQUIRE(gy && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3p: bad arguments");
-    HTD_REQUIRE(x3p_shape_ok(Co, Ci, kh, kw, 1, pad, 1), "conv2d_bwd_data_x3p: unsupported layer Ci=%d Co=%d k=%dx%d p=%d", Ci, Co,
+    HTD_REQUIRE((gy || gyplanes) && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3q: bad arguments");
+    HTD_REQUIRE(x3p_shape_ok(Co, Ci, kh, kw, 1, pad, 1), "conv2d_bwd_data_x3q: unsupported layer Ci=%d Co=%d k=%dx%d p=%d", Ci, Co,
                 kh, kw, pad);
+    HTD_REQUIRE(!gyplanes || kh == 1, "conv2d_bwd_data_x3q: gradient planes serve 1x1 layers only");
+    HTD_REQUIRE(!gxplanes || Ci % XK == 0, "conv2d_bwd_data_x3q: output planes need Ci %% 16 == 0 (Ci=%d)", Ci);
     X3Params p{};
     p.x = gy; p.wp = (const uint4 *)wplanesT; p.residual = accum; p.mask_src = mask_src; p.y = gx;
     p.Hx = H; p.Wx = W; p.Ho = H; p.Wo = W;          // stride 1, same size
     p.Ci = Co; p.Co = Ci; p.Cop = planes_np(Ci); p.kh = kh; p.stride = 1;
     p.M = (int64_t)B * H * W;
     p.ncs = Co / XK;
-    HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3p: operand too large");
+    p.xp = (const uint4 *)gyplanes; p.xp_rows = act_rows(p.M);
+    p.yp = (uint4 *)gxplanes; p.yp_rows = act_rows(p.M);
+    HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3q: operand too large");
     return launch_x3p(p, kw, (hipStream_t)stream, workspace);
+}
+
+extern "C" int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, const float *mask_src, const float *accum,
+                                       float *gx, int B, int H, int W, int Ci, int Co, int kh, int kw, int pad, void *workspace,
+                                       void *stream)
+{
+    HTD_REQUIRE(gy, "conv2d_bwd_data_x3p: bad arguments");
+    return htd_conv2d_bwd_data_x3q(gy, nullptr, wplanesT, mask_src, accum, gx, nullptr, B, H, W, Ci, Co, kh, kw, pad, workspace,
+                                   stream);
 }

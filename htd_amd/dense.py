@@ -124,6 +124,25 @@ _SIDE = {}
 _SIDE_CONSUMED = set()          # data_ptr of folded weights whose gradient is consumed by _BNFold.backward (side stream)
 
 
+class overlap_wgrad:
+    """`with overlap_wgrad(flag):` -- the weight-gradient stream on / off for the steps of ONE model (runner.Trainer reads
+    the model's `overlap_wgrad` attribute; None keeps the process default), instead of a module global that the
+    construction of a bf16 model would leave switched off for every model built after it."""
+
+    def __init__(self, flag):
+        self.flag = flag
+
+    def __enter__(self):
+        global OVERLAP_WGRAD
+        self.saved = OVERLAP_WGRAD
+        if self.flag is not None:
+            OVERLAP_WGRAD = bool(self.flag)
+
+    def __exit__(self, *exc):
+        global OVERLAP_WGRAD
+        OVERLAP_WGRAD = self.saved
+
+
 def side_stream(device=None):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     s = _SIDE.get(dev)
@@ -299,7 +318,47 @@ def _stem7_ok(x, weight, stride, padding, dilation, residual=None):
             padding == 3 and dilation == 1 and residual is None and capi.lib().htd_conv2d_set_math(-1) == 1)
 
 
-def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu, res_up=False):
+# Activation planes (csrc/conv_x3.hip, conv_x3q_kernel): the 3x3 layer of a bottleneck writes the bf16 planes of its output next
+# to the fp32 map and the 1x1 layer behind it reads both operands by LDS-DMA instead of splitting every element Co / 128 times
+# in its K loop.  Used where the consumer has at least ACT_PLANES_MIN_TILES column tiles of 128 (the split it saves grows
+# with them; the planes cost 6 bytes per element written and 2 more read).  HTD_ACT_PLANES=0 switches them off.
+ACT_PLANES = os.environ.get('HTD_ACT_PLANES', '1') != '0'
+ACT_PLANES_MIN_TILES = int(os.environ.get('HTD_ACT_PLANES_MIN_TILES', '2'))
+
+
+def _act_planes_buf(M, C, device):
+    return torch.empty(capi.lib().htd_act_planes_bytes(M, C) // 4, device=device, dtype=torch.int32)
+
+
+def act_planes(x):
+    """x (B,C,H,W) fp32 channels_last, C % 16 == 0 -> its plane image (htd_act_planes), as a pass of its own."""
+    x = x.contiguous(memory_format=CL)
+    B, C, H, W = x.shape
+    out = _act_planes_buf(B * H * W, C, x.device)
+    capi.call('htd_act_planes', _P(x), _P(out), B * H * W, C, _S(), work=('byte', 10.0 * x.numel()))
+    return out
+
+
+def _planes_pay(w_consumer, transposed=False):
+    """Should the producer of the input of the 1x1 / stride-1 layer with this weight emit planes for it?"""
+    if not ACT_PLANES or w_consumer.dim() != 4 or w_consumer.dtype != torch.float32:
+        return False
+    Co, Ci, kh, kw = w_consumer.shape
+    cred, cout = (Co, Ci) if transposed else (Ci, Co)
+    return kh == 1 and kw == 1 and cred % 16 == 0 and (cout + 127) // 128 >= ACT_PLANES_MIN_TILES and \
+        bool(capi.lib().htd_conv2d_x3p_supported(cred, cout, 1, 1, 1, 0, 1))
+
+
+def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu, res_up=False, x_planes=None, emit=None):
+    """emit = True / False (not None): -> (y, planes), planes = the plane image of y when emit is True and this layer's kernel
+    can write it, else None; x_planes: the planes of x (1x1 / stride-1 layers on conv_x3q_kernel)."""
+    y = _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up, x_planes, bool(emit))
+    if emit is not None:
+        return y if isinstance(y, tuple) else (y, None)
+    return y
+
+
+def _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up, x_planes, emit):
     B, Ci, H, W = x.shape
     Co, Ci_w, kh, kw = weight.shape
     if Ci != Ci_w:
@@ -318,10 +377,18 @@ def _fwd_raw(x, weight, bias, residual, stride, padding, dilation, relu, res_up=
     if _x3p_ok(Ci, Co, kh, kw, stride, padding, dilation, x.dtype):
         nb = capi.lib().htd_conv2d_x3p_workspace_bytes(B * Ho * Wo, Co, Ci, kh, kw)
         ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32) if nb > 0 else None
-        capi.call('htd_conv2d_fwd_x3p', _P(x), _P(x3_planes(weight, False)), _P(bias), _P(residual), rh, rw, _P(y), B, H, W, Ci,
-                  Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
-                  work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
-        return y
+        use_xp = x_planes is not None and kh == 1 and stride == 1
+        yp = _act_planes_buf(B * Ho * Wo, Co, x.device) if (emit and Co % 16 == 0) else None
+        if not use_xp and yp is None:
+            capi.call('htd_conv2d_fwd_x3p', _P(x), _P(x3_planes(weight, False)), _P(bias), _P(residual), rh, rw, _P(y), B, H, W,
+                      Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
+                      work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
+            return y
+        # (algorithmic bytes stay those of the fp32 operands: the planes are this implementation's traffic, not the layer's)
+        capi.call('htd_conv2d_fwd_x3q', _P(x), _P(x_planes) if use_xp else None, _P(x3_planes(weight, False)), _P(bias),
+                  _P(residual), rh, rw, _P(y), _P(yp), B, H, W, Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
+                  key='htd_conv2d_fwd_x3p', work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
+        return (y, yp) if emit else y
     capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), rh, rw, _P(y), B, H, W, Ci, Co, kh, kw, stride,
               padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
               work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
@@ -352,9 +419,17 @@ def _mask_raw(g, y):
     return gm
 
 
-def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, accum=None, wT=None):
+def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, accum=None, wT=None, g_planes=None, emit=None):
     """Data gradient of conv2d(x, weight) for gy = g, optionally + accum and masked by (mask_src > 0).
-    wT: the flipped / transposed image of `weight` when somebody made it already (htd_bn_fold_many_fwd)."""
+    wT: the flipped / transposed image of `weight` when somebody made it already (htd_bn_fold_many_fwd).
+    g_planes: the planes of g (1x1 layers); emit = True / False (not None): -> (gx, planes of gx or None)."""
+    gx = _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, wT, g_planes, bool(emit))
+    if emit is not None:
+        return gx if isinstance(gx, tuple) else (gx, None)
+    return gx
+
+
+def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, wT, g_planes, emit):
     B, Ci, H, W = x_shape
     Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
@@ -364,11 +439,17 @@ def _dgrad_raw(g, weight, x_shape, stride, padding, dilation, mask_src=None, acc
         gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
         nb = capi.lib().htd_conv2d_x3p_workspace_bytes(B * H * W, Ci, Co, kh, kw)
         ws = torch.empty(nb // 4, device=g.device, dtype=torch.float32) if nb > 0 else None
-        capi.call('htd_conv2d_bwd_data_x3p', _P(g), _P(x3_planes(weight, True)), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci,
-                  Co, kh, kw, padding, _P(ws), _S(),
-                  work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
-                        4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None)))))
-        return gx
+        use_gp = g_planes is not None and kh == 1
+        gxp = _act_planes_buf(B * H * W, Ci, g.device) if (emit and Ci % 16 == 0) else None
+        work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
+                4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None))))
+        if not use_gp and gxp is None:
+            capi.call('htd_conv2d_bwd_data_x3p', _P(g), _P(x3_planes(weight, True)), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci,
+                      Co, kh, kw, padding, _P(ws), _S(), work=work)
+            return gx
+        capi.call('htd_conv2d_bwd_data_x3q', _P(g), _P(g_planes) if use_gp else None, _P(x3_planes(weight, True)), _P(mask_src),
+                  _P(accum), _P(gx), _P(gxp), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(), key='htd_conv2d_bwd_data_x3p', work=work)
+        return (gx, gxp) if emit else gx
     gd, Cod = g, Co
     if Co % 8 != 0:      # skinny heads (RPN cls+reg Co=15, fc_cls 81, fc_reg 4): zero-pad the reduction channels
         Cod = Co + (-Co) % 8
@@ -415,10 +496,12 @@ def _wgrad_launch(x, g, weight, stride, padding, dilation, bias):
     return gw, gb, sink_w and sink_b
 
 
-def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None):
+def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None, overlap=True):
     """-> (gw, gbias); gbias = column sums of g from the same launch when `bias` is given (the bias tensor, whose flat
-    gradient slice is then written in place, or True), else None."""
-    if not OVERLAP_WGRAD or (capi.profiling() and not _OVERLAP_IN_PROFILE):
+    gradient slice is then written in place, or True), else None.  overlap=False keeps the launch on the main stream:
+    for a caller that hands `g` itself on to autograd (record_stream guards against reuse of the storage, not against
+    the engine's in-place `add_` into a gradient it owns while the side stream has not read it yet)."""
+    if not overlap or not OVERLAP_WGRAD or (capi.profiling() and not _OVERLAP_IN_PROFILE):
         return _wgrad_launch(x, g, weight, stride, padding, dilation, bias)[:2]
     main, side = torch.cuda.current_stream(), side_stream(g.device)
     side.wait_stream(main)
@@ -483,8 +566,12 @@ class Conv2dFunction(Function):
                             accum=galias.contiguous(memory_format=CL) if fuse else None)
             if galias is not None and not fuse:
                 gx = gx + galias
+        # a same-size residual gets `g` ITSELF as its gradient (below): autograd may then accumulate into that tensor in
+        # place on the main stream, so this layer's weight gradient must not still be reading it on the side stream
+        aliases_g = has_res and need_r and ctx.res_up is None
         if need_w:
-            gw, gb = _wgrad_raw(x, g, weight, stride, padding, dilation, ctx.bias_ref if want_b else None)
+            gw, gb = _wgrad_raw(x, g, weight, stride, padding, dilation, ctx.bias_ref if want_b else None,
+                                overlap=not aliases_g)
         gr = None
         if has_res and need_r:
             gr = g
@@ -660,14 +747,15 @@ class ResStageFunction(Function):
             w1, b1, w2, b2, w3, b3 = params[k:k + 6]
             k += 6
             h1 = _fwd_raw(x, w1, b1, None, 1, 0, 1, True)
-            h2 = _fwd_raw(h1, w2, b2, None, stride, dilation, dilation, True)
+            # conv2 writes the bf16 planes of h2 for conv3 (1x1, Co = 4 x mid: every element of h2 would be split Co / 128 times)
+            h2, h2p = _fwd_raw(h1, w2, b2, None, stride, dilation, dilation, True, emit=_planes_pay(w3))
             if ds:
                 wd, bd = params[k:k + 2]
                 k += 2
                 idn = _fwd_raw(x, wd, bd, None, stride, 0, 1, False)
             else:
                 idn = x
-            out = _fwd_raw(h2, w3, b3, idn, 1, 0, 1, True)
+            out = _fwd_raw(h2, w3, b3, idn, 1, 0, 1, True, x_planes=h2p)
             saved += [x, h1, h2, out]
             x = out
         ctx.save_for_backward(*saved, *params)
@@ -712,7 +800,9 @@ class ResStageFunction(Function):
             else:
                 gb2 = _colsum_raw(gm2)[1] if pneed[3] else None
             grads[k + 3] = gb2 if pneed[3] else None
-            gm1 = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1, wT=flipped[k + 2])
+            # (the planes of gm1 for conv1's data gradient, a 1x1 layer with 4 x mid or more output channels)
+            gm1, gm1p = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1, wT=flipped[k + 2],
+                                   emit=bool(need_x and _planes_pay(w1, True)))
             if pneed[0]:
                 grads[k], gb1 = _wgrad_raw(x, gm1, w1, 1, 0, 1, True if pneed[1] else None)
             else:
@@ -726,7 +816,8 @@ class ResStageFunction(Function):
                 grads[k + 7] = gb3 if pneed[7] else None
                 acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1, wT=flipped[k + 6]) if need_x else None
             if need_x:
-                g = _dgrad_raw(gm1, w1, x.shape, 1, 0, 1, mask_src=None if first else x, accum=acc, wT=flipped[k])
+                g = _dgrad_raw(gm1, w1, x.shape, 1, 0, 1, mask_src=None if first else x, accum=acc, wT=flipped[k],
+                               g_planes=gm1p)
                 premasked = not first
             else:
                 g = None

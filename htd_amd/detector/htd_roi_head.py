@@ -325,6 +325,8 @@ class HTDRoIHead(nn.Module):
     def _batched_test_ok(self, rois, img_metas, rescale):
         if not (self.batched_test and rois.is_cuda and len(img_metas) > 1):
             return False
+        if not all(getattr(h, 'with_reg', False) for h in self.bbox_head):
+            return False                                            # get_bboxes without deltas clips by scalar img_shape
         if dict(self.test_cfg.nms).get('type', 'nms') != 'nms':
             return False                                            # soft-NMS decays sequentially per class: per image
         kinds = {isinstance(m['scale_factor'], float) for m in img_metas}

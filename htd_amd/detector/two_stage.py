@@ -38,6 +38,7 @@ class BaseDetector(nn.Module):
                 raise TypeError(f'{name} must be a list, but got {type(var)}')
         if len(imgs) != len(img_metas):
             raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        self._drop_step_caches(imgs[0])
         for img, img_meta in zip(imgs, img_metas):
             for m in img_meta:
                 m['batch_intput_shape'] = tuple(img.size()[-2:])
@@ -231,8 +232,18 @@ class TwoStageDetector(BaseDetector):
             self._plain_weight_list = ws
         return ws
 
+    @staticmethod
+    def _drop_step_caches(img):
+        """A test pass with autograd ENABLED folds BN into fresh weight tensors on every call (the training branch of
+        frozen_bn_fold_many); their plane / flipped images are keyed by those tensors and would pile up in dense's per-step
+        caches, one backbone of weights per call.  Under no_grad the folded weights are cached and so are their images."""
+        if img.is_cuda and torch.is_grad_enabled():
+            from .. import dense
+            dense.new_step()
+
     def simple_test(self, img, img_metas, proposals=None, rescale=False):
         assert self.with_bbox, 'Bbox head must be implemented.'
+        self._drop_step_caches(img)
         x = self.extract_feat(img)
         proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
         x32 = x if x[0].dtype == torch.float32 else tuple(f.float() for f in x)

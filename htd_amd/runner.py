@@ -355,14 +355,14 @@ class Trainer:
     def train_step(self, data):
         self.flat.zero_grad()
         self.exchange.begin_step()
-        out = self.model.train_step(data, None)
-        out['loss'].backward()
+        with dense.overlap_wgrad(getattr(self.model, 'overlap_wgrad', None)):
+            out = self.model.train_step(data, None)
+            out['loss'].backward()
         self.exchange.finish_step()
         self.lr_dev.fill_(self.schedule.lr(self.iter))
         if self.flat.flat.is_cuda:
             M.sgd_momentum_step_(self.flat.flat, self.flat.grad, self.flat.momentum, self.lr_dev, self.momentum,
                                  self.weight_decay, grad_scale=1.0 / self.exchange.world)
-            from . import dense
             dense.new_step()        # the kernel rewrote the weights in place: this step's flipped images are stale
         else:   # gloo / CPU rehearsal of the distributed logic only (tests): same arithmetic in torch
             g = self.flat.grad / self.exchange.world + self.weight_decay * self.flat.flat

@@ -285,6 +285,26 @@ int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const float *bias, c
 int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, const float *mask_src, const float *accum,
                             float *gx, int B, int H, int W, int Ci, int Co, int kh, int kw, int pad, void *workspace,
                             void *stream);
+/* Round 4: ACTIVATION planes.  A 1x1 / stride-1 layer splits every input element Co / 128 times inside its K loop (8 x for
+ * layer3's conv3, backbones/resnet.py:260-300 -- cuDNN's role there); the layer that PRODUCES the map can write its three bf16
+ * planes once, next to the fp32 values, from the epilogue that already holds them.
+ *   layout: [C/16][3 planes x 2 halves][rows][8 bf16], rows = htd_act_planes_rows(M) = M rounded up to 128 (M = B*H*W pixels),
+ *       htd_act_planes_bytes(M, C) bytes, caller-owned (1.5 x the fp32 map); rows >= M are never written and never matter.
+ *   htd_act_planes: the planes of an fp32 NHWC map as a pass of its own (maps whose producer is not one of these kernels).
+ *   htd_conv2d_fwd_x3q / htd_conv2d_bwd_data_x3q = htd_conv2d_fwd_x3p / htd_conv2d_bwd_data_x3p plus two optional operands:
+ *       xplanes / gyplanes != NULL (1x1, stride 1 only): the input map's planes; the fp32 input is then not read and may be
+ *           NULL -- both operands reach LDS by DMA, no split in the loop (conv_x3q_kernel); same products in the same order,
+ *           so the result equals the fp32-input call bit for bit;
+ *       yplanes / gxplanes != NULL (output channels % 16 == 0): the planes of the values stored to y / gx. */
+int64_t htd_act_planes_rows(int64_t M);
+int64_t htd_act_planes_bytes(int64_t M, int C);
+int htd_act_planes(const float *x, void *planes, int64_t M, int C, void *stream);
+int htd_conv2d_fwd_x3q(const float *x, const void *xplanes, const void *wplanes, const float *bias, const float *residual,
+                       int res_h, int res_w, float *y, void *yplanes, int B, int H, int W, int Ci, int Co, int kh, int kw,
+                       int stride, int pad, int relu, void *workspace, void *stream);
+int htd_conv2d_bwd_data_x3q(const float *gy, const void *gyplanes, const void *wplanesT, const float *mask_src,
+                            const float *accum, float *gx, void *gxplanes, int B, int H, int W, int Ci, int Co, int kh, int kw,
+                            int pad, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Deformable convolution v1 / v2 (mask == NULL => v1 = the 'DCN' the HTD config uses,

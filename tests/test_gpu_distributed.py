@@ -75,16 +75,20 @@ def test_trainer_world2_on_gpu():
 
 
 @pytest.mark.gpu
-def test_weight_gradient_stream_gives_identical_step():
+@pytest.mark.parametrize('dcn', [False, True])
+def test_weight_gradient_stream_gives_identical_step(dcn):
     """dense.OVERLAP_WGRAD queues weight gradients on a second HIP stream; one optimizer step must leave the parameters of
     the single-stream run BIT FOR BIT (same kernels, same order per tensor; since round 3 no kernel of the step sums with float
-    atomics -- tools/repro_diag.py: 0 of 74.4 M gradient elements differ between two runs of a step)."""
+    atomics -- tools/repro_diag.py: 0 of 74.4 M gradient elements differ between two runs of a step).  dcn=True: the
+    stages with deformable layers run block by block through Conv2dFunction (resnet.py), whose same-size residual hands
+    its incoming gradient tensor on to autograd -- that layer's weight gradient must then stay on the main stream
+    (the engine may accumulate into the tensor in place while the side stream still reads it)."""
     import copy
     from htd_amd import dense
     from htd_amd.configs import build_htd_detector, htd_config
     from htd_amd.runner import Trainer, synthetic_batch
     dev = torch.device('cuda:0')
-    cfg = htd_config(50)
+    cfg = htd_config(50, dcn)
     cfg.train_cfg.rpn_proposal.update(nms_pre=300, nms_post=200, max_num=200)
     for r in cfg.train_cfg.rcnn:
         r.sampler.num = 64
