@@ -55,6 +55,8 @@ def parse():
     ap.add_argument('--trained-like', action='store_true', help='force 128 stage-2 positives per image (what a trained '
                     'detector yields) so the HTD regression branch (1.24 GFLOP per positive RoI) is inside the timed region; '
                     'random-init weights give ~6 per image')
+    ap.add_argument('--trained-like-steps', type=int, default=8, help='after the timed region: this many more timed steps with '
+                    'trained-like proposals, reported as config.trained_like (0 = skip)')
     ap.add_argument('--cpu-baseline-full', action='store_true', help='ONLY the CPU baseline, by the BASELINE.md section 3 protocol '
                     '(3 warm-up + 10 timed steps, B=4 @ 800x1344); prints its JSON object; no GPU needed')
     ap.add_argument('--dry-launch', action='store_true', help='launcher rehearsal on CPU: ranks rendezvous over gloo, take the '
@@ -306,6 +308,10 @@ def main():
         'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_fwd_x3p', 'htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_weight',
         'htd_bgemm_nt', 'htd_conv2d_fwd_bf16',
         'htd_conv2d_dgrad_bf16', 'htd_conv2d_bwd_weight_bf16'))
+    exchange = getattr(trainer, 'exchange', None)
+    if exchange is not None:
+        exchange.stats_begin()
+    npos_headline = None
     t0 = time.perf_counter()
     for i in range(args.steps):
         # kernel events on every 4th step of the timed region (all steps with --profile-kernels): their queue
@@ -316,10 +322,43 @@ def main():
     elapsed = time.perf_counter() - t0
     print(f'# timed region: {elapsed:.3f} s for {args.steps} steps', file=sys.stderr)
     prof = capi.profile_end()
+    comm = exchange.stats() if exchange is not None else None
+    if not args.infer and hasattr(model.roi_head, '_last_static'):
+        npos_headline = int(model.roi_head._last_static[1].npos.sum())
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
+        gathered = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([elapsed], device=dev, dtype=torch.float64))
+        rank_ms = [round(float(g) / args.steps * 1e3, 3) for g in gathered]
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+
+    # ---- the HTD workload a TRAINED detector sees, inside the same driver-timed process: with random-init
+    # weights stage 2 samples ~28 positives per batch and the regression branch (htd_bbox_head.py:77-113, 1.24 GFLOP per
+    # positive RoI) all but vanishes from the step above.  A few more steps with jittered gt boxes injected into the proposal
+    # lists (both stages then sample their 128 positives per image); reported beside the headline, never as `value`.
+    trained = None
+    if not args.infer and not args.trained_like and args.trained_like_steps > 0:
+        trained_like_proposals(model, data, args.batch)
+        for _ in range(2):
+            trainer.train_step(data)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.trained_like_steps):
+            trainer.train_step(data)
+        sync()
+        el = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        npos_t = int(model.roi_head._last_static[1].npos.sum()) if hasattr(model.roi_head, '_last_static') else None
+        trained = dict(img_s=round(args.batch * n_ranks * args.trained_like_steps / el, 3),
+                       ms_per_step=round(el / args.trained_like_steps * 1e3, 3), steps=args.trained_like_steps, warmup=2,
+                       stage2_positives=npos_t, reg_branch_gflop=round(npos_t * 1.2355, 1) if npos_t is not None else None,
+                       proposals='jittered gt boxes injected into the last 600 proposal slots of every image: 128 positives / '
+                                 'image / stage (bench.py trained_like_proposals)')
     if rank != 0:
         return
     ms = elapsed / args.steps * 1e3
@@ -384,11 +423,21 @@ def main():
     if not args.infer and hasattr(model.roi_head, '_last_static'):
         # how much of the HTD regression branch (3x3 256->576->576->576->1024 on 7x7, htd_bbox_head.py:77-113) the timed
         # step contained: it runs on stage-2 positives only (1.2355 GFLOP forward per positive RoI)
-        npos = int(model.roi_head._last_static[1].npos.sum())
+        npos = npos_headline
         out['config']['stage2_positives'] = npos
         out['config']['reg_branch_gflop'] = round(npos * 1.2355, 1)
         out['config']['proposals'] = 'trained-like (jittered gt boxes injected: 128 positives/img/stage)' if args.trained_like \
             else 'random-init RPN (few positives: the regression branch is nearly idle)'
+    if trained is not None:
+        out['config']['trained_like'] = trained
+    if world > 1 or comm is not None:
+        # what RCCL saw and what the exchange cost, so that a sub-linear point of the scaling curve can be attributed
+        try:
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        out['comm'] = dict(comm or {}, rccl_version=ver, process_group_ranks=n_ranks)
+        out['ms_per_step_per_rank'] = rank_ms
     if world == 1 and not args.no_cpu_baseline and not args.infer:
         out['cpu_baseline'] = cpu_baseline(args.depth, args.height, args.width, dcn=args.dcn)
     print(json.dumps(out))

@@ -46,6 +46,110 @@ __device__ __forceinline__ unsigned short f2bf(float f)      // round to nearest
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+// epilogue through an fp32 LDS stage: full output rows, 4 channels (8 bytes of bf16) per lane; bias / residual (optionally through
+// nearest up-sampling) / ReLU / producer's ReLU mask, one rounding to bf16.  Shared by conv_bf16_kernel and conv_bf16q_kernel
+// (2 x 2 waves, each TM x TN MFMA blocks of 32 x 32).
+template <int TM, int TN, typename Acc>
+__device__ __forceinline__ void bf16_epilogue(const BfParams &p, Acc &acc, unsigned char *smem, int64_t m0, int n0)
+{
+    constexpr int WGN = 2, BN = 2 * TN * 32;
+    constexpr int EPI_STRIDE = BN + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    float *stage = reinterpret_cast<float *>(smem);
+    constexpr int V = BN / 4, ROWS = 256 / V;                   // 32 quads per row, 8 rows per pass
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                stage[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
+            }
+        __syncthreads();
+        const int c4 = tid % V;
+        const int n = n0 + c4 * 4;
+        // four row passes at a time, their residual / mask loads issued before the first value is used (one flag test per
+        // batch instead of a branch around every single load: conv_x3.hip, epilogue)
+        const bool col_ok = n < p.Co;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(p.bias + n);
+        constexpr int NPASS = 64 / ROWS, UB = NPASS < 4 ? NPASS : 4;
+#pragma unroll
+        for (int pass0 = 0; pass0 < NPASS; pass0 += UB) {
+            float4 v[UB];
+            uint2 rv[UB], mv[UB];
+            int64_t o[UB];
+            bool ok[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int row = tid / V + (pass0 + u) * ROWS;
+                const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
+                ok[u] = m < p.M && col_ok;
+                o[u] = (m * p.Co + n) & -(int64_t)ok[u];              // rows / columns past the end: element 0, read and dropped
+                v[u] = *reinterpret_cast<const float4 *>(stage + row * EPI_STRIDE + c4 * 4);
+            }
+            if (p.residual != nullptr) {
+                int64_t ro[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) ro[u] = o[u];
+                if (p.res_H > 0) {              // ATen's nearest rule: source = min(floor(dst * in / out), in - 1)
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int row = tid / V + (pass0 + u) * ROWS;
+                        const unsigned mm = (unsigned)(m0 + ((row >> 5) * TM + i) * 32 + (row & 31));
+                        const unsigned wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+                        const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
+                        const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
+                        ro[u] = ((((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n) & -(int64_t)ok[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const uint2 *>(p.residual + ro[u]);
+            }
+            if (p.mask != nullptr) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) mv[u] = *reinterpret_cast<const uint2 *>(p.mask + o[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { v[u].x += bv.x; v[u].y += bv.y; v[u].z += bv.z; v[u].w += bv.w; }
+            if (p.residual != nullptr) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    v[u].x += bf2f((unsigned short)(rv[u].x & 0xffffu)); v[u].y += bf2f((unsigned short)(rv[u].x >> 16));
+                    v[u].z += bf2f((unsigned short)(rv[u].y & 0xffffu)); v[u].w += bf2f((unsigned short)(rv[u].y >> 16));
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
+                }
+            }
+            if (p.mask != nullptr) {            // ReLU backward of the layer that produced this map: keep where it was > 0
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    v[u].x = bf2f((unsigned short)(mv[u].x & 0xffffu)) > 0.f ? v[u].x : 0.f;
+                    v[u].y = bf2f((unsigned short)(mv[u].x >> 16)) > 0.f ? v[u].y : 0.f;
+                    v[u].z = bf2f((unsigned short)(mv[u].y & 0xffffu)) > 0.f ? v[u].z : 0.f;
+                    v[u].w = bf2f((unsigned short)(mv[u].y >> 16)) > 0.f ? v[u].w : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                uint2 ov;
+                ov.x = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
+                ov.y = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
+                if (ok[u]) *reinterpret_cast<uint2 *>(p.y + o[u]) = ov;
+            }
+        }
+        if (i + 1 < TM) __syncthreads();
+    }
+}
+
 // 4 waves (2x2), each wave TM x TN MFMA blocks of 32x32: 128x128 tiles (TM = TN = 2) for layers that fill the chip,
 // 64x64 tiles (TM = TN = 1) for the small ones -- with one 128x128 workgroup per CU there is a single wave per SIMD and
 // the global->LDS staging latency of every K slice is exposed; four small workgroups per CU hide it.
@@ -183,98 +287,271 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 5)) void conv_bf16_kernel(
         __syncthreads();
     }
 
-    // epilogue through an fp32 LDS stage: full output rows, 4 channels (8 bytes of bf16) per lane
-    float *stage = reinterpret_cast<float *>(smem);
-    constexpr int V = BN / 4, ROWS = 256 / V;                   // 32 quads per row, 8 rows per pass
+    bf16_epilogue<TM, TN>(p, acc, smem, m0, n0);
+}
+
+// ---- conv_bf16q_kernel (round 4): both operands by LDS-DMA, swizzled row images, a ring of tiles in flight ------------------
+// conv_bf16_kernel stages a K slice global -> registers -> ds_write behind two barriers with ONE slice of prefetch: on the
+// small layers of the bf16 configurations (layer3 / layer4 of R101: 24-52 us launches that need ~5 us at either roof,
+// VERDICT r03) every slice waits for its own loads.  Here
+//   * a K step is 64 channels of one filter tap = 128 bytes of every operand row: eight lanes fetch a row's eight 16-byte
+//     chunks with global_load_lds_dwordx4, so a wave instruction moves 8 whole rows (1 KiB, whole cache lines), straight from
+//     the NHWC map / the KRSC weights -- no repacked operand exists;
+//   * the LDS image is row-major with 128-byte rows.  LDS-DMA fixes the destination (base + 16 lane), so the XOR swizzle
+//     that makes the ds_read_b128 fragment reads conflict-free is applied to the SOURCE: slot s of row j holds chunk
+//     s ^ ((j >> 1) & 7); with the read-side XOR the 16 lanes of a ds_read_b128 group (rows distinct mod 16) hit 16 distinct
+//     16-byte slots of the 256-byte bank row (cdna_hip_programming.md T2);
+//   * 3x3 / stride-1 layers stage a HALO RUN per (channel slice, filter row) as conv_x3p_kernel does: BM + 2 consecutive input
+//     pixels serve the three taps of the row at row shifts 0 / 1 / 2; a lane whose tap falls outside the map reads the zero row;
+//   * NS weight tiles (1x1: NS (A, B) tile pairs) are in flight: the tile of tap t + NS - 1 is issued at the start of tap t
+//     and waited for with a counted s_waitcnt vmcnt at the end of tap t + NS - 2; ONE raw s_barrier per tap.
+template <int TM, int TN, int KW, int NS>
+constexpr int bf16q_occupancy()
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN, RUN = BM + KW - 1;
+    constexpr int a_rows = ((RUN + 7) / 8) * 8 + 8;
+    constexpr int main_bytes = (KW > 1 ? 2 : NS) * a_rows * 128 + NS * BN * 128;
+    constexpr int epi_bytes = 64 * (BN + 4) * 4;
+    constexpr int by_lds = 163840 / (main_bytes > epi_bytes ? main_bytes : epi_bytes);
+    constexpr int by_regs = TM * TN >= 4 ? 3 : 5;
+    return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
+}
+
+template <int N>
+__device__ __forceinline__ void q_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS-DMA of 64 x 16 bytes (conv_x3.hip): lane l's 16 bytes at `src` go to LDS byte address lds_dst + 16 l
+__device__ __forceinline__ void q_lds_dma16(const void *src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int TM, int TN, int KW, int NS>
+__global__ __launch_bounds__(256, (bf16q_occupancy<TM, TN, KW, NS>())) void conv_bf16q_kernel(BfParams p)
+{
+    constexpr int WGN = 2, BM = 64 * TM, BN = 64 * TN;
+    constexpr int RUN = BM + KW - 1;                              // staged rows of a step
+    constexpr int AI = (RUN + 7) / 8, BI = BN / 8;                // LDS-DMA instructions per A run / B tile (8 rows each)
+    constexpr int A_ROWS = AI * 8 + 8;                            // + one block whose first row is the zero row
+    constexpr int NSA = KW > 1 ? 2 : NS;                          // A buffers: per step (3x3) or per tap (1x1)
+    constexpr int A_BYTES = A_ROWS * 128, B_BYTES = BN * 128;
+    constexpr int MAIN_BYTES = NSA * A_BYTES + NS * B_BYTES;
+    constexpr int EPI_BYTES = 64 * (BN + 4) * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+    const unsigned lds_a0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)smem;
+    const unsigned lds_b0 = lds_a0 + NSA * A_BYTES;
+    constexpr int PADX = (KW - 1) / 2;
+    constexpr int D = NS - 1;                                     // prefetch distance in taps
+
+    const int nblk = p.mt * p.nt;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.nt, tile_n = bid % p.nt;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int PADY = (p.kh - 1) / 2;
+    const int ncs = p.Ci / 64;
+
+    // ---- DMA sources.  Instruction q of a tile covers rows 8 q .. 8 q + 7; lane l: row r = l >> 3, slot l & 7, which takes
+    // chunk (l & 7) ^ ((row >> 1) & 7) of the row's 128 bytes.  Wave w issues q = w, w + 4, ...
+    const int dr = lane >> 3, ds = lane & 7;
+    constexpr int NAW = (AI + 3) / 4, NBW = BI / 4;
+    // A: element offset of the lane's chunk at channel slice 0 (1x1: the decoded input pixel; 3x3: pixel m0 - 1 + row, may be
+    // negative -- validated per filter row), kept as a pixel index for the halo form
+    int a_pix[NAW];
+    unsigned a_chunk[NAW];
+    bool a_in[NAW];
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) {
+        const int q = wave_u + 4 * k, j = 8 * q + dr;
+        a_chunk[k] = (unsigned)((ds ^ ((j >> 1) & 7)) * 8);
+        if constexpr (KW > 1) {
+            a_pix[k] = (int)m0 - PADX + j;
+            a_in[k] = q < AI;
+        } else {
+            const int64_t m = m0 + j;
+            a_in[k] = q < AI && m < p.M;
+            const unsigned mm = a_in[k] ? (unsigned)m : 0u;
+            const unsigned wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+            const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+            a_pix[k] = (int)((b * (unsigned)p.H + ho * (unsigned)p.stride) * (unsigned)p.W + wo * (unsigned)p.stride);
+        }
+    }
+    const int Min = p.B * p.H * p.W;                              // input pixels (== M for the 3x3 / stride-1 form)
+    auto issue_a = [&](int cs, int ky, int buf) __attribute__((always_inline)) {
+        const int shift = KW > 1 ? (ky - PADY) * p.W : 0;
+#pragma unroll
+        for (int k = 0; k < NAW; ++k) {
+            const int q = wave_u + 4 * k;
+            if (AI % 4 != 0 && q >= AI) continue;
+            const int g = a_pix[k] + shift;
+            const bool ok = KW > 1 ? (unsigned)g < (unsigned)Min : a_in[k];
+            const unsigned off = ok ? (unsigned)g * (unsigned)p.Ci + (unsigned)(cs * 64) + a_chunk[k] : 0u;   // not valid: element 0, never used unmasked
+            q_lds_dma16(p.x + off, lds_a0 + (unsigned)(buf * A_BYTES + q * 1024));
+        }
+    };
+    // B: row n0 + 8 q + r of the KRSC weights (rows past Co: the last row, columns never stored)
+    const unsigned wrow = (unsigned)(p.kh * p.kw * p.Ci);
+    unsigned b_off[NBW];
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+        const int q = wave_u + 4 * k, j = 8 * q + dr;
+        const int n = min(n0 + j, p.Co - 1);
+        b_off[k] = (unsigned)n * wrow + (unsigned)((ds ^ ((j >> 1) & 7)) * 8);
+    }
+    auto issue_b = [&](int cs, int tap, int buf) __attribute__((always_inline)) {
+        const unsigned koff = (unsigned)(tap * p.Ci + cs * 64);
+#pragma unroll
+        for (int k = 0; k < NBW; ++k)
+            q_lds_dma16(p.w + b_off[k] + koff, lds_b0 + (unsigned)(buf * B_BYTES + (wave_u + 4 * k) * 1024));
+    };
+
+    // ---- per-lane tap validity of the MFMA rows (halo form): bit ky * KW + kx of vmask[i] for row block i
+    unsigned vmask[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        vmask[i] = 0xffffffffu;
+        if constexpr (KW > 1) {
+            const int64_t m = m0 + wm * TM * 32 + i * 32 + frow;
+            const unsigned mm = m < p.M ? (unsigned)m : 0u;
+            const int xx = (int)(mm % (unsigned)p.W), yy = (int)((mm / (unsigned)p.W) % (unsigned)p.H);
+            unsigned v = 0u;
+            for (int ky = 0; ky < p.kh; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    const bool ok = m < p.M && (unsigned)(yy + ky - PADY) < (unsigned)p.H && (unsigned)(xx + kx - PADX) < (unsigned)p.W;
+                    v |= ok ? (1u << (ky * KW + kx)) : 0u;
+                }
+            vmask[i] = v;
+        }
+    }
+    // zero rows of the A buffers (row AI * 8: no DMA instruction reaches it)
+    if (tid < NSA * 8) *reinterpret_cast<uint4 *>(smem + (tid >> 3) * A_BYTES + AI * 8 * 128 + (tid & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+    // fragment addressing: lane row, K half fhalf; step kk of a tap reads chunk 2 kk + fhalf at slot chunk ^ ((row >> 1) & 7)
+    const int a_j0 = wm * TM * 32 + frow;                          // the lane's row of block 0 in the run at tap shift 0
+    const int b_j = wn * TN * 32 + frow;
+    const int b_key = (b_j >> 1) & 7;                             // (+ 32 rows per block: the key does not change)
+    int b_addr[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) b_addr[kk] = b_j * 128 + (((2 * kk + fhalf) ^ b_key) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                stage[row * EPI_STRIDE + (wn * TN + j) * 32 + frow] = acc[i][j][r];
-            }
-        __syncthreads();
-        const int c4 = tid % V;
-        const int n = n0 + c4 * 4;
-        // four row passes at a time, their residual / mask loads issued before the first value is used (one flag test per
-        // batch instead of a branch around every single load: conv_x3.hip, epilogue)
-        const bool col_ok = n < p.Co;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const float4 *>(p.bias + n);
-        constexpr int NPASS = 64 / ROWS, UB = NPASS < 4 ? NPASS : 4;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mma_tap = [&](int abuf, int bbuf, int kx, int tap0) __attribute__((always_inline)) {
+        const unsigned char *la = smem + abuf * A_BYTES;
+        const unsigned char *lb = smem + NSA * A_BYTES + bbuf * B_BYTES;
+        const int j = a_j0 + kx, key = (j >> 1) & 7;
+        int arow[TM];
 #pragma unroll
-        for (int pass0 = 0; pass0 < NPASS; pass0 += UB) {
-            float4 v[UB];
-            uint2 rv[UB], mv[UB];
-            int64_t o[UB];
-            bool ok[UB];
+        for (int i = 0; i < TM; ++i) arow[i] = (j + i * 32) * 128;
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int row = tid / V + (pass0 + u) * ROWS;
-                const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
-                ok[u] = m < p.M && col_ok;
-                o[u] = (m * p.Co + n) & -(int64_t)ok[u];              // rows / columns past the end: element 0, read and dropped
-                v[u] = *reinterpret_cast<const float4 *>(stage + row * EPI_STRIDE + c4 * 4);
-            }
-            if (p.residual != nullptr) {
-                int64_t ro[UB];
+        for (int kk = 0; kk < 4; ++kk) {
+            const int acol = ((2 * kk + fhalf) ^ key) << 4;
+            bf16x8 fa[TM], fb[TN];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) ro[u] = o[u];
-                if (p.res_H > 0) {              // ATen's nearest rule: source = min(floor(dst * in / out), in - 1)
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        const int row = tid / V + (pass0 + u) * ROWS;
-                        const unsigned mm = (unsigned)(m0 + ((row >> 5) * TM + i) * 32 + (row & 31));
-                        const unsigned wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
-                        const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
-                        const int rh = min((int)floorf(ho * p.res_sh), p.res_H - 1);
-                        const int rw = min((int)floorf(wo * p.res_sw), p.res_W - 1);
-                        ro[u] = ((((int64_t)b * p.res_H + rh) * p.res_W + rw) * p.Co + n) & -(int64_t)ok[u];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u) rv[u] = *reinterpret_cast<const uint2 *>(p.residual + ro[u]);
-            }
-            if (p.mask != nullptr) {
-#pragma unroll
-                for (int u = 0; u < UB; ++u) mv[u] = *reinterpret_cast<const uint2 *>(p.mask + o[u]);
+            for (int i = 0; i < TM; ++i) {
+                int a = arow[i] + acol;
+                if constexpr (KW > 1) a = ((vmask[i] >> (tap0 + kx)) & 1u) ? a : AI * 8 * 128;
+                fa[i] = *reinterpret_cast<const bf16x8 *>(la + a);
             }
 #pragma unroll
-            for (int u = 0; u < UB; ++u) { v[u].x += bv.x; v[u].y += bv.y; v[u].z += bv.z; v[u].w += bv.w; }
-            if (p.residual != nullptr) {
+            for (int jn = 0; jn < TN; ++jn) fb[jn] = *reinterpret_cast<const bf16x8 *>(lb + b_addr[kk] + jn * 32 * 128);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    v[u].x += bf2f((unsigned short)(rv[u].x & 0xffffu)); v[u].y += bf2f((unsigned short)(rv[u].x >> 16));
-                    v[u].z += bf2f((unsigned short)(rv[u].y & 0xffffu)); v[u].w += bf2f((unsigned short)(rv[u].y >> 16));
-                }
-            }
-            if (p.relu) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f);
-                }
-            }
-            if (p.mask != nullptr) {            // ReLU backward of the layer that produced this map: keep where it was > 0
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jn], acc[i][jn], 0, 0, 0);
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // K order: channel slice, filter row, tap of the row (a run serves the KW taps of its row).  tap index t = (cs * kh + ky) * KW + kx
+    const int steps = ncs * p.kh, taps = steps * KW;
+    // the next tile to issue
+    int pt = 0, pcs = 0, pky = 0, pkx = 0, pbuf = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {     // the tile(s) of tap pt: 1x1: A then B; 3x3: B only
+        if constexpr (KW == 1) issue_a(pcs, 0, pbuf);
+        issue_b(pcs, pky * KW + pkx, pbuf);
+        ++pt;
+        pbuf = pbuf + 1 == NS ? 0 : pbuf + 1;
+        if (++pkx == KW) {
+            pkx = 0;
+            if (++pky == p.kh) { pky = 0; ++pcs; }
+        }
+    };
+    // counted waits.  Per tap a wave issues NBW (1x1: NAW + NBW) instructions for the ring, 3x3 layers additionally the next
+    // step's A run (at least NAMIN per wave) right after the ring tile of the step's FIRST tap.
+    constexpr int NAMIN = AI / 4;
+    constexpr int NTILE = KW == 1 ? (NAW + NBW) : NBW;            // (1x1: AI % 4 == 0, every wave issues NAW)
+    static_assert(KW > 1 || AI % 4 == 0, "1x1 tiles: whole DMA instructions per wave");
+
+    // prologue: the first run (3x3), D ring tiles; wait for tile 0 (and the run)
+    if constexpr (KW > 1) issue_a(0, 0, 0);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    v[u].x = bf2f((unsigned short)(mv[u].x & 0xffffu)) > 0.f ? v[u].x : 0.f;
-                    v[u].y = bf2f((unsigned short)(mv[u].x >> 16)) > 0.f ? v[u].y : 0.f;
-                    v[u].z = bf2f((unsigned short)(mv[u].y & 0xffffu)) > 0.f ? v[u].z : 0.f;
-                    v[u].w = bf2f((unsigned short)(mv[u].y >> 16)) > 0.f ? v[u].w : 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                uint2 ov;
-                ov.x = (unsigned)f2bf(v[u].x) | ((unsigned)f2bf(v[u].y) << 16);
-                ov.y = (unsigned)f2bf(v[u].z) | ((unsigned)f2bf(v[u].w) << 16);
-                if (ok[u]) *reinterpret_cast<uint2 *>(p.y + o[u]) = ov;
+    for (int d = 0; d < D; ++d)
+        if (pt < taps) issue_next();
+    if (taps >= D) q_wait_vm<(D - 1) * NTILE>();
+    else q_wait_vm<0>();
+    lds_barrier();
+
+    static_assert(KW == 1 || D < KW, "3x3: the next run must be older than the ring tile awaited at the step's last tap");
+    int ky = 0, kx = 0, abuf = 0, bbuf = 0;
+    int cs1 = 0, ky1 = 1;                                          // the step after the current one
+    if (ky1 == p.kh) { ky1 = 0; cs1 = 1; }
+#pragma unroll 1
+    for (int t = 0; t < taps; ++t) {
+        const bool more = pt < taps;
+        if (more) issue_next();
+        bool a_issued = false;
+        if constexpr (KW > 1) {
+            if (kx == 0 && cs1 < ncs) {                            // the next step's run, in flight for the KW taps of this step
+                issue_a(cs1, ky1, abuf ^ 1);
+                a_issued = true;
             }
         }
-        if (i + 1 < TM) __syncthreads();
+        mma_tap(abuf, bbuf, kx, ky * KW);
+        // at the end of tap t: ring tile t + 1 landed (the D - 1 younger ones may stay in flight); 3x3: the next run has landed
+        // at the end of the step's last tap -- until then it may stay in flight when it is younger than tile t + 1, i.e. while
+        // t + 1 - D <= (first tap of this step)  <=>  kx <= D - 1
+        if (!more) q_wait_vm<0>();
+        else if (KW > 1 && kx < KW - 1 && kx <= D - 1 && (kx > 0 || a_issued) && cs1 < ncs) q_wait_vm<(D - 1) * NTILE + NAMIN>();
+        else q_wait_vm<(D - 1) * NTILE>();
+        lds_barrier();
+        bbuf = bbuf + 1 == NS ? 0 : bbuf + 1;
+        if constexpr (KW == 1) abuf = bbuf;
+        if (++kx == KW) {
+            kx = 0;
+            if constexpr (KW > 1) abuf ^= 1;
+            ky = ky1;
+            if (++ky1 == p.kh) { ky1 = 0; ++cs1; }
+        }
     }
+    bf16_epilogue<TM, TN>(p, acc, smem, m0, n0);
 }
 
 }  // namespace
@@ -315,6 +592,55 @@ static int launch_conv_bf16(const char *what, const void *x, const void *w, cons
     // 3-5 % on the large layers (703 -> 670 TFLOP/s at 200x336), so tap-major stays the default (HTD_BF16_CMAJOR=1 flips it)
     static const int cmajor_env = getenv("HTD_BF16_CMAJOR") ? atoi(getenv("HTD_BF16_CMAJOR")) : 0;
     p.cmajor = kh * kw > 1 ? cmajor_env : 0;
+    // conv_bf16q_kernel (LDS-DMA operands, ring of tiles in flight) takes 1x1 layers of any stride and 3x3 / stride-1 / pad-1
+    // layers with Ci % 64 == 0.  HTD_BF16Q=0: every layer keeps conv_bf16_kernel; HTD_BF16Q_TUNE=1: the switches below are
+    // re-read on every call (tools/bench_conv_bf16.py A/B runs in one process).
+    static const bool q_tune = getenv("HTD_BF16Q_TUNE") != nullptr;
+    auto env_int = [&](const char *name, int dflt) {
+        const char *e = getenv(name);
+        return e ? atoi(e) : dflt;
+    };
+    static const int q_on0 = env_int("HTD_BF16Q", 1), q_tile0 = env_int("HTD_BF16Q_TILE", 0), q_ns0 = env_int("HTD_BF16Q_NS", 0);
+    const int q_on = q_tune ? env_int("HTD_BF16Q", 1) : q_on0;
+    const int q_tile = q_tune ? env_int("HTD_BF16Q_TILE", 0) : q_tile0;
+    const int q_ns = q_tune ? env_int("HTD_BF16Q_NS", 0) : q_ns0;
+    const bool q_shape = Ci % 64 == 0 && dil == 1 && ((kh == 1 && kw == 1 && pad == 0) || (kh == 3 && kw == 3 && stride == 1 && pad == 1)) &&
+                         (int64_t)B * H * W < (1ll << 31);
+    // Which layers it takes by default (tools/bench_conv_bf16.py under HTD_BF16Q_TUNE=1, B = 4 @ 800x1344, us old -> new): every
+    // 3x3 layer (P2 403 -> 339 = 936 TFLOP/s, P3 113 -> 108, layer3 46 -> 42, layer4 53 -> 47) and the 1x1 layers with a
+    // long reduction (Ci >= 1024: layer3 conv1 23.9 -> 22.6, layer4 conv1 28.3 -> 22.4, FC 12544 -> 1024 119 -> 87); the
+    // short-K 1x1 layers (Ci <= 512, four to eight K steps: all prologue and epilogue) run 5-15 % slower on it and keep
+    // conv_bf16_kernel.  A forced tile / ring depth (tune mode) takes every eligible layer.
+    const bool q_pays = kh == 3 || Ci >= 1024 || q_tile != 0 || q_ns != 0 || q_on == 2;
+    if (q_on && q_shape && q_pays) {
+        const int64_t big = htd::ceil_div(p.M, 128) * htd::ceil_div(Co, 128);
+        // 3x3: 128x128 tiles from about one per CU on (layer3: 264), 64x64 below; 1x1: 64x64 tiles, three ring tiles
+        const int bt = q_tile ? q_tile : (kh == 3 && big >= 200 ? 128 : 64);
+        p.mt = (int)htd::ceil_div(p.M, bt);
+        p.nt = (int)htd::ceil_div(Co, bt);
+        const dim3 grid((unsigned)(p.mt * p.nt));
+        const hipStream_t st = (hipStream_t)stream;
+        const int ns = q_ns ? q_ns : (kh == 3 ? 2 : 3);
+        if (kh == 1) {
+            if (bt == 128) {
+                if (ns == 2) hipLaunchKernelGGL((conv_bf16q_kernel<2, 2, 1, 2>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((conv_bf16q_kernel<2, 2, 1, 3>), grid, dim3(256), 0, st, p);
+            } else {
+                if (ns == 2) hipLaunchKernelGGL((conv_bf16q_kernel<1, 1, 1, 2>), grid, dim3(256), 0, st, p);
+                else if (ns == 4) hipLaunchKernelGGL((conv_bf16q_kernel<1, 1, 1, 4>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((conv_bf16q_kernel<1, 1, 1, 3>), grid, dim3(256), 0, st, p);
+            }
+        } else {
+            if (bt == 128) {
+                if (ns == 2) hipLaunchKernelGGL((conv_bf16q_kernel<2, 2, 3, 2>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((conv_bf16q_kernel<2, 2, 3, 3>), grid, dim3(256), 0, st, p);
+            } else {
+                if (ns == 2) hipLaunchKernelGGL((conv_bf16q_kernel<1, 1, 3, 2>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((conv_bf16q_kernel<1, 1, 3, 3>), grid, dim3(256), 0, st, p);
+            }
+        }
+        return htd::check_launch(what);
+    }
     static const int small_below = getenv("HTD_BF16_SMALL_TILES") ? atoi(getenv("HTD_BF16_SMALL_TILES")) : 768;
     static const int small_1x1_below = getenv("HTD_BF16_SMALL_TILES_1X1") ? atoi(getenv("HTD_BF16_SMALL_TILES_1X1")) : 5000;
     const int64_t big_tiles = htd::ceil_div(p.M, 128) * htd::ceil_div(Co, 128);

@@ -843,11 +843,13 @@ def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=Fals
         if res.size(0) != B or res.size(1) != Co or res.size(2) > Ho or res.size(3) > Wo:
             raise ValueError('conv2d_bf16: up-sampled residual %s does not fit the output %s' % (tuple(res.shape), tuple(y.shape)))
         capi.call('htd_conv2d_fwd_bf16_up', _P(x), _P(weight), _P(b), _P(res), res.size(2), res.size(3), _P(y), B, H, W, Ci,
-                  Co, kh, kw, int(stride), int(padding), int(dilation), int(bool(relu)), _S(),
-                  work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
+                  Co, kh, kw, int(stride), int(padding), int(dilation), int(bool(relu)), _S(), key='htd_conv2d_fwd_bf16',
+                  work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci, 2.0 * (x.numel() + weight.numel() + y.numel() + res.numel())))
         return y
     capi.call('htd_conv2d_fwd_bf16', _P(x), _P(weight), _P(b), _P(res), _P(y), B, H, W, Ci, Co, kh, kw, int(stride),
-              int(padding), int(dilation), int(bool(relu)), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci))
+              int(padding), int(dilation), int(bool(relu)), _S(),
+              work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
+                    2.0 * (x.numel() + weight.numel() + y.numel() * (2 if res is not None else 1))))
     return y
 
 
@@ -875,10 +877,11 @@ def conv2d_wgrad_bf16(x, gy, weight_shape, stride=1, padding=0, dilation=1, with
         gb = grad_out2(bias)[0] if (bias is not None and bias.dtype == torch.float32 and bias.numel() == Co) else \
             torch.empty(Co, device=x.device, dtype=torch.float32)
         capi.call('htd_conv2d_bwd_weight_bf16_bias', _P(x), _P(gy), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, int(stride),
-                  int(padding), int(dilation), _P(ws), _S(), work=('flop', 2.0 * gy.numel() * kh * kw * Ci))
+                  int(padding), int(dilation), _P(ws), _S(), key='htd_conv2d_bwd_weight_bf16',
+                  work=('flop', 2.0 * gy.numel() * kh * kw * Ci, 2.0 * (x.numel() + gy.numel()) + 4.0 * gw.numel()))
         return gw, gb
     capi.call('htd_conv2d_bwd_weight_bf16', _P(x), _P(gy), _P(gw), B, H, W, Ci, Co, kh, kw, int(stride), int(padding),
-              int(dilation), _P(ws), _S(), work=('flop', 2.0 * gy.numel() * kh * kw * Ci))
+              int(dilation), _P(ws), _S(), work=('flop', 2.0 * gy.numel() * kh * kw * Ci, 2.0 * (x.numel() + gy.numel()) + 4.0 * gw.numel()))
     return gw
 
 
@@ -936,7 +939,8 @@ def _dgrad_bf16_raw(g, wT, kh, pad, dil, mask_src=None, accum=None):
     Ho, Wo = _out_hw(H, W, kh, kh, 1, p, dil)
     gx = torch.empty((B, Ci, Ho, Wo), device=g.device, dtype=BF16, memory_format=CL)
     capi.call('htd_conv2d_dgrad_bf16', _P(g), _P(wT), _P(mask_src), _P(accum), _P(gx), B, H, W, Co, Ci, kh, kh, p, dil,
-              _S(), work=('flop', 2.0 * B * Ho * Wo * Ci * kh * kh * Co))
+              _S(), work=('flop', 2.0 * B * Ho * Wo * Ci * kh * kh * Co,
+                          2.0 * (g.numel() + wT.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None)))))
     return gx
 
 
@@ -1271,9 +1275,19 @@ def roofline_report(prof, peak_tflops, peak_gbs, peak_bf16_tflops=2500.0):
         if 'bf16' in name:                       # bf16 matrix-core peak for the bf16 kernels
             peak_tflops = peak_bf16_tflops
         achieved = work / (ms * 1e-3) / 1e12
-        return dict(kernel=name, bound='mfma', achieved=round(achieved, 3), peak=peak_tflops, unit='TFLOP/s',
-                    frac=round(achieved / peak_tflops, 4), traffic=None, launches=calls,
-                    avg_launch_ms=round(ms / calls, 4), algorithmic_bytes=int(nbytes / calls))
+        out = dict(kernel=name, bound='mfma', achieved=round(achieved, 3), peak=peak_tflops, unit='TFLOP/s',
+                   frac=round(achieved / peak_tflops, 4), traffic=None, launches=calls,
+                   avg_launch_ms=round(ms / calls, 4), algorithmic_bytes=int(nbytes / calls))
+        if 'bf16' in name and nbytes > 0:
+            # the bf16 configurations sit nearer the HBM roof than the matrix roof ("report both fractions"): price the
+            # class against the roof it is closer to, keep the other fraction beside it
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            out['hbm'] = dict(achieved=round(gbs, 1), peak=peak_gbs, unit='GB/s', frac=round(gbs / peak_gbs, 4),
+                              what='algorithmic bytes (bf16 operands and result once, fp32 weight gradients) / device time')
+            if gbs / peak_gbs > achieved / peak_tflops:
+                out.update(bound='hbm', mfma=dict(achieved=out['achieved'], peak=peak_tflops, unit='TFLOP/s', frac=out['frac']),
+                           achieved=round(gbs, 1), peak=peak_gbs, unit='GB/s', frac=round(gbs / peak_gbs, 4))
+        return out
     achieved = work / (ms * 1e-3) / 1e9
     return dict(kernel=name, bound='hbm', achieved=round(achieved, 2), peak=peak_gbs, unit='GB/s',
                 frac=round(achieved / peak_gbs, 4), traffic=None, launches=calls, avg_launch_ms=round(ms / calls, 4))

@@ -120,6 +120,13 @@ class GradientExchange:
         self.stream = torch.cuda.Stream() if (self.enabled and self.on_gpu) else None
         self._pending = None
         self._works = []
+        # ONE persistent payload buffer for the reduced-precision exchange (a bucket is cast into its slice, reduced there and
+        # cast back): no allocation per bucket, and the allocator never sees the comm stream
+        self._low = torch.empty_like(flat.grad, dtype=self.comm_dtype) if (self.enabled and self.comm_dtype is not None) else None
+        # communication account for bench.py's N > 1 line: payload bytes per step and the EXPOSED part of the exchange -- from
+        # the end of backward on the compute stream to the end of the last bucket on the comm stream (device events; wall clock
+        # for a host-side backend).  Sampled on the steps between stats_begin() and stats().
+        self._stat = None
         if self.enabled:
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
@@ -156,23 +163,46 @@ class GradientExchange:
         self._launched.add(b)
         lo, hi = self.flat.buckets[b]
         chunk = self.flat.grad[lo:hi]
+        low = self._low[lo:hi] if self._low is not None else None
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             if dense._SIDE:
                 self.stream.wait_stream(dense.side_stream(chunk.device))
             with torch.cuda.stream(self.stream):
-                if self.comm_dtype is None:
+                if low is None:
                     dist.all_reduce(chunk, group=self.group)
                 else:
-                    low = chunk.to(self.comm_dtype)
+                    low.copy_(chunk)
                     dist.all_reduce(low, group=self.group)
                     chunk.copy_(low)
-        elif self.comm_dtype is None:
+        elif low is None:
             self._works.append(dist.all_reduce(chunk, group=self.group, async_op=True))
         else:
-            low = chunk.to(self.comm_dtype)
+            low.copy_(chunk)
             dist.all_reduce(low, group=self.group)
             chunk.copy_(low)
+
+    # ---- communication account -------------------------------------------------------------------------------------
+    def stats_begin(self):
+        self._stat = dict(steps=0, events=[], host_ms=0.0)
+
+    def stats(self):
+        """-> dict(bytes_per_step, buckets, exposed_ms, ...) over the steps since stats_begin() (None when nothing is exchanged)."""
+        st, self._stat = self._stat, None
+        if not self.enabled or st is None or st['steps'] == 0:
+            return None
+        if st['events']:
+            torch.cuda.synchronize()
+            exposed = sum(max(0.0, a.elapsed_time(b)) for a, b in st['events']) / len(st['events'])
+            how = 'device events: end of backward (compute stream) -> end of the last bucket (comm stream)'
+        else:
+            exposed = st['host_ms'] / st['steps']
+            how = 'host clock around finish_step (host-side backend)'
+        item = 2 if self.comm_dtype is not None else 4
+        return dict(bytes_per_step=int(self.flat.grad.numel()) * item, buckets=len(self.flat.buckets),
+                    payload_dtype=str(self.comm_dtype or torch.float32).replace('torch.', ''),
+                    exposed_ms=round(exposed, 4), exposed_how=how, steps_sampled=st['steps'],
+                    backend=dist.get_backend(self.group) if dist.is_initialized() else None, n_ranks=self.world)
 
     def finish_step(self):
         """Reduce the remaining buckets (parameters that got no gradient this step contribute zeros), still in
@@ -181,13 +211,31 @@ class GradientExchange:
         self.flat.collect()              # every .grad is its flat slice again (unused parameters: zeros)
         if not self.enabled:
             return
+        st = self._stat
+        t0 = ev0 = None
+        if st is not None:
+            if self.stream is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()             # backward (and its weight-gradient stream) ends here on the compute stream
+            else:
+                import time
+                t0 = time.perf_counter()
         while self._next < len(self.flat.buckets):
             self._launch(self._next)
             self._next += 1
         for w in self._works:
             w.wait()
         if self.stream is not None:
+            if ev0 is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record(self.stream)  # the last bucket is done here on the comm stream
+                st['events'].append((ev0, ev1))
             torch.cuda.current_stream().wait_stream(self.stream)
+        if st is not None:
+            st['steps'] += 1
+            if t0 is not None:
+                import time
+                st['host_ms'] += (time.perf_counter() - t0) * 1e3
         self._pending = None
 
 

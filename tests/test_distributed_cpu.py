@@ -29,9 +29,15 @@ def _worker(rank, world, port, q, comm_dtype=None):
     assert ex.enabled and len(flat.buckets) > 1
     x = torch.full((5, 8), float(rank + 1))
     flat.zero_grad()
+    ex.stats_begin()
     ex.begin_step()
     model(x).sum().backward()
     ex.finish_step()
+    st = ex.stats()          # bench.py's `comm` object: payload bytes, buckets, exposed time, ranks seen
+    item = 4 if comm_dtype is None else 2
+    assert st['bytes_per_step'] == flat.grad.numel() * item and st['buckets'] == len(flat.buckets) and st['n_ranks'] == world
+    assert st['steps_sampled'] == 1 and st['exposed_ms'] >= 0.0 and st['backend'] == 'gloo'
+    assert ex.stats() is None                          # sampling ended with the read
     # reference: sum over ranks of the local gradients
     torch.manual_seed(0)
     ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
