@@ -287,6 +287,83 @@ __global__ __launch_bounds__(256) void roi_align_levels_fwd_kernel(LevelTable ta
     }
 }
 
+// Forward of EVERY RoI on EVERY level in one launch (AdptRoIExtractor / BA, adaptative_roi_extractor.py:66-76: four RoIAlign
+// calls over the same RoI list): task = (level, RoI, bin, chunk), level-major so that the wavefronts of a workgroup read one
+// map; out[l] is level l's (n, ph, pw, C) tensor.  WAVES = 1: a wavefront per task; WAVES = 8: a workgroup per task whose
+// wavefronts take every eighth footprint row (few RoIs with large footprints: the split form above).
+struct AllLevelsOut {
+    float *out[8];
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES == 1 ? 256 : 64 * WAVES) void roi_align_all_levels_fwd_kernel(
+    LevelTable tab, AllLevelsOut outs, const float *__restrict__ rois, int64_t n, int B, int C, int L, int ph, int pw,
+    int sampling_ratio, int aligned, int chunks, int64_t tasks)
+{
+    __shared__ float4 part[WAVES == 1 ? 1 : WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t task = WAVES == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+    if (WAVES == 1 && task >= tasks) return;
+    const int chunk = (int)(task % chunks);
+    int64_t t2 = task / chunks;
+    const int bin = (int)(t2 % (ph * pw));
+    t2 /= ph * pw;
+    const int64_t ri = t2 % n;
+    const int lv = (int)(t2 / n);
+    const int H = tab.H[lv], W = tab.W[lv];
+    const float *feat = tab.feat[lv];
+    const int bi = bin / pw, bj = bin % pw;
+    const RoiGeom g = roi_geometry(rois + 5 * ri, tab.scale[lv], ph, pw, sampling_ratio, aligned);
+    int r0, r1, c0, c1;
+    axis_span(g.start_h, g.bin_h, bi, g.grid_h, H, r0, r1);
+    axis_span(g.start_w, g.bin_w, bj, g.grid_w, W, c0, c1);
+    if (g.batch < 0 || g.batch >= B) { r0 = 0; r1 = -1; }
+    const size_t img_base = (size_t)g.batch * H * W * C;
+    const int ch = chunk * 256 + lane * 4;
+    const bool act = ch < C;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rb = r0; rb <= r1; rb += 64) {
+        const float wy_l = (rb + lane <= r1) ? axis_weight(g.start_h, g.bin_h, bi, g.grid_h, rb + lane, H) : 0.f;
+        const int rn = min(64, r1 - rb + 1);
+        for (int cb = c0; cb <= c1; cb += 64) {
+            const float wx_l = (cb + lane <= c1) ? axis_weight(g.start_w, g.bin_w, bj, g.grid_w, cb + lane, W) : 0.f;
+            const int cn = min(64, c1 - cb + 1);
+            for (int r = (WAVES == 1 ? 0 : wave); r < rn; r += WAVES) {
+                const float wy = lane_bcast(wy_l, r);
+                const float *row = feat + img_base + ((size_t)(rb + r) * W + cb) * C + ch;
+#pragma unroll 4
+                for (int c = 0; c < cn; ++c) {
+                    const float w = wy * lane_bcast(wx_l, c);
+                    if (act) {
+                        const float4 v = *reinterpret_cast<const float4 *>(row + (size_t)c * C);
+                        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                    }
+                }
+            }
+        }
+    }
+    float *dst = outs.out[lv] + ((size_t)ri * ph * pw + bin) * C + ch;
+    if constexpr (WAVES == 1) {
+        if (act) {
+            acc.x *= g.inv_count; acc.y *= g.inv_count; acc.z *= g.inv_count; acc.w *= g.inv_count;
+            *reinterpret_cast<float4 *>(dst) = acc;
+        }
+    } else {
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && act) {
+            float4 t = part[0][lane];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                const float4 v = part[w][lane];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            t.x *= g.inv_count; t.y *= g.inv_count; t.z *= g.inv_count; t.w *= g.inv_count;
+            *reinterpret_cast<float4 *>(dst) = t;
+        }
+    }
+}
+
 // Backward, row-wise: one wavefront owns (RoI, footprint row mod row_slots, 256-channel chunk); row_slots grows when
 // there are few RoIs (BA pools two dozen large RoIs from every level) so that the launch still fills the chip.  For its row r it
 // first folds the bins along y,  T[q][:] = sum_p Wy[p][r] * gout[p][q][:] / count  (registers), then walks the row's
@@ -413,14 +490,25 @@ __global__ __launch_bounds__(256) void roi_bbox_kernel(const float *__restrict__
 // CPL channels per lane (64 * CPL-channel chunks), ROWS feature-map rows per wavefront: a tile is ROWS x GW_TILE pixels.
 // Taller tiles share the gout loads of a bin row between the feature rows it reaches (a 4-row tile reads ~3.3x fewer
 // bytes per RoI than four 1-row strips: the kernel is bound by those L2 reads), at ROWS * GW_TILE * CPL accumulators.
-template <int CPL, int ROWS>
+// RS > 1 (round 4): the RS wavefronts of a group share ONE tile and deal its RoIs among themselves -- wavefront `part` takes the
+// hits with RoI index = part (mod RS) -- and their partial sums meet in LDS in part order (fixed: bit-stable like RS = 1, other
+// last bits).  What bounds this kernel is the CHAIN of RoIs a tile walks one after the other (geometry -> weights -> gout rows
+// -> sums: a few microseconds of dependent latency each): BA pools every positive RoI from EVERY level, so a strip of the
+// coarse maps walks all 128 RoIs of its image; RS wavefronts walk a quarter each.  `active` = the task exists (every
+// wavefront of the block reaches the barrier).
+template <int CPL, int ROWS, int RS>
 __device__ __forceinline__ void gather_tile(const float *__restrict__ gout, const float *__restrict__ rois,
                                             const RoiBox *__restrict__ box, float *__restrict__ gfeat, int64_t n, int B, int C,
                                             int H, int W, int ph, int pw, float scale, int sampling_ratio, int aligned,
-                                            int accumulate, int chunks, int segs, int hts, int64_t task)
+                                            int accumulate, int chunks, int segs, int hts, int64_t task, bool active)
 {
     static_assert(ROWS * MAXP <= 64, "one lane per (row, bin) weight");
+    static_assert(RS == 1 || ROWS == 1, "the RoI split keeps one-row tiles");
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, part = wave % RS;
+    // the RoIs of this wavefront: bits i of a 64-box ballot with i = part (mod RS) (the box index base + i has base % 64 == 0)
+    constexpr unsigned long long kEvery = RS == 4 ? 0x1111111111111111ull : (RS == 2 ? 0x5555555555555555ull : ~0ull);
+    const unsigned long long mine = kEvery << part;
     const int chunk = (int)(task % chunks);
     int64_t t2 = task / chunks;
     const int seg = (int)(t2 % segs);
@@ -440,13 +528,13 @@ __device__ __forceinline__ void gather_tile(const float *__restrict__ gout, cons
             for (int k = 0; k < CPL; ++k) acc[r][i][k] = 0.f;
     bool touched = false;
 
-    for (int64_t base = 0; base < n; base += 64) {
+    for (int64_t base = 0; base < (active ? n : 0); base += 64) {
         bool hit = false;
         if (base + lane < n) {
             const RoiBox o = box[base + lane];
             hit = o.b == b && o.r_lo <= y1 && y0 <= o.r_hi && o.c_lo <= x1 && o.c_hi >= x0;
         }
-        unsigned long long mask = __ballot(hit);
+        unsigned long long mask = __ballot(hit) & mine;
         while (mask) {
             const int src = __builtin_ctzll(mask);
             mask &= mask - 1;
@@ -514,7 +602,29 @@ __device__ __forceinline__ void gather_tile(const float *__restrict__ gout, cons
             }
         }
     }
-    if (!act || (accumulate && !touched)) return;
+    if constexpr (RS > 1) {
+        // partial sums of parts 1 .. RS - 1 -> LDS [wave][element][lane], added by part 0 in part order
+        __shared__ float lsum[4][GW_TILE * CPL][64];
+        __shared__ int ltouched[4];
+        if (part > 0) {
+#pragma unroll
+            for (int i = 0; i < GW_TILE; ++i)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) lsum[wave][i * CPL + k][lane] = acc[0][i][k];
+            if (lane == 0) ltouched[wave] = touched ? 1 : 0;
+        }
+        __syncthreads();
+        if (part > 0) return;
+#pragma unroll
+        for (int w = 1; w < RS; ++w) {
+#pragma unroll
+            for (int i = 0; i < GW_TILE; ++i)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) acc[0][i][k] += lsum[wave + w][i * CPL + k][lane];
+            touched = touched || ltouched[wave + w] != 0;
+        }
+    }
+    if (!active || !act || (accumulate && !touched)) return;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         if (y0 + r > y1) continue;
@@ -529,17 +639,17 @@ __device__ __forceinline__ void gather_tile(const float *__restrict__ gout, cons
     }
 }
 
-template <int CPL, int ROWS>
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ rois,
+template <int CPL, int ROWS, int RS>
+__global__ __launch_bounds__(256, (RS > 1 ? 4 : 1)) void roi_align_bwd_gather_kernel(const float *__restrict__ gout, const float *__restrict__ rois,
                                                                    const RoiBox *__restrict__ box, float *__restrict__ gfeat,
                                                                    int64_t n, int B, int C, int H, int W, int ph, int pw,
                                                                    float scale, int sampling_ratio, int aligned, int accumulate,
                                                                    int chunks, int segs, int hts, int64_t tasks)
 {
-    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (task >= tasks) return;                          // whole wave exits together
-    gather_tile<CPL, ROWS>(gout, rois, box, gfeat, n, B, C, H, W, ph, pw, scale, sampling_ratio, aligned, accumulate, chunks, segs,
-                           hts, task);
+    const int64_t task = (int64_t)blockIdx.x * (4 / RS) + (threadIdx.x >> 6) / RS;
+    if (RS == 1 && task >= tasks) return;               // whole wave exits together
+    gather_tile<CPL, ROWS, RS>(gout, rois, box, gfeat, n, B, C, H, W, ph, pw, scale, sampling_ratio, aligned, accumulate, chunks,
+                               segs, hts, task < tasks ? task : 0, task < tasks);
 }
 
 // All pyramid levels of one extractor in ONE launch.  Launched level by level, the coarse maps set the time: P5 has 600
@@ -549,6 +659,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_gather_kernel(const float *
 constexpr int GL_MAX = 6;
 struct GatherLevels {
     float *gfeat[GL_MAX];
+    const float *gout[GL_MAX];       // per slot (BA: every level has its own pooled tensor); NULL: the launch's shared grad_out
     const RoiBox *box[GL_MAX];
     int H[GL_MAX], W[GL_MAX], segs[GL_MAX], hts[GL_MAX], accumulate[GL_MAX], level[GL_MAX];
     float scale[GL_MAX];
@@ -556,20 +667,22 @@ struct GatherLevels {
     int slots;
 };
 
-template <int CPL, int ROWS>
-__global__ __launch_bounds__(256) void roi_align_bwd_gather_levels_kernel(const float *__restrict__ gout,
+template <int CPL, int ROWS, int RS>
+__global__ __launch_bounds__(256, (RS > 1 ? 4 : 1)) void roi_align_bwd_gather_levels_kernel(const float *__restrict__ gout,
                                                                           const float *__restrict__ rois, GatherLevels t, int64_t n,
                                                                           int B, int C, int ph, int pw, int sampling_ratio,
                                                                           int aligned, int chunks)
 {
-    const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (task >= t.task0[t.slots]) return;
+    int64_t task = (int64_t)blockIdx.x * (4 / RS) + (threadIdx.x >> 6) / RS;
+    const bool active = task < t.task0[t.slots];
+    if (RS == 1 && !active) return;
+    if (!active) task = 0;
     int k = 0;
 #pragma unroll
     for (int i = 1; i < GL_MAX; ++i)
         if (i < t.slots && task >= t.task0[i]) k = i;
-    gather_tile<CPL, ROWS>(gout, rois, t.box[k], t.gfeat[k], n, B, C, t.H[k], t.W[k], ph, pw, t.scale[k], sampling_ratio, aligned,
-                           t.accumulate[k], chunks, t.segs[k], t.hts[k], task - t.task0[k]);
+    gather_tile<CPL, ROWS, RS>(t.gout[k] ? t.gout[k] : gout, rois, t.box[k], t.gfeat[k], n, B, C, t.H[k], t.W[k], ph, pw, t.scale[k],
+                               sampling_ratio, aligned, t.accumulate[k], chunks, t.segs[k], t.hts[k], task - t.task0[k], active);
 }
 
 // footprint boxes of every RoI on every level slot of the table (blockIdx.y = slot; b = -1 where the RoI is on another level)
@@ -583,7 +696,7 @@ __global__ __launch_bounds__(256) void roi_bbox_levels_kernel(const float *__res
     const int H = t.H[k], W = t.W[k];
     RoiBox o{};
     o.b = -1;
-    if (roi_level[ri] == (int64_t)t.level[k]) {
+    if (!roi_level || roi_level[ri] == (int64_t)t.level[k]) {       // no level list: every RoI on every level (BA)
         const RoiGeom g = roi_geometry(rois + 5 * ri, t.scale[k], ph, pw, sampling_ratio, aligned);
         int r_lo, r_hi, c_lo, c_hi, t0, t1;
         axis_span(g.start_h, g.bin_h, 0, g.grid_h, H, r_lo, t0);
@@ -595,6 +708,19 @@ __global__ __launch_bounds__(256) void roi_bbox_levels_kernel(const float *__res
         if (ok) { o.b = (short)g.batch; o.r_lo = (short)r_lo; o.r_hi = (short)r_hi; o.c_lo = (short)c_lo; o.c_hi = (short)c_hi; }
     }
     const_cast<RoiBox *>(t.box[k])[ri] = o;
+}
+
+// Wavefronts per tile of the gather backward (gather_tile RS): HTD_ROI_BWD_SPLIT = 1 / 2 / 4 forces it.  Measured
+// (tools/bench_roi_align.py, B = 4 @ 800x1344): 2 048 RoIs, each on ONE level, all levels in one launch: 462 / 666 / 1 055 us
+// for 1 / 2 / 4 -- the chains are short and the split costs registers (96 -> 128 VGPRs) and a barrier; 512 RoIs on EVERY level
+// (BA), one launch: 1 220 / 1 146 / 1 213 us, launched level by level 2 309 / 1 694 / 1 543 us (the coarse maps' strips walk
+// all RoIs of their image: the split shortens exactly that chain).  So: 2 when every RoI sits on every level, else 1.
+int gather_split(int64_t n, int64_t tiles_min, bool every_level)
+{
+    static const int forced = getenv("HTD_ROI_BWD_SPLIT") ? atoi(getenv("HTD_ROI_BWD_SPLIT")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    (void)n; (void)tiles_min;
+    return every_level ? 2 : 1;
 }
 
 int launch(bool backward, const float *in, const float *rois, const int64_t *roi_level, int level, float *out,
@@ -671,6 +797,36 @@ extern "C" int htd_roi_align_levels_fwd(const float *const *feats, const int *H,
     return htd::check_launch("roi_align_levels");
 }
 
+// Every RoI pooled from every level (AdptRoIExtractor): outs[l] (n, ph, pw, C) <- RoIAlign(feats[l], rois), l < L, ONE launch.
+// The same arithmetic as L calls of htd_roi_align_fwd (bit-identical results).
+extern "C" int htd_roi_align_all_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                                            const float *rois, float *const *outs, int64_t n, int B, int C, int ph, int pw,
+                                            int sampling_ratio, int aligned, void *stream)
+{
+    HTD_REQUIRE(L > 0 && L <= 8 && n >= 0 && B > 0 && C > 0 && ph > 0 && pw > 0, "roi_align_all_levels: bad sizes");
+    HTD_REQUIRE(C % 4 == 0, "roi_align_all_levels: C=%d must be a multiple of 4", C);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(feats && H && W && scales && rois && outs, "roi_align_all_levels: null pointer");
+    LevelTable tab{};
+    AllLevelsOut o{};
+    for (int l = 0; l < L; ++l) {
+        HTD_REQUIRE(feats[l] && outs[l] && H[l] > 0 && W[l] > 0, "roi_align_all_levels: bad level %d", l);
+        tab.feat[l] = feats[l]; tab.H[l] = H[l]; tab.W[l] = W[l]; tab.scale[l] = scales[l];
+        o.out[l] = outs[l];
+    }
+    const int chunks = (C + 255) / 256;
+    const int64_t tasks = (int64_t)L * n * ph * pw * chunks;
+    HTD_REQUIRE(tasks < (1ll << 31), "roi_align_all_levels: too many tasks");
+    hipStream_t s = (hipStream_t)stream;
+    if (tasks < 4 * 8192)           // few bins (as htd_roi_align_fwd per level): a workgroup per bin
+        hipLaunchKernelGGL(roi_align_all_levels_fwd_kernel<8>, dim3((unsigned)tasks), dim3(512), 0, s, tab, o, rois, n, B, C, L, ph, pw,
+                           sampling_ratio, aligned, chunks, tasks);
+    else
+        hipLaunchKernelGGL(roi_align_all_levels_fwd_kernel<1>, dim3((unsigned)htd::ceil_div(tasks, 4)), dim3(256), 0, s, tab, o, rois, n,
+                           B, C, L, ph, pw, sampling_ratio, aligned, chunks, tasks);
+    return htd::check_launch("roi_align_all_levels");
+}
+
 extern "C" int64_t htd_roi_align_bwd_gather_workspace_bytes(int64_t n) { return (n > 0 ? n : 1) * (int64_t)sizeof(RoiBox); }
 
 // Gather-form backward (no atomics, bit-stable): grad_feat = (accumulate ? grad_feat : 0) + RoIAlign^T(grad_out).
@@ -706,56 +862,100 @@ extern "C" int htd_roi_align_bwd_gather(const float *grad_out, const float *rois
     const int64_t tasks = (int64_t)B * hts * segs * chunks;
     const int64_t blocks = htd::ceil_div(tasks, 4);
     HTD_REQUIRE(blocks < (1ll << 31), "roi_align_bwd_gather: too many tiles");
-    hipLaunchKernelGGL((roi_align_bwd_gather_kernel<4, rows>), dim3((unsigned)blocks), dim3(256), 0, s, grad_out, rois, box, grad_feat,
-                       n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, accumulate, chunks, segs, hts, tasks);
+    const int rs = gather_split(n, tasks, roi_level == nullptr);
+    if (rs == 4)
+        hipLaunchKernelGGL((roi_align_bwd_gather_kernel<4, rows, 4>), dim3((unsigned)tasks), dim3(256), 0, s, grad_out, rois, box,
+                           grad_feat, n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, accumulate, chunks, segs, hts, tasks);
+    else if (rs == 2)
+        hipLaunchKernelGGL((roi_align_bwd_gather_kernel<4, rows, 2>), dim3((unsigned)htd::ceil_div(tasks, 2)), dim3(256), 0, s, grad_out,
+                           rois, box, grad_feat, n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, accumulate, chunks, segs,
+                           hts, tasks);
+    else
+        hipLaunchKernelGGL((roi_align_bwd_gather_kernel<4, rows, 1>), dim3((unsigned)blocks), dim3(256), 0, s, grad_out, rois, box,
+                           grad_feat, n, B, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, accumulate, chunks, segs, hts, tasks);
     return htd::check_launch("roi_align_bwd_gather");
 }
 
-// Gather-form backward of a multi-level extractor (SingleRoIExtractor: every RoI pooled on the level roi_level names), all
-// levels in one launch: grad_feats[l] = (accumulate[l] ? grad_feats[l] : 0) + RoIAlign_l^T(grad_out rows of level l).
-// grad_feats[l] == NULL skips level l.  workspace: L * htd_roi_align_bwd_gather_workspace_bytes(n).
-extern "C" int htd_roi_align_levels_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level,
-                                               float *const *grad_feats, const int *H, const int *W, const float *scales,
-                                               const int *accumulate, int L, int64_t n, int B, int C, int ph, int pw,
-                                               int sampling_ratio, int aligned, void *workspace, void *stream)
+// Gather-form backward of a multi-level extractor, all levels in one launch:
+//   grad_feats[l] = (accumulate[l] ? grad_feats[l] : 0) + RoIAlign_l^T(rows of level l);  grad_feats[l] == NULL skips level l.
+// roi_level != NULL (SingleRoIExtractor): every RoI is pooled on the level roi_level names, one grad_out for all.
+// roi_level == NULL (AdptRoIExtractor, adaptative_roi_extractor.py:66-76): every RoI on EVERY level, grad_outs[l] per level.
+namespace {
+int levels_bwd_gather(const float *grad_out, const float *const *grad_outs, const float *rois, const int64_t *roi_level,
+                      float *const *grad_feats, const int *H, const int *W, const float *scales, const int *accumulate, int L,
+                      int64_t n, int B, int C, int ph, int pw, int sampling_ratio, int aligned, void *workspace, void *stream,
+                      const char *what)
 {
     HTD_REQUIRE(L > 0 && L <= GL_MAX && n >= 0 && B > 0 && C > 0 && ph > 0 && pw > 0 && ph <= MAXP && pw <= MAXP,
-                "roi_align_levels_bwd_gather: bad sizes L=%d n=%lld B=%d C=%d out=%dx%d", L, (long long)n, B, C, ph, pw);
+                "%s: bad sizes L=%d n=%lld B=%d C=%d out=%dx%d", what, L, (long long)n, B, C, ph, pw);
     HTD_REQUIRE(C % 4 == 0 && B < 32768 && grad_feats && H && W && scales && accumulate,
-                "roi_align_levels_bwd_gather: C=%d must be a multiple of 4, tables non-null", C);
-    HTD_REQUIRE(n == 0 || (grad_out && rois && roi_level && workspace), "roi_align_levels_bwd_gather: null pointer");
+                "%s: C=%d must be a multiple of 4, tables non-null", what, C);
+    HTD_REQUIRE(n == 0 || ((grad_out || grad_outs) && rois && workspace), "%s: null pointer", what);
     hipStream_t s = (hipStream_t)stream;
     GatherLevels t{};
     const int chunks = (C + 255) / 256;
-    int64_t tasks = 0;
+    int64_t tasks = 0, tiles_min = 1ll << 62;
     for (int l = L - 1; l >= 0; --l) {                     // coarsest level first: its strips have the longest RoI lists
         if (!grad_feats[l]) continue;
-        HTD_REQUIRE(H[l] > 0 && W[l] > 0 && H[l] < 32768 && W[l] < 32768, "roi_align_levels_bwd_gather: bad map size");
+        HTD_REQUIRE(H[l] > 0 && W[l] > 0 && H[l] < 32768 && W[l] < 32768, "%s: bad map size", what);
         if (n == 0) {
             if (!accumulate[l] && hipMemsetAsync(grad_feats[l], 0, (size_t)B * H[l] * W[l] * C * 4, s) != hipSuccess) {
-                htd::set_error("roi_align_levels_bwd_gather: memset failed");
+                htd::set_error("%s: memset failed", what);
                 return HTD_ERR_LAUNCH;
             }
             continue;
         }
         const int k = t.slots++;
         t.gfeat[k] = grad_feats[l];
+        t.gout[k] = grad_outs ? grad_outs[l] : nullptr;
+        HTD_REQUIRE(!grad_outs || grad_outs[l], "%s: level %d has a gradient map but no grad_out", what, l);
         t.box[k] = (const RoiBox *)workspace + (int64_t)l * n;
         t.H[k] = H[l]; t.W[k] = W[l]; t.scale[k] = scales[l]; t.accumulate[k] = accumulate[l]; t.level[k] = l;
         t.segs[k] = (W[l] + GW_TILE - 1) / GW_TILE;
         t.hts[k] = H[l];
         t.task0[k] = tasks;
-        tasks += (int64_t)B * t.hts[k] * t.segs[k] * chunks;
+        const int64_t tiles = (int64_t)B * t.hts[k] * t.segs[k] * chunks;
+        tiles_min = std::min(tiles_min, tiles);
+        tasks += tiles;
     }
     if (t.slots == 0) return HTD_OK;
     t.task0[t.slots] = tasks;
     hipLaunchKernelGGL(roi_bbox_levels_kernel, dim3((unsigned)htd::ceil_div(n, 256), (unsigned)t.slots), dim3(256), 0, s, rois,
                        roi_level, t, n, B, ph, pw, sampling_ratio, aligned);
-    const int64_t blocks = htd::ceil_div(tasks, 4);
-    HTD_REQUIRE(blocks < (1ll << 31), "roi_align_levels_bwd_gather: too many tiles");
-    hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, grad_out, rois, t, n, B, C,
-                       ph, pw, sampling_ratio, aligned, chunks);
-    return htd::check_launch("roi_align_levels_bwd_gather");
+    HTD_REQUIRE(tasks < (1ll << 31), "%s: too many tiles", what);
+    const int rs = gather_split(n, tiles_min, roi_level == nullptr);
+    if (rs == 4)
+        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 4>), dim3((unsigned)tasks), dim3(256), 0, s, grad_out, rois, t, n,
+                           B, C, ph, pw, sampling_ratio, aligned, chunks);
+    else if (rs == 2)
+        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 2>), dim3((unsigned)htd::ceil_div(tasks, 2)), dim3(256), 0, s,
+                           grad_out, rois, t, n, B, C, ph, pw, sampling_ratio, aligned, chunks);
+    else
+        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 1>), dim3((unsigned)htd::ceil_div(tasks, 4)), dim3(256), 0, s,
+                           grad_out, rois, t, n, B, C, ph, pw, sampling_ratio, aligned, chunks);
+    return htd::check_launch(what);
+}
+}  // namespace
+
+extern "C" int htd_roi_align_levels_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level,
+                                               float *const *grad_feats, const int *H, const int *W, const float *scales,
+                                               const int *accumulate, int L, int64_t n, int B, int C, int ph, int pw,
+                                               int sampling_ratio, int aligned, void *workspace, void *stream)
+{
+    HTD_REQUIRE(n == 0 || (grad_out && roi_level), "roi_align_levels_bwd_gather: null pointer");
+    return levels_bwd_gather(grad_out, nullptr, rois, roi_level, grad_feats, H, W, scales, accumulate, L, n, B, C, ph, pw,
+                             sampling_ratio, aligned, workspace, stream, "roi_align_levels_bwd_gather");
+}
+
+// every RoI pooled from EVERY level (BA): grad_outs[l] (n, ph, pw, C) is level l's pooled-feature gradient
+extern "C" int htd_roi_align_all_levels_bwd_gather(const float *const *grad_outs, const float *rois, float *const *grad_feats,
+                                                   const int *H, const int *W, const float *scales, const int *accumulate, int L,
+                                                   int64_t n, int B, int C, int ph, int pw, int sampling_ratio, int aligned,
+                                                   void *workspace, void *stream)
+{
+    HTD_REQUIRE(n == 0 || grad_outs, "roi_align_all_levels_bwd_gather: null pointer");
+    return levels_bwd_gather(nullptr, grad_outs, rois, nullptr, grad_feats, H, W, scales, accumulate, L, n, B, C, ph, pw,
+                             sampling_ratio, aligned, workspace, stream, "roi_align_all_levels_bwd_gather");
 }
 
 extern "C" int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *roi_level, int level,

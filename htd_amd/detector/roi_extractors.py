@@ -72,6 +72,9 @@ class SingleRoIExtractor(BaseRoIExtractor):
                                   [l.spatial_scale for l in self.roi_layers], l0.sampling_ratio, l0.aligned)
 
 
+BA_ONE_LAUNCH = __import__('os').environ.get('HTD_BA_ONE_LAUNCH', '1') != '0'      # 0: one RoIAlign launch per level (A/B runs)
+
+
 @ROI_EXTRACTORS.register_module()
 class AdptRoIExtractor(BaseRoIExtractor):
     """BA: every RoI is pooled from ALL levels, fused with per-RoI softmax attention over levels, plus the
@@ -103,7 +106,14 @@ class AdptRoIExtractor(BaseRoIExtractor):
         if roi_scale_factor is not None:
             rois = self.roi_rescale(rois, roi_scale_factor)
         L = len(feats)
-        if isinstance(feats, M.PyramidTaps):          # chained gradient maps (see mmcv_ops.PyramidTaps)
+        l0 = self.roi_layers[0]
+        same = all((l.output_size, l.sampling_ratio, l.aligned, l.pool_mode) == (l0.output_size, l0.sampling_ratio, l0.aligned,
+                                                                                   l0.pool_mode) for l in self.roi_layers[:L])
+        if BA_ONE_LAUNCH and same and rois.is_cuda:
+            # every RoI on every level: ONE RoIAlign launch forward, ONE gather launch backward (mmcv_ops._RoIAlignAllLevels)
+            lvl_feats = M.roi_align_all_levels(feats, rois, l0.output_size, [l.spatial_scale for l in self.roi_layers[:L]],
+                                               l0.sampling_ratio, l0.aligned)
+        elif isinstance(feats, M.PyramidTaps):        # chained gradient maps (see mmcv_ops.PyramidTaps)
             lvl_feats = []
             for i in range(L):
                 f, feats.levels[i] = self.roi_layers[i](feats.levels[i], rois, chain=True)

@@ -279,6 +279,101 @@ class _RoIAlignLevels(Function):
         return (None, None, None, None, None, None, None, *grads)
 
 
+class _RoIAlignAllLevels(Function):
+    """EVERY RoI pooled from EVERY level (AdptRoIExtractor / BA, adaptative_roi_extractor.py:66-76: one RoIAlign per level over
+    the same RoI list) as ONE launch forward (htd_roi_align_all_levels_fwd) and ONE gather launch backward
+    (htd_roi_align_all_levels_bwd_gather): launched level by level, the coarse maps' strips each walk all RoIs of their image
+    while the rest of the chip idles.  -> (out_0 .. out_{L-1}[, alias_0 .. alias_{L-1}]); same values as L roi_align calls."""
+
+    @staticmethod
+    def forward(ctx, rois, output_size, scales, sampling_ratio, aligned, chain, *feats):
+        _need_gpu(feats[0], 'roi_align')
+        if rois.dim() != 2 or rois.size(1) != 5:
+            raise AssertionError('RoI must be (idx, x1, y1, x2, y2)!')  # roi_align.py:136
+        srcs = feats
+        ph, pw = _pair(output_size)
+        rois = _f32(rois, 'roi_align').contiguous()
+        n, C, L = rois.size(0), feats[0].size(1), len(feats)
+        fs = [nhwc(_f32(f, 'roi_align')) for f in feats]
+        shapes = [(f.size(0), C, f.size(2), f.size(3)) for f in fs]
+        outs = [torch.empty((n, C, ph, pw), device=rois.device, dtype=torch.float32, memory_format=CL) for _ in range(L)]
+        if n:
+            ptrs = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fs])
+            optr = (ctypes.c_void_p * L)(*[o.data_ptr() for o in outs])
+            Hs = (ctypes.c_int * L)(*[s_[2] for s_ in shapes])
+            Ws = (ctypes.c_int * L)(*[s_[3] for s_ in shapes])
+            sc = (ctypes.c_float * L)(*[float(v) for v in scales])
+            capi.call('htd_roi_align_all_levels_fwd', ptrs, Hs, Ws, sc, L, _P(rois), optr, n, shapes[0][0], C, ph, pw,
+                      int(sampling_ratio), int(bool(aligned)), _S(), work=('byte', L * n * C * 4.0 * ph * pw))
+        ctx.save_for_backward(rois)
+        ctx.args = (shapes, ph, pw, tuple(float(v) for v in scales), int(sampling_ratio), int(bool(aligned)))
+        ctx.chain = bool(chain)
+        ctx.set_materialize_grads(False)      # unused outputs / aliases arrive as None, not as full-size zero maps
+        return (*outs, *[f.view_as(f) for f in srcs]) if chain else tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        rois, = ctx.saved_tensors
+        shapes, ph, pw, scales, sr, aligned = ctx.args
+        L, n = len(shapes), rois.size(0)
+        gouts = [nhwc(g) if g is not None else None for g in grads[:L]]
+        handed = [grads[L + i] if (ctx.chain and L + i < len(grads)) else None for i in range(L)]
+        need = [bool(ctx.needs_input_grad[6 + i]) for i in range(L)]
+        dev = rois.device
+        if n == 0 or ROI_BWD != 'gather' or ph > 8 or pw > 8 or L > 6:
+            res = []
+            for i, shape in enumerate(shapes):
+                if not need[i] or gouts[i] is None:
+                    res.append(handed[i] if need[i] else None)
+                    continue
+                res.append(_roi_align_bwd(gouts[i], rois, None, 0, handed[i], shape, ph, pw, scales[i], sr, aligned))
+            return (None, ) * 6 + tuple(res)
+        maps, accs = [], []
+        for i, shape in enumerate(shapes):
+            if not need[i] or gouts[i] is None:
+                maps.append(None)
+                accs.append(0)
+                continue
+            ga = handed[i]
+            usable = ga is not None and ga.dtype == torch.float32 and tuple(ga.shape) == tuple(shape) and \
+                ga.is_contiguous(memory_format=CL)
+            if usable:
+                maps.append(ga)
+                accs.append(1)
+            else:
+                gf = torch.empty(shape, device=dev, dtype=torch.float32, memory_format=CL)
+                if ga is not None:
+                    gf.copy_(ga)
+                maps.append(gf)
+                accs.append(1 if ga is not None else 0)
+        if any(m is not None for m in maps):
+            ws = torch.empty(L * capi.lib().htd_roi_align_bwd_gather_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            gptr = (ctypes.c_void_p * L)(*[g.data_ptr() if (g is not None and m is not None) else None for g, m in zip(gouts, maps)])
+            mptr = (ctypes.c_void_p * L)(*[m.data_ptr() if m is not None else None for m in maps])
+            Hs = (ctypes.c_int * L)(*[s_[2] for s_ in shapes])
+            Ws = (ctypes.c_int * L)(*[s_[3] for s_ in shapes])
+            sc = (ctypes.c_float * L)(*scales)
+            ac = (ctypes.c_int * L)(*accs)
+            B, C = shapes[0][0], shapes[0][1]
+            work = ('byte', 4.0 * sum(s_[0] * s_[2] * s_[3] * C * (1 + a) + n * ph * pw * C
+                                      for s_, a, m in zip(shapes, accs, maps) if m is not None))
+            capi.call('htd_roi_align_all_levels_bwd_gather', gptr, _P(rois), mptr, Hs, Ws, sc, ac, L, n, B, C, ph, pw, sr, aligned,
+                      _P(ws), _S(), work=work)
+        res = [m if m is not None else (handed[i] if need[i] else None) for i, m in enumerate(maps)]
+        return (None, ) * 6 + tuple(res)
+
+
+def roi_align_all_levels(feats, rois, output_size, scales, sampling_ratio=0, aligned=True):
+    """[RoIAlign(feats[i], rois) for i] in one launch each way.  feats: list of maps or a PyramidTaps (chained gradients)."""
+    L = len(scales)
+    if isinstance(feats, PyramidTaps):
+        res = _RoIAlignAllLevels.apply(rois, output_size, tuple(scales), sampling_ratio, aligned, True, *feats.levels[:L])
+        feats.levels[:L] = list(res[L:])
+        return list(res[:L])
+    return list(_RoIAlignAllLevels.apply(rois, output_size, tuple(scales), sampling_ratio, aligned, False, *list(feats)[:L]))
+
+
 # ====================================================================== max pooling (ResNet stem)
 class MaxPool2dFunction(Function):
     @staticmethod

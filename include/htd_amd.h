@@ -75,6 +75,16 @@ int htd_roi_align_levels_bwd_gather(const float *grad_out, const float *rois, co
                                     float *const *grad_feats, const int *H, const int *W, const float *scales,
                                     const int *accumulate, int L, int64_t n, int B, int C, int ph, int pw,
                                     int sampling_ratio, int aligned, void *workspace, void *stream);
+/* AdptRoIExtractor (BA, roi_extractors/adaptative_roi_extractor.py:66-76) pools EVERY RoI from EVERY level: the four RoIAlign
+ * calls of the reference as one launch each way.  outs[l] / grad_outs[l]: level l's (n, ph, pw, C) tensor.  The backward is the
+ * gather form above with roi_level == NULL (every RoI on every level); workspace: L * htd_roi_align_bwd_gather_workspace_bytes(n). */
+int htd_roi_align_all_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                                 const float *rois, float *const *outs, int64_t n, int B, int C, int ph, int pw,
+                                 int sampling_ratio, int aligned, void *stream);
+int htd_roi_align_all_levels_bwd_gather(const float *const *grad_outs, const float *rois, float *const *grad_feats,
+                                        const int *H, const int *W, const float *scales, const int *accumulate, int L,
+                                        int64_t n, int B, int C, int ph, int pw, int sampling_ratio, int aligned,
+                                        void *workspace, void *stream);
 int64_t htd_roi_align_bwd_gather_workspace_bytes(int64_t n);
 int htd_roi_align_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
                              float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,

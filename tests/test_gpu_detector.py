@@ -629,7 +629,7 @@ def test_bf16_train_step_tracks_the_fp32_step(det, golden):
     det.train()
     set_randperm(None)
     set_sample_keys(lambda cand: torch.frac(torch.sin((cand.round() * coef).sum(-1)) * 43758.5453).abs())
-    out = {}
+    out, stage2 = {}, {}
     try:
         for dt in (torch.float32, torch.bfloat16):
             det.backbone.compute_dtype = dt
@@ -641,6 +641,8 @@ def test_bf16_train_step_tracks_the_fp32_step(det, golden):
             loss.backward()
             out[dt] = ({k: float(v) for k, v in log_vars.items()},
                        {n: p.grad.detach().clone() for n, p in det.named_parameters() if p.grad is not None})
+            s1 = det.roi_head._last_static[1]
+            stage2[dt] = (s1.is_pos.clone(), s1.valid.clone())
     finally:
         det.backbone.compute_dtype = torch.float32
         for head in det.roi_head.bbox_head:
@@ -654,7 +656,13 @@ def test_bf16_train_step_tracks_the_fp32_step(det, golden):
         assert abs(l16[k] - l32[k]) <= 2e-2 * max(abs(l32[k]), 0.05), (k, l16[k], l32[k])
     # stage 2 samples again from boxes that stage 1 refined: a box that moves across an IoU threshold changes the sample
     # set of this (end-to-end) test; tests/test_gpu_configs.py replays the samples and holds every loss to 2e-2
-    assert abs(l16['s1.loss_cls'] - l32['s1.loss_cls']) <= 5e-2 * abs(l32['s1.loss_cls'])
+    # -- so the bound says so: 5e-2 when both runs labelled every stage-2 slot alike, plus what the slots that flipped between
+    # positive and negative can move a mean cross-entropy (a flipped sample's term is at most ~2x the mean at these logits)
+    (pos32, val32), (pos16, val16) = stage2[torch.float32], stage2[torch.bfloat16]
+    flipped = int(((pos32 != pos16) | (val32 != val16)).sum())
+    allowed = 5e-2 + 2.0 * flipped / max(1, int(val32.sum()))
+    assert flipped <= 0.02 * int(val32.sum()), (flipped, int(val32.sum()))        # a handful of threshold crossings, not a new sample set
+    assert abs(l16['s1.loss_cls'] - l32['s1.loss_cls']) <= allowed * abs(l32['s1.loss_cls']), (flipped, l16['s1.loss_cls'], l32['s1.loss_cls'])
     for n in ('backbone.layer2.0.conv1.weight', 'backbone.layer3.1.conv2.weight', 'neck.fpn_convs.0.conv.weight',
               'neck.lateral_convs.2.conv.weight', 'rpn_head.rpn_conv.weight', 'roi_head.bbox_head.0.shared_fcs.1.weight',
               'roi_head.bbox_head.1.fcs.0.weight'):

@@ -17,10 +17,14 @@ LAYERS = [('l2.conv2 3x3 128', 128, 100, 168, 128, 3, 1, 1), ('l2.conv3 1x1 128-
           ('fc1 12544-1024 x2048', 12544, 2048, 1, 1024, 1, 1, 0)]
 # with HTD_BF16Q_TUNE=1: conv_bf16_kernel (HTD_BF16Q=0) against every tile / ring depth of conv_bf16q_kernel, us per call
 VARIANTS = [('old', None, None), ('q64 ns2', 64, 2), ('q64 ns3', 64, 3), ('q64 ns4', 64, 4), ('q128 ns2', 128, 2), ('q128 ns3', 128, 3)]
+if os.environ.get('BENCH_ABLATE'):      # HTD_BF16Q_DBG: 1 = no epilogue, 2 = no K loop (results are wrong; only the time matters)
+    VARIANTS = [('old', None, None), ('q64 ns2', 64, 2), ('q64 ns3', 64, 3), ('q64 ns4', 64, 4), ('q128 ns2', 128, 2), ('q128 ns3', 128, 3)]
 dev = torch.device('cuda:0')
 if os.environ.get('HTD_BF16Q_TUNE'):
     print(f'{"layer":24s} {"GFLOP":>7s} {"MB":>6s} | ' + ' | '.join(f'{v[0]:>9s}' for v in VARIANTS) + '   us per call (TF/s of the best)')
     for name, Ci, H, W, Co, k, s, p in LAYERS:
+        if len(sys.argv) > 1 and sys.argv[1] not in name:
+            continue
         B = 1 if name.startswith('fc1') else 4
         x = torch.randn(B, Ci, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=CL)
         w = (torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5).to(torch.bfloat16).contiguous(memory_format=CL)

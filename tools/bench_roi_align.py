@@ -11,8 +11,9 @@ import torch
 from htd_amd import capi
 from htd_amd import mmcv_ops as M
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ARGS = [a for a in sys.argv[1:] if not a.startswith('--')]
+n = int(ARGS[0]) if len(ARGS) > 0 else 2048
+B = int(ARGS[1]) if len(ARGS) > 1 else 4
 dev = torch.device('cuda:0')
 CL = torch.channels_last
 g = torch.Generator().manual_seed(0)
@@ -25,14 +26,6 @@ cx, cy = torch.rand(n, generator=g) * 1333, torch.rand(n, generator=g) * 800
 rois = torch.stack([torch.sort(torch.randint(0, B, (n, ), generator=g).float())[0], (cx - w / 2).clamp(0, 1333), (cy - h / 2).clamp(0, 800),
                     (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], 1).to(dev)
 from htd_amd.detector.roi_extractors import map_roi_levels
-lv = map_roi_levels(rois, 4)
-scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
-print('RoIs per level', torch.bincount(lv, minlength=4).tolist())
-fd = [f.clone().requires_grad_() for f in feats]
-out = M.roi_align_levels(fd, rois, lv, 7, scales)
-go = torch.randn_like(out)
-map_bytes = sum(f.numel() for f in feats) * 4
-roi_bytes = n * 49 * 256 * 4
 
 
 def timed(fn, reps=10):
@@ -43,6 +36,43 @@ def timed(fn, reps=10):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
+
+
+if '--ba' in sys.argv:
+    # BA (AdptRoIExtractor): n positive RoIs, jittered copies of a few gt boxes per image (bench.py trained_like_proposals), pooled
+    # from EVERY level: per-level launches against the one-launch forms.  HTD_ROI_BWD_SPLIT=1/2/4 sets the wavefronts per strip.
+    gts = torch.rand(B, 5, 4, generator=g)
+    img = torch.sort(torch.randint(0, B, (n, ), generator=g))[0]
+    pick = gts[img, torch.randint(0, 5, (n, ), generator=g)]
+    cx, cy = pick[:, 0] * 1333, pick[:, 1] * 800
+    w, h = 30 + pick[:, 2] * 600, 30 + pick[:, 3] * 400
+    jit = (torch.rand(n, 4, generator=g) - 0.5) * 0.12 * torch.stack([w, h, w, h], 1)
+    rois = torch.stack([img.float(), (cx - w / 2 + jit[:, 0]).clamp(0, 1333), (cy - h / 2 + jit[:, 1]).clamp(0, 800),
+                        (cx + w / 2 + jit[:, 2]).clamp(0, 1333), (cy + h / 2 + jit[:, 3]).clamp(0, 800)], 1).to(dev)
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    fd = [f.clone().requires_grad_() for f in feats]
+    gos = [torch.randn(n, 256, 7, 7, device=dev).contiguous(memory_format=CL) for _ in range(4)]
+    t_lvl = timed(lambda: [M.roi_align(feats[i], rois, 7, scales[i], 0, 'avg', True) for i in range(4)])
+    t_all = timed(lambda: M.roi_align_all_levels(feats, rois, 7, scales))
+
+    def bwd(one):
+        for f in fd:
+            f.grad = None
+        outs = M.roi_align_all_levels(fd, rois, 7, scales) if one else [M.roi_align(fd[i], rois, 7, scales[i], 0, 'avg', True) for i in range(4)]
+        torch.autograd.backward(outs, gos)
+    tb_lvl = timed(lambda: bwd(False)) - t_lvl
+    tb_all = timed(lambda: bwd(True)) - t_all
+    print(f'BA {n} RoIs on 4 levels (split {os.environ.get("HTD_ROI_BWD_SPLIT", "default")}): forward per level {t_lvl * 1e6:8.1f} us, one launch {t_all * 1e6:8.1f} us; '
+          f'backward per level {tb_lvl * 1e6:8.1f} us, one launch {tb_all * 1e6:8.1f} us')
+    sys.exit(0)
+lv = map_roi_levels(rois, 4)
+scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+print('RoIs per level', torch.bincount(lv, minlength=4).tolist())
+fd = [f.clone().requires_grad_() for f in feats]
+out = M.roi_align_levels(fd, rois, lv, 7, scales)
+go = torch.randn_like(out)
+map_bytes = sum(f.numel() for f in feats) * 4
+roi_bytes = n * 49 * 256 * 4
 
 
 t = timed(lambda: M.roi_align_levels(feats, rois, lv, 7, scales))
