@@ -604,9 +604,28 @@ def batched_assign_and_sample(assigner, sampler, proposal_list, gt_bboxes, gt_la
     return out, counts
 
 
+_PAD_GT_LAST = {}
+_PAD_GT_CACHE = __import__('os').environ.get('HTD_PAD_GT_CACHE', '1') != '0'
+
+
 def pad_gt_batch(gt_bboxes, gt_labels=None):
     """Per-image gt lists -> zero-padded (B,K,4) boxes, (B,K) validity [, (B,K) labels] with two launches instead of
-    three slice assignments per image: one cat, one gather through an index built from the (host-known) list sizes."""
+    three slice assignments per image: one cat, one gather through an index built from the (host-known) list sizes.
+    The RPN targets and both RoI stages pad the same lists: the last result is kept (keyed by the tensors' identity and
+    version; it holds them alive, so an address cannot be recycled under the key)."""
+    key = (tuple((g.data_ptr(), g._version, tuple(g.shape)) for g in gt_bboxes),
+           None if gt_labels is None else tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in gt_labels))
+    hit = _PAD_GT_LAST.get(key) if _PAD_GT_CACHE else None
+    if hit is not None:
+        return hit[0]
+    out = _pad_gt_batch(gt_bboxes, gt_labels)
+    if len(_PAD_GT_LAST) >= 4:
+        _PAD_GT_LAST.clear()
+    _PAD_GT_LAST[key] = (out, list(gt_bboxes), None if gt_labels is None else list(gt_labels))
+    return out
+
+
+def _pad_gt_batch(gt_bboxes, gt_labels=None):
     dev = gt_bboxes[0].device
     sizes = tuple(int(g.size(0)) for g in gt_bboxes)
     B, K, tot = len(sizes), max(1, max(sizes)), sum(sizes)

@@ -452,3 +452,32 @@ extern "C" int htd_rpn_loss(const float *cls, const float *reg, const float *anc
                        grad_reg);
     return htd::check_launch("rpn_loss");
 }
+
+
+// ---- map_roi_levels (single_level_roi_extractor.py:32-51, htd_bbox_head.py:129-135) -------------------------------------
+// lvl = clamp(floor(log2(sqrt(w * h) / finest_scale + 1e-6)), 0, num_levels - 1) per RoI (idx, x1, y1, x2, y2): the reference's
+// five element-wise tensor operations (nine launches here through ATen, three call sites per train step) as one pass, in
+// the same fp32 operations in the same order (this file is compiled with -ffp-contract=off).
+namespace {
+__global__ __launch_bounds__(256) void map_roi_levels_kernel(const float *__restrict__ rois, int64_t *__restrict__ lvls, int64_t n,
+                                                             int num_levels, float finest_scale)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rois + 5 * i;
+    const float scale = sqrtf((r[3] - r[1]) * (r[4] - r[2]));
+    float l = floorf(log2f(scale / finest_scale + 1e-6f));
+    l = fminf(fmaxf(l, 0.f), (float)(num_levels - 1));         // (fmaxf / fminf drop a NaN -- a box of negative area -- to level 0:
+    lvls[i] = (int64_t)l;                                      //  the result is used as an index, it must stay inside [0, L))
+}
+}  // namespace
+
+extern "C" int htd_map_roi_levels(const float *rois, int64_t *lvls, int64_t n, int num_levels, float finest_scale, void *stream)
+{
+    HTD_REQUIRE(n >= 0 && num_levels > 0 && finest_scale > 0.f, "map_roi_levels: bad arguments");
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(rois && lvls, "map_roi_levels: null pointer");
+    hipLaunchKernelGGL(map_roi_levels_kernel, dim3((unsigned)htd::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rois, lvls, n,
+                       num_levels, finest_scale);
+    return htd::check_launch("map_roi_levels");
+}

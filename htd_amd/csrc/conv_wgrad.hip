@@ -1239,9 +1239,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
     }
 }
 
+// acc != 0: the sums are ADDED to what out / out2 hold (htd_conv2d_bwd_weight_acc: a weight shared by several layers -- the RPN
+// convolutions over five pyramid levels -- collects its gradient in place, level after level on one stream: a fixed order)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, float *__restrict__ out,
                                                             int64_t n, int splits, const float *__restrict__ ws2 = nullptr,
-                                                            float *__restrict__ out2 = nullptr, int n2 = 0)
+                                                            float *__restrict__ out2 = nullptr, int n2 = 0, int acc = 0)
 {
     // a second, small set of partials (bias gradient [splits][n2]) rides along in ceil(n2/256) extra workgroups
     // appended to the grid: one column per thread, four loads in flight
@@ -1249,7 +1251,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     if ((int)blockIdx.x >= (int)gridDim.x - extra) {
         const int i = ((int)blockIdx.x - ((int)gridDim.x - extra)) * 256 + threadIdx.x;
         if (i < n2) {
-            float s = 0.f;
+            float s = acc ? out2[i] : 0.f;
             int k = 0;
             for (; k + 3 < splits; k += 4) {
                 const float a = ws2[(int64_t)k * n2 + i], b = ws2[(int64_t)(k + 1) * n2 + i];
@@ -1265,7 +1267,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     // out[i] = sum_k ws[k][i] in fixed order; float4 lanes, four partial slabs in flight per thread
     const int64_t n4 = (n & 3) == 0 ? (n >> 2) : 0;      // slabs are 16-byte aligned only when n % 4 == 0
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)main_blocks * blockDim.x) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s = acc ? *reinterpret_cast<const float4 *>(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         int k = 0;
         for (; k + 3 < splits; k += 4) {
             float4 v[4];
@@ -1282,7 +1284,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     }
     if (blockIdx.x == 0)
         for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) {
-            float s = 0.f;
+            float s = acc ? out[i] : 0.f;
             for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * n + i];
             out[i] = s;
         }
@@ -1469,9 +1471,9 @@ extern "C" int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci,
 }
 
 // gbias (may be NULL): also returns the bias gradient, column sums of gy, accumulated by the same kernel.
-extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W,
-                                     int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
-                                     void *stream)
+// accumulate: gw (and gbias) += the gradient; the kernels then always write partials and the reduce pass adds them in.
+static int bwd_weight_impl(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W, int Ci, int Co, int kh,
+                           int kw, int stride, int pad, int dil, void *workspace, void *stream, int accumulate)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_bwd_weight: bad sizes");
@@ -1496,9 +1498,10 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         const int64_t slices = htd::ceil_div((int64_t)B * H * (W + 1), XH_KS);
         p.slices_per_split = htd::ceil_div(slices, p.splits);
         p.splits = (int)htd::ceil_div(slices, p.slices_per_split);
-        p.out = p.splits == 1 ? gw : (float *)workspace;
+        const bool direct = p.splits == 1 && !accumulate;
+        p.out = direct ? gw : (float *)workspace;
         float *bias_part = (float *)workspace + (int64_t)p.splits * Co * p.Ntot;
-        p.bias_out = !gbias ? nullptr : (p.splits == 1 ? gbias : bias_part);
+        p.bias_out = !gbias ? nullptr : (direct ? gbias : bias_part);
         hipStream_t s = (hipStream_t)stream;
         const dim3 grid((unsigned)(p.mt * p.nt * 3 * p.splits));
         static const bool x3hd_on = !(getenv("HTD_WGRAD_X3D") && atoi(getenv("HTD_WGRAD_X3D")) == 0);
@@ -1517,21 +1520,22 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         }
         else if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_x3h_kernel<false>, grid, dim3(256), 0, s, p);
-        if (p.splits > 1) {
+        if (!direct) {
             const int64_t n = (int64_t)Co * p.Ntot;
             const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
             const unsigned extra = gbias ? (unsigned)htd::ceil_div(Co, 256) : 0u;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + extra), dim3(256), 0, s, (const float *)workspace, gw, n,
-                               p.splits, (const float *)(gbias ? bias_part : nullptr), gbias, Co);
+                               p.splits, (const float *)(gbias ? bias_part : nullptr), gbias, Co, accumulate);
         }
         return htd::check_launch("conv2d_bwd_weight");
     }
     const Cfg c = choose(Co, p.Ntot, p.K);
     p.mt = c.mt; p.nt = c.nt; p.splits = c.splits;
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
-    p.out = c.splits == 1 ? gw : (float *)workspace;
+    const bool direct = c.splits == 1 && !accumulate;
+    p.out = direct ? gw : (float *)workspace;
     float *bias_partial = (float *)workspace + (int64_t)c.splits * Co * p.Ntot;
-    p.bias_out = !gbias ? nullptr : (c.splits == 1 ? gbias : bias_partial);
+    p.bias_out = !gbias ? nullptr : (direct ? gbias : bias_partial);
     hipStream_t s = (hipStream_t)stream;
     p.slices_per_split = htd::ceil_div(htd::ceil_div(p.K, BKW), c.splits);
     dim3 grid((unsigned)(c.mt * c.nt * c.splits));
@@ -1565,14 +1569,31 @@ extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw,
         launch_wgrad<1, 4, 1, 1>(pix, covec, grid, s, p);
     else
         launch_wgrad<2, 2, 2, 2>(pix, covec, grid, s, p);
-    if (c.splits > 1) {
+    if (!direct) {
         const int64_t n = (int64_t)Co * p.Ntot;
         const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
         const unsigned extra = gbias ? (unsigned)htd::ceil_div(Co, 256) : 0u;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + extra), dim3(256), 0, s, (const float *)workspace, gw, n,
-                           c.splits, (const float *)(gbias ? bias_partial : nullptr), gbias, Co);
+                           c.splits, (const float *)(gbias ? bias_partial : nullptr), gbias, Co, accumulate);
     }
     return htd::check_launch("conv2d_bwd_weight");
+}
+
+extern "C" int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W,
+                                     int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
+                                     void *stream)
+{
+    return bwd_weight_impl(x, gy, gw, gbias, B, H, W, Ci, Co, kh, kw, stride, pad, dil, workspace, stream, 0);
+}
+
+// gw += the weight gradient, gbias += the bias gradient: for a parameter that several layers share (RPNHead's convolutions run
+// on five pyramid levels, anchor_head.py:123-140; the stage-1 classifier that stage 2 reuses, htd_bbox_head.py:158): the
+// gradient collects in place, call after call on one stream, instead of five tensors that autograd then adds.
+extern "C" int htd_conv2d_bwd_weight_acc(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W,
+                                         int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
+                                         void *stream)
+{
+    return bwd_weight_impl(x, gy, gw, gbias, B, H, W, Ci, Co, kh, kw, stride, pad, dil, workspace, stream, 1);
 }
 
 // g [rows][C], y (may be NULL) [rows][C]; gm (out, required iff y) ; gbias [C]; workspace >= 2048*C*4 bytes

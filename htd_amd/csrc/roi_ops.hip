@@ -187,13 +187,17 @@ __global__ __launch_bounds__(256) void ba_fuse_bwd_kernel(Ptr4 lvl, int L, const
     for (int e = threadIdx.x; e < P * C4; e += blockDim.x) {
         const int p = e / C4;
         const float4 g = ld4(go + (base + e) * 4);
+        const bool ring = on_ring(p, ph, pw, edge);
         for (int l = 0; l < L; ++l) {
             const float4 v = ld4(lvl.p[l] + (base + e) * 4);
             d[l] += g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w;
-            st4(glvl.p[l] + (base + e) * 4, make_float4(w[l] * g.x, w[l] * g.y, w[l] * g.z, w[l] * g.w));
+            float4 o = make_float4(w[l] * g.x, w[l] * g.y, w[l] * g.z, w[l] * g.w);
+            if (l == 0 && gborder == nullptr && ring) {       // the border source IS level 0: its share lands in the same map
+                o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w;
+            }
+            st4(glvl.p[l] + (base + e) * 4, o);
         }
-        const bool ring = on_ring(p, ph, pw, edge);
-        st4(gborder + (base + e) * 4, ring ? g : make_float4(0.f, 0.f, 0.f, 0.f));
+        if (gborder != nullptr) st4(gborder + (base + e) * 4, ring ? g : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     __shared__ float red[4][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -233,8 +237,10 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float *__restrict__ 
     out[b * C + c] = acc / (float)P;
 }
 
+// acc != 0: gx += g / P (gx already holds another consumer's gradient of the pooled map: BA's level features feed the
+// attention pooling AND the weighted sum -- the pooling's share is added in place instead of a second map that autograd sums)
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ g, float *__restrict__ gx,
-                                                      int64_t total4, int P, int C4)
+                                                      int64_t total4, int P, int C4, int acc)
 {
     const float inv = 1.f / (float)P;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
@@ -242,7 +248,12 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float *__restrict__ 
         const int c4 = (int)(idx % C4);
         const int64_t b = idx / ((int64_t)P * C4);
         const float4 v = ld4(g + (b * C4 + c4) * 4);
-        st4(gx + idx * 4, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
+        float4 o = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+        if (acc) {
+            const float4 t = ld4(gx + idx * 4);
+            o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+        }
+        st4(gx + idx * 4, o);
     }
 }
 
@@ -729,7 +740,9 @@ extern "C" int htd_ba_fuse_bwd(const float *const *lvl, int L, const float *att,
     HTD_REQUIRE(L >= 1 && L <= 4, "ba_fuse: L=%d not in [1,4]", L);
     HTD_REQUIRE(C % 4 == 0 && ph > 0 && pw > 0 && edge >= 0, "ba_fuse: bad sizes");
     if (n == 0) return HTD_OK;
-    HTD_REQUIRE(lvl && att && grad_out && grad_lvl && grad_border && grad_att, "ba_fuse_bwd: null pointer");
+    // grad_border == NULL: the border source is level 0 (AdptRoIExtractor: the same RoIAlign output) and its gradient is added
+    // into grad_lvl[0] by the kernel
+    HTD_REQUIRE(lvl && att && grad_out && grad_lvl && grad_att, "ba_fuse_bwd: null pointer");
     Ptr4 p{};
     MPtr4 g{};
     for (int l = 0; l < L; ++l) { p.p[l] = lvl[l]; g.p[l] = grad_lvl[l]; }
@@ -755,8 +768,19 @@ extern "C" int htd_global_avg_pool_bwd(const float *g, float *gx, int64_t B, int
     HTD_REQUIRE(g && gx, "global_avg_pool_bwd: null pointer");
     const int64_t total4 = B * P * (C / 4);
     hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, g, gx, total4, P,
-                       C / 4);
+                       C / 4, 0);
     return htd::check_launch("global_avg_pool_bwd");
+}
+
+// gx [B][P][C] += g [B][C] / P
+extern "C" int htd_global_avg_pool_bwd_acc(const float *g, float *gx, int64_t B, int P, int C, void *stream)
+{
+    HTD_REQUIRE(B >= 0 && P > 0 && C > 0 && C % 4 == 0, "global_avg_pool_bwd_acc: bad sizes");
+    if (B == 0) return HTD_OK;
+    HTD_REQUIRE(g && gx, "global_avg_pool_bwd_acc: null pointer");
+    const int64_t total4 = B * P * (C / 4);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, g, gx, total4, P, C / 4, 1);
+    return htd::check_launch("global_avg_pool_bwd_acc");
 }
 
 extern "C" int htd_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,

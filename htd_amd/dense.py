@@ -68,6 +68,32 @@ def unregister_grad_sinks(keys, used):
             del _GRAD_SINK[k]
 
 
+_TEMP_USED = set()
+_TEMP_KEYS = []
+
+
+def temp_grad_sink(t):
+    """A gradient buffer for the NON-LEAF tensor t that several layers read (the RPN's merged 1x1 head weights, made once per
+    step and used on five pyramid levels): the first weight gradient of the step is written into it and returned to autograd,
+    the later ones are added in place by the kernel and return nothing (_wgrad_launch) -- one defined contribution instead of
+    five tensors to sum.  Dropped by new_step()."""
+    import weakref
+    if not (t.is_cuda and t.requires_grad and SINK_ACCUMULATE):
+        return
+    _GRAD_SINK[t.data_ptr()] = (torch.empty_like(t), weakref.ref(t), _TEMP_USED)
+    _TEMP_USED.discard(t.data_ptr())
+    _TEMP_KEYS.append(t.data_ptr())
+
+
+def _drop_temp_sinks():
+    for k in _TEMP_KEYS:
+        ent = _GRAD_SINK.get(k)
+        if ent is not None and ent[2] is _TEMP_USED:
+            del _GRAD_SINK[k]
+    _TEMP_KEYS.clear()
+    _TEMP_USED.clear()
+
+
 def reset_grad_sinks(used=None):
     if used is not None:
         used.clear()
@@ -80,6 +106,27 @@ def reset_grad_sinks(used=None):
 def grad_out(like):
     """Tensor to write the gradient of `like` into: an alias of its registered flat-gradient slice, else a new one."""
     return grad_out2(like)[0]
+
+
+def grad_sink_again(like):
+    """The registered flat-gradient slice of `like` when it was ALREADY handed out this step (a parameter several layers share),
+    viewed in like's layout -- for a kernel that adds into it (htd_conv2d_bwd_weight_acc); else None."""
+    key = like.data_ptr()
+    ent = _GRAD_SINK.get(key)
+    if ent is None or torch.is_grad_enabled():
+        return None
+    v, ref, used = ent
+    owner = ref()
+    if owner is None or owner.data_ptr() != key or key not in used or v.numel() != like.numel():
+        return None
+    if v.shape == like.shape and v.stride() == like.stride():
+        return v.view_as(v)
+    if like.dim() == 4 and like.shape[2:] == (1, 1) and like.size(0) == v.size(0):
+        if v.dim() == 4 and v.is_contiguous(memory_format=CL):
+            v = v.permute(0, 2, 3, 1).reshape(v.size(0), -1)
+        if v.dim() == 2 and v.is_contiguous():
+            return v.view(v.size(0), 1, 1, v.size(1)).permute(0, 3, 1, 2)
+    return None
 
 
 def grad_out2(like):
@@ -95,7 +142,9 @@ def grad_out2(like):
     if ent is not None and key not in used and v.numel() == like.numel() and torch.is_grad_enabled() is False:
         if v.shape == like.shape and v.stride() == like.stride():
             used.add(key)
-            return v.view_as(v), True
+            # (a temporary sink's buffer is read by autograd on the MAIN stream -- CatBackward of the merged RPN head weights --
+            #  so it does not count as a flat-buffer sink for the weight-gradient stream's "nobody waits" rule, _wgrad_raw)
+            return v.view_as(v), used is not _TEMP_USED
         if like.dim() == 4 and like.shape[2:] == (1, 1) and like.size(0) == v.size(0):
             if v.dim() == 4 and v.is_contiguous(memory_format=CL):       # TileLinear: (out,C,h,w) stored (out,h,w,C)
                 v = v.permute(0, 2, 3, 1).reshape(v.size(0), -1)
@@ -191,6 +240,7 @@ def _flip_key(w):
 def new_step():
     _STEP_FLIPS.clear()
     _STEP_PLANES.clear()
+    _drop_temp_sinks()
 
 
 # bf16 plane images of the weights (csrc/conv_x3.hip: the B operand of conv_x3p_kernel, split once per step instead of
@@ -258,7 +308,7 @@ def planes_many(items):
         desc[i, 4] = block0
         block0 += (n32 // 4 // 6 + 255) // 256          # elements = uint4 count / 6 chunks
         _STEP_PLANES[key] = (w, out)
-    table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+    table = capi.upload_table(desc, dev)
     capi.call('htd_conv2d_x3_planes_many', _P(table), len(todo), block0, _S())
 
 
@@ -293,7 +343,7 @@ def flip_many(weights):
         desc[i, 9] = taps | (tile0 << 32)
         tile0 += taps * ((Co + 31) // 32) * ((Ci + 31) // 32)
         _STEP_FLIPS[_flip_key(w)] = (w, wT)
-    table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+    table = capi.upload_table(desc, dev)
     capi.call('htd_bn_fold_many_fwd', _P(table), len(ws), tile0, 0.0, _S())
 
 
@@ -475,10 +525,26 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
     return gx
 
 
+SINK_ACCUMULATE = os.environ.get('HTD_SINK_ACC', '1') != '0'      # 0: shared parameters collect their gradient through autograd adds
+
+
 def _wgrad_launch(x, g, weight, stride, padding, dilation, bias):
     B, Ci, H, W = x.shape
     Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
+    # A parameter shared by several layers (the RPN's convolutions on five pyramid levels, the stage-1 classifier that stage 2
+    # reuses): its first gradient of the step was written into the flat-buffer slice; this one is ADDED there by the kernel
+    # (htd_conv2d_bwd_weight_acc) and nothing is returned -- autograd has one defined contribution and no sums to launch.
+    aw = grad_sink_again(weight) if SINK_ACCUMULATE else None
+    ab = grad_sink_again(bias) if (aw is not None and torch.is_tensor(bias)) else None
+    if aw is not None and (bias is None or ab is not None) and B * Ho * Wo > 0:
+        nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
+        ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
+        capi.call('htd_conv2d_bwd_weight_acc', _P(x), _P(g), _P(aw), _P(ab), B, H, W, Ci, Co, kh, kw, stride, padding,
+                  dilation, _P(ws), _S(), key='htd_conv2d_bwd_weight',
+                  work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci, 4.0 * (x.numel() + g.numel() + aw.numel())))
+        ent = _GRAD_SINK.get(weight.data_ptr())
+        return None, None, not (ent is not None and ent[2] is _TEMP_USED)
     gw, sink_w = grad_out2(weight)
     gb, sink_b = (None, True)
     if bias is not None:            # True: bias gradient wanted, no parameter to look a sink up for
@@ -510,7 +576,8 @@ def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None, overlap=True)
     with torch.cuda.stream(side):
         gw, gb, sinks = _wgrad_launch(x, g, weight, stride, padding, dilation, bias)
     if not sinks and weight.data_ptr() not in _SIDE_CONSUMED:
-        gw.record_stream(main)
+        if gw is not None:
+            gw.record_stream(main)
         if gb is not None:
             gb.record_stream(main)
         main.wait_stream(side)          # autograd consumes these gradients on the main stream
@@ -735,11 +802,15 @@ class ResStageFunction(Function):
         the bias gradients come out of the wgrad launches: no separate pass over any gradient map;
       * the identity / downsample branch joins through `accum` in the conv1 dgrad epilogue (no separate add);
       * blocks after the first hand their predecessor a gradient already masked by the predecessor's output ReLU.
-    args: x, n_blocks, strides (tuple), dilation, has_ds (tuple of bool), then per block w1,b1,w2,b2,w3,b3[,wd,bd]."""
+    args: x, strides (tuple), dilation, has_ds (tuple of bool), chain, then per block w1,b1,w2,b2,w3,b3[,wd,bd].
+    chain=True: also returns an identity alias of x (see Conv2dFunction): a later consumer of x -- the FPN lateral of this
+    pyramid level -- reads the alias, and its gradient joins in the first block's data-gradient epilogues (`accum`) instead
+    of a full-map add by autograd (C3: 138 MB, C4: 69 MB per step)."""
 
     @staticmethod
-    def forward(ctx, x, strides, dilation, has_ds, *params):
+    def forward(ctx, x, strides, dilation, has_ds, chain, *params):
         _need_gpu(x, 'res_stage')
+        src = x
         x = x.contiguous(memory_format=CL)
         params = [t.contiguous(memory_format=CL) if t.dim() == 4 else t.contiguous() for t in params]
         saved, k = [], 0
@@ -761,12 +832,17 @@ class ResStageFunction(Function):
         ctx.save_for_backward(*saved, *params)
         ctx.cfg = (strides, dilation, has_ds)
         ctx.flipped = [take_flipped(t) if t.dim() == 4 else None for t in params]      # same indexing as params
+        if chain:
+            ctx.set_materialize_grads(False)              # an unused alias arrives as None, not as a map of zeros
+            return x, src.view_as(src)
         return x
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, galias=None):
         strides, dilation, has_ds = ctx.cfg
+        if g is None:                                     # (chain) the stage's own output was not used
+            return (galias, None, None, None, None) + (None, ) * (len(ctx.saved_tensors) - 4 * len(strides))
         nb = len(strides)
         saved, params = ctx.saved_tensors[:4 * nb], ctx.saved_tensors[4 * nb:]
         flipped = ctx.flipped
@@ -777,12 +853,14 @@ class ResStageFunction(Function):
         need = ctx.needs_input_grad
         grads = [None] * len(params)
         g = g.contiguous(memory_format=CL)
+        if galias is not None:
+            galias = galias.contiguous(memory_format=CL)
         premasked = False
         for i in range(nb - 1, -1, -1):
             x, h1, h2, out = saved[4 * i:4 * i + 4]
             k, stride, ds = offs[i], strides[i], has_ds[i]
             w1, b1, w2, b2, w3, b3 = params[k:k + 6]
-            pneed = need[4 + k:4 + k + (8 if ds else 6)]
+            pneed = need[5 + k:5 + k + (8 if ds else 6)]
             first = i == 0
             need_x = need[0] if first else True
             # bias gradients are by-products of the wgrad launches (column sums of the staged gy tiles); a conv whose
@@ -814,14 +892,20 @@ class ResStageFunction(Function):
                 if pneed[6]:
                     grads[k + 6] = _wgrad_raw(x, gm3, wd, stride, 0, 1)[0]
                 grads[k + 7] = gb3 if pneed[7] else None
-                acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1, wT=flipped[k + 6]) if need_x else None
+                # (first block: the chained consumer's gradient of x rides this epilogue, then conv1's below)
+                acc = _dgrad_raw(gm3, wd, x.shape, stride, 0, 1, wT=flipped[k + 6],
+                                 accum=galias if first else None) if need_x else None
+            elif first and galias is not None and need_x:
+                acc = gm3 + galias                        # (no downsample branch in the first block: not a ResNet stage)
             if need_x:
                 g = _dgrad_raw(gm1, w1, x.shape, 1, 0, 1, mask_src=None if first else x, accum=acc, wT=flipped[k],
                                g_planes=gm1p)
                 premasked = not first
             else:
                 g = None
-        return (g, None, None, None, *grads)
+        if g is None and galias is not None and need[0]:
+            g = galias
+        return (g, None, None, None, None, *grads)
 
 
 def conv2d_bf16(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, res_up=False):
@@ -926,7 +1010,7 @@ def _prep_bf16_many(items):
         desc[i, 5] = tile0
         tile0 += kh * kw * ((Co + 31) // 32) * ((Ci + 31) // 32)
         out.append((wb, wT))
-    table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+    table = capi.upload_table(desc, dev)
     capi.call('htd_weights_prep_bf16_many', _P(table), len(ws), tile0, _S())
     return out
 

@@ -170,7 +170,7 @@ class _BNFoldMany(torch.autograd.Function):
             tile0 += taps * ((Co + 31) // 32) * ((Ci + 31) // 32)
             outs += [wf, bf]
             flips.append(wT)
-        table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+        table = capi.upload_table(desc, dev)
         capi.call('htd_bn_fold_many_fwd', capi.ptr(table), n, tile0, float(eps), capi.current_stream_ptr())
         # bf16 plane images of the folded weights (conv_x3p_kernel operands, csrc/conv_x3.hip): one more launch per stage
         if want_planes:                                      # fp32 stages only: the bf16 stages make bf16 operands of their own
@@ -210,7 +210,7 @@ class _BNFoldMany(torch.autograd.Function):
                 desc[i, 10] = row0
                 row0 += Co
                 outs.append((gw, gg, gb))
-            table = torch.from_numpy(desc.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+            table = capi.upload_table(desc, dev)
             capi.call('htd_bn_fold_many_bwd', capi.ptr(table), n, row0, ctx.eps, capi.current_stream_ptr())
             return outs, all_sinks, keep
         if not dense.OVERLAP_WGRAD or (capi.profiling() and not dense._OVERLAP_IN_PROFILE):

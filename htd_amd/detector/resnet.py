@@ -136,10 +136,12 @@ class ResLayer(nn.Sequential):
                 return False
         return True
 
-    def forward(self, x):
+    def forward(self, x, chain=False):
+        """chain=True (fp32 one-node stages only): -> (out, alias of x) -- see dense.ResStageFunction; otherwise (out, x)."""
         if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or not self._fusable() or \
                 (x.dtype == torch.bfloat16 and not FUSE_BF16_STAGE):
-            return super().forward(x)           # CPU / DCN or grouped blocks: block by block
+            y = super().forward(x)              # CPU / DCN or grouped blocks: block by block
+            return (y, x) if chain else y
         pairs = []
         for blk in self:
             pairs += [(blk.conv1.weight, blk.norm1), (blk.conv2.weight, blk.norm2), (blk.conv3.weight, blk.norm3)]
@@ -150,9 +152,17 @@ class ResLayer(nn.Sequential):
         params = frozen_bn_fold_many(pairs, want_flips=x.dtype == torch.float32 and
                                      (x.requires_grad or any(w.requires_grad for w, _ in pairs)),
                                      want_planes=x.dtype == torch.float32)
-        fn = ResStageFunction if x.dtype == torch.float32 else ResStageBf16Function
-        return fn.apply(x, tuple(blk.conv2_stride for blk in self), self[0].dilation,
-                        tuple(blk.downsample is not None for blk in self), *params)
+        strides, has_ds = tuple(blk.conv2_stride for blk in self), tuple(blk.downsample is not None for blk in self)
+        if x.dtype == torch.float32:
+            # (a strided first block -- layers 2-4 of every ResNet -- cannot take the chained gradient: the strided data gradient
+            #  of its 1x1 shortcut has no `accum` operand, htd_conv2d_bwd_data; autograd adds the two maps as before)
+            use = bool(chain and x.requires_grad and torch.is_grad_enabled() and strides[0] == 1)
+            y = ResStageFunction.apply(x, strides, self[0].dilation, has_ds, use, *params)
+            if chain:
+                return y if use else (y, x)
+            return y
+        y = ResStageBf16Function.apply(x, strides, self[0].dilation, has_ds, *params)
+        return (y, x) if chain else y
 
 
 @BACKBONES.register_module()
@@ -257,7 +267,13 @@ class ResNet(nn.Module):
             x = x.to(torch.bfloat16)            # bf16 configurations: stages (and the neck) run on the bf16 kernels
         outs = []
         for i, name in enumerate(self.res_layers):
-            x = getattr(self, name)(x)
+            layer = getattr(self, name)
+            if isinstance(layer, ResLayer) and outs and (i - 1) in self.out_indices:
+                # the previous stage's output has two consumers, this stage and the neck: the neck reads the alias this
+                # stage hands back, so its gradient joins inside the stage's backward (dense.ResStageFunction, chain)
+                x, outs[-1] = layer(x, chain=True)
+            else:
+                x = layer(x)
             if i in self.out_indices:
                 outs.append(x)
         return tuple(outs)

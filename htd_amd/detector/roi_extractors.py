@@ -43,6 +43,13 @@ class BaseRoIExtractor(nn.Module):
 def map_roi_levels(rois, num_levels, finest_scale=56):
     """scale < 2*finest -> 0, < 4*finest -> 1, ... (single_level_roi_extractor.py:32-51,
     htd_bbox_head.py:129-135)."""
+    if rois.is_cuda and rois.dtype == torch.float32 and rois.dim() == 2 and rois.size(1) == 5 and not rois.requires_grad:
+        from .. import capi
+        r = rois.contiguous()
+        lvls = torch.empty(r.size(0), device=r.device, dtype=torch.int64)
+        capi.call('htd_map_roi_levels', capi.ptr(r), capi.ptr(lvls), r.size(0), int(num_levels), float(finest_scale),
+                  capi.current_stream_ptr())
+        return lvls
     scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
     lvls = torch.floor(torch.log2(scale / finest_scale + 1e-6))
     return lvls.clamp(min=0, max=num_levels - 1).long()
@@ -120,7 +127,14 @@ class AdptRoIExtractor(BaseRoIExtractor):
                 lvl_feats.append(f)
         else:
             lvl_feats = [self.roi_layers[i](feats[i], rois) for i in range(L)]
-        pooled = torch.cat([M.global_avg_pool(f).view(n, -1) for f in lvl_feats], 0)
+        if rois.is_cuda and torch.is_grad_enabled() and any(f.requires_grad for f in lvl_feats):
+            # a level's features feed the pooling AND the weighted sum below: the sum reads the pooling node's alias, so the two
+            # gradients of a level meet inside the pooling's backward (mmcv_ops.GlobalAvgPoolFunction, chain)
+            pairs = [M.global_avg_pool(f, chain=True) for f in lvl_feats]
+            pooled = torch.cat([p.view(n, -1) for p, _ in pairs], 0)
+            lvl_feats = [a for _, a in pairs]
+        else:
+            pooled = torch.cat([M.global_avg_pool(f).view(n, -1) for f in lvl_feats], 0)
         att = self.attention_logits(pooled).view(L, n)          # n == 1 keeps its axis (reference .squeeze() bug)
         # roi_layers[0](feats[0], rois) of :87 equals lvl_feats[0]: evaluated once
         return M.ba_fuse(att, lvl_feats, self.edge)

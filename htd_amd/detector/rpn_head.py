@@ -130,6 +130,10 @@ class RPNHead(nn.Module):
         cls, reg = [], []
         taps = isinstance(feats, M.PyramidTaps)      # the pyramid as a chain of consumers: see Conv2dFunction(chain=True)
         from .. import dense
+        if torch.is_grad_enabled() and w.requires_grad:
+            # five levels read these two tensors: their gradients collect in one buffer each (dense.temp_grad_sink)
+            dense.temp_grad_sink(w)
+            dense.temp_grad_sink(b)
         for i in range(len(feats)):
             x = feats[i]
             if x.dtype == torch.float32 and x.size(1) % 8 == 0:

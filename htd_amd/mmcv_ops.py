@@ -659,12 +659,11 @@ class BAFuseFunction(Function):
         n, C, ph, pw = lv[0].shape
         go = nhwc(go)
         glv = [torch.empty_like(f, memory_format=CL) for f in lv]
-        gborder = torch.empty_like(lv[0], memory_format=CL)
         gatt = torch.empty_like(att)
         arr = (ctypes.c_void_p * L)(*[f.data_ptr() for f in lv])
         garr = (ctypes.c_void_p * L)(*[f.data_ptr() for f in glv])
-        capi.call('htd_ba_fuse_bwd', arr, L, _P(att), _P(go), garr, _P(gborder), _P(gatt), n, ph, pw, C, ctx.edge, _S())
-        glv[0] = glv[0] + gborder
+        # (no border map: the border source is level 0, the kernel adds the ring's gradient into glv[0])
+        capi.call('htd_ba_fuse_bwd', arr, L, _P(att), _P(go), garr, None, _P(gatt), n, ph, pw, C, ctx.edge, _S())
         return (gatt, None, *glv)
 
 
@@ -679,27 +678,40 @@ class GlobalAvgPoolFunction(Function):
     AvgPool of the reg branch (htd_bbox_head.py:122,188)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, chain=False):
+        """chain=True: -> (pooled, identity alias of x).  A second consumer of x that reads the alias hands its gradient to
+        THIS node's backward, which adds the pooling's share into it in place (htd_global_avg_pool_bwd_acc) -- x's producer
+        gets one gradient map and autograd has nothing to add (BA: four (n,256,7,7) adds per step)."""
         _need_gpu(x, 'global_avg_pool')
+        src = x
         x = nhwc(_f32(x, 'global_avg_pool'))
         n, C, h, w = x.shape
         out = torch.empty(n, C, device=x.device, dtype=x.dtype)
         capi.call('htd_global_avg_pool_fwd', _P(x), _P(out), n, h * w, C, _S())
         ctx.shape = (n, C, h, w)
+        if chain:
+            ctx.set_materialize_grads(False)
+            return out.view(n, C, 1, 1), src.view_as(src)
         return out.view(n, C, 1, 1)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, galias=None):
         n, C, h, w = ctx.shape
+        if g is None:
+            return galias, None
         g = g.reshape(n, C).contiguous()
+        if galias is not None and galias.dtype == g.dtype and tuple(galias.shape) == (n, C, h, w) and \
+                galias.is_contiguous(memory_format=CL):
+            capi.call('htd_global_avg_pool_bwd_acc', _P(g), _P(galias), n, h * w, C, _S())
+            return galias, None
         gx = torch.empty((n, C, h, w), device=g.device, dtype=g.dtype, memory_format=CL)
         capi.call('htd_global_avg_pool_bwd', _P(g), _P(gx), n, h * w, C, _S())
-        return gx
+        return (gx if galias is None else gx + galias), None
 
 
-def global_avg_pool(x):
-    return GlobalAvgPoolFunction.apply(x)
+def global_avg_pool(x, chain=False):
+    return GlobalAvgPoolFunction.apply(x, chain)
 
 
 class GroupNormReLUFunction(Function):
@@ -715,6 +727,7 @@ class GroupNormReLUFunction(Function):
                   int(num_groups), float(eps), int(bool(relu)), _S())
         ctx.save_for_backward(x, y, weight, mean, rstd)
         ctx.meta = (int(num_groups), int(bool(relu)))
+        ctx.bias_ref = bias                   # only its address is used (gradient sink lookup)
         return y
 
     @staticmethod
@@ -725,8 +738,9 @@ class GroupNormReLUFunction(Function):
         n, C, h, w = x.shape
         gy = nhwc(gy)
         gx = torch.empty_like(x, memory_format=CL)
-        gw = torch.empty_like(weight)
-        gb = torch.empty_like(weight)
+        from . import dense
+        gw = dense.grad_out(weight)           # straight into the flat gradient buffer when the parameters are registered there
+        gb = dense.grad_out(ctx.bias_ref) if ctx.bias_ref is not None and ctx.bias_ref.shape == weight.shape else torch.empty_like(weight)
         ws = torch.empty(2 * max(n, 1) * C, device=x.device, dtype=torch.float32)      # per-tile sums, added in a fixed order
         capi.call('htd_group_norm_relu_bwd_ws', _P(x), _P(y), _P(weight), _P(mean), _P(rstd), _P(gy), _P(gx), _P(gw),
                   _P(gb), n, h * w, C, G, relu, _P(ws), _S())

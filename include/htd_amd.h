@@ -247,6 +247,11 @@ int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, in
 int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W,
                           int Ci, int Co, int kh, int kw, int stride, int pad, int dil, void *workspace,
                           void *stream);
+/* The same with gw += and gbias +=: the gradient of a parameter shared by several layers (the RPN convolutions over five
+ * pyramid levels, dense_heads/anchor_head.py:123-140; stage 1's classifier reused by stage 2, bbox_heads/htd_bbox_head.py:158)
+ * collects in place, call after call on one stream (a fixed summation order). */
+int htd_conv2d_bwd_weight_acc(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W, int Ci,
+                              int Co, int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream);
 int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows,
                             int C, void *workspace, void *stream);
 /* The ResNet stem (backbones/resnet.py:596-607 `conv1`: 7x7, stride 2, padding 3, 3 -> 64 channels; what cuDNN's
@@ -351,6 +356,9 @@ int htd_deform_col2im_bf16(const void *x, const float *offset, const float *mask
  * ---------------------------------------------------------------------------------- */
 int htd_global_avg_pool_fwd(const float *x, float *out, int64_t B, int P, int C, void *stream);
 int htd_global_avg_pool_bwd(const float *g, float *gx, int64_t B, int P, int C, void *stream);
+/* gx += g / P: the pooled map has a second consumer whose gradient gx already holds (adaptative_roi_extractor.py:72-86: a
+ * level's RoI features feed the attention pooling and the weighted sum). */
+int htd_global_avg_pool_bwd_acc(const float *g, float *gx, int64_t B, int P, int C, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * GroupNorm + ReLU on NHWC RoI tiles (GN36 over 576 channels, htd_bbox_head.py:48,89,111):
@@ -424,6 +432,9 @@ int htd_roi_targets(const float *boxes, const float *gt_boxes, const int64_t *gt
 int htd_delta2bbox_clip(const float *rois, const float *deltas, const float *lim_wh, const uint8_t *keep, int64_t n,
                         int64_t rows_per_img, const float *means4, const float *stds4, float wh_ratio_clip,
                         float *out, void *stream);
+/* map_roi_levels (roi_extractors/single_level_roi_extractor.py:32-51, bbox_heads/htd_bbox_head.py:129-135):
+ * lvls[i] = clamp(floor(log2(sqrt(w_i * h_i) / finest_scale + 1e-6)), 0, num_levels - 1) for rois (n, 5), int64 out. */
+int htd_map_roi_levels(const float *rois, int64_t *lvls, int64_t n, int num_levels, float finest_scale, void *stream);
 
 /* RPN loss of the whole batch in one pass (AnchorHead.loss / loss_single, dense_heads/anchor_head.py:373-488, with the
  * targets of _get_targets_single :172-269 and bbox2delta formed on the fly).  cls [B*A] logits (one sigmoid channel),

@@ -507,3 +507,24 @@ def test_random_sample_kernel_equals_tensor_formulation(dev, B, A, num, frac, ub
         n = int(pos_ref[b].sum() + neg_ref[b].sum())
         assert order[b, :n].cpu().tolist() == ref_order[b, :n].tolist()
         assert int(order[b, n:].abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_map_roi_levels_kernel_equals_the_tensor_formula():
+    """htd_map_roi_levels against the reference's five tensor operations (single_level_roi_extractor.py:32-51), including boxes
+    whose scale sits exactly on a level boundary (112, 224, 448 px) and empty slots"""
+    from htd_amd.detector.roi_extractors import map_roi_levels
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(4)
+    n = 5000
+    size = torch.exp(torch.rand(n, generator=g) * 6.0 + 1.0)
+    ar = torch.exp(torch.rand(n, generator=g) * 2 - 1)
+    x1, y1 = torch.rand(n, generator=g) * 900, torch.rand(n, generator=g) * 600
+    rois = torch.stack([torch.zeros(n), x1, y1, x1 + size * ar, y1 + size / ar], 1)
+    edge = torch.tensor([[0, 10., 20., 10 + s, 20 + s] for s in (56., 111.99999, 112., 112.00001, 224., 448., 447.99997, 896., 0., 1e-3)])
+    rois = torch.cat([rois, edge, torch.zeros(7, 5)]).to(dev)
+    for L in (4, 5, 1):
+        scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+        ref = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=L - 1).long()
+        got = map_roi_levels(rois, L, 56)
+        assert got.dtype == torch.int64 and torch.equal(got, ref)
