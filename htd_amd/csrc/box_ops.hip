@@ -481,3 +481,86 @@ extern "C" int htd_map_roi_levels(const float *rois, int64_t *lvls, int64_t n, i
                        num_levels, finest_scale);
     return htd::check_launch("map_roi_levels");
 }
+
+
+// ---- RPN head outputs of all pyramid levels <-> the flat per-anchor form (anchor_head.py:172-269 targets / loss, rpn_head.py:
+// 78-168 proposals: both flatten every level's (B, A*C, h, w) map with permute(0, 2, 3, 1).reshape and concatenate) -----------
+// y[l]: the merged head's output of level l, NHWC [B][P_l][C] with channel c < na the objectness of anchor c and channels
+// na + 4 a + j the deltas of anchor a (RPNHead.forward: rpn_cls and rpn_reg as one convolution; C - 5 na padding channels).
+//   gather:  cls[b][off_l + p na + a] = y_l[b][p][a],   reg[b][off_l + p na + a][j] = y_l[b][p][na + 4 a + j]
+//   scatter: the transpose, padding channels zero -- the gradient of y_l written in full.
+// One launch each instead of ~45 slice / clone / concatenate launches per train step.
+namespace {
+struct HeadLevels {
+    const float *y[8];
+    float *gy[8];
+    int64_t pix[8];        // P_l = h_l * w_l
+    int64_t off[8];        // first anchor of level l in an image's flat list
+    int64_t t0[9];         // first thread of level l (prefix of B * P_l)
+    int L;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void rpn_heads_kernel(HeadLevels t, float *__restrict__ cls, float *__restrict__ reg, int64_t atot,
+                                                        int C, int na)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.t0[t.L]) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < t.L && i >= t.t0[k]) l = k;
+    const int64_t r = i - t.t0[l], P = t.pix[l];
+    const int64_t b = r / P, p = r - b * P;
+    const int64_t a0 = b * atot + t.off[l] + p * na;
+    if (!SCATTER) {
+        const float *src = t.y[l] + r * C;
+        for (int a = 0; a < na; ++a) cls[a0 + a] = src[a];
+        for (int k = 0; k < 4 * na; ++k) reg[a0 * 4 + k] = src[na + k];
+    } else {
+        float *dst = t.gy[l] + r * C;
+        for (int a = 0; a < na; ++a) dst[a] = cls[a0 + a];
+        for (int k = 0; k < 4 * na; ++k) dst[na + k] = reg[a0 * 4 + k];
+        for (int c = 5 * na; c < C; ++c) dst[c] = 0.f;
+    }
+}
+
+int rpn_heads_launch(bool scatter, const float *const *y, float *const *gy, const int64_t *pix, int L, int B, int C, int na,
+                     float *cls, float *reg, void *stream, const char *what)
+{
+    HTD_REQUIRE(L > 0 && L <= 8 && B > 0 && na > 0 && C >= 5 * na && pix && cls && reg, "%s: bad arguments", what);
+    HeadLevels t{};
+    t.L = L;
+    int64_t atot = 0, threads = 0;
+    for (int l = 0; l < L; ++l) {
+        HTD_REQUIRE(pix[l] > 0 && (scatter ? gy && gy[l] : y && y[l]), "%s: bad level %d", what, l);
+        t.y[l] = scatter ? nullptr : y[l];
+        t.gy[l] = scatter ? gy[l] : nullptr;
+        t.pix[l] = pix[l];
+        t.off[l] = atot;
+        t.t0[l] = threads;
+        atot += pix[l] * na;
+        threads += (int64_t)B * pix[l];
+    }
+    t.t0[L] = threads;
+    const unsigned blocks = (unsigned)htd::ceil_div(threads, 256);
+    if (scatter)
+        hipLaunchKernelGGL(rpn_heads_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, cls, reg, atot, C, na);
+    else
+        hipLaunchKernelGGL(rpn_heads_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, cls, reg, atot, C, na);
+    return htd::check_launch(what);
+}
+}  // namespace
+
+extern "C" int htd_rpn_heads_gather(const float *const *y, const int64_t *pix, int L, int B, int C, int na, float *cls, float *reg,
+                                    void *stream)
+{
+    return rpn_heads_launch(false, y, nullptr, pix, L, B, C, na, cls, reg, stream, "rpn_heads_gather");
+}
+
+extern "C" int htd_rpn_heads_scatter(const float *gcls, const float *greg, float *const *gy, const int64_t *pix, int L, int B,
+                                     int C, int na, void *stream)
+{
+    return rpn_heads_launch(true, nullptr, gy, pix, L, B, C, na, const_cast<float *>(gcls), const_cast<float *>(greg), stream,
+                            "rpn_heads_scatter");
+}

@@ -75,6 +75,59 @@ class _SplitHeads(torch.autograd.Function):
         return g, None, None
 
 
+RPN_FLAT_HEADS = __import__('os').environ.get('HTD_RPN_FLAT', '1') != '0'       # 0: per-level split / reshape / cat (A/B runs)
+
+
+class LevelList(list):
+    """The per-level (B, A*C, h, w) maps the reference's head API passes around (anchor_head.py:123-140), as VIEWS of one flat
+    per-anchor tensor `.flat` -- (B, A_total) objectness or (B, A_total, 4) deltas, level-major, the order
+    permute(0, 2, 3, 1).reshape + cat gives -- which the batched loss and the proposal stage read directly."""
+    flat = None
+
+
+class _RPNGatherHeads(torch.autograd.Function):
+    """merged head outputs y_l (B, C, h_l, w_l) channels_last of all levels -> (cls (B, A), reg (B, A, 4)) in ONE launch
+    (htd_rpn_heads_gather); backward: the gradients of every y_l, written in full by one launch (htd_rpn_heads_scatter) --
+    instead of a channel split, two reshape copies per level, two concatenations and their mirror images in backward."""
+
+    @staticmethod
+    def forward(ctx, na, *ys):
+        import ctypes
+        from .. import capi
+        ys = [y.contiguous(memory_format=torch.channels_last) for y in ys]
+        B, C = ys[0].size(0), ys[0].size(1)
+        L = len(ys)
+        pix = [y.size(2) * y.size(3) for y in ys]
+        A = na * sum(pix)
+        cls = torch.empty(B, A, device=ys[0].device, dtype=torch.float32)
+        reg = torch.empty(B, A, 4, device=ys[0].device, dtype=torch.float32)
+        capi.call('htd_rpn_heads_gather', (ctypes.c_void_p * L)(*[y.data_ptr() for y in ys]), (ctypes.c_int64 * L)(*pix), L, B, C,
+                  int(na), capi.ptr(cls), capi.ptr(reg), capi.current_stream_ptr())
+        ctx.meta = (int(na), [tuple(y.shape) for y in ys])
+        ctx.set_materialize_grads(False)
+        return cls, reg
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gcls, greg):
+        import ctypes
+        from .. import capi
+        na, shapes = ctx.meta
+        if gcls is None and greg is None:
+            return (None, ) * (1 + len(shapes))
+        B, C = shapes[0][0], shapes[0][1]
+        L = len(shapes)
+        pix = [s_[2] * s_[3] for s_ in shapes]
+        A = na * sum(pix)
+        ref = gcls if gcls is not None else greg
+        gcls = gcls.contiguous() if gcls is not None else ref.new_zeros(B, A)
+        greg = greg.contiguous() if greg is not None else ref.new_zeros(B, A, 4)
+        gys = [torch.empty(s_, device=ref.device, dtype=torch.float32, memory_format=torch.channels_last) for s_ in shapes]
+        capi.call('htd_rpn_heads_scatter', capi.ptr(gcls), capi.ptr(greg), (ctypes.c_void_p * L)(*[g.data_ptr() for g in gys]),
+                  (ctypes.c_int64 * L)(*pix), L, B, C, na, capi.current_stream_ptr())
+        return (None, *gys)
+
+
 @HEADS.register_module()
 class RPNHead(nn.Module):
     def __init__(self, in_channels, feat_channels=256,
@@ -127,7 +180,7 @@ class RPNHead(nn.Module):
         w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight] +
                       ([self.rpn_cls.weight.new_zeros(pad, *self.rpn_cls.weight.shape[1:])] if pad else []))
         b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias] + ([self.rpn_cls.bias.new_zeros(pad)] if pad else []))
-        cls, reg = [], []
+        cls, reg, merged = [], [], []
         taps = isinstance(feats, M.PyramidTaps)      # the pyramid as a chain of consumers: see Conv2dFunction(chain=True)
         from .. import dense
         if torch.is_grad_enabled() and w.requires_grad:
@@ -146,6 +199,21 @@ class RPNHead(nn.Module):
                 if h.dtype != torch.float32:     # bf16 pyramid: the heads and all box math stay fp32
                     h = h.float()
                 y = self.rpn_cls(h, weight=w, bias=b)
+            merged.append(y)
+        if RPN_FLAT_HEADS and self.cls_out_channels == 1 and nr == 4 * nc and all(y.dtype == torch.float32 for y in merged):
+            # all levels -> the flat per-anchor tensors in one launch; the per-level maps of the head API are views of them
+            cls_all, reg_all = _RPNGatherHeads.apply(nc, *merged)
+            cls, reg, off = LevelList(), LevelList(), 0
+            B = cls_all.size(0)
+            for y in merged:
+                hh, ww = y.size(2), y.size(3)
+                n = hh * ww * nc
+                cls.append(cls_all[:, off:off + n].view(B, hh, ww, nc).permute(0, 3, 1, 2))
+                reg.append(reg_all[:, off:off + n].reshape(B, hh, ww, nr).permute(0, 3, 1, 2))
+                off += n
+            cls.flat, reg.flat = cls_all, reg_all
+            return cls, reg
+        for y in merged:
             c, r = _SplitHeads.apply(y, nc, nr)
             cls.append(c)
             reg.append(r)
@@ -280,8 +348,11 @@ class RPNHead(nn.Module):
             pos, neg = batched_random_sample(assigned, sc.num, sc.pos_fraction, sc.get('neg_pos_ub', -1), keys)
             n_pos, n_neg = pos.sum(1), neg.sum(1)
         num_total = (n_pos.clamp(min=1) + n_neg.clamp(min=1)).sum().to(torch.float32)       # anchor_head.py:354-355
-        cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
-        reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
+        if getattr(cls_scores, 'flat', None) is not None and getattr(bbox_preds, 'flat', None) is not None:
+            cls, reg = cls_scores.flat.view(B, -1, self.cls_out_channels), bbox_preds.flat      # (RPNHead.forward made them)
+        else:
+            cls = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.cls_out_channels) for c in cls_scores], 1)
+            reg = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for r in bbox_preds], 1)
         self._last_rpn_sample = (assigned, pos, neg, inside)  # exposed for tests
         if self._fused_loss_ok():
             s_cls, s_box = _RPNLossFunction.apply(cls.reshape(-1), reg.reshape(-1, 4), flat_anchors, gts, assigned,
@@ -336,7 +407,7 @@ class RPNHead(nn.Module):
         B = cls_scores[0].size(0)
         dev = cls_scores[0].device
         featmap_sizes = [c.shape[-2:] for c in cls_scores]
-        mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
+        mlvl_anchors = None                                 # (made on demand: the flat path keeps its concatenation cached)
         scores_l, deltas_l, anchors_l, seg_sizes = [], [], [], []
         record = getattr(self, 'record_trail', False)       # tests: which candidates survive, in which order
         flat_ids, level_off = [], 0
@@ -348,12 +419,36 @@ class RPNHead(nn.Module):
             # every (image, level) ranking of the call in one segmented top-k (htd_segmented_topk): the sorted first nms_pre of
             # `scores.sort(descending=True)` (rpn_head.py:122-133), equal scores by ascending anchor index
             total = sum(Ns)
-            sig = torch.cat([c.detach().permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1).sigmoid_()
+            if getattr(cls_scores, 'flat', None) is not None:
+                sig = cls_scores.flat.detach().sigmoid()
+            else:
+                sig = torch.cat([c.detach().permute(0, 2, 3, 1).reshape(B, -1) for c in cls_scores], 1).sigmoid_()
             offs = [sum(Ns[:l]) for l in range(L)]
             top_idx, top_val = M.segmented_topk(sig, [(b * total + offs[l], Ns[l], ks[l]) for b in range(B) for l in range(L)])
             top_idx, top_val = top_idx.view(B, sum(ks)), top_val.view(B, sum(ks))
+        flat_ok = fused and getattr(cls_scores, 'flat', None) is not None and getattr(bbox_preds, 'flat', None) is not None and \
+            not record
+        if flat_ok:
+            # the levels' candidates through ONE gather each: rank inside (image, level) + the level's first anchor = index into
+            # the flat per-anchor tensors and the level-concatenated anchors (constants of the map sizes: cached)
+            ck = (tuple(Ns), tuple(ks), str(dev))
+            cache = self.__dict__.setdefault('_prop_cache', {})
+            if ck not in cache:
+                if len(cache) > 32:
+                    cache.clear()
+                mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
+                col_off = torch.cat([torch.full((k, ), offs[l], dtype=torch.int64) for l, k in enumerate(ks)]).to(dev)
+                lvl_ids = torch.cat([torch.full((k, ), float(l)) for l, k in enumerate(ks)]).to(dev)
+                cache[ck] = (col_off, lvl_ids, torch.cat(mlvl_anchors))
+            col_off, lvl_ids, all_anchors = cache[ck]
+            gidx = top_idx + col_off[None]
+            scores_l, seg_sizes = [top_val], list(ks)
+            deltas_l = [torch.gather(bbox_preds.flat.detach(), 1, gidx[..., None].expand(B, gidx.size(1), 4))]
+            anchors_l = [all_anchors[gidx]]
         koff = 0
-        for lvl in range(L):
+        if not flat_ok:
+            mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=dev)
+        for lvl in range(L if not flat_ok else 0):
             d = bbox_preds[lvl].detach().permute(0, 2, 3, 1).reshape(B, -1, 4)
             k = ks[lvl]
             if fused:
@@ -370,10 +465,11 @@ class RPNHead(nn.Module):
             if record:
                 flat_ids.append(idx + level_off)
                 level_off += Ns[lvl]
-        scores = torch.cat(scores_l, 1)                       # (B, K): level-major, descending inside a level
+        one = len(scores_l) == 1
+        scores = scores_l[0] if one else torch.cat(scores_l, 1)     # (B, K): level-major, descending inside a level
         K = scores.size(1)
-        deltas = torch.cat(deltas_l, 1).reshape(B * K, 4)
-        anchors = torch.cat(anchors_l, 1).reshape(B * K, 4)
+        deltas = (deltas_l[0] if one else torch.cat(deltas_l, 1)).reshape(B * K, 4)
+        anchors = (anchors_l[0] if one else torch.cat(anchors_l, 1)).reshape(B * K, 4)
         lim = const_tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas], dev, torch.float32) \
             if self.bbox_coder.clip_border else None                                      # (B, 2) w,h
         proposals = delta2bbox_clip_device(anchors, deltas, self.bbox_coder.means, self.bbox_coder.stds, lim, None,
@@ -399,7 +495,7 @@ class RPNHead(nn.Module):
                 return torch.stack([torch.nn.functional.pad(d, (0, 0, 0, cfg.nms_post - d.size(0))) for d in out]), n_keep
             return out
         # level id as class: shift by id*(max+1) like batched_nms does (per image), one segment per (image, level)
-        ids = torch.cat([scores.new_full((k, ), i) for i, k in enumerate(seg_sizes)])
+        ids = lvl_ids if flat_ok else torch.cat([scores.new_full((k, ), i) for i, k in enumerate(seg_sizes)])
         max_coord = proposals.reshape(B, -1).max(dim=1)[0]
         shifted = proposals + (ids.view(1, K) * (max_coord.view(B, 1) + 1)).unsqueeze(-1)
         offs = [0]

@@ -435,6 +435,15 @@ int htd_delta2bbox_clip(const float *rois, const float *deltas, const float *lim
 /* map_roi_levels (roi_extractors/single_level_roi_extractor.py:32-51, bbox_heads/htd_bbox_head.py:129-135):
  * lvls[i] = clamp(floor(log2(sqrt(w_i * h_i) / finest_scale + 1e-6)), 0, num_levels - 1) for rois (n, 5), int64 out. */
 int htd_map_roi_levels(const float *rois, int64_t *lvls, int64_t n, int num_levels, float finest_scale, void *stream);
+/* The RPN head outputs of all pyramid levels <-> the flat per-anchor tensors that targets, loss and proposal generation use
+ * (dense_heads/anchor_head.py:172-269, rpn_head.py:78-168: permute(0, 2, 3, 1).reshape per level, then concatenate).
+ * y[l]: level l's merged head output [B][pix[l]][C], channel a < na = objectness of anchor a, na + 4 a + j = delta j of
+ * anchor a, the rest padding.  gather: cls [B][A] and reg [B][A][4], A = na * sum(pix), level-major; scatter: the transpose
+ * (gradient of y[l], padding channels zero).  One launch each for all levels. */
+int htd_rpn_heads_gather(const float *const *y, const int64_t *pix, int L, int B, int C, int na, float *cls, float *reg,
+                         void *stream);
+int htd_rpn_heads_scatter(const float *gcls, const float *greg, float *const *gy, const int64_t *pix, int L, int B, int C,
+                          int na, void *stream);
 
 /* RPN loss of the whole batch in one pass (AnchorHead.loss / loss_single, dense_heads/anchor_head.py:373-488, with the
  * targets of _get_targets_single :172-269 and bbox2delta formed on the fly).  cls [B*A] logits (one sigmoid channel),

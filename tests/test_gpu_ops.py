@@ -528,3 +528,47 @@ def test_map_roi_levels_kernel_equals_the_tensor_formula():
         ref = torch.floor(torch.log2(scale / 56 + 1e-6)).clamp(min=0, max=L - 1).long()
         got = map_roi_levels(rois, L, 56)
         assert got.dtype == torch.int64 and torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_rpn_flat_heads_equal_the_per_level_formulation():
+    """RPNHead.forward hands loss and proposal stage the flat per-anchor tensors made by ONE gather launch
+    (htd_rpn_heads_gather / _scatter): losses, their gradients and the proposals must equal the per-level split / reshape /
+    concatenate formulation (anchor_head.py:172-269, rpn_head.py:78-168) bit for bit -- the same values in the same order."""
+    from htd_amd.configs import build_htd_detector, htd_config
+    from htd_amd.detector import rpn_head as R
+    from htd_amd.runner import synthetic_batch
+    dev = torch.device('cuda:0')
+    cfg = htd_config(50)
+    cfg.train_cfg.rpn_proposal.update(nms_pre=300, nms_post=200, max_num=200)
+    torch.manual_seed(3)
+    det = build_htd_detector(cfg=cfg).to(dev).train()
+    data = synthetic_batch(2, 192, 256, 250, device=dev, seed=5)
+    feats = [f.detach() for f in det.extract_feat(data['img'])]
+    out = {}
+    saved = R.RPN_FLAT_HEADS
+    try:
+        for flat in (False, True):
+            R.RPN_FLAT_HEADS = flat
+            det.zero_grad()
+            fs = [f.clone().requires_grad_() for f in feats]
+            torch.manual_seed(7)
+            cls, reg = det.rpn_head(fs)
+            assert (getattr(cls, 'flat', None) is not None) == flat
+            losses = det.rpn_head.loss(cls, reg, data['gt_bboxes'], data['img_metas'])
+            props = det.rpn_head.get_bboxes(cls, reg, data['img_metas'], cfg=det.train_cfg.rpn_proposal, padded=True)
+            total = sum(v for vs in losses.values() for v in vs)
+            total.backward()
+            out[flat] = ([c.detach().clone() for c in cls], [r.detach().clone() for r in reg], float(total), props,
+                         [f.grad.clone() for f in fs], {n: p.grad.clone() for n, p in det.rpn_head.named_parameters()})
+    finally:
+        R.RPN_FLAT_HEADS = saved
+    a, b = out[False], out[True]
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert x.shape == y.shape and torch.equal(x, y)
+    assert a[2] == b[2]
+    assert torch.equal(a[3][0], b[3][0]) and torch.equal(a[3][1], b[3][1])
+    for x, y in zip(a[4], b[4]):
+        assert torch.equal(x, y)
+    for n in a[5]:
+        assert torch.equal(a[5][n], b[5][n]), n
