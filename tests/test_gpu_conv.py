@@ -371,6 +371,14 @@ def test_balanced_tail_epilogue_mask_and_accum():
     torch.testing.assert_close(plain.double(), ref, rtol=1e-4, atol=1e-3)
 
 
+# Round 4: the bounds of round 2 again (rms <= 1.5 x the native fp32 MFMA's error, largest error <= 2 x).  They were widened to 2 x /
+# 3 x in round 3 after one run read 1.89 x on the 48 -> 96 3x3 data gradient; the kernels at the end of round 3 and since measure
+# 0.48-1.22 x (rms) and 0.41-1.42 x (largest) over the four cases x three passes (printed below; profiles/r04_x3_accuracy.log
+# holds the five-seed table: 3x3 layers 0.61-1.09 x rms on either MFMA shape) -- the excursion belonged to an intermediate state
+# of conv_x3p_kernel's K loop, not to the arithmetic.
+RMS_BOUND, MAX_BOUND = float(__import__('os').environ.get('X3_RMS_BOUND', '1.5')), float(__import__('os').environ.get('X3_MAX_BOUND', '2.0'))
+
+
 def _wide(shape, g, spread):
     return torch.randn(shape, generator=g) * torch.exp(torch.randn(shape, generator=g) * spread)
 
@@ -419,9 +427,10 @@ def test_split_bf16_products_are_fp32_accurate(Ci, Co, k, H, W):
     npix = ref.shape[0] * ref.shape[2] * ref.shape[3]
     for i, (what, K) in enumerate((('forward', Ci * k * k), ('data gradient', Co * k * k), ('weight gradient', npix))):
         (max0, rms0), (max1, rms1) = err[0][i], err[1][i]
+        print(f'{what:15s} K={K:6d}: split-bf16 / native  rms {rms1 / rms0:.2f}  max {max1 / max0:.2f}')
         assert max0 < 1.5e-7 * K ** 0.5 and max1 < 1.5e-7 * K ** 0.5, (what, err, K)
-        assert rms1 <= 2.0 * rms0, (what, err, K)
-        assert max1 <= 3.0 * max0 + 2e-8, (what, err, K)
+        assert rms1 <= RMS_BOUND * rms0, (what, err, K)
+        assert max1 <= MAX_BOUND * max0 + 2e-8, (what, err, K)
 
 
 X3P_CASES = [

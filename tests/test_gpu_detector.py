@@ -364,7 +364,8 @@ def test_train_step_b3_end_to_end_against_the_oracle(det, ragged):
     lists agree row for row the samples are the same and losses / gradients must agree like in the B = 2 fixture test; rows may
     differ only where two candidates' scores sit within one ulp of each other (device sigmoid vs host sigmoid reorders them:
     tests/test_gpu_configs.py::test_r101_inference_512_proposals_against_the_oracle proves that cause) -- then the kept sets
-    must still share all but a few boxes and the losses agree to the looser bound a handful of swapped samples allow."""
+    must still share all but four boxes, and the RoI head is run on the ORACLE's lists so that losses AND gradients are still
+    held to the bounds of identical inputs (that branch used to check losses at 5e-2 and no gradient)."""
     from oracle import detector as D
     dev = torch.device('cuda:0')
     H, W, B = 96, 160, 3
@@ -405,26 +406,32 @@ def test_train_step_b3_end_to_end_against_the_oracle(det, ragged):
             # the two lists still hold (nearly) the same boxes: every reference box but a few has a partner within 2e-3
             d = (mine[None, :, :4] - ref[:, None, :4]).abs().max(-1)[0]
             assert int((d.min(1)[0] > 2e-3).sum()) <= 4, 'proposal lists differ by more than a reordering of near-ties'
+    if not exact:
+        # The product's lists differ from the oracle's in near-tie rows (bounded above: at most four boxes without a partner).
+        # The RoI head then samples other RoIs -- a discrete change no tolerance describes -- so it is fed the ORACLE's
+        # lists (as test_train_step_matches_oracle_other_seed does) and everything below, gradients included, is held to the
+        # bounds of identical inputs; the RPN losses and their gradients stay the product's own.
+        proposals = [ref.to(dev) for ref in trace['proposals']]
     losses.update(det.roi_head.forward_train(x, metas, proposals, gts_d, labels_d))
     loss, log_vars = det._parse_losses(losses)
     for k, v in log_vars.items():
-        np.testing.assert_allclose(v, ref_log[k], rtol=5e-4 if exact else 5e-2, atol=1e-4 if exact else 2e-2, err_msg=k)
+        np.testing.assert_allclose(v, ref_log[k], rtol=5e-4, atol=1e-4, err_msg=k)
     det.zero_grad()
     loss.backward()
-    if exact:
-        params = dict(det.named_parameters())
-        for k in ('backbone.layer2.0.conv1.weight', 'neck.fpn_convs.0.conv.weight', 'rpn_head.rpn_cls.weight',
-                  'roi_head.bbox_head.0.fc_cls.weight', 'roi_head.bbox_head.1.fcs.0.weight',
-                  'roi_head.bbox_head.1.graph_lvl1_cls.weight', 'roi_head.bbox_head.1.convs.2.gn.bias',
-                  'roi_head.bbox_roi_extractor.1.conv2.weight', 'roi_head.glbctx_head.convs.3.conv.weight'):
-            a = params[k].grad.detach().cpu() if params[k].grad is not None else torch.zeros_like(params[k]).cpu()
-            b = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
-            a = a.reshape(b.shape)
-            scale = max(b.abs().max().item(), 1e-6)
-            # 1e-2 of the largest entry: the product's own proposals (within 2e-3 px of the oracle's) move every RoIAlign
-            # sample a little; fed the oracle's proposals (test_train_step_matches_oracle_other_seed) the bound is 2e-3.
-            # Measured here: 4.1e-3 (backbone.layer2.0.conv1.weight), the others below 2e-3.
-            assert (a - b).abs().max().item() <= 1e-2 * scale + 1e-6, (k, (a - b).abs().max().item(), scale)
+    params = dict(det.named_parameters())
+    for k in ('backbone.layer2.0.conv1.weight', 'neck.fpn_convs.0.conv.weight', 'rpn_head.rpn_cls.weight',
+              'roi_head.bbox_head.0.fc_cls.weight', 'roi_head.bbox_head.1.fcs.0.weight',
+              'roi_head.bbox_head.1.graph_lvl1_cls.weight', 'roi_head.bbox_head.1.convs.2.gn.bias',
+              'roi_head.bbox_roi_extractor.1.conv2.weight', 'roi_head.glbctx_head.convs.3.conv.weight'):
+        a = params[k].grad.detach().cpu() if params[k].grad is not None else torch.zeros_like(params[k]).cpu()
+        b = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        a = a.reshape(b.shape)
+        scale = max(b.abs().max().item(), 1e-6)
+        # own proposals (within 2e-3 px of the oracle's): 1e-2 of the largest entry -- they move every RoIAlign sample a
+        # little (measured 4.1e-3 on backbone.layer2.0.conv1.weight, the others below 2e-3); the oracle's proposals: 2e-3,
+        # the bound of test_train_step_matches_oracle_other_seed
+        bound = 1e-2 if exact else 2e-3
+        assert (a - b).abs().max().item() <= bound * scale + 1e-6, (k, (a - b).abs().max().item(), scale, exact)
     print('B=3 end to end (%s): proposal lists' % ('ragged' if ragged else 'same shapes'), 'identical' if exact else 'differ in near-tie rows')
 
 
