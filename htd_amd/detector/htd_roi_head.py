@@ -17,6 +17,9 @@ from ..core.misc import arange_cached, const_tensor
 from ..registry import HEADS, build_assigner, build_head, build_roi_extractor, build_sampler
 
 
+POS_BUCKET = max(1, int(__import__('os').environ.get('HTD_POS_BUCKET', '16')))    # stage-2 regression rows: multiples of this
+
+
 @HEADS.register_module()
 class HTDRoIHead(nn.Module):
     def __init__(self, num_stages, stage_loss_weights, with_global=False, bbox_roi_extractor=None, bbox_head=None,
@@ -304,7 +307,18 @@ class HTDRoIHead(nn.Module):
         npos_ready.synchronize()
         npos = [int(v) for v in npos_host.tolist()]
         if sum(npos) > 0:
-            pos_rows = torch.cat([torch.arange(b * n, b * n + k, device=dev) for b, k in enumerate(npos)])
+            # The count changes from step to step, and with it the size of every tensor of the regression branch: the caching
+            # allocator then keeps a block per size it has seen (+277 MB of reserve per 500 steps with the optimizer
+            # on).  The row list is therefore padded to a multiple of POS_BUCKET with slots that are NOT positives (the first
+            # image's next slots: negatives or unused ones); their predictions land in rows whose regression weight is zero
+            # (bbox_head.py:165-183), so losses and gradients are unchanged and the sizes repeat.
+            take = list(npos)
+            pad = (-sum(npos)) % POS_BUCKET
+            for b in range(B):
+                extra = min(pad, n - take[b])
+                take[b] += extra
+                pad -= extra
+            pos_rows = torch.cat([torch.arange(b * n, b * n + k, device=dev) for b, k in enumerate(take)])
             pos_rois = torch.index_select(rois, 0, pos_rows)
             enhanced = enhanced_extractor(feats, pos_rois)
             pos_feats = M.select_rows_via(stash, pos_rows) if (stash is not None and stash.alias is not None) else \
