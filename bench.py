@@ -383,7 +383,7 @@ def main():
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:
         # passes taken on the kernels of that arithmetic: the newest round that has them
-        names = ['r03_hbm_traffic.json', 'r02_hbm_traffic.json'] if x3 else ['r01_hbm_traffic.json']
+        names = ['r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json'] if x3 else ['r01_hbm_traffic.json']
         cls = 'conv_wgrad' if 'wgrad' in roof['kernel'] else ('conv_x3p' if 'x3p' in roof['kernel'] else 'conv_igemm')
         for name in names:
             path = os.path.join(ROOT, 'profiles', name)

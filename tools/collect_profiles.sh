@@ -2,7 +2,7 @@
 # Evidence runs of a round (MI355X box, through gpurun): bench lines, rocprofv3 kernel stats and PMC passes.
 # usage: bash tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>/*
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 [ -z "$R" ] && R=$(pwd)
 OUT=$R/gpurun_out/$TAG
@@ -12,7 +12,7 @@ B="python3 $R/bench.py"
 echo "== bench lines"
 $B --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 HTD_CONV_MATH=0 $B --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_fp32mfma.json 2>/dev/null
-$B --steps 20 --warmup 5 --no-cpu-baseline --trained-like > $OUT/bench_trained_like.json 2>/dev/null
+$B --steps 20 --warmup 5 --no-cpu-baseline --trained-like --trained-like-steps 0 > $OUT/bench_trained_like.json 2>/dev/null
 $B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 > $OUT/bench_r101.json 2>/dev/null
 $B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 --bf16 > $OUT/bench_r101_bf16.json 2>/dev/null
 $B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 --dcn > $OUT/bench_r101_dcn.json 2>/dev/null
@@ -55,5 +55,9 @@ HTD_WGRAD_X3D=0 python3 $R/tools/bench_wgrad.py --all > $OUT/wgrad_phased.txt 2>
 echo "== RoIAlign"
 python3 $R/tools/bench_roi_align.py 2048 4 > $OUT/roi_align_2048.log 2>&1
 python3 $R/tools/bench_roi_align.py 32768 4 > $OUT/roi_align_32768.log 2>&1
+python3 $R/tools/bench_roi_align.py 512 4 --ba > $OUT/roi_align_ba_512.log 2>&1
+echo "== round 4: plane-fed 1x1 layers, bf16 LDS-DMA kernel"
+HTD_X3P_TUNE=1 python3 $R/tools/bench_planes.py > $OUT/bench_planes.log 2>&1
+HTD_BF16Q_TUNE=1 python3 $R/tools/bench_conv_bf16.py > $OUT/bench_conv_bf16q.log 2>&1
 python3 $R/tools/summarize_collection.py $OUT > $OUT/summary.txt 2>&1
 ls -la $OUT

@@ -14,7 +14,7 @@ launches = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Kernel_Name']
-    cls = 'conv_igemm' if 'conv_igemm_kernel' in n else 'conv_x3p' if 'conv_x3p_kernel' in n else 'conv_wgrad' if 'conv_wgrad' in n else None
+    cls = 'conv_igemm' if 'conv_igemm_kernel' in n else 'conv_x3p' if ('conv_x3p_kernel' in n or 'conv_x3q_kernel' in n) else 'conv_wgrad' if 'conv_wgrad' in n else None
     if cls is None:
         continue
     acc[cls][r['Counter_Name']] += float(r['Counter_Value'])

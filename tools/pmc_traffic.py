@@ -11,7 +11,7 @@ def load(path, counter):
         if r['Counter_Name'] != counter:
             continue
         n = r['Kernel_Name']
-        cls = 'conv_x3p' if 'conv_x3p_kernel' in n else 'conv_igemm' if 'conv_igemm_kernel' in n else 'conv_wgrad' if 'conv_wgrad' in n else \
+        cls = 'conv_x3p' if ('conv_x3p_kernel' in n or 'conv_x3q_kernel' in n) else 'conv_igemm' if 'conv_igemm_kernel' in n else 'conv_wgrad' if 'conv_wgrad' in n else \
             'roi_align_fwd' if 'roi_align_kernel<false>' in n else 'roi_align_bwd' if 'roi_align' in n and 'bbox' not in n else None
         if cls is None:
             continue

@@ -21,7 +21,7 @@ for k, v in h['kernels'].items():
     print('hbm', k, v.get('hbm_bytes_per_launch_corrected'), v.get('launches'))
 for name in ('kernel_stats_no_overlap_top60.csv', 'kernel_stats_top60.csv'):
     rows = list(csv.DictReader(open(os.path.join(d, name))))
-    x = [r for r in rows if 'conv_x3p_kernel' in r['Name']]
+    x = [r for r in rows if 'conv_x3p_kernel' in r['Name'] or 'conv_x3q_kernel' in r['Name']]
     calls = sum(int(r['Calls']) for r in x)
     ns = sum(float(r['TotalDurationNs']) for r in x)
     e = [r for r in rows if 'conv_x3p_splitk' in r['Name']]
