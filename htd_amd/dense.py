@@ -370,10 +370,15 @@ def _stem7_ok(x, weight, stride, padding, dilation, residual=None):
 
 # Activation planes (csrc/conv_x3.hip, conv_x3q_kernel): the 3x3 layer of a bottleneck writes the bf16 planes of its output next
 # to the fp32 map and the 1x1 layer behind it reads both operands by LDS-DMA instead of splitting every element Co / 128 times
-# in its K loop.  Used where the consumer has at least ACT_PLANES_MIN_TILES column tiles of 128 (the split it saves grows
-# with them; the planes cost 6 bytes per element written and 2 more read).  HTD_ACT_PLANES=0 switches them off.
+# in its K loop.  Measured per bottleneck (tools/bench_planes.py, profiles/r04_bench_planes.log, B = 4 @ 800x1344, with the
+# residual epilogue): the plane-fed conv3 is 5.0 us faster in layer3 (59.4 -> 54.4) and 4.2 us in layer4, nothing in layer2 (its
+# 128 -> 512 layer is bound by 276 MB of output + residual traffic, not by its loop), while the 3x3 producer pays 2.2 us
+# (layer3), 4.4 us (layer2) and 5.1 us (layer4: 66 tiles, the planes come out of the K-range reduce pass) for writing them.
+# So: where the consumer has >= ACT_PLANES_MIN_TILES = 8 column tiles of 128 AND the map has >= ACT_PLANES_MIN_ROWS = 8192
+# pixels -- layer3 of the ResNets (23 blocks in R101).  HTD_ACT_PLANES=0 switches them off.
 ACT_PLANES = os.environ.get('HTD_ACT_PLANES', '1') != '0'
-ACT_PLANES_MIN_TILES = int(os.environ.get('HTD_ACT_PLANES_MIN_TILES', '2'))
+ACT_PLANES_MIN_TILES = int(os.environ.get('HTD_ACT_PLANES_MIN_TILES', '8'))
+ACT_PLANES_MIN_ROWS = int(os.environ.get('HTD_ACT_PLANES_MIN_ROWS', '8192'))
 
 
 def _act_planes_buf(M, C, device):
@@ -389,9 +394,11 @@ def act_planes(x):
     return out
 
 
-def _planes_pay(w_consumer, transposed=False):
-    """Should the producer of the input of the 1x1 / stride-1 layer with this weight emit planes for it?"""
+def _planes_pay(w_consumer, transposed=False, rows=None):
+    """Should the producer of the input of the 1x1 / stride-1 layer with this weight emit planes for it?  rows: pixels of the map."""
     if not ACT_PLANES or w_consumer.dim() != 4 or w_consumer.dtype != torch.float32:
+        return False
+    if rows is not None and rows < ACT_PLANES_MIN_ROWS:
         return False
     Co, Ci, kh, kw = w_consumer.shape
     cred, cout = (Co, Ci) if transposed else (Ci, Co)
@@ -819,7 +826,8 @@ class ResStageFunction(Function):
             k += 6
             h1 = _fwd_raw(x, w1, b1, None, 1, 0, 1, True)
             # conv2 writes the bf16 planes of h2 for conv3 (1x1, Co = 4 x mid: every element of h2 would be split Co / 128 times)
-            h2, h2p = _fwd_raw(h1, w2, b2, None, stride, dilation, dilation, True, emit=_planes_pay(w3))
+            h2, h2p = _fwd_raw(h1, w2, b2, None, stride, dilation, dilation, True,
+                               emit=_planes_pay(w3, rows=h1.size(0) * (h1.size(2) // stride) * (h1.size(3) // stride)))
             if ds:
                 wd, bd = params[k:k + 2]
                 k += 2
@@ -880,7 +888,7 @@ class ResStageFunction(Function):
             grads[k + 3] = gb2 if pneed[3] else None
             # (the planes of gm1 for conv1's data gradient, a 1x1 layer with 4 x mid or more output channels)
             gm1, gm1p = _dgrad_raw(gm2, w2, h1.shape, stride, dilation, dilation, mask_src=h1, wT=flipped[k + 2],
-                                   emit=bool(need_x and _planes_pay(w1, True)))
+                                   emit=bool(need_x and _planes_pay(w1, True, rows=h1.size(0) * h1.size(2) * h1.size(3))))
             if pneed[0]:
                 grads[k], gb1 = _wgrad_raw(x, gm1, w1, 1, 0, 1, True if pneed[1] else None)
             else:

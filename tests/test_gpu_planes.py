@@ -166,3 +166,52 @@ def test_every_instantiation_of_the_plane_fed_kernel_matches_its_twin():
     env = dict(os.environ, HTD_X3P_TUNE='1')
     r = subprocess.run([sys.executable, '-c', _VARIANTS % ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_res_stage_with_and_without_planes_is_bit_identical():
+    """dense.ResStageFunction threads the planes conv2 -> conv3 (forward) and conv2's data gradient -> conv1's (backward).  With
+    the thresholds lowered so that every block of a small stage uses them, outputs and ALL gradients must equal the run without
+    planes bit for bit."""
+    import torch.nn as nn
+    from htd_amd import dense
+    from htd_amd.detector.resnet import Bottleneck, ResLayer
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    layer = ResLayer(Bottleneck, 256, 64, 3, stride=1, norm_cfg=dict(type='BN', requires_grad=True)).to(dev)
+    for m in layer.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    layer.eval()                                  # frozen-BN statistics, parameters still trainable (norm_eval)
+    x0 = torch.randn(2, 256, 24, 40, device=dev).contiguous(memory_format=CL)
+    g = torch.randn(2, 256, 24, 40, device=dev).contiguous(memory_format=CL)
+    saved = (dense.ACT_PLANES, dense.ACT_PLANES_MIN_TILES, dense.ACT_PLANES_MIN_ROWS)
+    out = {}
+    try:
+        for on in (False, True):
+            dense.ACT_PLANES, dense.ACT_PLANES_MIN_TILES, dense.ACT_PLANES_MIN_ROWS = on, 1, 0
+            dense.new_step()
+            layer.zero_grad()
+            x = x0.clone().requires_grad_()
+            calls = []
+            orig = dense.capi.call
+
+            def spy(name, *a, **k):
+                calls.append(name)
+                return orig(name, *a, **k)
+            dense.capi.call = spy
+            try:
+                y = layer(x)
+                y.backward(g)
+            finally:
+                dense.capi.call = orig
+            assert ('htd_conv2d_fwd_x3q' in calls) == on and ('htd_conv2d_bwd_data_x3q' in calls) == on
+            out[on] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters()})
+    finally:
+        dense.ACT_PLANES, dense.ACT_PLANES_MIN_TILES, dense.ACT_PLANES_MIN_ROWS = saved
+        dense.new_step()
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+    for n in out[True][2]:
+        assert torch.equal(out[True][2][n], out[False][2][n]), n

@@ -20,12 +20,12 @@ $B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 --dcn --bf16 > $OUT/bench
 $B --steps 5 --warmup 2 --infer --depth 101 --batch 64 > $OUT/bench_infer_r101_b64.json 2>/dev/null
 $B --steps 5 --warmup 2 --infer --depth 101 --batch 64 --bf16 > $OUT/bench_infer_r101_b64_bf16.json 2>/dev/null
 echo "== kernel stats"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/a -o a -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/a -o a -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --trained-like-steps 0 > $OUT/prof_train.log 2>&1
 head -61 /tmp/p_$TAG/a/*kernel_stats.csv > $OUT/kernel_stats_top60.csv
 # the same with the weight gradients on the main stream, as in the steps bench.py brackets with events (overlapped kernels share CUs and each takes longer)
-HTD_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/a0 -o a0 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_train_no_overlap.log 2>&1
+HTD_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/a0 -o a0 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --trained-like-steps 0 > $OUT/prof_train_no_overlap.log 2>&1
 head -61 /tmp/p_$TAG/a0/*kernel_stats.csv > $OUT/kernel_stats_no_overlap_top60.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/b -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --depth 101 --bf16 > $OUT/prof_bf16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/b -o b -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --trained-like-steps 0 --depth 101 --bf16 > $OUT/prof_bf16.log 2>&1
 head -61 /tmp/p_$TAG/b/*kernel_stats.csv > $OUT/kernel_stats_r101_bf16_top60.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$TAG/c -o c -- python3 $R/bench.py --steps 3 --warmup 1 --infer --depth 101 --batch 64 > $OUT/prof_infer.log 2>&1
 head -61 /tmp/p_$TAG/c/*kernel_stats.csv > $OUT/kernel_stats_infer_r101_b64_top60.csv
@@ -42,10 +42,10 @@ for tag, name, steps in (('a', 'HTD-R50 fp32 train step', 13), ('b', 'HTD-R101 b
 PY
 echo "== PMC passes (each alone; every set validated by tools/pmc_plan.py)"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do python3 $R/tools/pmc_plan.py $set || exit 2; done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_$TAG/f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_$TAG/w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p_$TAG/f -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --trained-like-steps 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p_$TAG/w -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --trained-like-steps 0 > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py /tmp/p_$TAG/f/*counter_collection.csv /tmp/p_$TAG/w/*counter_collection.csv $OUT/hbm_traffic.json > /dev/null
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d /tmp/p_$TAG/m -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d /tmp/p_$TAG/m -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --trained-like-steps 0 > /dev/null 2>&1
 python3 $R/tools/pmc_mfma.py /tmp/p_$TAG/m/*counter_collection.csv $OUT/mfma_busy.json > /dev/null
 echo "== per-layer convolution tables (stand-alone, warm device)"
 python3 $R/tools/bench_conv.py > $OUT/bench_conv_new.log 2>&1
