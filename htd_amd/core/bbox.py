@@ -661,6 +661,9 @@ class StaticSamples:
         return torch.cat([img, self.boxes], -1).view(B * S, 5)
 
 
+STATIC_FINISH = __import__('os').environ.get('HTD_STATIC_FINISH', '1') != '0'       # 0: the tensor formulation (A/B runs, tests)
+
+
 def static_assign_and_sample(assigner, sampler, props, pvalid, gt_bboxes, gt_labels):
     """MaxIoUAssigner + RandomSampler for every image (htd_roi_head.py:254-264,292-310) with NO device->host
     copy: props (B,P,4) zero-padded with validity mask pvalid (B,P).  -> StaticSamples."""
@@ -670,20 +673,37 @@ def static_assign_and_sample(assigner, sampler, props, pvalid, gt_bboxes, gt_lab
     gts, gvalid, glabels = pad_gt_batch(gt_bboxes, gt_labels)
     K = gts.size(1)
     assigned, _ = batched_max_iou_assign(assigner, props, pvalid, gts, gvalid)
-    if sampler.add_gt_as_proposals:      # AssignResult.add_gt_: gt i is a candidate matched to itself
+    add_gt = bool(sampler.add_gt_as_proposals)
+    if add_gt:                           # AssignResult.add_gt_: gt i is a candidate matched to itself
         self_inds = torch.where(gvalid, arange_cached(K, dev, start=1).expand(B, K), const_tensor([-1], dev, torch.int64))
         assigned = torch.cat([self_inds, assigned], 1)
         cand = torch.cat([gts, props], 1)
-        is_gt = torch.cat([gvalid, torch.zeros_like(pvalid)], 1)
     else:
-        cand, is_gt = props, torch.zeros_like(pvalid)
+        cand = props
     A = cand.size(1)
     if A < S:                            # fewer candidates than slots: pad with candidates that can never be drawn
         cand = torch.cat([cand, cand.new_zeros(B, S - A, 4)], 1)
         assigned = torch.cat([assigned, assigned.new_full((B, S - A), -1)], 1)
-        is_gt = torch.cat([is_gt, is_gt.new_zeros(B, S - A)], 1)
         A = S
     keys = sample_keys(cand)
+    if _sample_on_device(assigned, keys, S) and STATIC_FINISH and props.dtype == torch.float32:
+        # masks, drawn counts and the slot order (drawn positives, then drawn negatives, ascending index) from one call, the
+        # fixed-slot result from a second (htd_static_samples_finish) instead of ~14 gather / compare / concatenate launches
+        from .. import capi
+        pos, neg, counts, order = random_sample_device(assigned, keys, S, sampler.pos_fraction, sampler.neg_pos_ub, slots=S)
+        boxes = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+        valid, is_pos, pos_is_gt = (torch.empty(B, S, device=dev, dtype=torch.bool) for _ in range(3))
+        pgb = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+        pgl = torch.empty(B, S, device=dev, dtype=torch.int64)
+        P_ = props.size(1)
+        capi.call('htd_static_samples_finish', capi.ptr(gts.contiguous()), capi.ptr(gvalid.contiguous()), capi.ptr(glabels.contiguous()),
+                  capi.ptr(props.contiguous()), capi.ptr(assigned.contiguous()), capi.ptr(order), capi.ptr(counts), B, K, P_, A, S,
+                  int(add_gt), capi.ptr(boxes), capi.ptr(valid), capi.ptr(is_pos), capi.ptr(pgb), capi.ptr(pgl), capi.ptr(pos_is_gt),
+                  capi.current_stream_ptr())
+        return StaticSamples(boxes, valid, is_pos, counts[:, 0], counts[:, 1], pgb, pgl, pos_is_gt)
+    is_gt = torch.cat([gvalid, torch.zeros_like(pvalid)], 1) if add_gt else torch.zeros_like(pvalid)
+    if is_gt.size(1) < A:
+        is_gt = torch.cat([is_gt, is_gt.new_zeros(B, A - is_gt.size(1))], 1)
     if _sample_on_device(assigned, keys, S):
         # masks, drawn counts and the slot order (drawn positives, then drawn negatives, ascending index) from one call
         pos, neg, counts, order = random_sample_device(assigned, keys, S, sampler.pos_fraction, sampler.neg_pos_ub, slots=S)

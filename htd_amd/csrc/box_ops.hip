@@ -564,3 +564,58 @@ extern "C" int htd_rpn_heads_scatter(const float *gcls, const float *greg, float
     return rpn_heads_launch(true, nullptr, gy, pix, L, B, C, na, const_cast<float *>(gcls), const_cast<float *>(greg), stream,
                             "rpn_heads_scatter");
 }
+
+
+// ---- StaticSamples from the sampler's slot order (htd_roi_head.py:254-264,292-310; sampling_result.py:40-60) -------------
+// order[b][s]: candidate index of slot s (drawn positives first, then drawn negatives: htd_random_sample), counts[b] = (drawn
+// positives, drawn negatives).  Candidates are [gts (K, when add_gt) | proposals (P) | never-drawn padding]; assigned[b][c] is
+// the 1-based gt index of candidate c (<= 0: none).  One pass writes what ~14 gather / compare / concatenate launches made:
+//   boxes = candidate box * (slot used), valid, is_pos, the assigned gt's box and label per slot, pos_is_gt.
+namespace {
+__global__ __launch_bounds__(256) void static_samples_finish_kernel(
+    const float *__restrict__ gts, const uint8_t *__restrict__ gvalid, const int64_t *__restrict__ glabels,
+    const float *__restrict__ props, const int64_t *__restrict__ assigned, const int64_t *__restrict__ order,
+    const int64_t *__restrict__ counts, int B, int K, int P, int A, int S, int add_gt, float *__restrict__ boxes,
+    uint8_t *__restrict__ valid, uint8_t *__restrict__ is_pos, float *__restrict__ pos_gt_boxes, int64_t *__restrict__ pos_gt_labels,
+    uint8_t *__restrict__ pos_is_gt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * S) return;
+    const int b = i / S, s = i - b * S;
+    const int64_t npos = counts[2 * b], n = npos + counts[2 * b + 1];
+    const bool v = s < n, ip = s < npos;
+    const int64_t c = order[i];
+    const int koff = add_gt ? K : 0;
+    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool from_gt = false;
+    if (add_gt && c < K) {
+        box = *reinterpret_cast<const float4 *>(gts + ((int64_t)b * K + c) * 4);
+        from_gt = gvalid[(int64_t)b * K + c] != 0;
+    } else if (c - koff < P) {
+        box = *reinterpret_cast<const float4 *>(props + ((int64_t)b * P + (c - koff)) * 4);
+    }
+    const float m = v ? 1.f : 0.f;          // (the tensor form multiplies by the mask: a negative coordinate of an unused slot is -0)
+    *reinterpret_cast<float4 *>(boxes + (int64_t)i * 4) = make_float4(box.x * m, box.y * m, box.z * m, box.w * m);
+    valid[i] = v;
+    is_pos[i] = ip;
+    int64_t g = assigned[(int64_t)b * A + c] - 1;
+    g = g < 0 ? 0 : g;
+    *reinterpret_cast<float4 *>(pos_gt_boxes + (int64_t)i * 4) = *reinterpret_cast<const float4 *>(gts + ((int64_t)b * K + g) * 4);
+    pos_gt_labels[i] = glabels[(int64_t)b * K + g];
+    pos_is_gt[i] = from_gt && ip;
+}
+}  // namespace
+
+extern "C" int htd_static_samples_finish(const float *gts, const uint8_t *gvalid, const int64_t *glabels, const float *props,
+                                         const int64_t *assigned, const int64_t *order, const int64_t *counts, int B, int K, int P,
+                                         int A, int S, int add_gt, float *boxes, uint8_t *valid, uint8_t *is_pos,
+                                         float *pos_gt_boxes, int64_t *pos_gt_labels, uint8_t *pos_is_gt, void *stream)
+{
+    HTD_REQUIRE(B > 0 && K > 0 && P >= 0 && S > 0 && A >= (add_gt ? K : 0) + P, "static_samples_finish: bad sizes");
+    HTD_REQUIRE(gts && gvalid && glabels && (props || P == 0) && assigned && order && counts && boxes && valid && is_pos &&
+                    pos_gt_boxes && pos_gt_labels && pos_is_gt, "static_samples_finish: null pointer");
+    hipLaunchKernelGGL(static_samples_finish_kernel, dim3((unsigned)htd::ceil_div((int64_t)B * S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, gts, gvalid, glabels, props, assigned, order, counts, B, K, P, A, S, add_gt, boxes, valid,
+                       is_pos, pos_gt_boxes, pos_gt_labels, pos_is_gt);
+    return htd::check_launch("static_samples_finish");
+}

@@ -444,6 +444,14 @@ int htd_rpn_heads_gather(const float *const *y, const int64_t *pix, int L, int B
                          void *stream);
 int htd_rpn_heads_scatter(const float *gcls, const float *greg, float *const *gy, const int64_t *pix, int L, int B, int C,
                           int na, void *stream);
+/* The fixed-slot sampling result of a batch (SamplingResult, core/bbox/samplers/sampling_result.py:40-60, for every image of
+ * htd_roi_head.py:254-264,292-310) from htd_random_sample's slot order and counts: boxes (B,S,4) zeroed past the drawn
+ * count, valid / is_pos / pos_is_gt (B,S) as bytes, the assigned gt's box and label per slot.  Candidates are
+ * [gts (K, when add_gt) | proposals (P) | padding]; assigned (B,A) holds 1-based gt indices. */
+int htd_static_samples_finish(const float *gts, const uint8_t *gvalid, const int64_t *glabels, const float *props,
+                              const int64_t *assigned, const int64_t *order, const int64_t *counts, int B, int K, int P,
+                              int A, int S, int add_gt, float *boxes, uint8_t *valid, uint8_t *is_pos,
+                              float *pos_gt_boxes, int64_t *pos_gt_labels, uint8_t *pos_is_gt, void *stream);
 
 /* RPN loss of the whole batch in one pass (AnchorHead.loss / loss_single, dense_heads/anchor_head.py:373-488, with the
  * targets of _get_targets_single :172-269 and bbox2delta formed on the fly).  cls [B*A] logits (one sigmoid channel),

@@ -572,3 +572,41 @@ def test_rpn_flat_heads_equal_the_per_level_formulation():
         assert torch.equal(x, y)
     for n in a[5]:
         assert torch.equal(a[5][n], b[5][n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('add_gt,P,S', [(True, 300, 64), (False, 300, 64), (True, 20, 64), (True, 1000, 512)])
+def test_static_samples_finish_kernel_equals_the_tensor_formulation(add_gt, P, S):
+    """core.bbox.static_assign_and_sample: the fixed-slot result written by htd_static_samples_finish against the gather / compare
+    / concatenate formulation it replaces (sampling_result.py:40-60 per image) -- every member torch.equal, including images
+    without gt, fewer candidates than slots (P = 20) and unused slots."""
+    from htd_amd.core import bbox as Bx
+    from htd_amd.core.bbox import MaxIoUAssigner, RandomSampler, set_sample_keys
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(P + S)
+    B = 3
+    props = torch.rand(B, P, 4, generator=g) * 200
+    props[..., 2:] = props[..., :2] + torch.rand(B, P, 2, generator=g) * 120 + 1
+    pvalid = torch.rand(B, P, generator=g) > 0.1
+    props = (props * pvalid[..., None]).to(dev)
+    gts = [torch.tensor([[20., 30., 120., 160.], [100., 50., 220., 180.], [5., 5., 60., 40.]]).to(dev), torch.zeros(0, 4).to(dev),
+           torch.tensor([[60., 60., 190., 200.]]).to(dev)]
+    labels = [torch.tensor([3, 7, 1]).to(dev), torch.zeros(0, dtype=torch.int64).to(dev), torch.tensor([5]).to(dev)]
+    assigner = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False, ignore_iof_thr=-1)
+    sampler = RandomSampler(num=S, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=add_gt)
+    coef = torch.tensor([12.9898, 78.233, 37.719, 93.989], device=dev)
+    set_sample_keys(lambda cand: torch.frac(torch.sin((cand * coef).sum(-1)) * 43758.5453).abs())
+    saved = Bx.STATIC_FINISH
+    out = {}
+    try:
+        for fin in (False, True):
+            Bx.STATIC_FINISH = fin
+            out[fin] = Bx.static_assign_and_sample(assigner, sampler, props, pvalid.to(dev), gts, labels)
+    finally:
+        Bx.STATIC_FINISH = saved
+        set_sample_keys(None)
+    a, b = out[False], out[True]
+    for name in ('boxes', 'valid', 'is_pos', 'npos', 'nneg', 'pos_gt_bboxes', 'pos_gt_labels', 'pos_is_gt'):
+        x, y = getattr(a, name), getattr(b, name)
+        assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y), name
+    assert int(b.npos.sum()) > 0 and bool((b.valid.sum(1) <= S).all())
