@@ -575,6 +575,9 @@ def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None, overlap=True)
     for a caller that hands `g` itself on to autograd (record_stream guards against reuse of the storage, not against
     the engine's in-place `add_` into a gradient it owns while the side stream has not read it yet)."""
     if not overlap or not OVERLAP_WGRAD or (capi.profiling() and not _OVERLAP_IN_PROFILE):
+        if OVERLAP_WGRAD and _SIDE and SINK_ACCUMULATE and grad_sink_again(weight) is not None:
+            # this launch ADDS into a slice whose earlier contributions may still be in the weight-gradient stream's queue
+            torch.cuda.current_stream().wait_stream(side_stream(g.device))
         return _wgrad_launch(x, g, weight, stride, padding, dilation, bias)[:2]
     main, side = torch.cuda.current_stream(), side_stream(g.device)
     side.wait_stream(main)
