@@ -26,13 +26,16 @@ KEY = re.compile(r'^(htd_conv2d_fwd|htd_conv2d_bwd_data|htd_conv2d_fwd_x3p|htd_c
 
 def signature(name, ints, mask):
     """(M, Co, Ci, taps, epi) as conv_fwd.hip::launch_conv keys the launch, or None when the table does not apply."""
+    # (calls of htd_conv2d_fwd_x3q / _bwd_data_x3q are accounted under the x3p names, dense.py; they carry two more pointer slots:
+    #  x, xplanes, wplanes, bias, residual, y, yplanes, ws, stream  /  gy, gyplanes, wplanesT, mask_src, accum, gx, gxplanes, ws, stream)
+    q = len(mask) == 9
     if name == 'htd_conv2d_fwd_x3p':         # conv_x3.hip::launch_x3p
         res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, relu = ints
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-        return (B * Ho * Wo, Co, Ci, kh * kw, int(mask[3] == '1'))
+        return (B * Ho * Wo, Co, Ci, kh * kw, int(mask[4 if q else 3] == '1'))
     if name == 'htd_conv2d_bwd_data_x3p':
         B, H, W, Ci, Co, kh, kw, pad = ints
-        return (B * H * W, Ci, Co, kh * kw, int(mask[3] == '1') | (int(mask[2] == '1') << 1))
+        return (B * H * W, Ci, Co, kh * kw, int(mask[4 if q else 3] == '1') | (int(mask[3 if q else 2] == '1') << 1))
     if name == 'htd_conv2d_fwd':
         res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, dil, relu = ints
         Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
