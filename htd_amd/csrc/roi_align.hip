@@ -496,12 +496,18 @@ __global__ __launch_bounds__(256) void roi_bbox_kernel(const float *__restrict__
 // -> sums: a few microseconds of dependent latency each): BA pools every positive RoI from EVERY level, so a strip of the
 // coarse maps walks all 128 RoIs of its image; RS wavefronts walk a quarter each.  `active` = the task exists (every
 // wavefront of the block reaches the barrier).
-template <int CPL, int ROWS, int RS>
+// FOLD (round 4): the bins of a RoI are folded along y ONCE per (RoI, map row) by roi_fold_kernel into tbuf [n][H][pw][C] and a
+// strip only fetches the one or two folded vectors its eight pixels touch -- a strip used to fetch and fold the 7-14 bin
+// vectors itself, the ~20 strips of a large RoI's row each doing the same work (2 KB instead of 7-14 KB of L2 traffic and
+// none of the fold's arithmetic per (strip, RoI) pair).  Same sums in the same order: bit-identical to FOLD = false.
+template <int CPL, int ROWS, int RS, bool FOLD>
 __device__ __forceinline__ void gather_tile(const float *__restrict__ gout, const float *__restrict__ rois,
                                             const RoiBox *__restrict__ box, float *__restrict__ gfeat, int64_t n, int B, int C,
                                             int H, int W, int ph, int pw, float scale, int sampling_ratio, int aligned,
-                                            int accumulate, int chunks, int segs, int hts, int64_t task, bool active)
+                                            int accumulate, int chunks, int segs, int hts, int64_t task, bool active,
+                                            const float *__restrict__ tbuf)
 {
+    static_assert(!FOLD || ROWS == 1, "folded rows: one-row tiles");
     static_assert(ROWS * MAXP <= 64, "one lane per (row, bin) weight");
     static_assert(RS == 1 || ROWS == 1, "the RoI split keeps one-row tiles");
     const int lane = threadIdx.x & 63;
@@ -541,6 +547,38 @@ __device__ __forceinline__ void gather_tile(const float *__restrict__ gout, cons
             const int64_t ri = base + src;              // wave-uniform, ascending: the summation order is fixed
             touched = true;
             const RoiGeom g = roi_geometry(rois + 5 * ri, scale, ph, pw, sampling_ratio, aligned);
+            if constexpr (FOLD) {
+                static_assert(GW_TILE * MAXP == 64, "one lane per (bin, pixel) weight");
+                const int xi_f = lane % GW_TILE, q_f = lane / GW_TILE;
+                const float wx_f = (x0 + xi_f <= x1 && q_f < pw) ? axis_weight(g.start_w, g.bin_w, q_f, g.grid_w, x0 + xi_f, W) : 0.f;
+                const float *tp = tbuf + (((size_t)ri * H + y0) * pw) * C + ch;
+#pragma unroll
+                for (int q = 0; q < MAXP; ++q) {
+                    if (q >= pw) continue;
+                    if (__ballot(q_f == q && wx_f != 0.f) == 0ull) continue;       // no pixel of the strip takes bin q (wave-uniform)
+                    float v[CPL];
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) v[k] = 0.f;
+                    if (act) {
+                        if constexpr (CPL == 4) {
+                            const float4 t4 = *reinterpret_cast<const float4 *>(tp + (size_t)q * C);
+                            v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < CPL; ++k) v[k] = tp[(size_t)q * C + k];
+                        }
+                    }
+#pragma unroll
+                    for (int xi = 0; xi < GW_TILE; ++xi) {
+                        const float w = lane_bcast(wx_f, q * GW_TILE + xi);
+                        if (w != 0.f) {
+#pragma unroll
+                            for (int k = 0; k < CPL; ++k) acc[0][xi][k] += w * v[k];
+                        }
+                    }
+                }
+                continue;
+            }
             // y weights: lane (r, p) = (lane / MAXP, lane % MAXP) holds Wy[p][y0 + r] / count
             const int r_l = lane / MAXP, p_l = lane % MAXP;
             const float wy_l = (r_l < ROWS && p_l < ph && y0 + r_l <= y1)
@@ -648,8 +686,8 @@ __global__ __launch_bounds__(256, (RS > 1 ? 4 : 1)) void roi_align_bwd_gather_ke
 {
     const int64_t task = (int64_t)blockIdx.x * (4 / RS) + (threadIdx.x >> 6) / RS;
     if (RS == 1 && task >= tasks) return;               // whole wave exits together
-    gather_tile<CPL, ROWS, RS>(gout, rois, box, gfeat, n, B, C, H, W, ph, pw, scale, sampling_ratio, aligned, accumulate, chunks,
-                               segs, hts, task < tasks ? task : 0, task < tasks);
+    gather_tile<CPL, ROWS, RS, false>(gout, rois, box, gfeat, n, B, C, H, W, ph, pw, scale, sampling_ratio, aligned, accumulate,
+                                      chunks, segs, hts, task < tasks ? task : 0, task < tasks, nullptr);
 }
 
 // All pyramid levels of one extractor in ONE launch.  Launched level by level, the coarse maps set the time: P5 has 600
@@ -660,6 +698,8 @@ constexpr int GL_MAX = 6;
 struct GatherLevels {
     float *gfeat[GL_MAX];
     const float *gout[GL_MAX];       // per slot (BA: every level has its own pooled tensor); NULL: the launch's shared grad_out
+    float *tbuf[GL_MAX];             // FOLD: the slot's folded bins [n][H][pw][C] (roi_fold_kernel)
+    int64_t ftask0[GL_MAX + 1];      // roi_fold_kernel: first task of slot k (n * H[k] * chunks tasks each)
     const RoiBox *box[GL_MAX];
     int H[GL_MAX], W[GL_MAX], segs[GL_MAX], hts[GL_MAX], accumulate[GL_MAX], level[GL_MAX];
     float scale[GL_MAX];
@@ -667,7 +707,53 @@ struct GatherLevels {
     int slots;
 };
 
-template <int CPL, int ROWS, int RS>
+// T[ri][y][q][:] = sum_p Wy_ri[p][y] * gout_ri[p][q][:] / count_ri for every map row y of RoI ri's footprint, every level slot of
+// the table: one wavefront per (slot, RoI, row, 256-channel chunk); rows outside the footprint exit at once.
+__global__ __launch_bounds__(256) void roi_fold_kernel(const float *__restrict__ gout, const float *__restrict__ rois, GatherLevels t,
+                                                       int64_t n, int C, int ph, int pw, int sampling_ratio, int aligned, int chunks)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= t.ftask0[t.slots]) return;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < GL_MAX; ++i)
+        if (i < t.slots && task >= t.ftask0[i]) k = i;
+    int64_t r = task - t.ftask0[k];
+    const int chunk = (int)(r % chunks);
+    r /= chunks;
+    const int H = t.H[k];
+    const int y = (int)(r % H);
+    const int64_t ri = r / H;
+    const RoiBox o = t.box[k][ri];
+    if (o.b < 0 || y < o.r_lo || y > o.r_hi) return;                 // wave-uniform
+    const RoiGeom g = roi_geometry(rois + 5 * ri, t.scale[k], ph, pw, sampling_ratio, aligned);
+    const float wy_l = lane < ph ? axis_weight(g.start_h, g.bin_h, lane, g.grid_h, y, H) * g.inv_count : 0.f;
+    const int ch = chunk * 256 + lane * 4;
+    if (ch >= C) return;
+    float T[MAXP][4];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T[q][c] = 0.f;
+    const float *go = (t.gout[k] ? t.gout[k] : gout) + (size_t)ri * ph * pw * C + ch;
+    for (int p = 0; p < ph; ++p) {
+        const float wy = lane_bcast(wy_l, p);
+        if (wy == 0.f) continue;
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q)
+            if (q < pw) {
+                const float4 v = *reinterpret_cast<const float4 *>(go + ((size_t)p * pw + q) * C);
+                T[q][0] += wy * v.x; T[q][1] += wy * v.y; T[q][2] += wy * v.z; T[q][3] += wy * v.w;
+            }
+    }
+    float *dst = t.tbuf[k] + (((size_t)ri * H + y) * pw) * C + ch;
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+        if (q < pw) *reinterpret_cast<float4 *>(dst + (size_t)q * C) = make_float4(T[q][0], T[q][1], T[q][2], T[q][3]);
+}
+
+template <int CPL, int ROWS, int RS, bool FOLD>
 __global__ __launch_bounds__(256, (RS > 1 ? 4 : 1)) void roi_align_bwd_gather_levels_kernel(const float *__restrict__ gout,
                                                                           const float *__restrict__ rois, GatherLevels t, int64_t n,
                                                                           int B, int C, int ph, int pw, int sampling_ratio,
@@ -681,8 +767,9 @@ __global__ __launch_bounds__(256, (RS > 1 ? 4 : 1)) void roi_align_bwd_gather_le
 #pragma unroll
     for (int i = 1; i < GL_MAX; ++i)
         if (i < t.slots && task >= t.task0[i]) k = i;
-    gather_tile<CPL, ROWS, RS>(t.gout[k] ? t.gout[k] : gout, rois, t.box[k], t.gfeat[k], n, B, C, t.H[k], t.W[k], ph, pw, t.scale[k],
-                               sampling_ratio, aligned, t.accumulate[k], chunks, t.segs[k], t.hts[k], task - t.task0[k], active);
+    gather_tile<CPL, ROWS, RS, FOLD>(t.gout[k] ? t.gout[k] : gout, rois, t.box[k], t.gfeat[k], n, B, C, t.H[k], t.W[k], ph, pw,
+                                     t.scale[k], sampling_ratio, aligned, t.accumulate[k], chunks, t.segs[k], t.hts[k],
+                                     task - t.task0[k], active, t.tbuf[k]);
 }
 
 // footprint boxes of every RoI on every level slot of the table (blockIdx.y = slot; b = -1 where the RoI is on another level)
@@ -884,7 +971,7 @@ namespace {
 int levels_bwd_gather(const float *grad_out, const float *const *grad_outs, const float *rois, const int64_t *roi_level,
                       float *const *grad_feats, const int *H, const int *W, const float *scales, const int *accumulate, int L,
                       int64_t n, int B, int C, int ph, int pw, int sampling_ratio, int aligned, void *workspace, void *stream,
-                      const char *what)
+                      const char *what, void *fold_ws = nullptr)
 {
     HTD_REQUIRE(L > 0 && L <= GL_MAX && n >= 0 && B > 0 && C > 0 && ph > 0 && pw > 0 && ph <= MAXP && pw <= MAXP,
                 "%s: bad sizes L=%d n=%lld B=%d C=%d out=%dx%d", what, L, (long long)n, B, C, ph, pw);
@@ -920,18 +1007,41 @@ int levels_bwd_gather(const float *grad_out, const float *const *grad_outs, cons
     }
     if (t.slots == 0) return HTD_OK;
     t.task0[t.slots] = tasks;
+    int64_t ftasks = 0, foff = 0;            // folded bins: slot k's buffer behind the previous ones
+    for (int k = 0; k < t.slots; ++k) {
+        t.tbuf[k] = fold_ws ? (float *)fold_ws + foff : nullptr;
+        foff += n * (int64_t)t.H[k] * pw * C;
+        t.ftask0[k] = ftasks;
+        ftasks += n * (int64_t)t.H[k] * chunks;
+    }
+    t.ftask0[t.slots] = ftasks;
     hipLaunchKernelGGL(roi_bbox_levels_kernel, dim3((unsigned)htd::ceil_div(n, 256), (unsigned)t.slots), dim3(256), 0, s, rois,
                        roi_level, t, n, B, ph, pw, sampling_ratio, aligned);
     HTD_REQUIRE(tasks < (1ll << 31), "%s: too many tiles", what);
     const int rs = gather_split(n, tiles_min, roi_level == nullptr);
+    if (fold_ws) {
+        HTD_REQUIRE(ftasks < (1ll << 33), "%s: too many fold tasks", what);
+        hipLaunchKernelGGL(roi_fold_kernel, dim3((unsigned)htd::ceil_div(ftasks, 4)), dim3(256), 0, s, grad_out, rois, t, n, C, ph, pw,
+                           sampling_ratio, aligned, chunks);
+        if (rs == 4)
+            hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 4, true>), dim3((unsigned)tasks), dim3(256), 0, s, grad_out, rois,
+                               t, n, B, C, ph, pw, sampling_ratio, aligned, chunks);
+        else if (rs == 2)
+            hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 2, true>), dim3((unsigned)htd::ceil_div(tasks, 2)), dim3(256), 0,
+                               s, grad_out, rois, t, n, B, C, ph, pw, sampling_ratio, aligned, chunks);
+        else
+            hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 1, true>), dim3((unsigned)htd::ceil_div(tasks, 4)), dim3(256), 0,
+                               s, grad_out, rois, t, n, B, C, ph, pw, sampling_ratio, aligned, chunks);
+        return htd::check_launch(what);
+    }
     if (rs == 4)
-        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 4>), dim3((unsigned)tasks), dim3(256), 0, s, grad_out, rois, t, n,
-                           B, C, ph, pw, sampling_ratio, aligned, chunks);
+        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 4, false>), dim3((unsigned)tasks), dim3(256), 0, s, grad_out, rois, t,
+                           n, B, C, ph, pw, sampling_ratio, aligned, chunks);
     else if (rs == 2)
-        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 2>), dim3((unsigned)htd::ceil_div(tasks, 2)), dim3(256), 0, s,
+        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 2, false>), dim3((unsigned)htd::ceil_div(tasks, 2)), dim3(256), 0, s,
                            grad_out, rois, t, n, B, C, ph, pw, sampling_ratio, aligned, chunks);
     else
-        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 1>), dim3((unsigned)htd::ceil_div(tasks, 4)), dim3(256), 0, s,
+        hipLaunchKernelGGL((roi_align_bwd_gather_levels_kernel<4, 1, 1, false>), dim3((unsigned)htd::ceil_div(tasks, 4)), dim3(256), 0, s,
                            grad_out, rois, t, n, B, C, ph, pw, sampling_ratio, aligned, chunks);
     return htd::check_launch(what);
 }
@@ -956,6 +1066,36 @@ extern "C" int htd_roi_align_all_levels_bwd_gather(const float *const *grad_outs
     HTD_REQUIRE(n == 0 || grad_outs, "roi_align_all_levels_bwd_gather: null pointer");
     return levels_bwd_gather(nullptr, grad_outs, rois, nullptr, grad_feats, H, W, scales, accumulate, L, n, B, C, ph, pw,
                              sampling_ratio, aligned, workspace, stream, "roi_align_all_levels_bwd_gather");
+}
+
+// The same two entry points with the bins folded along y once per (RoI, map row) in a pass of its own (roi_fold_kernel) instead of
+// by every strip that the row crosses: bit-identical gradient maps, 2-4 x less L2 traffic in the gather.  fold_ws:
+// htd_roi_align_fold_workspace_bytes(...) bytes; the buffers of the levels lie behind one another in launch order.
+extern "C" int64_t htd_roi_align_fold_workspace_bytes(int64_t n, const int *H, int L, int pw, int C)
+{
+    int64_t rows = 0;
+    for (int l = 0; l < L; ++l) rows += H[l];
+    return (n > 0 ? n : 1) * rows * pw * C * 4;
+}
+
+extern "C" int htd_roi_align_levels_bwd_gather_folded(const float *grad_out, const float *rois, const int64_t *roi_level,
+                                                      float *const *grad_feats, const int *H, const int *W, const float *scales,
+                                                      const int *accumulate, int L, int64_t n, int B, int C, int ph, int pw,
+                                                      int sampling_ratio, int aligned, void *workspace, void *fold_ws, void *stream)
+{
+    HTD_REQUIRE(n == 0 || (grad_out && roi_level && fold_ws), "roi_align_levels_bwd_gather_folded: null pointer");
+    return levels_bwd_gather(grad_out, nullptr, rois, roi_level, grad_feats, H, W, scales, accumulate, L, n, B, C, ph, pw,
+                             sampling_ratio, aligned, workspace, stream, "roi_align_levels_bwd_gather_folded", fold_ws);
+}
+
+extern "C" int htd_roi_align_all_levels_bwd_gather_folded(const float *const *grad_outs, const float *rois, float *const *grad_feats,
+                                                          const int *H, const int *W, const float *scales, const int *accumulate,
+                                                          int L, int64_t n, int B, int C, int ph, int pw, int sampling_ratio,
+                                                          int aligned, void *workspace, void *fold_ws, void *stream)
+{
+    HTD_REQUIRE(n == 0 || (grad_outs && fold_ws), "roi_align_all_levels_bwd_gather_folded: null pointer");
+    return levels_bwd_gather(nullptr, grad_outs, rois, nullptr, grad_feats, H, W, scales, accumulate, L, n, B, C, ph, pw,
+                             sampling_ratio, aligned, workspace, stream, "roi_align_all_levels_bwd_gather_folded", fold_ws);
 }
 
 extern "C" int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *roi_level, int level,

@@ -12,6 +12,7 @@ Memory layout contract: 4-D activations are logical NCHW tensors in
 torch.channels_last memory format (= physical NHWC, what the kernels index).
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -108,6 +109,25 @@ def _roi_align_bwd(g, rois, lvls, level, galias, shape, ph, pw, scale, sr, align
     return gf
 
 
+ROI_FOLD = os.environ.get('HTD_ROI_FOLD', '1') != '0'                  # 0: every strip folds its RoIs' bins itself (A/B runs)
+ROI_FOLD_MAX_BYTES = int(float(os.environ.get('HTD_ROI_FOLD_MAX_GB', '8')) * 2**30)
+ROI_FOLD_MIN_ROIS = int(os.environ.get('HTD_ROI_FOLD_MIN_ROIS', '64'))
+# One level per RoI (SingleRoIExtractor): a RoI is 7-14 pixels wide on ITS level, one or two strips per row, and the extra pass
+# costs more than it saves (2048 RoIs: 470 -> 546 us).  BA pools every RoI from every level: ~20 strips per row on the fine ones.
+ROI_FOLD_SINGLE = os.environ.get('HTD_ROI_FOLD_SINGLE', '0') != '0'
+
+
+def _fold_workspace(n, Hs, L, pw, C, dev):
+    """Folded-bin buffer of the two-pass gather backward (htd_roi_align_*_bwd_gather_folded), or None when folding is off, the
+    buffer would not fit the cap, or there are too few RoIs for the extra launch to pay."""
+    if not ROI_FOLD or n < ROI_FOLD_MIN_ROIS:
+        return None
+    nbytes = capi.lib().htd_roi_align_fold_workspace_bytes(n, Hs, L, pw, C)
+    if nbytes > ROI_FOLD_MAX_BYTES:
+        return None
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
 def _roi_align_levels_bwd(g, rois, lvls, handed, need, shapes, ph, pw, scales, sr, aligned):
     """Gradient maps of every level that needs one, ONE launch (htd_roi_align_levels_bwd_gather): handed[i] (+)= RoIAlign_i^T(g),
     or a fresh map where nothing was handed down."""
@@ -139,8 +159,13 @@ def _roi_align_levels_bwd(g, rois, lvls, handed, need, shapes, ph, pw, scales, s
     # algorithmic bytes: every map written once (+ read when accumulating) + every RoI's 7x7xC gradient read once
     work = ('byte', 4.0 * (sum(s_[0] * s_[2] * s_[3] * C * (1 + a) for s_, a, m in zip(shapes, accs, maps) if m is not None) +
                            n * ph * pw * C))
-    capi.call('htd_roi_align_levels_bwd_gather', _P(g), _P(rois), _P(lvls), ptrs, Hs, Ws, sc, ac, L, n, B, C, ph, pw, int(sr),
-              int(bool(aligned)), _P(ws), _S(), work=work)
+    fold = _fold_workspace(n, Hs, L, pw, C, g.device) if (C % 4 == 0 and ROI_FOLD_SINGLE) else None
+    if fold is not None:
+        capi.call('htd_roi_align_levels_bwd_gather_folded', _P(g), _P(rois), _P(lvls), ptrs, Hs, Ws, sc, ac, L, n, B, C, ph, pw,
+                  int(sr), int(bool(aligned)), _P(ws), _P(fold), _S(), work=work, key='htd_roi_align_levels_bwd_gather')
+    else:
+        capi.call('htd_roi_align_levels_bwd_gather', _P(g), _P(rois), _P(lvls), ptrs, Hs, Ws, sc, ac, L, n, B, C, ph, pw, int(sr),
+                  int(bool(aligned)), _P(ws), _S(), work=work)
     return maps
 
 
@@ -358,8 +383,13 @@ class _RoIAlignAllLevels(Function):
             B, C = shapes[0][0], shapes[0][1]
             work = ('byte', 4.0 * sum(s_[0] * s_[2] * s_[3] * C * (1 + a) + n * ph * pw * C
                                       for s_, a, m in zip(shapes, accs, maps) if m is not None))
-            capi.call('htd_roi_align_all_levels_bwd_gather', gptr, _P(rois), mptr, Hs, Ws, sc, ac, L, n, B, C, ph, pw, sr, aligned,
-                      _P(ws), _S(), work=work)
+            fold = _fold_workspace(n, Hs, L, pw, C, dev) if C % 4 == 0 else None
+            if fold is not None:
+                capi.call('htd_roi_align_all_levels_bwd_gather_folded', gptr, _P(rois), mptr, Hs, Ws, sc, ac, L, n, B, C, ph, pw, sr,
+                          aligned, _P(ws), _P(fold), _S(), work=work, key='htd_roi_align_all_levels_bwd_gather')
+            else:
+                capi.call('htd_roi_align_all_levels_bwd_gather', gptr, _P(rois), mptr, Hs, Ws, sc, ac, L, n, B, C, ph, pw, sr, aligned,
+                          _P(ws), _S(), work=work)
         res = [m if m is not None else (handed[i] if need[i] else None) for i, m in enumerate(maps)]
         return (None, ) * 6 + tuple(res)
 

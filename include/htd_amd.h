@@ -85,6 +85,18 @@ int htd_roi_align_all_levels_bwd_gather(const float *const *grad_outs, const flo
                                         const int *H, const int *W, const float *scales, const int *accumulate, int L,
                                         int64_t n, int B, int C, int ph, int pw, int sampling_ratio, int aligned,
                                         void *workspace, void *stream);
+/* Both level-fused gather backwards with the bins of a RoI folded along y ONCE per (RoI, map row) by a pass of its own
+ * (the strips of a row used to fetch and fold the same 7-14 bin vectors each): bit-identical gradient maps.
+ * fold_ws: htd_roi_align_fold_workspace_bytes(n, H, L, pw, C) bytes = n * sum(H) * pw * C floats. */
+int64_t htd_roi_align_fold_workspace_bytes(int64_t n, const int *H, int L, int pw, int C);
+int htd_roi_align_levels_bwd_gather_folded(const float *grad_out, const float *rois, const int64_t *roi_level,
+                                           float *const *grad_feats, const int *H, const int *W, const float *scales,
+                                           const int *accumulate, int L, int64_t n, int B, int C, int ph, int pw,
+                                           int sampling_ratio, int aligned, void *workspace, void *fold_ws, void *stream);
+int htd_roi_align_all_levels_bwd_gather_folded(const float *const *grad_outs, const float *rois, float *const *grad_feats,
+                                               const int *H, const int *W, const float *scales, const int *accumulate,
+                                               int L, int64_t n, int B, int C, int ph, int pw, int sampling_ratio,
+                                               int aligned, void *workspace, void *fold_ws, void *stream);
 int64_t htd_roi_align_bwd_gather_workspace_bytes(int64_t n);
 int htd_roi_align_bwd_gather(const float *grad_out, const float *rois, const int64_t *roi_level, int level,
                              float *grad_feat, int64_t n, int B, int C, int H, int W, int ph, int pw,

@@ -79,3 +79,44 @@ def test_all_levels_backward_adds_into_chained_maps():
     (sum((o * o).sum() for o in outs2) + single2.sum()).backward()
     for a, b in zip(base, ref):
         torch.testing.assert_close(a.grad, b.grad, rtol=2e-5, atol=2e-6 * float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize('n,B,clustered', [(64, 1, False), (130, 2, True), (600, 3, False), (512, 4, True)])
+def test_folded_backward_is_bit_identical_to_the_unfolded_one(n, B, clustered, monkeypatch):
+    """htd_roi_align_{all_,}levels_bwd_gather_folded: the bins folded along y once per (RoI, map row) by roi_fold_kernel, the strips
+    fetching folded vectors -- the same sums in the same order as the strips folding for themselves, so the same bits."""
+    M, feats, scales, rois = _setup(n, B, 100 + n, clustered)
+    from htd_amd.detector.roi_extractors import map_roi_levels
+    lv = map_roi_levels(rois, 4)
+    g = torch.Generator().manual_seed(2)
+
+    def run(fold):
+        monkeypatch.setattr(M, 'ROI_FOLD', fold)
+        monkeypatch.setattr(M, 'ROI_FOLD_SINGLE', fold)
+        fa = [f.clone().requires_grad_() for f in feats]
+        outs = M.roi_align_all_levels(fa, rois, 7, scales)
+        g.manual_seed(2)
+        gos = [torch.randn(o.shape, generator=g).to(o.device).contiguous(memory_format=CL) for o in outs]
+        torch.autograd.backward(outs, gos)
+        fb = [f.clone().requires_grad_() for f in feats]
+        one = M.roi_align_levels(fb, rois, lv, 7, scales)
+        one.backward(gos[0])
+        return [f.grad for f in fa], [f.grad for f in fb]
+
+    a_all, a_one = run(True)
+    b_all, b_one = run(False)
+    for x, y in zip(a_all + a_one, b_all + b_one):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert torch.equal(x, y)
+
+
+def test_fold_is_skipped_past_the_workspace_cap(monkeypatch):
+    M, feats, scales, rois = _setup(128, 2, 5, False)
+    monkeypatch.setattr(M, 'ROI_FOLD_MAX_BYTES', 1 << 20)
+    import ctypes
+    Hs = (ctypes.c_int * 4)(*[f.shape[2] for f in feats])
+    assert M._fold_workspace(128, Hs, 4, 7, 256, rois.device) is None
+    monkeypatch.setattr(M, 'ROI_FOLD_MAX_BYTES', 8 << 30)
+    ws = M._fold_workspace(128, Hs, 4, 7, 256, rois.device)
+    assert ws is not None and ws.numel() == 128 * sum(f.shape[2] for f in feats) * 7 * 256 * 4
