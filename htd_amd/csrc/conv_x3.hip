@@ -37,8 +37,40 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
 constexpr int XK = 16;            // channels per K slice
 constexpr int NCH = 6;            // 16-byte chunks of a row slice: 3 planes x 2 halves of 8 channels
+
+// ---- "H2" arithmetic (round 4): fp32 products through TWO fp16 pieces per operand, three matrix instructions instead of six ----
+// a = (a0 + a1) / sa with a0 = fp16(sa a), a1 = fp16(sa a - a0): 11 + 11 significant bits, |a - (a0 + a1) / sa| <= 2^-22 |a|, and
+// a b ~ (a0 b0 + a0 b1 + a1 b0) / (sa sb); the dropped a1 b1 is <= 2^-22 |a b| (2^-24 rms), the size of the terms the bf16 form
+// drops.  fp16 has 5 exponent bits, so the operands are block-scaled by powers of two (exact): sa from the largest magnitude of
+// the WHOLE activation tensor (a device scalar, htd_absmax, so that sa |a| < 2^15), sb[n] per output channel of the weights;
+// the epilogue multiplies column n by 1 / (sa sb[n]).  Elements more than 2^29 below their tensor's maximum fall into fp16's
+// subnormals (kept by the matrix pipe: tools/micro/mfma_split_products.hip) and lose relative precision from there on -- their
+// ABSOLUTE error stays <= 2^-40 of the tensor maximum, far below fp32's rounding of any sum the large elements take part in.
+// Why: under the socket power cap the six-product form's matrix-pipe roof is 284 algorithmic TF/s, this one's 539
+// (same micro-benchmark), and the 3x3 layers ran at 75 % of the former.
+struct H2Scale { float s, inv; };
+__device__ __forceinline__ H2Scale h2_scale(const float *amax)
+{
+    const unsigned E = (__float_as_uint(*amax) >> 23) & 0xffu;        // amax = 1.m x 2^(E - 127) < 2^(E - 126)
+    int e = E == 0u ? 126 : (E == 255u ? 0 : 141 - (int)E);            // 2^e amax in [2^14, 2^15)
+    e = e > 126 ? 126 : e;
+    return H2Scale{__uint_as_float((unsigned)(127 + e) << 23), __uint_as_float((unsigned)(127 - e) << 23)};
+}
+// two (scaled) floats -> two packed fp16 pairs (element 0 in the low half): the value and what it left over
+__device__ __forceinline__ void split2hx2(float a, float b, unsigned &h, unsigned &l)
+{
+    union { f16x2 v; unsigned u; } c;
+    c.v = __builtin_convertvector(f32x2{a, b}, f16x2);
+    h = c.u;
+    const f32x2 back = __builtin_convertvector(c.v, f32x2);
+    c.v = __builtin_convertvector(f32x2{a - back[0], b - back[1]}, f16x2);
+    l = c.u;
+}
 
 // two floats -> three packed bf16 pairs (element 0 in the low half), see conv_fwd.hip
 __device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned &m, unsigned &l)
@@ -122,6 +154,9 @@ struct X3Params {
     const uint4 *xp;
     uint4 *yp;
     int64_t xp_rows, yp_rows;
+    // H2 arithmetic: amax = device scalar holding max |x| of the A operand's tensor, wscale = the weight image's per-column
+    // 1 / sb[n] ([Cop] floats behind the planes).  NULL: the six-product bf16 form.
+    const float *amax, *wscale;
 };
 
 // planes of four consecutive channels n .. n + 3 (n % 4 == 0) of row m: 8 bytes into each of the three plane chunks
@@ -162,6 +197,14 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
     float *le = reinterpret_cast<float *>(lds);
     const bool vec_ok = (p.Co & 3) == 0;
     constexpr int V = BN / 4, RPP = 256 / V;
+    // H2: column n of the accumulators carries sa sb[n] (exact powers of two)
+    const bool scaled = p.wscale != nullptr;
+    float4 cscale = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (scaled) {
+        const float ia = h2_scale(p.amax).inv;
+        const float4 w4 = *reinterpret_cast<const float4 *>(p.wscale + n0 + (tid % V) * 4);      // (n < Cop: the image's padded columns)
+        cscale = make_float4(w4.x * ia, w4.y * ia, w4.z * ia, w4.w * ia);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if constexpr (MF16) {       // D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
@@ -206,6 +249,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
                     ok[u] = m < p.M && col_ok;
                     o[u] = (m * p.Co + n) & -(int64_t)ok[u];          // rows / columns past the end: element 0, read and dropped
                     v[u] = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
+                    if (scaled) { v[u].x *= cscale.x; v[u].y *= cscale.y; v[u].z *= cscale.z; v[u].w *= cscale.w; }
                 }
                 if (p.residual != nullptr) {
 #pragma unroll
@@ -254,6 +298,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
             const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
             if (m >= p.M || n >= p.Co) continue;
             float4 v = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
+            if (scaled) { v.x *= cscale.x; v.y *= cscale.y; v.z *= cscale.z; v.w *= cscale.w; }
             const int64_t o = m * p.Co + n;
             if (part) {
                 float *dst = region_b ? p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * p.m_rem0 * p.Co : 0) +
@@ -332,9 +377,10 @@ constexpr int x3p_occupancy()
     return by_lds < by_regs ? by_lds : by_regs;
 }
 
-template <int WGM, int WGN, int TM, int TN, int KW, bool MF16, int NB>
+template <int WGM, int WGN, int TM, int TN, int KW, bool MF16, int NB, bool H2 = false>
 __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) void conv_x3p_kernel(X3Params p)
 {
+    static_assert(!(H2 && MF16), "H2: 32x32x16 form only");
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     using G = Geo<BM, KW>;
     constexpr int PADX = (KW - 1) / 2;
@@ -467,6 +513,8 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
 #pragma unroll
     for (int i = 0; i < 2 * NPT; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned ra_ok = 0u;
+    float h2s = 1.f;
+    if constexpr (H2) h2s = h2_scale(p.amax).s;
     // (no divisions inside the K loop: the step's channel slice / filter row and the prefetch pointers advance incrementally)
     auto load_pass = [&](int shift, int koff, int i, int slot, bool live) __attribute__((always_inline)) {   // pass i of the run at pixel shift `shift`
         bool ok;
@@ -497,17 +545,26 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
         if constexpr (KW > 1) ok = (ra_ok >> i) & 1u;
         else ok = a_in[i];
         const float4 v = make_float4(ok ? ra[slot][0] : 0.f, ok ? ra[slot][1] : 0.f, ok ? ra[slot][2] : 0.f, ok ? ra[slot][3] : 0.f);
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split3x2(v.x, v.y, h0, m0_, l0);
-        split3x2(v.z, v.w, h1, m1, l1);
         // chunk = plane * 2 + (vcol >> 1); 8 bytes at half (vcol & 1) of the row's 16
         const unsigned d = lds_a0 + (unsigned)(buf * A_VEC * 16 + ((vcol >> 1) * G::PITCH + j) * 16 + (vcol & 1) * 8);
-        lds_store8<0>(d, h0, h1);
-        lds_store8<2 * G::PITCH * 16>(d, m0_, m1);
-        lds_store8<4 * G::PITCH * 16>(d, l0, l1);
+        if constexpr (H2) {
+            unsigned h0, l0, h1, l1;
+            split2hx2(v.x * h2s, v.y * h2s, h0, l0);
+            split2hx2(v.z * h2s, v.w * h2s, h1, l1);
+            lds_store8<0>(d, h0, h1);
+            lds_store8<2 * G::PITCH * 16>(d, l0, l1);
+        } else {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3x2(v.x, v.y, h0, m0_, l0);
+            split3x2(v.z, v.w, h1, m1, l1);
+            lds_store8<0>(d, h0, h1);
+            lds_store8<2 * G::PITCH * 16>(d, m0_, m1);
+            lds_store8<4 * G::PITCH * 16>(d, l0, l1);
+        }
     };
     // B tile of (step s, tap kx) -> LDS buffer `buf`, LDS-DMA: instruction idx = chunk * (BN / 64) + half covers 64 rows
-    constexpr int NI = NCH * BN / 64;                             // LDS-DMA instructions per B tile, dealt round-robin to the waves
+    // (H2: the image's first four chunks -- two planes -- only)
+    constexpr int NI = (H2 ? 4 : NCH) * BN / 64;                  // LDS-DMA instructions per B tile, dealt round-robin to the waves
     const uint4 *bsrc[(NI + 3) / 4];                              // the lane's source of the wave's k-th instruction, tile (tap 0, slice 0)
 #pragma unroll
     for (int k = 0; k < (NI + 3) / 4; ++k) {
@@ -532,7 +589,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
         asm volatile("" ::: "memory");
     };
     constexpr int DIST = NB - 1;                                  // prefetch distance of the B tiles, in taps
-    constexpr int NI_MIN = NCH * BN / 64 / 4;                     // LDS-DMA instructions every wave issues per B tile
+    constexpr int NI_MIN = NI / 4;                                // LDS-DMA instructions every wave issues per B tile
     static_assert(NI_MIN >= 1, "every wave issues at least one LDS-DMA per B tile");
     // At the end of a tap the A pass issued in the PREVIOUS tap and the B tile of the next tap must have landed.  A tap issues
     // its B tile first, then its A pass(es): with DIST = 1 the B tile is this tap's own and only the A loads behind it may stay
@@ -596,6 +653,26 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa01[i], fb01, acc[i][j], 0, 0, 0);   // a0 b0 + a1 b1
                 }
             }
+        } else if constexpr (H2) {
+            f16x8 fa[RB][2], fb[CB][2];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    fa[i][q] = *reinterpret_cast<const f16x8 *>(la + arow[i] + a_c0 + q * 2 * G::PITCH * 16);
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    fb[j][q] = *reinterpret_cast<const f16x8 *>(lb + b_c0 + j * 32 * 16 + q * 2 * BN * 16);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {      // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+                }
         } else {
             bf16x8 fa[RB][3], fb[CB][3];
 #pragma unroll
@@ -698,7 +775,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
             } else {
                 store_pass(abuf ^ 1, kx, P ^ 1);
             }
-            constexpr int NM = RB * CB * (MF16 ? 3 : 6);              // MFMAs of the tap
+            constexpr int NM = RB * CB * ((MF16 || H2) ? 3 : 6);      // MFMAs of the tap
             constexpr int PER = (NPT * 36 + NM - 1) / NM;             // ~36 vector instructions per staged pass
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #pragma unroll
@@ -1110,6 +1187,158 @@ __global__ __launch_bounds__(256) void x3_planes_many_kernel(const PlanesDesc *_
 
 inline int planes_np(int N) { return (int)htd::ceil_div(N, 128) * 128; }
 
+// ---- H2 weight image: the same [taps][K/16][6][Np] x 16 B layout with the two fp16 pieces of sb[n] w in chunks 0..3 (chunks 4, 5
+// unused) and, behind the planes, Np floats 1 / sb[n] (what the epilogue multiplies by) and Np floats sb[n].
+// Pass 1, one workgroup per output row n: sb[n] = the power of two that puts the row's largest magnitude into [2^14, 2^15).
+__device__ __forceinline__ void x3h_rowscale_row(const float *__restrict__ w, float *__restrict__ scales, int Co, int taps, int Ci,
+                                                 int Np, int transposed, int n, float *red)
+{
+    const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
+    float mx = 0.f;
+    if (n < N) {
+        if (!transposed) {
+            const float *row = w + (int64_t)n * taps * Ci;
+            for (int e = threadIdx.x; e < taps * Ci; e += 256) mx = fmaxf(mx, fabsf(row[e]));
+        } else {
+            for (int e = threadIdx.x; e < K * taps; e += 256) mx = fmaxf(mx, fabsf(w[(int64_t)e * Ci + n]));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const H2Scale sc = h2_scale(&mx);
+        scales[n] = sc.inv;
+        scales[Np + n] = sc.s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void x3h_planes_element(const float *__restrict__ w, uint4 *__restrict__ out, const float *__restrict__ scales,
+                                                   int Co, int taps, int Ci, int Np, int transposed, int64_t e)
+{
+    const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
+    const int ncs = K / XK;
+    const int n = (int)(e % Np);
+    const int64_t t2 = e / Np;
+    const int cs = (int)(t2 % ncs), tap = (int)(t2 / ncs);
+    float v[XK];
+    if (n < N) {
+        const float sb = scales[Np + n];
+        if (!transposed) {
+            const float4 *src = reinterpret_cast<const float4 *>(w + ((int64_t)n * taps + tap) * Ci + cs * XK);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 f = src[q];
+                v[4 * q] = f.x * sb; v[4 * q + 1] = f.y * sb; v[4 * q + 2] = f.z * sb; v[4 * q + 3] = f.w * sb;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < XK; ++k) v[k] = w[((int64_t)(cs * XK + k) * taps + (taps - 1 - tap)) * Ci + n] * sb;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < XK; ++k) v[k] = 0.f;
+    }
+    unsigned pl[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split2hx2(v[2 * k], v[2 * k + 1], pl[0][k], pl[1][k]);
+    uint4 *dst = out + ((int64_t)(tap * ncs + cs) * NCH) * Np + n;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            dst[(int64_t)(q * 2 + h) * Np] = make_uint4(pl[q][4 * h], pl[q][4 * h + 1], pl[q][4 * h + 2], pl[q][4 * h + 3]);
+}
+
+__host__ __device__ inline int64_t planes_vec(int taps, int K, int Np) { return (int64_t)taps * (K / XK) * NCH * Np; }      // uint4 of the planes
+
+__global__ __launch_bounds__(256) void x3h_rowscale_kernel(const float *__restrict__ w, float *__restrict__ scales, int Co, int taps,
+                                                           int Ci, int Np, int transposed)
+{
+    __shared__ float red[4];
+    x3h_rowscale_row(w, scales, Co, taps, Ci, Np, transposed, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(256) void x3h_planes_kernel(const float *__restrict__ w, uint4 *__restrict__ out,
+                                                         const float *__restrict__ scales, int Co, int taps, int Ci, int Np,
+                                                         int transposed)
+{
+    const int K = transposed ? Co : Ci;
+    const int64_t total = (int64_t)taps * (K / XK) * Np;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+        x3h_planes_element(w, out, scales, Co, taps, Ci, Np, transposed, e);
+}
+
+// many images, two launches (row scales, then planes): PlanesDesc with `transposed` bit 1 set marks an H2 entry -- the bf16 and
+// the H2 images of a step are made by the same two tables; row0 = prefix sum of Np over the H2 entries
+struct PlanesDescH {
+    const float *w;
+    uint4 *out;
+    int Co, taps, Ci, transposed;
+    int64_t block0, row0;
+};
+
+__global__ __launch_bounds__(256) void x3h_rowscale_many_kernel(const PlanesDescH *__restrict__ descs, int n)
+{
+    __shared__ float red[4];
+    int lo = 0, hi = n - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].row0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PlanesDescH d = descs[lo];
+    const int tr = d.transposed & 1;
+    const int N = tr ? d.Ci : d.Co, K = tr ? d.Co : d.Ci;
+    const int Np = ((N + 127) / 128) * 128;
+    float *scales = reinterpret_cast<float *>(d.out + planes_vec(d.taps, K, Np));
+    x3h_rowscale_row(d.w, scales, d.Co, d.taps, d.Ci, Np, tr, (int)(b - d.row0), red);
+}
+
+__global__ __launch_bounds__(256) void x3h_planes_many_kernel(const PlanesDescH *__restrict__ descs, int n)
+{
+    int lo = 0, hi = n - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const PlanesDescH d = descs[lo];
+    const int tr = d.transposed & 1;
+    const int N = tr ? d.Ci : d.Co, K = tr ? d.Co : d.Ci;
+    const int Np = ((N + 127) / 128) * 128;
+    const int64_t total = (int64_t)d.taps * (K / XK) * Np;
+    const int64_t e = (b - d.block0) * 256 + threadIdx.x;
+    const float *scales = reinterpret_cast<const float *>(d.out + planes_vec(d.taps, K, Np));
+    if (e < total) x3h_planes_element(d.w, d.out, scales, d.Co, d.taps, d.Ci, Np, tr, e);
+}
+
+// max |x| over a tensor into a device scalar that is ZERO (or an earlier maximum) on entry: one atomic per wavefront on the
+// bits of the non-negative value (they order like unsigned integers; a NaN sorts above everything and stays)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ out)
+{
+    const int64_t n4 = n >> 2;
+    float mx = 0.f;
+    unsigned nan = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float t = x[(n4 << 2) + threadIdx.x];
+        mx = fmaxf(mx, fabsf(t));
+        nan |= t != t;
+    }
+    unsigned bits = nan ? 0x7fc00000u : __float_as_uint(mx);
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
+    if ((threadIdx.x & 63) == 0 && bits != 0u) atomicMax(out, bits);
+}
+
 // fp32 map x [M][C] (NHWC pixels x channels, C % 16 == 0) -> activation planes [C/16][6][rows] x 16 B (X3Params::xp): what a
 // producer's epilogue writes through X3Params::yp, as a pass of its own for maps whose producer is not one of these kernels.
 // One thread per (pixel, 8 channels): two float4 in, three 16-byte chunks out, consecutive lanes = consecutive pixels.
@@ -1371,7 +1600,14 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     p.nt = (int)htd::ceil_div(p.Co, kXCfg[cfg].bn);
     HTD_REQUIRE(pl.grid > 0 && pl.grid < (1ll << 31), "conv2d_x3p: bad grid");
     const dim3 grid((unsigned)pl.grid);
-    if (p.xp != nullptr) {          // A operand pre-split: conv_x3q_kernel (1x1, stride 1)
+    if (p.amax != nullptr) {        // H2 arithmetic (3x3 layers)
+        switch (cfg) {
+        case 0: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 1, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 2, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 1, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 2, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        }
+    } else if (p.xp != nullptr) {   // A operand pre-split: conv_x3q_kernel (1x1, stride 1)
         switch (cfg) {
         case 0: launch_tile_q<1, 1>(p, grid, s); break;
         case 1: launch_tile_q<2, 2>(p, grid, s); break;
@@ -1412,6 +1648,20 @@ bool x3p_shape_ok(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
 extern "C" int htd_conv2d_x3p_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
 {
     return (!x3p_off() && htd::conv_math() == 1 && x3p_shape_ok(Ci, Co, kh, kw, stride, pad, dil)) ? 1 : 0;
+}
+
+// H2 arithmetic (two fp16 pieces per operand, three products): 1 when htd_conv2d_fwd_x3h / htd_conv2d_bwd_data_x3h take the layer.
+// HTD_CONV_H2=0 switches it off (every layer on the six-product bf16 form); htd_conv2d_set_h2 does the same at run time.
+int g_conv_h2 = getenv("HTD_CONV_H2") ? atoi(getenv("HTD_CONV_H2")) : 1;
+extern "C" int htd_conv2d_set_h2(int on)
+{
+    const int prev = g_conv_h2;
+    if (on == 0 || on == 1) g_conv_h2 = on;
+    return prev;
+}
+extern "C" int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
+{
+    return (g_conv_h2 == 1 && kh == 3 && htd_conv2d_x3p_supported(Ci, Co, kh, kw, stride, pad, dil)) ? 1 : 0;
 }
 
 // Tuned tile table of conv_x3p_kernel (see choose_cfg).  cfg: 0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases the entry.
@@ -1455,7 +1705,7 @@ extern "C" int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, in
 {
     const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
     if (N <= 0 || K <= 0 || K % XK != 0 || kh <= 0 || kw <= 0) return 0;
-    return (int64_t)kh * kw * (K / XK) * NCH * planes_np(N) * 16;
+    return (int64_t)kh * kw * (K / XK) * NCH * planes_np(N) * 16 + 2 * planes_np(N) * 4;       // (+ the H2 image's row scales)
 }
 
 extern "C" int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream)
@@ -1470,6 +1720,47 @@ extern "C" int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh
     hipLaunchKernelGGL(x3_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint4 *)planes, Co, kh * kw, Ci, Np,
                        transposed);
     return htd::check_launch("x3_planes");
+}
+
+// The H2 image of one weight (layout of htd_conv2d_x3_planes, fp16 pieces in chunks 0..3, row scales behind the planes).
+extern "C" int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream)
+{
+    HTD_REQUIRE(w && planes && Co > 0 && Ci > 0 && kh > 0 && kw > 0, "x3h_planes: bad arguments");
+    const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
+    HTD_REQUIRE(K % XK == 0, "x3h_planes: reduction length %d must be a multiple of 16", K);
+    HTD_REQUIRE(transposed || Ci % 4 == 0, "x3h_planes: Ci %% 4");
+    const int Np = planes_np(N);
+    float *scales = reinterpret_cast<float *>((uint4 *)planes + planes_vec(kh * kw, K, Np));
+    hipLaunchKernelGGL(x3h_rowscale_kernel, dim3((unsigned)Np), dim3(256), 0, (hipStream_t)stream, w, scales, Co, kh * kw, Ci, Np,
+                       transposed);
+    const int64_t total = (int64_t)kh * kw * (K / XK) * Np;
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 16384);
+    hipLaunchKernelGGL(x3h_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint4 *)planes, scales, Co, kh * kw,
+                       Ci, Np, transposed);
+    return htd::check_launch("x3h_planes");
+}
+
+// desc: device array of n entries { const float *w; void *planes; int Co, taps, Ci, transposed; int64_t block0, row0; } (48
+// bytes); block0 as in htd_conv2d_x3_planes_many, row0 = prefix sum of Np (= N rounded up to 128) over the entries.
+extern "C" int htd_conv2d_x3h_planes_many(const void *desc, int n, int64_t total_blocks, int64_t total_rows, void *stream)
+{
+    static_assert(sizeof(PlanesDescH) == 48, "PlanesDescH layout is part of the ABI");
+    HTD_REQUIRE(desc && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31) && total_rows > 0 && total_rows < (1ll << 31),
+                "x3h_planes_many: bad arguments");
+    hipLaunchKernelGGL(x3h_rowscale_many_kernel, dim3((unsigned)total_rows), dim3(256), 0, (hipStream_t)stream,
+                       (const PlanesDescH *)desc, n);
+    hipLaunchKernelGGL(x3h_planes_many_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const PlanesDescH *)desc, n);
+    return htd::check_launch("x3h_planes_many");
+}
+
+// *amax = max(*amax, max |x[i]|): *amax must hold zero (or an earlier maximum) on entry; NaN in x makes it NaN.
+extern "C" int htd_absmax(const float *x, int64_t n, float *amax, void *stream)
+{
+    HTD_REQUIRE(x && amax && n > 0 && ((uintptr_t)x & 15) == 0, "absmax: bad arguments");
+    const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n >> 2, (int64_t)256 * 8) + 1, 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, (unsigned *)amax);
+    return htd::check_launch("absmax");
 }
 
 // desc: device array of n entries { const float *w; void *planes; int Co, taps, Ci, transposed; int64_t block0; } (40 bytes),
@@ -1583,4 +1874,56 @@ extern "C" int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, co
     HTD_REQUIRE(gy, "conv2d_bwd_data_x3p: bad arguments");
     return htd_conv2d_bwd_data_x3q(gy, nullptr, wplanesT, mask_src, accum, gx, nullptr, B, H, W, Ci, Co, kh, kw, pad, workspace,
                                    stream);
+}
+
+// The 3x3 layers on the H2 arithmetic (two fp16 pieces per operand, three matrix instructions per product block instead of six;
+// see h2_scale above).  amax: device scalar >= max |x| of the whole input tensor (htd_absmax); wplanes: htd_conv2d_x3h_planes.
+extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void *wplanes, const float *bias, const float *residual,
+                                  int res_h, int res_w, float *y, void *yplanes, int B, int H, int W, int Ci, int Co, int kh, int kw,
+                                  int stride, int pad, int relu, void *workspace, void *stream)
+{
+    HTD_REQUIRE(!yplanes || Co % XK == 0, "conv2d_fwd_x3h: output planes need Co %% 16 == 0 (Co=%d)", Co);
+    HTD_REQUIRE(x && amax && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3h: bad arguments");
+    HTD_REQUIRE(kh == 3 && x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3h: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d",
+                Ci, Co, kh, kw, stride, pad);
+    HTD_REQUIRE((res_h > 0) == (res_w > 0) && res_h >= 0 && (res_h == 0 || ((Co & 3) == 0 && residual)),
+                "conv2d_fwd_x3h: bad residual up-sampling arguments");
+    X3Params p{};
+    p.x = x; p.wp = (const uint4 *)wplanes; p.bias = bias; p.residual = residual; p.y = y;
+    p.Hx = H; p.Wx = W;
+    p.Ho = (H + 2 * pad - kh) / stride + 1;
+    p.Wo = (W + 2 * pad - kw) / stride + 1;
+    p.Ci = Ci; p.Co = Co; p.Cop = planes_np(Co); p.kh = kh; p.stride = stride; p.relu = relu;
+    p.M = (int64_t)B * p.Ho * p.Wo;
+    p.ncs = Ci / XK;
+    p.amax = amax;
+    p.wscale = reinterpret_cast<const float *>(p.wp + planes_vec(kh * kw, Ci, p.Cop));
+    p.yp = (uint4 *)yplanes; p.yp_rows = act_rows(p.M);
+    HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.M * Co < (1ll << 40), "conv2d_fwd_x3h: operand too large");
+    if (res_h > 0) {
+        p.res_H = res_h; p.res_W = res_w;
+        p.res_sh = (float)res_h / (float)p.Ho; p.res_sw = (float)res_w / (float)p.Wo;
+    }
+    return launch_x3p(p, kw, (hipStream_t)stream, workspace);
+}
+
+extern "C" int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const void *wplanesT, const float *mask_src,
+                                       const float *accum, float *gx, void *gxplanes, int B, int H, int W, int Ci, int Co, int kh,
+                                       int kw, int pad, void *workspace, void *stream)
+{
+    HTD_REQUIRE(!gxplanes || Ci % XK == 0, "conv2d_bwd_data_x3h: output planes need Ci %% 16 == 0 (Ci=%d)", Ci);
+    HTD_REQUIRE(gy && amax && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3h: bad arguments");
+    HTD_REQUIRE(kh == 3 && x3p_shape_ok(Co, Ci, kh, kw, 1, pad, 1), "conv2d_bwd_data_x3h: unsupported layer Ci=%d Co=%d k=%dx%d p=%d", Ci,
+                Co, kh, kw, pad);
+    X3Params p{};
+    p.x = gy; p.wp = (const uint4 *)wplanesT; p.residual = accum; p.mask_src = mask_src; p.y = gx;
+    p.Hx = H; p.Wx = W; p.Ho = H; p.Wo = W;          // stride 1, same size
+    p.Ci = Co; p.Co = Ci; p.Cop = planes_np(Ci); p.kh = kh; p.stride = 1;
+    p.M = (int64_t)B * H * W;
+    p.ncs = Co / XK;
+    p.amax = amax;
+    p.wscale = reinterpret_cast<const float *>(p.wp + planes_vec(kh * kw, Co, p.Cop));
+    p.yp = (uint4 *)gxplanes; p.yp_rows = act_rows(p.M);
+    HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3h: operand too large");
+    return launch_x3p(p, kw, (hipStream_t)stream, workspace);
 }

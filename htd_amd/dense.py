@@ -240,7 +240,33 @@ def _flip_key(w):
 def new_step():
     _STEP_FLIPS.clear()
     _STEP_PLANES.clear()
+    _AMAX_POOL.clear()
     _drop_temp_sinks()
+
+
+# ---- H2 arithmetic of the 3x3 layers (csrc/conv_x3.hip, h2_scale): the kernel scales its activation operand by a power of two
+# taken from the tensor's largest magnitude, a device scalar that htd_absmax leaves in a slot of a per-step pool of zeros
+# (one fill per step, no host read).  Never cached per tensor: the allocator hands the same address to different tensors.
+_AMAX_POOL = {}
+_AMAX_SLOTS = 512
+
+
+def _x3h_ok(Cred, Cout, kh, kw, stride, padding, dilation, dtype):
+    return kh == 3 and dtype == torch.float32 and \
+        bool(capi.lib().htd_conv2d_x3h_supported(Cred, Cout, kh, kw, stride, padding, dilation))
+
+
+def absmax(x):
+    """-> device scalar (1-element view) holding max |x| (x dense fp32 on the GPU)."""
+    key = x.device.index
+    ent = _AMAX_POOL.get(key)
+    if ent is None or ent[1] >= _AMAX_SLOTS:
+        ent = [torch.zeros(_AMAX_SLOTS, device=x.device, dtype=torch.float32), 0]
+        _AMAX_POOL[key] = ent
+    slot = ent[0][ent[1]:ent[1] + 1]
+    ent[1] += 1
+    capi.call('htd_absmax', _P(x), x.numel(), _P(slot), _S(), work=('byte', 4.0 * x.numel()))
+    return slot
 
 
 # bf16 plane images of the weights (csrc/conv_x3.hip: the B operand of conv_x3p_kernel, split once per step instead of
@@ -253,17 +279,26 @@ def _planes_key(w, transposed):
     return _flip_key(w) + (bool(transposed), )
 
 
+def _planes_h2(w, transposed):
+    """Is the image of this weight the H2 one (two fp16 pieces + row scales)?  One rule for whoever makes it and whoever reads it:
+    the 3x3 weights that conv_x3p_kernel takes, while the arithmetic is switched on."""
+    Co, Ci, kh, kw = w.shape
+    cred, cout = (Co, Ci) if transposed else (Ci, Co)
+    return kh == 3 and kw == 3 and bool(capi.lib().htd_conv2d_x3h_supported(cred, cout, 3, 3, 1, 1, 1))
+
+
 def x3_planes(weight, transposed):
     """weight (Co,Ci,kh,kw) channels_last fp32 -> its plane image (forward operand, or data-gradient operand when
     `transposed`), made once per step."""
-    key = _planes_key(weight, transposed)
+    h2 = _planes_h2(weight, transposed)
+    key = _planes_key(weight, transposed) + (h2, )
     hit = _STEP_PLANES.get(key)
     if hit is not None:
         return hit[1]
     Co, Ci, kh, kw = weight.shape
     nbytes = capi.lib().htd_conv2d_x3_planes_bytes(Co, kh, kw, Ci, int(transposed))
     planes = torch.empty(nbytes // 4, device=weight.device, dtype=torch.int32)
-    capi.call('htd_conv2d_x3_planes', _P(weight), _P(planes), Co, kh, kw, Ci, int(transposed), _S())
+    capi.call('htd_conv2d_x3h_planes' if h2 else 'htd_conv2d_x3_planes', _P(weight), _P(planes), Co, kh, kw, Ci, int(transposed), _S())
     _STEP_PLANES[key] = (weight, planes)
     return planes
 
@@ -286,7 +321,7 @@ def planes_many(items):
         w4 = w if w.dim() == 4 else w.view(w.size(0), w.size(1), 1, 1)
         if not _planes_wanted(w4, tr):
             continue
-        key = _planes_key(w4, tr)
+        key = _planes_key(w4, tr) + (_planes_h2(w4, tr), )
         if key not in _STEP_PLANES and key not in seen:
             seen.add(key)
             todo.append((key, w4, tr))
@@ -294,22 +329,34 @@ def planes_many(items):
         return
     L = capi.lib()
     dev = todo[0][1].device
-    sizes = [L.htd_conv2d_x3_planes_bytes(w.size(0), w.size(2), w.size(3), w.size(1), int(tr)) // 4 for _, w, tr in todo]
-    flat = torch.empty(sum(sizes), device=dev, dtype=torch.int32)
-    desc = np.zeros((len(todo), 5), dtype=np.int64)
-    off = block0 = 0
-    for i, ((key, w, tr), n32) in enumerate(zip(todo, sizes)):
-        out = flat[off:off + n32]
-        off += n32
-        Co, Ci, taps = w.size(0), w.size(1), w.size(2) * w.size(3)
-        desc[i, 0], desc[i, 1] = w.data_ptr(), out.data_ptr()
-        desc[i, 2] = Co | (taps << 32)                  # two int32 per int64 slot (little endian)
-        desc[i, 3] = Ci | (int(tr) << 32)
-        desc[i, 4] = block0
-        block0 += (n32 // 4 // 6 + 255) // 256          # elements = uint4 count / 6 chunks
-        _STEP_PLANES[key] = (w, out)
-    table = capi.upload_table(desc, dev)
-    capi.call('htd_conv2d_x3_planes_many', _P(table), len(todo), block0, _S())
+    for h2 in (False, True):                 # the bf16 images in one launch, the H2 images (row scales, then planes) in two
+        part = [t for t in todo if t[0][-1] == h2]
+        if not part:
+            continue
+        sizes = [L.htd_conv2d_x3_planes_bytes(w.size(0), w.size(2), w.size(3), w.size(1), int(tr)) // 4 for _, w, tr in part]
+        flat = torch.empty(sum(sizes), device=dev, dtype=torch.int32)
+        desc = np.zeros((len(part), 6 if h2 else 5), dtype=np.int64)
+        off = block0 = row0 = 0
+        for i, ((key, w, tr), n32) in enumerate(zip(part, sizes)):
+            out = flat[off:off + n32]
+            off += n32
+            Co, Ci, taps = w.size(0), w.size(1), w.size(2) * w.size(3)
+            N = Ci if tr else Co
+            Np = (N + 127) // 128 * 128
+            desc[i, 0], desc[i, 1] = w.data_ptr(), out.data_ptr()
+            desc[i, 2] = Co | (taps << 32)                  # two int32 per int64 slot (little endian)
+            desc[i, 3] = Ci | (int(tr) << 32)
+            desc[i, 4] = block0
+            if h2:
+                desc[i, 5] = row0
+                row0 += Np
+            block0 += ((n32 - 2 * Np) // 4 // 6 + 255) // 256          # elements = uint4 count of the planes / 6 chunks
+            _STEP_PLANES[key] = (w, out)
+        table = capi.upload_table(desc, dev)
+        if h2:
+            capi.call('htd_conv2d_x3h_planes_many', _P(table), len(part), block0, row0, _S())
+        else:
+            capi.call('htd_conv2d_x3_planes_many', _P(table), len(part), block0, _S())
 
 
 def _x3p_ok(Cred, Cout, kh, kw, stride, padding, dilation, dtype):
@@ -436,6 +483,11 @@ def _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up
         ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32) if nb > 0 else None
         use_xp = x_planes is not None and kh == 1 and stride == 1
         yp = _act_planes_buf(B * Ho * Wo, Co, x.device) if (emit and Co % 16 == 0) else None
+        if _x3h_ok(Ci, Co, kh, kw, stride, padding, dilation, x.dtype):
+            capi.call('htd_conv2d_fwd_x3h', _P(x), _P(absmax(x)), _P(x3_planes(weight, False)), _P(bias), _P(residual), rh, rw,
+                      _P(y), _P(yp), B, H, W, Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
+                      work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
+            return (y, yp) if emit else y
         if not use_xp and yp is None:
             capi.call('htd_conv2d_fwd_x3p', _P(x), _P(x3_planes(weight, False)), _P(bias), _P(residual), rh, rw, _P(y), B, H, W,
                       Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
@@ -500,6 +552,10 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
         gxp = _act_planes_buf(B * H * W, Ci, g.device) if (emit and Ci % 16 == 0) else None
         work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
                 4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None))))
+        if _x3h_ok(Co, Ci, kh, kw, 1, padding, dilation, g.dtype):
+            capi.call('htd_conv2d_bwd_data_x3h', _P(g), _P(absmax(g)), _P(x3_planes(weight, True)), _P(mask_src), _P(accum), _P(gx),
+                      _P(gxp), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(), work=work)
+            return (gx, gxp) if emit else gx
         if not use_gp and gxp is None:
             capi.call('htd_conv2d_bwd_data_x3p', _P(g), _P(x3_planes(weight, True)), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci,
                       Co, kh, kw, padding, _P(ws), _S(), work=work)

@@ -333,6 +333,28 @@ int htd_conv2d_bwd_data_x3q(const float *gy, const void *gyplanes, const void *w
                             const float *accum, float *gx, void *gxplanes, int B, int H, int W, int Ci, int Co, int kh, int kw,
                             int pad, void *workspace, void *stream);
 
+/* "H2" arithmetic for the 3x3 layers (round 4): every fp32 product through TWO fp16 pieces per operand -- a0 b0 + a0 b1 + a1 b0,
+ * three matrix instructions per block instead of the six of the three-piece bf16 form, operands block-scaled by powers of two
+ * (activations: one scale per tensor from its largest magnitude; weights: one per output channel).  Error per product
+ * <= 2^-21 |a b| (2^-23.5 rms), like the bf16 form's; role in the reference: cuDNN behind backbones/resnet.py:260-300 and
+ * necks/fpn.py, dense_heads/rpn_head.py:25-27.
+ *   htd_absmax               *amax = max(*amax, max |x[i]|); *amax is zero (or an earlier maximum) on entry; device scalar
+ *   htd_conv2d_x3h_planes    the weight image (htd_conv2d_x3_planes_bytes bytes), transposed = 1: data-gradient operand
+ *   htd_conv2d_x3h_planes_many  desc: { const float *w; void *planes; int Co, taps, Ci, transposed; int64_t block0, row0; }
+ *   htd_conv2d_fwd_x3h / htd_conv2d_bwd_data_x3h   = htd_conv2d_fwd_x3q / htd_conv2d_bwd_data_x3q with `amax` of the input
+ *   htd_conv2d_set_h2        0 / 1 switches the arithmetic off / on (-1: query), returns the previous setting */
+int htd_conv2d_set_h2(int on);
+int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+int htd_absmax(const float *x, int64_t n, float *amax, void *stream);
+int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);
+int htd_conv2d_x3h_planes_many(const void *desc, int n, int64_t total_blocks, int64_t total_rows, void *stream);
+int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void *wplanes, const float *bias, const float *residual,
+                       int res_h, int res_w, float *y, void *yplanes, int B, int H, int W, int Ci, int Co, int kh, int kw,
+                       int stride, int pad, int relu, void *workspace, void *stream);
+int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const void *wplanesT, const float *mask_src,
+                            const float *accum, float *gx, void *gxplanes, int B, int H, int W, int Ci, int Co, int kh,
+                            int kw, int pad, void *workspace, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Deformable convolution v1 / v2 (mask == NULL => v1 = the 'DCN' the HTD config uses,
  * configs/htd/htd_resnet101_dcn_2x_mstrain.py:142; built at backbones/resnet.py:186-194).  The reference-era

@@ -50,7 +50,7 @@ def device_rates(x, w, g, s, p, flop, n=8):
         dense.conv2d(xg, wg, None, s, p, 1).backward(g)
     prof = capi.profile_end()
     out = []
-    for ks in (('htd_conv2d_fwd_x3p', 'htd_conv2d_fwd'), ('htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_data'), ('htd_conv2d_bwd_weight', )):
+    for ks in (('htd_conv2d_fwd_x3h', 'htd_conv2d_fwd_x3p', 'htd_conv2d_fwd'), ('htd_conv2d_bwd_data_x3h', 'htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_data'), ('htd_conv2d_bwd_weight', )):
         k = next(k for k in ks if k in prof)          # conv_x3p_kernel where it takes the layer, conv_igemm_kernel otherwise
         calls = max(prof[k][0] for k in ks if k in prof)
         ms = sum(prof[k][1] for k in ks if k in prof)
