@@ -1,0 +1,191 @@
+"""H2 arithmetic of the 3x3 layers (csrc/conv_x3.hip, h2_scale): every fp32 product through two block-scaled fp16 pieces per
+operand, a0 b0 + a0 b1 + a1 b0.  Role in the reference: cuDNN behind the 3x3 convolutions of backbones/resnet.py:260-300,
+necks/fpn.py:77-90, dense_heads/rpn_head.py:25-27 and the regression branch of htd_bbox_head.py:77-113.
+
+Bars: error against an fp64 reference no larger than RMS_BOUND x the fp32-input MFMA kernel's on the same data (forward and data
+gradient, wide-dynamic-range inputs); integer-exact where fp32 is; the pieces, the scales and the maximum themselves bit-exact
+against their tensor formulation; and the ranges the block scaling has to survive: tiny and huge tensors, one outlier 2^20 above
+everything else, all zeros, a NaN."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+RMS_BOUND, MAX_BOUND = 1.5, 2.0
+
+
+@pytest.fixture
+def h2():
+    from htd_amd import capi, dense
+    L = capi.lib()
+    if not L.htd_conv2d_x3h_supported(256, 256, 3, 3, 1, 1, 1):
+        pytest.skip('H2 arithmetic switched off')
+    yield L
+    L.htd_conv2d_set_h2(1)
+    L.htd_conv2d_set_math(1)
+    dense.new_step()
+
+
+def _run(dense, x, w, gy, bias=None):
+    dense.new_step()
+    xr = x.clone().requires_grad_()
+    y = dense.conv2d(xr, w, bias, 1, 1, 1)
+    y.backward(gy)
+    return y.detach(), xr.grad
+
+
+@pytest.mark.parametrize('Ci,Co,H,W,B', [(256, 256, 40, 56, 2), (48, 96, 33, 47, 2), (576, 576, 7, 7, 16), (64, 64, 50, 70, 1)])
+def test_h2_is_as_accurate_as_the_fp32_matrix_instructions(h2, Ci, Co, H, W, B):
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(Ci + H)
+    x = (torch.randn(B, Ci, H, W, generator=g) * torch.exp(torch.randn(B, Ci, H, W, generator=g) * 2)).to(dev).contiguous(memory_format=CL)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * torch.exp(torch.randn(Co, Ci, 3, 3, generator=g)) / (Ci * 9) ** 0.5).to(dev)
+    w = w.contiguous(memory_format=CL)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    scale = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    gy = torch.randn(ref.shape, generator=g).to(dev).contiguous(memory_format=CL)
+    gref = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 1, 1)
+    gscale = torch.nn.grad.conv2d_input(x.shape, w.double().abs(), gy.double().abs(), 1, 1)
+    err = {}
+    for mode in ('native', 'h2'):
+        h2.htd_conv2d_set_math(0 if mode == 'native' else 1)
+        h2.htd_conv2d_set_h2(1 if mode == 'h2' else 0)
+        calls = []
+        orig = dense.capi.call
+
+        def spy(name, *a, **k):
+            calls.append(name)
+            return orig(name, *a, **k)
+        dense.capi.call = spy
+        try:
+            y, gx = _run(dense, x, w, gy)
+        finally:
+            dense.capi.call = orig
+        assert ('htd_conv2d_fwd_x3h' in calls) == (mode == 'h2') and ('htd_conv2d_bwd_data_x3h' in calls) == (mode == 'h2')
+        ef, eg = (y.double() - ref).abs() / scale, (gx.double() - gref).abs() / gscale
+        err[mode] = (float(ef.max()), float(ef.pow(2).mean().sqrt()), float(eg.max()), float(eg.pow(2).mean().sqrt()))
+    n, h = err['native'], err['h2']
+    assert h[1] <= RMS_BOUND * n[1] and h[3] <= RMS_BOUND * n[3], (n, h)
+    assert h[0] <= MAX_BOUND * n[0] and h[2] <= MAX_BOUND * n[2], (n, h)
+
+
+def test_h2_is_exact_on_small_integers(h2):
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-40, 41, (2, 64, 19, 23), generator=g).float().to(dev).contiguous(memory_format=CL)
+    w = torch.randint(-9, 10, (96, 64, 3, 3), generator=g).float().to(dev).contiguous(memory_format=CL)
+    b = torch.randint(-5, 6, (96, ), generator=g).float().to(dev)
+    gy = torch.randint(-7, 8, (2, 96, 19, 23), generator=g).float().to(dev).contiguous(memory_format=CL)
+    y, gx = _run(dense, x, w, gy, b)
+    assert torch.equal(y.double(), F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+    assert torch.equal(gx.double(), torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 1, 1))
+
+
+def test_absmax_kernel(h2):
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 3, 4, 5, 1023, 4096 + 2, 3_000_001):
+        x = torch.randn(n, generator=g).to(dev)
+        x[n // 2] = -77.5
+        dense.new_step()
+        assert float(dense.absmax(x)) == 77.5
+    x = torch.zeros(1000, device=dev)
+    assert float(dense.absmax(x)) == 0.0
+    x[17] = float('nan')
+    assert torch.isnan(dense.absmax(x)).item()
+    x[17] = float('-inf')
+    assert float(dense.absmax(x)) == float('inf')
+    # slots of one step are independent
+    dense.new_step()
+    a, b = dense.absmax(torch.full((64, ), 2.0, device=dev)), dense.absmax(torch.full((64, ), 0.5, device=dev))
+    assert float(a) == 2.0 and float(b) == 0.5
+
+
+def test_h2_weight_image_is_the_exact_two_piece_split(h2):
+    """htd_conv2d_x3h_planes: row scale = the power of two that puts the row's largest magnitude into [2^14, 2^15); pieces
+    a0 = fp16(s w), a1 = fp16(s w - a0) (round to nearest even); both operand orientations; the 'many' launch writes the same."""
+    from htd_amd import capi, dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    Co, Ci = 80, 48
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * torch.exp(torch.randn(Co, 1, 1, 1, generator=g) * 3)).to(dev).contiguous(memory_format=CL)
+    w[7] = 0.0                                         # an all-zero output channel
+    for tr in (0, 1):
+        N, K = (Ci, Co) if tr else (Co, Ci)
+        Np = (N + 127) // 128 * 128
+        nbytes = h2.htd_conv2d_x3_planes_bytes(Co, 3, 3, Ci, tr)
+        img = torch.zeros(nbytes // 4, device=dev, dtype=torch.int32)
+        capi.call('htd_conv2d_x3h_planes', capi.ptr(w), capi.ptr(img), Co, 3, 3, Ci, tr, capi.current_stream_ptr())
+        nvec = 9 * (K // 16) * 6 * Np
+        scales = img[nvec * 4:].view(torch.float32)
+        inv, fwd = scales[:Np], scales[Np:2 * Np]
+        # rows of the operand: forward w[n][tap][k]; transposed w[k][8 - tap][n]
+        wk = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci)            # [co][tap][ci]
+        rows = wk if not tr else wk.flip(1).permute(2, 1, 0)      # [n][tap][k]
+        amax = rows.abs().amax(dim=(1, 2))
+        e = torch.where(amax > 0, 14 - torch.floor(torch.log2(amax.double())), torch.full_like(amax, 126).double()).clamp(max=126)
+        assert torch.equal(fwd[:N].double().cpu(), torch.ldexp(torch.ones(N, dtype=torch.float64), e.cpu().int()))
+        assert torch.equal((fwd[:N] * inv[:N]), torch.ones(N, device=dev))
+        s = rows * fwd[:N, None, None]
+        a0 = s.half()
+        a1 = (s - a0.float()).half()
+        planes = img[:nvec * 4].view(torch.float16).view(9, K // 16, 6, Np, 8)
+        for piece, t in ((0, a0), (1, a1)):
+            got = planes[:, :, 2 * piece:2 * piece + 2, :N]                                   # [tap][cs][half][n][8]
+            want = t.view(N, 9, K // 16, 2, 8).permute(1, 2, 3, 0, 4)
+            assert torch.equal(got, want), (tr, piece)
+        assert float(a0.float().abs().max()) < 32768.0
+        # the same image out of the step's table launch
+        dense.new_step()
+        dense.planes_many([(w, bool(tr))])
+        many = dense.x3_planes(w, bool(tr))
+        assert torch.equal(many[:nvec * 4].view(9, K // 16, 6, Np, 4)[:, :, :4, :N], img[:nvec * 4].view(9, K // 16, 6, Np, 4)[:, :, :4, :N])
+        assert torch.equal(many[nvec * 4:nvec * 4 + 2 * Np], img[nvec * 4:nvec * 4 + 2 * Np])
+    dense.new_step()
+
+
+@pytest.mark.parametrize('case', ['tiny', 'huge', 'outlier', 'zeros', 'nan'])
+def test_h2_ranges(h2, case):
+    """What the per-tensor scale has to survive.  tiny / huge: 2^-100 / 2^100 times ordinary data (the scale is exact, the result
+    is the scaled result of the ordinary data bit for bit); outlier: one element 2^20 above the rest -- the rest loses relative
+    precision to fp16's subnormal floor (absolute precision 2^-40 of the tensor maximum per element), and the outputs the outlier
+    dominates show the 22 significant bits of a two-piece operand; zeros in, zeros out; a NaN in the input poisons the outputs it reaches, like fp32."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 64, 24, 30, generator=g).to(dev).contiguous(memory_format=CL)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(dev).contiguous(memory_format=CL)
+    gy = torch.randn(1, 64, 24, 30, generator=g).to(dev).contiguous(memory_format=CL)
+    y0, g0 = _run(dense, x, w, gy)
+    if case in ('tiny', 'huge'):
+        f = 2.0 ** (-100 if case == 'tiny' else 100)
+        y, gx = _run(dense, x * f, w, gy * f)
+        assert torch.equal(y, y0 * f) and torch.equal(gx, g0 * f)
+    elif case == 'outlier':
+        x2 = x.clone()
+        x2[0, 5, 7, 9] = 2.0 ** 20
+        y, _ = _run(dense, x2, w, gy)
+        ref = F.conv2d(x2.double(), w.double(), None, 1, 1)
+        err = (y.double() - ref).abs()
+        mag = F.conv2d(x2.double().abs(), w.double().abs(), None, 1, 1)
+        # two fp16 pieces carry 22 significant bits (x exact here, w 2^-22, the dropped a1 b1 2^-22), and the 16 products of one
+        # matrix instruction are aligned to their largest before they are added -- both show where ONE product dominates a sum:
+        # measured 2^-20.8 of the magnitude, bound 2^-20 (fp32 itself: 2^-24 per product, K 2^-24 per sum)
+        far = torch.ones_like(err, dtype=torch.bool)
+        far[:, :, 6:9, 8:11] = False
+        assert float((err / mag)[~far].max()) <= 2.0 ** -20
+        # outputs the outlier does not reach: the ordinary elements sit 2^20 below the tensor maximum and keep an absolute
+        # precision of 2^-40 of it (= 2^-20 each), summed over K = 576 products with random signs
+        assert float(err[far].max()) <= 2.0 ** -20 * float(w.abs().pow(2).sum(dim=(1, 2, 3)).sqrt().max()) * 6 + 2e-5
+    elif case == 'zeros':
+        y, gx = _run(dense, torch.zeros_like(x), w, torch.zeros_like(gy))
+        assert float(y.abs().max()) == 0.0 and float(gx.abs().max()) == 0.0
+    else:
+        x2 = x.clone()
+        x2[0, 3, 4, 5] = float('nan')
+        y, _ = _run(dense, x2, w, gy)
+        assert torch.isnan(y[0, :, 3:6, 4:7]).all()
