@@ -157,7 +157,45 @@ struct X3Params {
     // H2 arithmetic: amax = device scalar holding max |x| of the A operand's tensor, wscale = the weight image's per-column
     // 1 / sb[n] ([Cop] floats behind the planes).  NULL: the six-product bf16 form.
     const float *amax, *wscale;
+    // amax_out != NULL: the epilogue also leaves max |y| of the values it stores in this device scalar (zero, or an earlier maximum,
+    // on entry) -- the `amax` of whoever consumes y on the H2 arithmetic, without a pass over y.
+    // h2_flag: set to 1 by an H2 launch that met a scaled element beyond fp16's range, i.e. an `amax` that was NOT the tensor's
+    // maximum (a caller's bug: the result then holds infinities); the host checks it once in a while and fails loudly.
+    float *amax_out;
+    unsigned *h2_flag;
 };
+
+// the block's largest stored magnitude -> *out, one atomic per workgroup.
+// Bits of non-negative floats order like unsigned integers; NaN sorts above everything and stays.
+__device__ __forceinline__ void block_absmax_out(float mx, float *out, float *red)
+{
+    unsigned bits = (mx != mx) ? 0x7fc00000u : __float_as_uint(mx);
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
+    __syncthreads();                                   // `red` aliases the epilogue's LDS tile
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned *>(red)[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned *r = reinterpret_cast<const unsigned *>(red);
+        bits = max(max(r[0], r[1]), max(r[2], r[3]));
+        // (no read of the scalar first: the workgroup would wait a memory round trip for it; the atomic returns nothing)
+        if (bits != 0u) __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// the same per wavefront, no barrier: for the short reduce kernels, whose workgroups live for one element per thread
+__device__ __forceinline__ void wave_absmax_out(float mx, float *out)
+{
+    unsigned bits = (mx != mx) ? 0x7fc00000u : __float_as_uint(mx);
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
+    if ((threadIdx.x & 63) == 0 && bits != 0u)
+        __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float absmax4(float mx, float4 v)
+{
+    // (fmaxf drops NaNs: carry them by hand)
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const bool nan = (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    return nan ? __uint_as_float(0x7fc00000u) : ((mx != mx) ? mx : fmaxf(mx, m));
+}
 
 // planes of four consecutive channels n .. n + 3 (n % 4 == 0) of row m: 8 bytes into each of the three plane chunks
 __device__ __forceinline__ void emit_planes4(uint4 *yp, int64_t rows, int64_t m, int n, float4 v)
@@ -197,6 +235,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
     float *le = reinterpret_cast<float *>(lds);
     const bool vec_ok = (p.Co & 3) == 0;
     constexpr int V = BN / 4, RPP = 256 / V;
+    float omax = 0.f;                                  // largest stored magnitude (X3Params::amax_out)
     // H2: column n of the accumulators carries sa sb[n] (exact powers of two)
     const bool scaled = p.wscale != nullptr;
     float4 cscale = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -280,7 +319,10 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
                 }
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
-                    if (ok[u]) *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
+                    if (ok[u]) {
+                        *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
+                        omax = absmax4(omax, v[u]);
+                    }
                 if (p.yp != nullptr) {           // bf16 planes of the same values for a 1x1 consumer
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
@@ -337,6 +379,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
                     v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4 *>(p.y + o) = v;
+                omax = absmax4(omax, v);
                 if (p.yp != nullptr) emit_planes4(p.yp, p.yp_rows, m, n, v);
             } else {
                 auto put = [&](int e, float t) {
@@ -346,12 +389,14 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
                     if (p.relu) t = fmaxf(t, 0.f);
                     if (p.mask_src) t = p.mask_src[o + e] > 0.f ? t : 0.f;
                     p.y[o + e] = t;
+                    omax = absmax4(omax, make_float4(t, 0.f, 0.f, 0.f));
                 };
                 put(0, v.x); put(1, v.y); put(2, v.z); put(3, v.w);
             }
         }
         if (i + 1 < TM) __syncthreads();
     }
+    if (p.amax_out != nullptr && !part) block_absmax_out(omax, p.amax_out, le);
 }
 
 // MF16: the products run on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  Its 32 k per instruction carry TWO of
@@ -513,7 +558,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
 #pragma unroll
     for (int i = 0; i < 2 * NPT; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned ra_ok = 0u;
-    float h2s = 1.f;
+    float h2s = 1.f, h2big = 0.f;                     // h2big: the largest scaled magnitude this thread split (overflow check)
     if constexpr (H2) h2s = h2_scale(p.amax).s;
     // (no divisions inside the K loop: the step's channel slice / filter row and the prefetch pointers advance incrementally)
     auto load_pass = [&](int shift, int koff, int i, int slot, bool live) __attribute__((always_inline)) {   // pass i of the run at pixel shift `shift`
@@ -549,8 +594,10 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
         const unsigned d = lds_a0 + (unsigned)(buf * A_VEC * 16 + ((vcol >> 1) * G::PITCH + j) * 16 + (vcol & 1) * 8);
         if constexpr (H2) {
             unsigned h0, l0, h1, l1;
-            split2hx2(v.x * h2s, v.y * h2s, h0, l0);
-            split2hx2(v.z * h2s, v.w * h2s, h1, l1);
+            const float t0 = v.x * h2s, t1 = v.y * h2s, t2 = v.z * h2s, t3 = v.w * h2s;
+            if (p.h2_flag != nullptr) h2big = fmaxf(h2big, fmaxf(fmaxf(fabsf(t0), fabsf(t1)), fmaxf(fabsf(t2), fabsf(t3))));
+            split2hx2(t0, t1, h0, l0);
+            split2hx2(t2, t3, h1, l1);
             lds_store8<0>(d, h0, h1);
             lds_store8<2 * G::PITCH * 16>(d, l0, l1);
         } else {
@@ -828,6 +875,11 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
 #pragma unroll
     for (int i = 0; i < 2 * NPT; ++i) landed(ra[i]);
 
+    if constexpr (H2) {
+        // a finite element that left fp16's range: `amax` was not the tensor's maximum (infinities and NaNs of the INPUT are the
+        // caller's data and propagate like in fp32)
+        if (h2big > 65504.f && h2big < __builtin_inff() && p.h2_flag != nullptr) atomicOr(p.h2_flag, 1u);
+    }
     x3_epilogue<WGM, WGN, TM, TN, MF16>(p, acc, lds, m0, n0, part, region_b, split);
 }
 
@@ -1032,6 +1084,7 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
     const int64_t lo = p.splits_a > 1 ? 0 : p.m_rem0 * p.Co, hi = p.splits_b > 1 ? p.M * p.Co : p.m_rem0 * p.Co;
     const int64_t na = p.m_rem0 * p.Co, nb = (p.M - p.m_rem0) * p.Co;
     const float *pb = p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * na : 0);
+    float omax = 0.f;
     for (int64_t o = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < hi; o += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
         if (o < na) {
@@ -1056,7 +1109,9 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
         p.y[o] = v;
+        omax = absmax4(omax, make_float4(v, 0.f, 0.f, 0.f));
     }
+    if (p.amax_out != nullptr) wave_absmax_out(omax, p.amax_out);
 }
 
 // the same for Co % 4 == 0, four channels per thread: float4 loads of the partials (independent across the ranges), 32-bit
@@ -1068,6 +1123,7 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_vec_kernel(X3Par
     const int64_t na = p.m_rem0 * C4, nb = (p.M - p.m_rem0) * C4;
     const float4 *pa = reinterpret_cast<const float4 *>(p.partial);
     const float4 *pb = pa + (p.splits_a > 1 ? (int64_t)p.splits_a * na : 0);
+    float omax = 0.f;
     for (int64_t q = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < hi; q += (int64_t)gridDim.x * blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool in_a = q < na;
@@ -1104,8 +1160,10 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_vec_kernel(X3Par
             v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
         }
         *reinterpret_cast<float4 *>(p.y + o) = v;
+        omax = absmax4(omax, v);
         if (p.yp != nullptr) emit_planes4(p.yp, p.yp_rows, (int64_t)m, (int)n, v);
     }
+    if (p.amax_out != nullptr) wave_absmax_out(omax, p.amax_out);
 }
 
 // ---- weight planes --------------------------------------------------------------------------------------------------
@@ -1188,34 +1246,61 @@ __global__ __launch_bounds__(256) void x3_planes_many_kernel(const PlanesDesc *_
 inline int planes_np(int N) { return (int)htd::ceil_div(N, 128) * 128; }
 
 // ---- H2 weight image: the same [taps][K/16][6][Np] x 16 B layout with the two fp16 pieces of sb[n] w in chunks 0..3 (chunks 4, 5
-// unused) and, behind the planes, Np floats 1 / sb[n] (what the epilogue multiplies by) and Np floats sb[n].
-// Pass 1, one workgroup per output row n: sb[n] = the power of two that puts the row's largest magnitude into [2^14, 2^15).
-__device__ __forceinline__ void x3h_rowscale_row(const float *__restrict__ w, float *__restrict__ scales, int Co, int taps, int Ci,
-                                                 int Np, int transposed, int n, float *red)
+// unused) and, behind the planes, Np floats 1 / sb[n] (what the epilogue multiplies by), Np floats sb[n] and the chunk maxima.
+// Pass 1: sb[n] = the power of two that puts row n's largest magnitude into [2^14, 2^15).
+// Pass 1, one workgroup per (64 output rows, chunk of H2_ECH reduction elements): the largest magnitude of every row within the
+// chunk -> part[chunk][Np] (behind the scales).  transposed (rows are strided columns of w): lane = row, the four waves share
+// the chunk, every load is 64 consecutive floats; forward operand (a row is contiguous): a wave takes 16 rows one after the
+// other, its lanes stride along the row.  Pass 2 is the planes kernel, which folds the chunks of its row.
+constexpr int H2_ECH = 1024;
+__host__ __device__ inline int h2_chunks(int taps, int K) { return (taps * K + H2_ECH - 1) / H2_ECH; }
+
+__device__ __forceinline__ void x3h_rowmax_part(const float *__restrict__ w, float *__restrict__ part, int Co, int taps, int Ci, int Np,
+                                                int transposed, int n0, int chunk, float *red /* [4][64] */)
 {
     const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
-    float mx = 0.f;
-    if (n < N) {
-        if (!transposed) {
-            const float *row = w + (int64_t)n * taps * Ci;
-            for (int e = threadIdx.x; e < taps * Ci; e += 256) mx = fmaxf(mx, fabsf(row[e]));
-        } else {
-            for (int e = threadIdx.x; e < K * taps; e += 256) mx = fmaxf(mx, fabsf(w[(int64_t)e * Ci + n]));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e0 = chunk * H2_ECH, e1 = min(taps * K, e0 + H2_ECH);
+    if (transposed) {
+        const int n = n0 + lane;
+        float mx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n < N) {
+            int e = e0 + wave;
+            for (; e + 12 < e1; e += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mx[u] = fmaxf(mx[u], fabsf(w[(int64_t)(e + 4 * u) * Ci + n]));
+            }
+            for (; e < e1; e += 4) mx[0] = fmaxf(mx[0], fabsf(w[(int64_t)e * Ci + n]));
+        }
+        red[wave * 64 + lane] = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+    } else {
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wave * 16 + r;
+            float mx = 0.f;
+            if (n < N) {
+                const float *row = w + (int64_t)n * taps * Ci;
+                for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, fabsf(row[e]));
+            }
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0) red[wave * 16 + r] = mx;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        const H2Scale sc = h2_scale(&mx);
-        scales[n] = sc.inv;
-        scales[Np + n] = sc.s;
+    if (threadIdx.x < 64) {
+        const float mx = transposed ? fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane])) : red[lane];
+        part[(int64_t)chunk * Np + n0 + lane] = mx;
     }
-    __syncthreads();
 }
 
-__device__ __forceinline__ void x3h_planes_element(const float *__restrict__ w, uint4 *__restrict__ out, const float *__restrict__ scales,
+// the row's scale from its chunk maxima (pass 2, by whoever needs it)
+__device__ __forceinline__ H2Scale x3h_row_scale(const float *__restrict__ part, int nch, int Np, int n)
+{
+    float mx = 0.f;
+    for (int c = 0; c < nch; ++c) mx = fmaxf(mx, part[(int64_t)c * Np + n]);
+    return h2_scale(&mx);
+}
+
+__device__ __forceinline__ void x3h_planes_element(const float *__restrict__ w, uint4 *__restrict__ out, float *__restrict__ scales,
                                                    int Co, int taps, int Ci, int Np, int transposed, int64_t e)
 {
     const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
@@ -1224,8 +1309,13 @@ __device__ __forceinline__ void x3h_planes_element(const float *__restrict__ w, 
     const int64_t t2 = e / Np;
     const int cs = (int)(t2 % ncs), tap = (int)(t2 / ncs);
     float v[XK];
+    const H2Scale rs = x3h_row_scale(scales + 2 * Np, h2_chunks(taps, K), Np, n);
+    if (tap == 0 && cs == 0) {
+        scales[n] = rs.inv;
+        scales[Np + n] = rs.s;
+    }
     if (n < N) {
-        const float sb = scales[Np + n];
+        const float sb = rs.s;
         if (!transposed) {
             const float4 *src = reinterpret_cast<const float4 *>(w + ((int64_t)n * taps + tap) * Ci + cs * XK);
 #pragma unroll
@@ -1257,12 +1347,13 @@ __host__ __device__ inline int64_t planes_vec(int taps, int K, int Np) { return 
 __global__ __launch_bounds__(256) void x3h_rowscale_kernel(const float *__restrict__ w, float *__restrict__ scales, int Co, int taps,
                                                            int Ci, int Np, int transposed)
 {
-    __shared__ float red[4];
-    x3h_rowscale_row(w, scales, Co, taps, Ci, Np, transposed, blockIdx.x, red);
+    __shared__ float red[256];
+    const int groups = Np / 64;
+    x3h_rowmax_part(w, scales + 2 * Np, Co, taps, Ci, Np, transposed, (blockIdx.x % groups) * 64, blockIdx.x / groups, red);
 }
 
 __global__ __launch_bounds__(256) void x3h_planes_kernel(const float *__restrict__ w, uint4 *__restrict__ out,
-                                                         const float *__restrict__ scales, int Co, int taps, int Ci, int Np,
+                                                         float *__restrict__ scales, int Co, int taps, int Ci, int Np,
                                                          int transposed)
 {
     const int K = transposed ? Co : Ci;
@@ -1282,9 +1373,9 @@ struct PlanesDescH {
 
 __global__ __launch_bounds__(256) void x3h_rowscale_many_kernel(const PlanesDescH *__restrict__ descs, int n)
 {
-    __shared__ float red[4];
+    __shared__ float red[256];
     int lo = 0, hi = n - 1;
-    const int64_t b = blockIdx.x;
+    const int64_t b = blockIdx.x;                        // row0: prefix sum of (Np / 64) * chunks over the entries
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (descs[mid].row0 <= b) lo = mid;
@@ -1295,7 +1386,8 @@ __global__ __launch_bounds__(256) void x3h_rowscale_many_kernel(const PlanesDesc
     const int N = tr ? d.Ci : d.Co, K = tr ? d.Co : d.Ci;
     const int Np = ((N + 127) / 128) * 128;
     float *scales = reinterpret_cast<float *>(d.out + planes_vec(d.taps, K, Np));
-    x3h_rowscale_row(d.w, scales, d.Co, d.taps, d.Ci, Np, tr, (int)(b - d.row0), red);
+    const int groups = Np / 64, r = (int)(b - d.row0);
+    x3h_rowmax_part(d.w, scales + 2 * Np, d.Co, d.taps, d.Ci, Np, tr, (r % groups) * 64, r / groups, red);
 }
 
 __global__ __launch_bounds__(256) void x3h_planes_many_kernel(const PlanesDescH *__restrict__ descs, int n)
@@ -1313,7 +1405,7 @@ __global__ __launch_bounds__(256) void x3h_planes_many_kernel(const PlanesDescH 
     const int Np = ((N + 127) / 128) * 128;
     const int64_t total = (int64_t)d.taps * (K / XK) * Np;
     const int64_t e = (b - d.block0) * 256 + threadIdx.x;
-    const float *scales = reinterpret_cast<const float *>(d.out + planes_vec(d.taps, K, Np));
+    float *scales = reinterpret_cast<float *>(d.out + planes_vec(d.taps, K, Np));
     if (e < total) x3h_planes_element(d.w, d.out, scales, d.Co, d.taps, d.Ci, Np, tr, e);
 }
 
@@ -1600,12 +1692,19 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     p.nt = (int)htd::ceil_div(p.Co, kXCfg[cfg].bn);
     HTD_REQUIRE(pl.grid > 0 && pl.grid < (1ll << 31), "conv2d_x3p: bad grid");
     const dim3 grid((unsigned)pl.grid);
-    if (p.amax != nullptr) {        // H2 arithmetic (3x3 layers)
+    if (p.amax != nullptr && kw == 3) {        // H2 arithmetic
         switch (cfg) {
         case 0: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 1, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
         case 1: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 2, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 1, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 2, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        }
+    } else if (p.amax != nullptr) {
+        switch (cfg) {
+        case 0: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 1, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 2, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 1, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 2, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
         }
     } else if (p.xp != nullptr) {   // A operand pre-split: conv_x3q_kernel (1x1, stride 1)
         switch (cfg) {
@@ -1661,7 +1760,7 @@ extern "C" int htd_conv2d_set_h2(int on)
 }
 extern "C" int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
 {
-    return (g_conv_h2 == 1 && kh == 3 && htd_conv2d_x3p_supported(Ci, Co, kh, kw, stride, pad, dil)) ? 1 : 0;
+    return (g_conv_h2 == 1 && htd_conv2d_x3p_supported(Ci, Co, kh, kw, stride, pad, dil)) ? 1 : 0;
 }
 
 // Tuned tile table of conv_x3p_kernel (see choose_cfg).  cfg: 0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases the entry.
@@ -1705,7 +1804,8 @@ extern "C" int64_t htd_conv2d_x3_planes_bytes(int Co, int kh, int kw, int Ci, in
 {
     const int N = transposed ? Ci : Co, K = transposed ? Co : Ci;
     if (N <= 0 || K <= 0 || K % XK != 0 || kh <= 0 || kw <= 0) return 0;
-    return (int64_t)kh * kw * (K / XK) * NCH * planes_np(N) * 16 + 2 * planes_np(N) * 4;       // (+ the H2 image's row scales)
+    // (+ the H2 image's row scales, 1 / sb and sb, and the chunk maxima they are made from)
+    return (int64_t)kh * kw * (K / XK) * NCH * planes_np(N) * 16 + (int64_t)(2 + h2_chunks(kh * kw, K)) * planes_np(N) * 4;
 }
 
 extern "C" int htd_conv2d_x3_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream)
@@ -1731,8 +1831,8 @@ extern "C" int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int k
     HTD_REQUIRE(transposed || Ci % 4 == 0, "x3h_planes: Ci %% 4");
     const int Np = planes_np(N);
     float *scales = reinterpret_cast<float *>((uint4 *)planes + planes_vec(kh * kw, K, Np));
-    hipLaunchKernelGGL(x3h_rowscale_kernel, dim3((unsigned)Np), dim3(256), 0, (hipStream_t)stream, w, scales, Co, kh * kw, Ci, Np,
-                       transposed);
+    hipLaunchKernelGGL(x3h_rowscale_kernel, dim3((unsigned)(Np / 64 * h2_chunks(kh * kw, K))), dim3(256), 0, (hipStream_t)stream, w,
+                       scales, Co, kh * kw, Ci, Np, transposed);
     const int64_t total = (int64_t)kh * kw * (K / XK) * Np;
     const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 16384);
     hipLaunchKernelGGL(x3h_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint4 *)planes, scales, Co, kh * kw,
@@ -1741,7 +1841,8 @@ extern "C" int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int k
 }
 
 // desc: device array of n entries { const float *w; void *planes; int Co, taps, Ci, transposed; int64_t block0, row0; } (48
-// bytes); block0 as in htd_conv2d_x3_planes_many, row0 = prefix sum of Np (= N rounded up to 128) over the entries.
+// bytes); block0 as in htd_conv2d_x3_planes_many, row0 = prefix sum of (Np / 64) * ceil(taps * K / 1024) over the entries (the
+// workgroups of the row-maximum pass; Np = N rounded up to 128), total_rows = its end.
 extern "C" int htd_conv2d_x3h_planes_many(const void *desc, int n, int64_t total_blocks, int64_t total_rows, void *stream)
 {
     static_assert(sizeof(PlanesDescH) == 48, "PlanesDescH layout is part of the ABI");
@@ -1806,8 +1907,8 @@ extern "C" int htd_act_planes(const float *x, void *planes, int64_t M, int C, vo
 //                     x is then not read and may be NULL (conv_x3q_kernel: both operands by LDS-DMA)
 //   yplanes  != NULL: the planes of y (Co % 16 == 0), written next to y by the same epilogue
 extern "C" int htd_conv2d_fwd_x3q(const float *x, const void *xplanes, const void *wplanes, const float *bias,
-                                  const float *residual, int res_h, int res_w, float *y, void *yplanes, int B, int H, int W, int Ci,
-                                  int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream)
+                                  const float *residual, int res_h, int res_w, float *y, void *yplanes, float *amax_out, int B, int H,
+                                  int W, int Ci, int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream)
 {
     HTD_REQUIRE((x || xplanes) && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3q: bad arguments");
     HTD_REQUIRE(x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3q: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d", Ci,
@@ -1826,6 +1927,7 @@ extern "C" int htd_conv2d_fwd_x3q(const float *x, const void *xplanes, const voi
     p.ncs = Ci / XK;
     p.xp = (const uint4 *)xplanes; p.xp_rows = act_rows(p.M);
     p.yp = (uint4 *)yplanes; p.yp_rows = act_rows(p.M);
+    p.amax_out = amax_out;
     HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.M * Co < (1ll << 40), "conv2d_fwd_x3q: operand too large");
     if (res_h > 0) {
         p.res_H = res_h; p.res_W = res_w;
@@ -1839,16 +1941,16 @@ extern "C" int htd_conv2d_fwd_x3p(const float *x, const void *wplanes, const flo
                                   int relu, void *workspace, void *stream)
 {
     HTD_REQUIRE(x, "conv2d_fwd_x3p: bad arguments");
-    return htd_conv2d_fwd_x3q(x, nullptr, wplanes, bias, residual, res_h, res_w, y, nullptr, B, H, W, Ci, Co, kh, kw, stride, pad,
-                              relu, workspace, stream);
+    return htd_conv2d_fwd_x3q(x, nullptr, wplanes, bias, residual, res_h, res_w, y, nullptr, nullptr, B, H, W, Ci, Co, kh, kw, stride,
+                              pad, relu, workspace, stream);
 }
 
 // gx[B][H][W][Ci] from gy[B][Ho][Wo][Co] and the transposed planes of the layer's weights (htd_conv2d_x3_planes(...,
 // transposed = 1)); stride 1 only (kh = 1: pad 0; kh = 3: pad 1).  mask_src / accum as htd_conv2d_bwd_data.
 // gyplanes != NULL (1x1 layers): the planes of gy, gy itself is then not read; gxplanes != NULL: the planes of gx (Ci % 16 == 0).
 extern "C" int htd_conv2d_bwd_data_x3q(const float *gy, const void *gyplanes, const void *wplanesT, const float *mask_src,
-                                       const float *accum, float *gx, void *gxplanes, int B, int H, int W, int Ci, int Co, int kh,
-                                       int kw, int pad, void *workspace, void *stream)
+                                       const float *accum, float *gx, void *gxplanes, float *amax_out, int B, int H, int W, int Ci,
+                                       int Co, int kh, int kw, int pad, void *workspace, void *stream)
 {
     HTD_REQUIRE((gy || gyplanes) && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3q: bad arguments");
     HTD_REQUIRE(x3p_shape_ok(Co, Ci, kh, kw, 1, pad, 1), "conv2d_bwd_data_x3q: unsupported layer Ci=%d Co=%d k=%dx%d p=%d", Ci, Co,
@@ -1863,6 +1965,7 @@ extern "C" int htd_conv2d_bwd_data_x3q(const float *gy, const void *gyplanes, co
     p.ncs = Co / XK;
     p.xp = (const uint4 *)gyplanes; p.xp_rows = act_rows(p.M);
     p.yp = (uint4 *)gxplanes; p.yp_rows = act_rows(p.M);
+    p.amax_out = amax_out;
     HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3q: operand too large");
     return launch_x3p(p, kw, (hipStream_t)stream, workspace);
 }
@@ -1872,20 +1975,20 @@ extern "C" int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, co
                                        void *stream)
 {
     HTD_REQUIRE(gy, "conv2d_bwd_data_x3p: bad arguments");
-    return htd_conv2d_bwd_data_x3q(gy, nullptr, wplanesT, mask_src, accum, gx, nullptr, B, H, W, Ci, Co, kh, kw, pad, workspace,
-                                   stream);
+    return htd_conv2d_bwd_data_x3q(gy, nullptr, wplanesT, mask_src, accum, gx, nullptr, nullptr, B, H, W, Ci, Co, kh, kw, pad,
+                                   workspace, stream);
 }
 
 // The 3x3 layers on the H2 arithmetic (two fp16 pieces per operand, three matrix instructions per product block instead of six;
 // see h2_scale above).  amax: device scalar >= max |x| of the whole input tensor (htd_absmax); wplanes: htd_conv2d_x3h_planes.
 extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void *wplanes, const float *bias, const float *residual,
-                                  int res_h, int res_w, float *y, void *yplanes, int B, int H, int W, int Ci, int Co, int kh, int kw,
-                                  int stride, int pad, int relu, void *workspace, void *stream)
+                                  int res_h, int res_w, float *y, void *yplanes, float *amax_out, void *h2_flag, int B, int H, int W,
+                                  int Ci, int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream)
 {
     HTD_REQUIRE(!yplanes || Co % XK == 0, "conv2d_fwd_x3h: output planes need Co %% 16 == 0 (Co=%d)", Co);
     HTD_REQUIRE(x && amax && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3h: bad arguments");
-    HTD_REQUIRE(kh == 3 && x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3h: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d",
-                Ci, Co, kh, kw, stride, pad);
+    HTD_REQUIRE(x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3h: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d", Ci, Co,
+                kh, kw, stride, pad);
     HTD_REQUIRE((res_h > 0) == (res_w > 0) && res_h >= 0 && (res_h == 0 || ((Co & 3) == 0 && residual)),
                 "conv2d_fwd_x3h: bad residual up-sampling arguments");
     X3Params p{};
@@ -1899,6 +2002,7 @@ extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void 
     p.amax = amax;
     p.wscale = reinterpret_cast<const float *>(p.wp + planes_vec(kh * kw, Ci, p.Cop));
     p.yp = (uint4 *)yplanes; p.yp_rows = act_rows(p.M);
+    p.amax_out = amax_out; p.h2_flag = (unsigned *)h2_flag;
     HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.M * Co < (1ll << 40), "conv2d_fwd_x3h: operand too large");
     if (res_h > 0) {
         p.res_H = res_h; p.res_W = res_w;
@@ -1908,13 +2012,13 @@ extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void 
 }
 
 extern "C" int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const void *wplanesT, const float *mask_src,
-                                       const float *accum, float *gx, void *gxplanes, int B, int H, int W, int Ci, int Co, int kh,
-                                       int kw, int pad, void *workspace, void *stream)
+                                       const float *accum, float *gx, void *gxplanes, float *amax_out, void *h2_flag, int B, int H,
+                                       int W, int Ci, int Co, int kh, int kw, int pad, void *workspace, void *stream)
 {
     HTD_REQUIRE(!gxplanes || Ci % XK == 0, "conv2d_bwd_data_x3h: output planes need Ci %% 16 == 0 (Ci=%d)", Ci);
     HTD_REQUIRE(gy && amax && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3h: bad arguments");
-    HTD_REQUIRE(kh == 3 && x3p_shape_ok(Co, Ci, kh, kw, 1, pad, 1), "conv2d_bwd_data_x3h: unsupported layer Ci=%d Co=%d k=%dx%d p=%d", Ci,
-                Co, kh, kw, pad);
+    HTD_REQUIRE(x3p_shape_ok(Co, Ci, kh, kw, 1, pad, 1), "conv2d_bwd_data_x3h: unsupported layer Ci=%d Co=%d k=%dx%d p=%d", Ci, Co, kh,
+                kw, pad);
     X3Params p{};
     p.x = gy; p.wp = (const uint4 *)wplanesT; p.residual = accum; p.mask_src = mask_src; p.y = gx;
     p.Hx = H; p.Wx = W; p.Ho = H; p.Wo = W;          // stride 1, same size
@@ -1924,6 +2028,7 @@ extern "C" int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const
     p.amax = amax;
     p.wscale = reinterpret_cast<const float *>(p.wp + planes_vec(kh * kw, Co, p.Cop));
     p.yp = (uint4 *)gxplanes; p.yp_rows = act_rows(p.M);
+    p.amax_out = amax_out; p.h2_flag = (unsigned *)h2_flag;
     HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3h: operand too large");
     return launch_x3p(p, kw, (hipStream_t)stream, workspace);
 }

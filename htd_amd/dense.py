@@ -248,25 +248,83 @@ def new_step():
 # taken from the tensor's largest magnitude, a device scalar that htd_absmax leaves in a slot of a per-step pool of zeros
 # (one fill per step, no host read).  Never cached per tensor: the allocator hands the same address to different tensors.
 _AMAX_POOL = {}
-_AMAX_SLOTS = 512
+_AMAX_SLOTS = 1024
+_H2_FLAGS = {}                 # device index -> one int32 word the H2 kernels set when an element left fp16's range
+# The 1x1 layers run on H2 only when the maximum of their input comes for free -- left behind by the epilogue that wrote the
+# tensor (X3Params::amax_out, carried on the tensor object as `_htd_amax`); a pass of htd_absmax over the input would cost a
+# 1x1 layer more than the arithmetic saves.  The 3x3 layers fall back to that pass.  HTD_H2_1X1=0: 3x3 layers only.
+H2_1X1 = os.environ.get('HTD_H2_1X1', '1') != '0'
+H2_CHECK = os.environ.get('HTD_H2_CHECK', '0') == '1'        # tests: every carried maximum is compared with a fresh htd_absmax
 
 
 def _x3h_ok(Cred, Cout, kh, kw, stride, padding, dilation, dtype):
-    return kh == 3 and dtype == torch.float32 and \
+    return dtype == torch.float32 and (kh == 3 or H2_1X1) and \
         bool(capi.lib().htd_conv2d_x3h_supported(Cred, Cout, kh, kw, stride, padding, dilation))
+
+
+def _amax_slot(device):
+    ent = _AMAX_POOL.get(device.index)
+    if ent is None or ent[1] >= _AMAX_SLOTS:
+        ent = [torch.zeros(_AMAX_SLOTS, device=device, dtype=torch.float32), 0]
+        _AMAX_POOL[device.index] = ent
+    slot = ent[0][ent[1]:ent[1] + 1]
+    ent[1] += 1
+    return slot
 
 
 def absmax(x):
     """-> device scalar (1-element view) holding max |x| (x dense fp32 on the GPU)."""
-    key = x.device.index
-    ent = _AMAX_POOL.get(key)
-    if ent is None or ent[1] >= _AMAX_SLOTS:
-        ent = [torch.zeros(_AMAX_SLOTS, device=x.device, dtype=torch.float32), 0]
-        _AMAX_POOL[key] = ent
-    slot = ent[0][ent[1]:ent[1] + 1]
-    ent[1] += 1
+    slot = _amax_slot(x.device)
     capi.call('htd_absmax', _P(x), x.numel(), _P(slot), _S(), work=('byte', 4.0 * x.numel()))
     return slot
+
+
+# HTD_H2_GUARD=1 (and the check mode): every H2 launch also verifies that no finite element left fp16's range and raises the
+# device flag if one did (h2_check()).  Off by default: two more vector instructions per staged float4, and an overflow is not
+# silent anyway -- it puts infinities into the layer's output and a NaN into the loss.
+H2_GUARD = H2_CHECK or os.environ.get('HTD_H2_GUARD', '0') == '1'
+
+
+def h2_flag(device):
+    if not H2_GUARD:
+        return None
+    f = _H2_FLAGS.get(device.index)
+    if f is None:
+        f = _H2_FLAGS[device.index] = torch.zeros(1, device=device, dtype=torch.int32)
+    return f
+
+
+def h2_check(device=None):
+    """Raise if an H2 launch since the last call met an element beyond its tensor's `amax` (reads the device: a sync)."""
+    for idx, f in list(_H2_FLAGS.items()):
+        if device is not None and idx != device.index:
+            continue
+        if int(f.item()) != 0:
+            f.zero_()
+            raise RuntimeError('htd_amd: an H2 convolution was given a maximum smaller than its input tensor holds (stale _htd_amax); '
+                               'its output contains infinities')
+
+
+def tag_amax(t, slot):
+    """Remember on the tensor object that `slot` holds max |t| (written by the kernel that is filling t)."""
+    t._htd_amax = (slot, t.data_ptr(), t.numel(), t._version)
+
+
+def drop_amax(t):
+    """t is about to be modified in place by a kernel torch does not see: its carried maximum is void."""
+    if t is not None and hasattr(t, '_htd_amax'):
+        del t._htd_amax
+
+
+def carried_amax(t):
+    a = getattr(t, '_htd_amax', None)
+    if a is None or a[1] != t.data_ptr() or a[2] != t.numel() or a[3] != t._version:
+        return None
+    if H2_CHECK:
+        fresh = absmax(t)
+        if not torch.equal(fresh, a[0]) and not (torch.isnan(fresh).item() and torch.isnan(a[0]).item()):
+            raise RuntimeError(f'stale carried maximum: {float(a[0])} against {float(fresh)} on a tensor of shape {tuple(t.shape)}')
+    return a[0]
 
 
 # bf16 plane images of the weights (csrc/conv_x3.hip: the B operand of conv_x3p_kernel, split once per step instead of
@@ -279,22 +337,29 @@ def _planes_key(w, transposed):
     return _flip_key(w) + (bool(transposed), )
 
 
+_ALSO_WANTED = set()          # (weight address, shape, transposed, h2): images that a step asked for outside its table launch
+
+
 def _planes_h2(w, transposed):
-    """Is the image of this weight the H2 one (two fp16 pieces + row scales)?  One rule for whoever makes it and whoever reads it:
-    the 3x3 weights that conv_x3p_kernel takes, while the arithmetic is switched on."""
+    """Is the image the step's table launch makes for this weight the H2 one (two fp16 pieces + row scales)?  The layers that
+    run on H2 whenever they can; the other image of a weight is made on demand (x3_planes(..., h2=...))."""
     Co, Ci, kh, kw = w.shape
     cred, cout = (Co, Ci) if transposed else (Ci, Co)
-    return kh == 3 and kw == 3 and bool(capi.lib().htd_conv2d_x3h_supported(cred, cout, 3, 3, 1, 1, 1))
+    return kh == kw and _x3h_ok(cred, cout, kh, kw, 1, kh // 2, 1, w.dtype)
 
 
-def x3_planes(weight, transposed):
+def x3_planes(weight, transposed, h2=None):
     """weight (Co,Ci,kh,kw) channels_last fp32 -> its plane image (forward operand, or data-gradient operand when
-    `transposed`), made once per step."""
-    h2 = _planes_h2(weight, transposed)
-    key = _planes_key(weight, transposed) + (h2, )
+    `transposed`), made once per step.  h2: the H2 image (None: whatever the table launch makes for this weight)."""
+    if h2 is None:
+        h2 = _planes_h2(weight, transposed)
+    key = _planes_key(weight, transposed) + (bool(h2), )
     hit = _STEP_PLANES.get(key)
     if hit is not None:
         return hit[1]
+    # made on demand, one launch (two for H2) for this weight alone: remember the request, the next steps' table launch
+    # (planes_many) makes this image too
+    _ALSO_WANTED.add((weight.data_ptr(), tuple(weight.shape), bool(transposed), bool(h2)))
     Co, Ci, kh, kw = weight.shape
     nbytes = capi.lib().htd_conv2d_x3_planes_bytes(Co, kh, kw, Ci, int(transposed))
     planes = torch.empty(nbytes // 4, device=weight.device, dtype=torch.int32)
@@ -321,10 +386,12 @@ def planes_many(items):
         w4 = w if w.dim() == 4 else w.view(w.size(0), w.size(1), 1, 1)
         if not _planes_wanted(w4, tr):
             continue
-        key = _planes_key(w4, tr) + (_planes_h2(w4, tr), )
-        if key not in _STEP_PLANES and key not in seen:
-            seen.add(key)
-            todo.append((key, w4, tr))
+        h2 = _planes_h2(w4, tr)
+        for v in ((h2, ) if (w4.data_ptr(), tuple(w4.shape), bool(tr), not h2) not in _ALSO_WANTED else (h2, not h2)):
+            key = _planes_key(w4, tr) + (v, )
+            if key not in _STEP_PLANES and key not in seen:
+                seen.add(key)
+                todo.append((key, w4, tr))
     if not todo:
         return
     L = capi.lib()
@@ -347,10 +414,12 @@ def planes_many(items):
             desc[i, 2] = Co | (taps << 32)                  # two int32 per int64 slot (little endian)
             desc[i, 3] = Ci | (int(tr) << 32)
             desc[i, 4] = block0
+            K = Co if tr else Ci
+            nch = (taps * K + 1023) // 1024                               # chunks of the row-maximum pass (csrc: H2_ECH)
             if h2:
                 desc[i, 5] = row0
-                row0 += Np
-            block0 += ((n32 - 2 * Np) // 4 // 6 + 255) // 256          # elements = uint4 count of the planes / 6 chunks
+                row0 += Np // 64 * nch
+            block0 += ((n32 - (2 + nch) * Np) // 4 // 6 + 255) // 256     # elements = uint4 count of the planes / 6 chunks
             _STEP_PLANES[key] = (w, out)
         table = capi.upload_table(desc, dev)
         if h2:
@@ -445,6 +514,8 @@ def _planes_pay(w_consumer, transposed=False, rows=None):
     """Should the producer of the input of the 1x1 / stride-1 layer with this weight emit planes for it?  rows: pixels of the map."""
     if not ACT_PLANES or w_consumer.dim() != 4 or w_consumer.dtype != torch.float32:
         return False
+    if H2_1X1 and capi.lib().htd_conv2d_set_h2(-1) == 1:
+        return False            # the 1x1 consumer runs on H2 from the producer's carried maximum: nobody would read the planes
     if rows is not None and rows < ACT_PLANES_MIN_ROWS:
         return False
     Co, Ci, kh, kw = w_consumer.shape
@@ -483,20 +554,25 @@ def _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up
         ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32) if nb > 0 else None
         use_xp = x_planes is not None and kh == 1 and stride == 1
         yp = _act_planes_buf(B * Ho * Wo, Co, x.device) if (emit and Co % 16 == 0) else None
-        if _x3h_ok(Ci, Co, kh, kw, stride, padding, dilation, x.dtype):
-            capi.call('htd_conv2d_fwd_x3h', _P(x), _P(absmax(x)), _P(x3_planes(weight, False)), _P(bias), _P(residual), rh, rw,
-                      _P(y), _P(yp), B, H, W, Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
-                      work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
-            return (y, yp) if emit else y
-        if not use_xp and yp is None:
-            capi.call('htd_conv2d_fwd_x3p', _P(x), _P(x3_planes(weight, False)), _P(bias), _P(residual), rh, rw, _P(y), B, H, W,
-                      Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
-                      work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
-            return y
+        work = ('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0)))
+        h2 = _x3h_ok(Ci, Co, kh, kw, stride, padding, dilation, x.dtype)
+        out_slot = _amax_slot(x.device) if h2 else None          # the epilogue leaves max |y| for the layer behind this one
+        if h2:
+            am = carried_amax(x)
+            if am is None and kh == 3:
+                am = absmax(x)
+            if am is not None:
+                capi.call('htd_conv2d_fwd_x3h', _P(x), _P(am), _P(x3_planes(weight, False, True)), _P(bias), _P(residual), rh, rw,
+                          _P(y), _P(yp), _P(out_slot), _P(h2_flag(x.device)), B, H, W, Ci, Co, kh, kw, stride, padding,
+                          int(bool(relu)), _P(ws), _S(), work=work)
+                tag_amax(y, out_slot)
+                return (y, yp) if emit else y
         # (algorithmic bytes stay those of the fp32 operands: the planes are this implementation's traffic, not the layer's)
-        capi.call('htd_conv2d_fwd_x3q', _P(x), _P(x_planes) if use_xp else None, _P(x3_planes(weight, False)), _P(bias),
-                  _P(residual), rh, rw, _P(y), _P(yp), B, H, W, Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(),
-                  key='htd_conv2d_fwd_x3p', work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
+        capi.call('htd_conv2d_fwd_x3q', _P(x), _P(x_planes) if use_xp else None, _P(x3_planes(weight, False, False)), _P(bias),
+                  _P(residual), rh, rw, _P(y), _P(yp), _P(out_slot), B, H, W, Ci, Co, kh, kw, stride, padding, int(bool(relu)),
+                  _P(ws), _S(), key='htd_conv2d_fwd_x3p', work=work)
+        if out_slot is not None:
+            tag_amax(y, out_slot)
         return (y, yp) if emit else y
     capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), rh, rw, _P(y), B, H, W, Ci, Co, kh, kw, stride,
               padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
@@ -552,16 +628,22 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
         gxp = _act_planes_buf(B * H * W, Ci, g.device) if (emit and Ci % 16 == 0) else None
         work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
                 4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None))))
-        if _x3h_ok(Co, Ci, kh, kw, 1, padding, dilation, g.dtype):
-            capi.call('htd_conv2d_bwd_data_x3h', _P(g), _P(absmax(g)), _P(x3_planes(weight, True)), _P(mask_src), _P(accum), _P(gx),
-                      _P(gxp), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(), work=work)
-            return (gx, gxp) if emit else gx
-        if not use_gp and gxp is None:
-            capi.call('htd_conv2d_bwd_data_x3p', _P(g), _P(x3_planes(weight, True)), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci,
-                      Co, kh, kw, padding, _P(ws), _S(), work=work)
-            return gx
-        capi.call('htd_conv2d_bwd_data_x3q', _P(g), _P(g_planes) if use_gp else None, _P(x3_planes(weight, True)), _P(mask_src),
-                  _P(accum), _P(gx), _P(gxp), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(), key='htd_conv2d_bwd_data_x3p', work=work)
+        h2 = _x3h_ok(Co, Ci, kh, kw, 1, padding, dilation, g.dtype)
+        out_slot = _amax_slot(g.device) if h2 else None
+        if h2:
+            am = carried_amax(g)
+            if am is None and kh == 3:
+                am = absmax(g)
+            if am is not None:
+                capi.call('htd_conv2d_bwd_data_x3h', _P(g), _P(am), _P(x3_planes(weight, True, True)), _P(mask_src), _P(accum), _P(gx),
+                          _P(gxp), _P(out_slot), _P(h2_flag(g.device)), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(), work=work)
+                tag_amax(gx, out_slot)
+                return (gx, gxp) if emit else gx
+        capi.call('htd_conv2d_bwd_data_x3q', _P(g), _P(g_planes) if use_gp else None, _P(x3_planes(weight, True, False)), _P(mask_src),
+                  _P(accum), _P(gx), _P(gxp), _P(out_slot), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(),
+                  key='htd_conv2d_bwd_data_x3p', work=work)
+        if out_slot is not None:
+            tag_amax(gx, out_slot)
         return (gx, gxp) if emit else gx
     gd, Cod = g, Co
     if Co % 8 != 0:      # skinny heads (RPN cls+reg Co=15, fc_cls 81, fc_reg 4): zero-pad the reduction channels

@@ -24,6 +24,11 @@ from . import capi
 CL = torch.channels_last
 
 
+def _drop_amax(t):
+    if t is not None and hasattr(t, '_htd_amax'):
+        del t._htd_amax
+
+
 def _need_gpu(t, name):
     if not t.is_cuda:
         raise NotImplementedError(f'{name}: only GPU tensors are supported (libhtd_amd.so has no CPU path)')
@@ -95,6 +100,7 @@ def _roi_align_bwd(g, rois, lvls, level, galias, shape, ph, pw, scale, sr, align
         galias.is_contiguous(memory_format=CL)
     if usable:
         gf, acc = galias, 1
+        _drop_amax(gf)             # modified in place behind torch's back: a carried maximum (dense.tag_amax) is void
     else:
         gf = torch.empty(shape, device=g.device, dtype=g.dtype, memory_format=CL)
         acc = 0
@@ -141,6 +147,7 @@ def _roi_align_levels_bwd(g, rois, lvls, handed, need, shapes, ph, pw, scales, s
         ga = handed[i]
         usable = ga is not None and ga.dtype == g.dtype and tuple(ga.shape) == tuple(shape) and ga.is_contiguous(memory_format=CL)
         if usable:
+            _drop_amax(ga)
             maps.append(ga)
             accs.append(1)
         else:
@@ -364,6 +371,7 @@ class _RoIAlignAllLevels(Function):
             usable = ga is not None and ga.dtype == torch.float32 and tuple(ga.shape) == tuple(shape) and \
                 ga.is_contiguous(memory_format=CL)
             if usable:
+                _drop_amax(ga)
                 maps.append(ga)
                 accs.append(1)
             else:
@@ -733,6 +741,7 @@ class GlobalAvgPoolFunction(Function):
         g = g.reshape(n, C).contiguous()
         if galias is not None and galias.dtype == g.dtype and tuple(galias.shape) == (n, C, h, w) and \
                 galias.is_contiguous(memory_format=CL):
+            _drop_amax(galias)
             capi.call('htd_global_avg_pool_bwd_acc', _P(g), _P(galias), n, h * w, C, _S())
             return galias, None
         gx = torch.empty((n, C, h, w), device=g.device, dtype=g.dtype, memory_format=CL)

@@ -153,8 +153,10 @@ def test_fpn_fused_top_down_matches_interpolate_add():
     (o1, g1, p1), (o2, g2, p2) = res
     for a, b in zip(o1, o2):
         assert torch.equal(a, b)
+    # (the two formulations need not run the lateral layers' data gradient on the same product arithmetic -- H2 where the
+    # gradient map carries its maximum, the three-piece bf16 form where it does not: both fp32-accurate, not bit-equal)
     for a, b in zip(g1, g2):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=4e-5)
     for n in p2:
         torch.testing.assert_close(p1[n], p2[n], rtol=1e-4, atol=1e-4 * float(p2[n].abs().max()), msg=n)
 
