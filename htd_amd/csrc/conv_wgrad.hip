@@ -32,6 +32,9 @@ struct WgradParams {
     int Ntot;              // kh*kw*Ci
     int mt, nt, splits;
     int64_t slices_per_split;
+    // H2 arithmetic (conv_x3.hip, h2_scale): device scalars holding max |x| and max |gy| of the two tensors; both non-NULL: two fp16
+    // pieces per operand scaled by powers of two from these maxima, three products per block, partial sums scaled back
+    const float *amax_x, *amax_g;
 };
 
 constexpr int BKW = 32;    // pixels per K slice
@@ -312,6 +315,33 @@ __device__ __forceinline__ void split3x2w(float a, float b, unsigned &h, unsigne
     l = c.u;
 }
 
+// H2 (see conv_x3.hip): scale from a tensor's largest magnitude, and the two-piece fp16 split of two scaled floats
+using f16x8w = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2w = __attribute__((ext_vector_type(2))) _Float16;
+struct H2ScaleW { float s, inv; };
+__device__ __forceinline__ H2ScaleW h2w_scale(const float *amax)
+{
+    const unsigned E = (__float_as_uint(*amax) >> 23) & 0xffu;
+    int e = E == 0u ? 126 : (E == 255u ? 0 : 141 - (int)E);
+    e = e > 126 ? 126 : e;
+    return H2ScaleW{__uint_as_float((unsigned)(127 + e) << 23), __uint_as_float((unsigned)(127 - e) << 23)};
+}
+__device__ __forceinline__ void split2w(float a, float b, unsigned &h, unsigned &l)
+{
+    union { f16x2w v; unsigned u; } c;
+    c.v = __builtin_convertvector(f32x2w{a, b}, f16x2w);
+    h = c.u;
+    const f32x2w back = __builtin_convertvector(c.v, f32x2w);
+    c.v = __builtin_convertvector(f32x2w{a - back[0], b - back[1]}, f16x2w);
+    l = c.u;
+}
+template <bool H2>
+__device__ __forceinline__ f32x16 mfma_x3w(bf16x8w a, bf16x8w b, f32x16 c)
+{
+    if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8w, a), __builtin_bit_cast(f16x8w, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ bf16x8w tr_frag(const unsigned short *img, int k0, int c0, int lane)
 {
     // lane l: h = l>>5 takes k0 + 8h .. +7; its 16-lane group covers columns c0 + 16*((l>>4)&1) .. +15
@@ -537,12 +567,17 @@ constexpr int XD_BUF = 6 * XD_PLANE;           // three gy planes + three x plan
 // TM x TN 32x32 blocks per wave (2 x 2 waves): 128x128 tiles, or 64x128 / 128x64 for layers with 64 output or 64 reduction-side
 // channels (layer1, the stem), where half of a 128-wide tile would multiply zeros.  p.mt / p.nt count tiles of THIS shape; the
 // split count and the K ranges are those of the 128x128 form (same summation order, same bits).
-template <int PIX, int TM, int TN>
+template <int PIX, int TM, int TN, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
 {
     constexpr int WGN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32;
     constexpr int VA = BM / 4, VB = BN / 4, PA = XD_KS * VA / 256, PB = XD_KS * VB / 256;      // float4 per thread, operand and slice
-    static_assert(PA >= 1 && PB >= 1 && (6 * TM * TN) % (2 * (PA + PB)) == 0, "whole MFMAs per split chunk");
+    static_assert(PA >= 1 && PB >= 1 && (H2 || (6 * TM * TN) % (2 * (PA + PB)) == 0), "whole MFMAs per split chunk");
+    float sg = 1.f, sx = 1.f, sg_inv = 1.f, sx_inv = 1.f;          // H2: power-of-two scales of the two operands
+    if constexpr (H2) {
+        const H2ScaleW a = h2w_scale(p.amax_g), b = h2w_scale(p.amax_x);
+        sg = a.s; sg_inv = a.inv; sx = b.s; sx_inv = b.inv;
+    }
     __shared__ __attribute__((aligned(16))) unsigned short lds[2 * XD_BUF];
 
     // Workgroup -> (tile, split).  Consecutive workgroups go to consecutive XCDs, each with its own L2:
@@ -661,24 +696,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
     };
     const bool do_bias = p.bias_out != nullptr && tile_n == 0;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto put = [&](unsigned short *img, int row, int col, float4 v) {
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split3x2w(v.x, v.y, h0, m0_, l0);
-        split3x2w(v.z, v.w, h1, m1, l1);
+    auto put = [&](unsigned short *img, int row, int col, float4 v, float sc) {
         unsigned short *d = img + row * X3_ROW + col;
-        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(m0_, m1);
-        *reinterpret_cast<uint2 *>(d + 2 * XD_PLANE) = make_uint2(l0, l1);
+        if constexpr (H2) {
+            unsigned h0, l0, h1, l1;
+            split2w(v.x * sc, v.y * sc, h0, l0);
+            split2w(v.z * sc, v.w * sc, h1, l1);
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(l0, l1);
+        } else {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3x2w(v.x, v.y, h0, m0_, l0);
+            split3x2w(v.z, v.w, h1, m1, l1);
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(m0_, m1);
+            *reinterpret_cast<uint2 *>(d + 2 * XD_PLANE) = make_uint2(l0, l1);
+        }
     };
     auto store_slice = [&](unsigned short *buf, const float4 (&qa)[PA], const float4 (&qb)[PB]) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const float4 v = qa[i];
-            put(buf, a_row[i], a_col, v);
+            put(buf, a_row[i], a_col, v, sg);
             bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;      // every tile (a branch would cut the loop body in two)
         }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) put(buf + 3 * XD_PLANE, b_row[i], b_col, qb[i]);
+        for (int i = 0; i < PB; ++i) put(buf + 3 * XD_PLANE, b_row[i], b_col, qb[i], sx);
     };
 
     f32x16 acc[TM][TN];
@@ -694,38 +737,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
     // instructions) and MPC MFMAs (eight chunks of three for the 128x128 tile), pinned in this order by sched_barrier: left to itself hipcc moves all MFMAs behind
     // all of the vector work, and the matrix pipe idles through the split as it did in conv_wgrad_x3_kernel
     auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[PA], float4 (&qb)[PB]) {
+        constexpr int NPL = H2 ? 2 : 3;             // planes per operand
         bf16x8w fa[TM][3], fb[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag(rd + q * XD_PLANE, 0, wm * TM * 32 + i * 32, lane);
+            for (int q = 0; q < NPL; ++q) fa[i][q] = tr_frag(rd + q * XD_PLANE, 0, wm * TM * 32 + i * 32, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fb[j][q] = tr_frag(rd + (3 + q) * XD_PLANE, 0, wn * TN * 32 + j * 32, lane);
+            for (int q = 0; q < NPL; ++q) fb[j][q] = tr_frag(rd + (3 + q) * XD_PLANE, 0, wn * TN * 32 + j * 32, lane);
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as conv_wgrad_x3_kernel
+        // smallest terms first, as conv_wgrad_x3_kernel; H2: a1 b0, a0 b1, a0 b0
+        constexpr int QA[6] = {H2 ? 1 : 2, 0, H2 ? 0 : 1, 1, 0, 0}, QB[6] = {0, H2 ? 1 : 2, H2 ? 0 : 1, 0, 1, 0};
         unsigned h[2], m[2], l[2];
+        constexpr int NC = 2 * (PA + PB), NM = (H2 ? 3 : 6) * TM * TN;       // split chunks; MFMAs of the slice
 #pragma unroll
-        for (int c = 0; c < 2 * (PA + PB); ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int u = c >> 1;                    // staged float4: gy rows first, then x rows
             const bool is_a = u < PA;
             const float4 v = is_a ? qa[u] : qb[u - PA];
+            const float sc = is_a ? sg : sx;
             if ((c & 1) == 0) {
-                split3x2w(v.x, v.y, h[0], m[0], l[0]);
+                if constexpr (H2) split2w(v.x * sc, v.y * sc, h[0], l[0]);
+                else split3x2w(v.x, v.y, h[0], m[0], l[0]);
             } else {
-                split3x2w(v.z, v.w, h[1], m[1], l[1]);
+                if constexpr (H2) split2w(v.z * sc, v.w * sc, h[1], l[1]);
+                else split3x2w(v.z, v.w, h[1], m[1], l[1]);
                 unsigned short *d = (is_a ? wr + a_row[u] * X3_ROW + a_col : wr + 3 * XD_PLANE + b_row[u - PA] * X3_ROW + b_col);
                 *reinterpret_cast<uint2 *>(d) = make_uint2(h[0], h[1]);
-                *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(m[0], m[1]);
-                *reinterpret_cast<uint2 *>(d + 2 * XD_PLANE) = make_uint2(l[0], l[1]);
+                if constexpr (H2) {
+                    *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(l[0], l[1]);
+                } else {
+                    *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(m[0], m[1]);
+                    *reinterpret_cast<uint2 *>(d + 2 * XD_PLANE) = make_uint2(l[0], l[1]);
+                }
                 if (is_a) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }     // every tile: no branch in the body
             }
-            constexpr int MPC = 6 * TM * TN / (2 * (PA + PB));       // MFMAs per chunk
 #pragma unroll
-            for (int t = MPC * c; t < MPC * c + MPC; ++t) {          // MFMA t: product q of block (i, j)
+            for (int t = c * NM / NC; t < (c + 1) * NM / NC; ++t) {          // MFMA t: product q of block (i, j)
                 const int q = t / (TM * TN), i = (t % (TM * TN)) / TN, j = t % TN;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[q]], fb[j][QB[q]], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma_x3w<H2>(fa[i][QA[q]], fb[j][QB[q]], acc[i][j]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -774,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[i][j][r];
+                if (m < p.Co) out[(int64_t)m * p.Ntot + n] = H2 ? acc[i][j][r] * sg_inv * sx_inv : acc[i][j][r];
             }
         }
 }
@@ -1011,9 +1063,14 @@ constexpr int XHD_KS = 16;
 constexpr int XHD_RUN = XHD_KS + 2;
 constexpr int XHD_PLANE_A = XHD_KS * X3_ROW, XHD_PLANE_B = XHD_RUN * XH_ROWB;
 constexpr int XHD_BUF = 3 * XHD_PLANE_A + 3 * XHD_PLANE_B;
-template <int TM>
+template <int TM, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
 {
+    float sg = 1.f, sx = 1.f, sg_inv = 1.f, sx_inv = 1.f;          // H2: power-of-two scales of the two operands
+    if constexpr (H2) {
+        const H2ScaleW a = h2w_scale(p.amax_g), b = h2w_scale(p.amax_x);
+        sg = a.s; sg_inv = a.inv; sx = b.s; sx_inv = b.inv;
+    }
     // TM 32-row blocks of output channels per wave: 128 co per workgroup, or 64 for the 64-channel layers (layer1), where half of
     // a 128-row tile would multiply zeros; p.mt counts tiles of this height, the splits are those of the 128-row form
     constexpr int BM = 2 * TM * 32, BNC = 64;
@@ -1119,13 +1176,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
     };
     const bool do_bias = p.bias_out != nullptr && tile_nc == 0 && ky == 1;       // the centre row sees every gy row once
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto put = [&](unsigned short *d, int plane, float4 v) {
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split3x2w(v.x, v.y, h0, m0_, l0);
-        split3x2w(v.z, v.w, h1, m1, l1);
-        *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m0_, m1);
-        *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l0, l1);
+    auto put = [&](unsigned short *d, int plane, float4 v, float sc) {
+        if constexpr (H2) {
+            unsigned h0, l0, h1, l1;
+            split2w(v.x * sc, v.y * sc, h0, l0);
+            split2w(v.z * sc, v.w * sc, h1, l1);
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + plane) = make_uint2(l0, l1);
+        } else {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3x2w(v.x, v.y, h0, m0_, l0);
+            split3x2w(v.z, v.w, h1, m1, l1);
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m0_, m1);
+            *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l0, l1);
+        }
     };
     const int a_lds0 = a_row0 * X3_ROW + a_col, a_lds1 = (a_row0 + RA) * X3_ROW + a_col;
     const int b_lds0 = 3 * XHD_PLANE_A + b_row0 * XH_ROWB + b_col, b_lds1 = 3 * XHD_PLANE_A + (16 + b_row0) * XH_ROWB + b_col;
@@ -1141,54 +1206,63 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
     // one half of the loop body (see conv_wgrad_x3d_kernel): 36 MFMAs on the slice in `rd`, the split of the staged registers
     // into `wr` in six chunks of one split3x2w between them, the ragged rows of the x run last
     auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[PA], float4 (&qb)[2]) {
+        constexpr int NPL = H2 ? 2 : 3;             // planes per operand
         bf16x8w fa[TM][3], fb[3][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fa[i][q] = tr_frag_row<X3_ROW>(rd + q * XHD_PLANE_A, 0, wm * TM * 32 + i * 32, lane);
+            for (int q = 0; q < NPL; ++q) fa[i][q] = tr_frag_row<X3_ROW>(rd + q * XHD_PLANE_A, 0, wm * TM * 32 + i * 32, lane);
 #pragma unroll
         for (int t = 0; t < 3; ++t)            // tap kx = t reads the run one row further: gy row k meets x row k + t
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fb[t][q] = tr_frag_row<XH_ROWB>(rd + 3 * XHD_PLANE_A + q * XHD_PLANE_B, t, wn * 32, lane);
+            for (int q = 0; q < NPL; ++q) fb[t][q] = tr_frag_row<XH_ROWB>(rd + 3 * XHD_PLANE_A + q * XHD_PLANE_B, t, wn * 32, lane);
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first, as conv_wgrad_x3h_kernel
+        // smallest terms first, as conv_wgrad_x3h_kernel; H2: a1 b0, a0 b1, a0 b0
+        constexpr int QA[6] = {H2 ? 1 : 2, 0, H2 ? 0 : 1, 1, 0, 0}, QB[6] = {0, H2 ? 1 : 2, H2 ? 0 : 1, 0, 1, 0};
         unsigned h[2], m[2], l[2];
-        constexpr int NC = 2 * (PA + 1), NM = 18 * TM;       // split chunks; MFMAs of the slice (6 products x 3 taps x TM blocks)
+        constexpr int NC = 2 * (PA + 1), NM = (H2 ? 9 : 18) * TM;       // split chunks; MFMAs of the slice (products x 3 taps x TM blocks)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int u = c >> 1;                    // staged float4: the gy row(s), then the x row
             const float4 v = u < PA ? qa[u < PA ? u : 0] : qb[0];
+            const float sc = u < PA ? sg : sx;
             if ((c & 1) == 0) {
-                split3x2w(v.x, v.y, h[0], m[0], l[0]);
+                if constexpr (H2) split2w(v.x * sc, v.y * sc, h[0], l[0]);
+                else split3x2w(v.x, v.y, h[0], m[0], l[0]);
             } else {
-                split3x2w(v.z, v.w, h[1], m[1], l[1]);
+                if constexpr (H2) split2w(v.z * sc, v.w * sc, h[1], l[1]);
+                else split3x2w(v.z, v.w, h[1], m[1], l[1]);
                 unsigned short *d = wr + (u >= PA ? b_lds0 : u == 0 ? a_lds0 : a_lds1);
                 const int plane = u < PA ? XHD_PLANE_A : XHD_PLANE_B;
                 *reinterpret_cast<uint2 *>(d) = make_uint2(h[0], h[1]);
-                *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m[0], m[1]);
-                *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l[0], l[1]);
+                if constexpr (H2) {
+                    *reinterpret_cast<uint2 *>(d + plane) = make_uint2(l[0], l[1]);
+                } else {
+                    *reinterpret_cast<uint2 *>(d + plane) = make_uint2(m[0], m[1]);
+                    *reinterpret_cast<uint2 *>(d + 2 * plane) = make_uint2(l[0], l[1]);
+                }
                 if (u < PA) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }    // every tile: no branch in the body
             }
 #pragma unroll
             for (int e = c * NM / NC; e < (c + 1) * NM / NC; ++e) {          // MFMA e: product q of block (tap t, row block i)
                 const int q = e / (3 * TM), t = (e % (3 * TM)) / TM, i = e % TM;
-                acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][QA[q]], fb[t][QB[q]], acc[t][i], 0, 0, 0);
+                acc[t][i] = mfma_x3w<H2>(fa[i][QA[q]], fb[t][QB[q]], acc[t][i]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (__builtin_amdgcn_readfirstlane(wave) == 0) {      // a scalar branch: the other three waves skip the instructions
-            if (ragged) put(wr + b_lds1, XHD_PLANE_B, qb[1]);
+            if (ragged) put(wr + b_lds1, XHD_PLANE_B, qb[1], sx);
         }
         load_slice(qa, qb);
         __syncthreads();
     };
     auto store_slice = [&](unsigned short *wr, const float4 (&qa)[PA], const float4 (&qb)[2]) {
-        put(wr + a_lds0, XHD_PLANE_A, qa[0]);
-        if constexpr (PA > 1) put(wr + a_lds1, XHD_PLANE_A, qa[PA - 1]);
+        put(wr + a_lds0, XHD_PLANE_A, qa[0], sg);
+        if constexpr (PA > 1) put(wr + a_lds1, XHD_PLANE_A, qa[PA - 1], sg);
 #pragma unroll
         for (int i = 0; i < PA; ++i) { bsum.x += qa[i].x; bsum.y += qa[i].y; bsum.z += qa[i].z; bsum.w += qa[i].w; }     // row by row
-        put(wr + b_lds0, XHD_PLANE_B, qb[0]);
-        if (ragged) put(wr + b_lds1, XHD_PLANE_B, qb[1]);
+        put(wr + b_lds0, XHD_PLANE_B, qb[0], sx);
+        if (ragged) put(wr + b_lds1, XHD_PLANE_B, qb[1], sx);
     };
 
     unsigned short *buf0 = lds, *buf1 = lds + XHD_BUF;
@@ -1233,7 +1307,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3hd_kernel(WgradParams p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    if (m < p.Co) out[(int64_t)m * p.Ntot + n] = acc[t][i][r];
+                    if (m < p.Co) out[(int64_t)m * p.Ntot + n] = H2 ? acc[t][i][r] * sg_inv * sx_inv : acc[t][i][r];
                 }
         }
     }
@@ -1473,7 +1547,8 @@ extern "C" int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci,
 // gbias (may be NULL): also returns the bias gradient, column sums of gy, accumulated by the same kernel.
 // accumulate: gw (and gbias) += the gradient; the kernels then always write partials and the reduce pass adds them in.
 static int bwd_weight_impl(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W, int Ci, int Co, int kh,
-                           int kw, int stride, int pad, int dil, void *workspace, void *stream, int accumulate)
+                           int kw, int stride, int pad, int dil, void *workspace, void *stream, int accumulate,
+                           const float *amax_x = nullptr, const float *amax_g = nullptr)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
                 "conv2d_bwd_weight: bad sizes");
@@ -1481,6 +1556,8 @@ static int bwd_weight_impl(const float *x, const float *gy, float *gw, float *gb
     HTD_REQUIRE(x && gy && gw && workspace, "conv2d_bwd_weight: null pointer");
     WgradParams p{};
     p.x = x; p.gy = gy;
+    p.amax_x = amax_x; p.amax_g = amax_g;
+    const bool h2 = amax_x != nullptr && amax_g != nullptr;
     p.B = B; p.H = H; p.W = W; p.Ci = Ci; p.Co = Co; p.kh = kh; p.kw = kw; p.stride = stride; p.pad = pad; p.dil = dil;
     p.Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1;
     p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
@@ -1513,13 +1590,20 @@ static int bwd_weight_impl(const float *x, const float *gy, float *gw, float *gb
             static const bool tile64 = !(getenv("HTD_WGRAD_TILE64") && atoi(getenv("HTD_WGRAD_TILE64")) == 0);
             if (tile64 && Co <= 64) {                 // 64 output channels: 64-row tiles (same tile count, no rows of zeros)
                 p.mt = (int)htd::ceil_div(Co, 64);
-                hipLaunchKernelGGL(conv_wgrad_x3hd_kernel<1>, dim3((unsigned)(p.mt * p.nt * 3 * p.splits)), dim3(256), 0, s, p);
+                const dim3 g64((unsigned)(p.mt * p.nt * 3 * p.splits));
+                if (h2) hipLaunchKernelGGL((conv_wgrad_x3hd_kernel<1, true>), g64, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((conv_wgrad_x3hd_kernel<1, false>), g64, dim3(256), 0, s, p);
+            } else if (h2) {
+                hipLaunchKernelGGL((conv_wgrad_x3hd_kernel<2, true>), grid, dim3(256), 0, s, p);
             } else {
-                hipLaunchKernelGGL(conv_wgrad_x3hd_kernel<2>, grid, dim3(256), 0, s, p);
+                hipLaunchKernelGGL((conv_wgrad_x3hd_kernel<2, false>), grid, dim3(256), 0, s, p);
             }
         }
-        else if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(conv_wgrad_x3h_kernel<false>, grid, dim3(256), 0, s, p);
+        else {
+            HTD_REQUIRE(!h2, "conv2d_bwd_weight_h2: this 3x3 layer is not taken by the H2 kernels (htd_conv2d_bwd_weight_h2_supported)");
+            if (W + 1 >= XH_KS) hipLaunchKernelGGL(conv_wgrad_x3h_kernel<true>, grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(conv_wgrad_x3h_kernel<false>, grid, dim3(256), 0, s, p);
+        }
         if (!direct) {
             const int64_t n = (int64_t)Co * p.Ntot;
             const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(n, 256), 2048);
@@ -1556,15 +1640,27 @@ static int bwd_weight_impl(const float *x, const float *gy, float *gw, float *gb
             // splits % 8 != 0: (split, N tile) groups dealt over the 8 XCDs, mt workgroups each (see the kernel)
             const dim3 gd = c.splits % 8 == 0 ? dim3((unsigned)(p.mt * p.nt * c.splits))
                                               : dim3((unsigned)(8 * htd::ceil_div(p.nt * c.splits, 8) * p.mt));
-            if (m64 && pix == PIX_POINTWISE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 1, 2>), gd, dim3(256), 0, s, p);
+            if (h2) {
+                if (m64 && pix == PIX_POINTWISE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 1, 2, true>), gd, dim3(256), 0, s, p);
+                else if (m64) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_WIDE, 1, 2, true>), gd, dim3(256), 0, s, p);
+                else if (n64) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 2, 1, true>), gd, dim3(256), 0, s, p);
+                else if (pix == PIX_POINTWISE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 2, 2, true>), gd, dim3(256), 0, s, p);
+                else if (pix == PIX_WIDE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_WIDE, 2, 2, true>), gd, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_GENERAL, 2, 2, true>), gd, dim3(256), 0, s, p);
+            }
+            else if (m64 && pix == PIX_POINTWISE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 1, 2>), gd, dim3(256), 0, s, p);
             else if (m64) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_WIDE, 1, 2>), gd, dim3(256), 0, s, p);
             else if (n64) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 2, 1>), gd, dim3(256), 0, s, p);
             else if (pix == PIX_POINTWISE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_POINTWISE, 2, 2>), gd, dim3(256), 0, s, p);
             else if (pix == PIX_WIDE) hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_WIDE, 2, 2>), gd, dim3(256), 0, s, p);
             else hipLaunchKernelGGL((conv_wgrad_x3d_kernel<PIX_GENERAL, 2, 2>), gd, dim3(256), 0, s, p);
+        } else if (h2) {
+            HTD_REQUIRE(false, "conv2d_bwd_weight_h2: operands too large for the H2 kernels (htd_conv2d_bwd_weight_h2_supported)");
         } else if (pix == PIX_POINTWISE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_POINTWISE>, grid, dim3(256), 0, s, p);
         else if (pix == PIX_WIDE) hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_WIDE>, grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL(conv_wgrad_x3_kernel<PIX_GENERAL>, grid, dim3(256), 0, s, p);
+    } else if (h2) {
+        HTD_REQUIRE(false, "conv2d_bwd_weight_h2: layer not taken by the H2 kernels (htd_conv2d_bwd_weight_h2_supported)");
     } else if (c.bm == 32)
         launch_wgrad<1, 4, 1, 1>(pix, covec, grid, s, p);
     else
@@ -1594,6 +1690,36 @@ extern "C" int htd_conv2d_bwd_weight_acc(const float *x, const float *gy, float 
                                          void *stream)
 {
     return bwd_weight_impl(x, gy, gw, gbias, B, H, W, Ci, Co, kh, kw, stride, pad, dil, workspace, stream, 1);
+}
+
+// The weight gradient on the H2 arithmetic (conv_x3.hip: two fp16 pieces per operand, three products): amax_x / amax_g are device
+// scalars holding max |x| / max |gy| of the two tensors (htd_absmax, or what the epilogue that wrote them left behind).
+// htd_conv2d_bwd_weight_h2_supported: 1 when the layer runs on the kernels that have the H2 form (the tap-fused 3x3 kernel and
+// the 128-wide split-in-the-shadow kernel); accumulate != 0: htd_conv2d_bwd_weight_acc's semantics.
+extern "C" int htd_conv2d_bwd_weight_h2_supported(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
+{
+    static const int math_env = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
+    if (htd_conv2d_set_h2(-1) != 1 || (g_wgrad_math < 0 ? math_env : g_wgrad_math) != 1) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || (Ci & 3) != 0 || stride <= 0 || dil <= 0 || pad < 0) return 0;
+    const int Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) / stride + 1, Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    const int64_t K = (int64_t)B * Ho * Wo;
+    static const bool d_on = !(getenv("HTD_WGRAD_X3D") && atoi(getenv("HTD_WGRAD_X3D")) == 0);
+    if (!d_on || (int64_t)B * H * W * Ci * 4 >= (1ll << 31) || K * Co * 4 >= (1ll << 31)) return 0;
+    if (x3h_takes(Ci, Co, kh, kw, stride, pad, dil)) return XHD_KS / (W + 1) + 1 <= H ? 1 : 0;
+    const Cfg c = choose(Co, kh * kw * Ci, K);
+    return (c.bm == 128 && (Co & 3) == 0) ? 1 : 0;
+}
+
+extern "C" int htd_conv2d_bwd_weight_h2(const float *x, const float *gy, const float *amax_x, const float *amax_g, float *gw,
+                                        float *gbias, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                                        int dil, int accumulate, void *workspace, void *stream)
+{
+    HTD_REQUIRE(amax_x && amax_g, "conv2d_bwd_weight_h2: null maximum");
+    HTD_REQUIRE(htd_conv2d_bwd_weight_h2_supported(B, H, W, Ci, Co, kh, kw, stride, pad, dil) == 1,
+                "conv2d_bwd_weight_h2: layer not taken by the H2 kernels");
+    return bwd_weight_impl(x, gy, gw, gbias, B, H, W, Ci, Co, kh, kw, stride, pad, dil, workspace, stream, accumulate ? 1 : 0, amax_x,
+                           amax_g);
 }
 
 // g [rows][C], y (may be NULL) [rows][C]; gm (out, required iff y) ; gbias [C]; workspace >= 2048*C*4 bytes

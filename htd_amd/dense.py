@@ -673,7 +673,27 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
 SINK_ACCUMULATE = os.environ.get('HTD_SINK_ACC', '1') != '0'      # 0: shared parameters collect their gradient through autograd adds
 
 
-def _wgrad_launch(x, g, weight, stride, padding, dilation, bias):
+H2_WGRAD = os.environ.get('HTD_H2_WGRAD', '1') != '0'          # 0: the weight gradients stay on the three-piece bf16 form
+
+
+def _wgrad_amax(x, g, weight, stride, padding, dilation):
+    """The two maxima of an H2 weight-gradient launch, or None when the layer stays on the bf16 form: both carried by the tensors
+    (left by the epilogues that wrote them), or -- 3x3 layers only, where the arithmetic saves more than two passes cost --
+    measured now.  Called on the stream that produced x and g, before the launch moves to the weight-gradient stream."""
+    if not H2_WGRAD or x.dtype != torch.float32:
+        return None
+    B, Ci, H, W = x.shape
+    Co, _, kh, kw = weight.shape
+    if B * g.size(2) * g.size(3) == 0 or \
+            not capi.lib().htd_conv2d_bwd_weight_h2_supported(B, H, W, Ci, Co, kh, kw, stride, padding, dilation):
+        return None
+    ax, ag = carried_amax(x), carried_amax(g)
+    if (ax is None or ag is None) and kh != 3:
+        return None
+    return (ax if ax is not None else absmax(x)), (ag if ag is not None else absmax(g))
+
+
+def _wgrad_launch(x, g, weight, stride, padding, dilation, bias, amax=None):
     B, Ci, H, W = x.shape
     Co, _, kh, kw = weight.shape
     Ho, Wo = g.shape[2], g.shape[3]
@@ -685,9 +705,13 @@ def _wgrad_launch(x, g, weight, stride, padding, dilation, bias):
     if aw is not None and (bias is None or ab is not None) and B * Ho * Wo > 0:
         nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
         ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
-        capi.call('htd_conv2d_bwd_weight_acc', _P(x), _P(g), _P(aw), _P(ab), B, H, W, Ci, Co, kh, kw, stride, padding,
-                  dilation, _P(ws), _S(), key='htd_conv2d_bwd_weight',
-                  work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci, 4.0 * (x.numel() + g.numel() + aw.numel())))
+        work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci, 4.0 * (x.numel() + g.numel() + aw.numel()))
+        if amax is not None:
+            capi.call('htd_conv2d_bwd_weight_h2', _P(x), _P(g), _P(amax[0]), _P(amax[1]), _P(aw), _P(ab), B, H, W, Ci, Co, kh, kw,
+                      stride, padding, dilation, 1, _P(ws), _S(), key='htd_conv2d_bwd_weight', work=work)
+        else:
+            capi.call('htd_conv2d_bwd_weight_acc', _P(x), _P(g), _P(aw), _P(ab), B, H, W, Ci, Co, kh, kw, stride, padding,
+                      dilation, _P(ws), _S(), key='htd_conv2d_bwd_weight', work=work)
         ent = _GRAD_SINK.get(weight.data_ptr())
         return None, None, not (ent is not None and ent[2] is _TEMP_USED)
     gw, sink_w = grad_out2(weight)
@@ -701,9 +725,13 @@ def _wgrad_launch(x, g, weight, stride, padding, dilation, bias):
         return gw, gb, sink_w and sink_b
     nbytes = capi.lib().htd_conv2d_wgrad_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding, dilation)
     ws = torch.empty(nbytes // 4 + 1, device=g.device, dtype=g.dtype)
-    capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, stride, padding,
-              dilation, _P(ws), _S(), work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
-                                            4.0 * (x.numel() + g.numel() + gw.numel())))
+    work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci, 4.0 * (x.numel() + g.numel() + gw.numel()))
+    if amax is not None:
+        capi.call('htd_conv2d_bwd_weight_h2', _P(x), _P(g), _P(amax[0]), _P(amax[1]), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw,
+                  stride, padding, dilation, 0, _P(ws), _S(), key='htd_conv2d_bwd_weight', work=work)
+    else:
+        capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, stride, padding,
+                  dilation, _P(ws), _S(), work=work)
     return gw, gb, sink_w and sink_b
 
 
@@ -712,17 +740,18 @@ def _wgrad_raw(x, g, weight, stride, padding, dilation, bias=None, overlap=True)
     gradient slice is then written in place, or True), else None.  overlap=False keeps the launch on the main stream:
     for a caller that hands `g` itself on to autograd (record_stream guards against reuse of the storage, not against
     the engine's in-place `add_` into a gradient it owns while the side stream has not read it yet)."""
+    amax = _wgrad_amax(x, g, weight, stride, padding, dilation)
     if not overlap or not OVERLAP_WGRAD or (capi.profiling() and not _OVERLAP_IN_PROFILE):
         if OVERLAP_WGRAD and _SIDE and SINK_ACCUMULATE and grad_sink_again(weight) is not None:
             # this launch ADDS into a slice whose earlier contributions may still be in the weight-gradient stream's queue
             torch.cuda.current_stream().wait_stream(side_stream(g.device))
-        return _wgrad_launch(x, g, weight, stride, padding, dilation, bias)[:2]
+        return _wgrad_launch(x, g, weight, stride, padding, dilation, bias, amax)[:2]
     main, side = torch.cuda.current_stream(), side_stream(g.device)
     side.wait_stream(main)
     x.record_stream(side)
     g.record_stream(side)
     with torch.cuda.stream(side):
-        gw, gb, sinks = _wgrad_launch(x, g, weight, stride, padding, dilation, bias)
+        gw, gb, sinks = _wgrad_launch(x, g, weight, stride, padding, dilation, bias, amax)
     if not sinks and weight.data_ptr() not in _SIDE_CONSUMED:
         if gw is not None:
             gw.record_stream(main)

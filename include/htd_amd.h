@@ -347,6 +347,12 @@ int htd_conv2d_bwd_data_x3q(const float *gy, const void *gyplanes, const void *w
  *     finite scaled element left fp16's range, i.e. `amax` was NOT the tensor's maximum (the caller's bug; check and fail)
  *   htd_conv2d_set_h2        0 / 1 switches the arithmetic off / on (-1: query), returns the previous setting */
 int htd_conv2d_set_h2(int on);
+/* the weight gradient on the same arithmetic: amax_x / amax_g = max |x| / max |gy| of the two tensors (device scalars);
+ * accumulate != 0: htd_conv2d_bwd_weight_acc's semantics; workspace: htd_conv2d_wgrad_workspace_bytes */
+int htd_conv2d_bwd_weight_h2_supported(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+int htd_conv2d_bwd_weight_h2(const float *x, const float *gy, const float *amax_x, const float *amax_g, float *gw,
+                             float *gbias, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                             int dil, int accumulate, void *workspace, void *stream);
 int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
 int htd_absmax(const float *x, int64_t n, float *amax, void *stream);
 int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);

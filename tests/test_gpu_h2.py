@@ -189,3 +189,70 @@ def test_h2_ranges(h2, case):
         x2[0, 3, 4, 5] = float('nan')
         y, _ = _run(dense, x2, w, gy)
         assert torch.isnan(y[0, :, 3:6, 4:7]).all()
+
+
+@pytest.mark.parametrize('Ci,Co,k,H,W,B', [(256, 256, 3, 40, 56, 2), (64, 64, 3, 50, 70, 2), (1024, 256, 1, 50, 84, 2), (128, 512, 1, 33, 47, 3),
+                                           (64, 256, 1, 60, 80, 2), (576, 576, 3, 7, 7, 16)])
+def test_h2_weight_gradient_is_as_accurate_as_the_fp32_matrix_instructions(h2, Ci, Co, k, H, W, B):
+    """htd_conv2d_bwd_weight_h2 (conv_wgrad_x3d_kernel / conv_wgrad_x3hd_kernel with H2 = true): both operands are activations,
+    each scaled from its own tensor maximum; wide-dynamic-range data; error against fp64 relative to the accumulated magnitude."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(Ci + H + k)
+    x = (torch.randn(B, Ci, H, W, generator=g) * torch.exp(torch.randn(B, Ci, H, W, generator=g) * 2)).to(dev).contiguous(memory_format=CL)
+    gy = (torch.randn(B, Co, H, W, generator=g) * torch.exp(torch.randn(B, Co, H, W, generator=g) * 2) * 1e-3).to(dev).contiguous(memory_format=CL)
+    w = torch.zeros(Co, Ci, k, k, device=dev).contiguous(memory_format=CL)
+    if not h2.htd_conv2d_bwd_weight_h2_supported(B, H, W, Ci, Co, k, k, 1, k // 2, 1):
+        pytest.skip('layer not on the H2 weight-gradient kernels')
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), 1, k // 2)
+    mag = torch.nn.grad.conv2d_weight(x.double().abs(), w.shape, gy.double().abs(), 1, k // 2)
+    bref = gy.double().sum(dim=(0, 2, 3))
+    err = {}
+    for mode in ('native', 'h2'):
+        h2.htd_conv2d_set_math(0 if mode == 'native' else 1)
+        h2.htd_conv2d_set_h2(1 if mode == 'h2' else 0)
+        dense.new_step()
+        if mode == 'h2':                              # (1x1 layers take the arithmetic only when both maxima are carried)
+            dense.tag_amax(x, dense.absmax(x))
+            dense.tag_amax(gy, dense.absmax(gy))
+        calls = []
+        orig = dense.capi.call
+
+        def spy(name, *a, **kw):
+            calls.append(name)
+            return orig(name, *a, **kw)
+        dense.capi.call = spy
+        try:
+            gw, gb = dense._wgrad_raw(x, gy, w, 1, k // 2, 1, bias=True, overlap=False)
+        finally:
+            dense.capi.call = orig
+        assert ('htd_conv2d_bwd_weight_h2' in calls) == (mode == 'h2')
+        e = (gw.double() - ref).abs() / mag
+        err[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()))
+        torch.testing.assert_close(gb.double(), bref, rtol=1e-4, atol=1e-4 * float(bref.abs().max()))
+    n, h = err['native'], err['h2']
+    assert h[1] <= RMS_BOUND * n[1] and h[0] <= MAX_BOUND * n[0], (n, h)
+
+
+def test_h2_weight_gradient_accumulates_and_is_exact_on_integers(h2):
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(-30, 31, (2, 64, 17, 21), generator=g).float().to(dev).contiguous(memory_format=CL)
+    gy = torch.randint(-9, 10, (2, 128, 17, 21), generator=g).float().to(dev).contiguous(memory_format=CL)
+    for k in (1, 3):
+        w = torch.zeros(128, 64, k, k, device=dev).contiguous(memory_format=CL)
+        ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), 1, k // 2)
+        dense.new_step()
+        dense.tag_amax(x, dense.absmax(x))
+        dense.tag_amax(gy, dense.absmax(gy))
+        gw, _ = dense._wgrad_raw(x, gy, w, 1, k // 2, 1, overlap=False)
+        assert torch.equal(gw.double(), ref)
+        # accumulate form through the C-ABI: gw += the gradient
+        from htd_amd import capi
+        acc = gw.clone()
+        nbytes = h2.htd_conv2d_wgrad_workspace_bytes(2, 17, 21, 64, 128, k, k, 1, k // 2, 1)
+        ws = torch.empty(nbytes // 4 + 1, device=dev)
+        capi.call('htd_conv2d_bwd_weight_h2', capi.ptr(x), capi.ptr(gy), capi.ptr(dense.absmax(x)), capi.ptr(dense.absmax(gy)),
+                  capi.ptr(acc), None, 2, 17, 21, 64, 128, k, k, 1, k // 2, 1, 1, capi.ptr(ws), capi.current_stream_ptr())
+        assert torch.equal(acc.double(), 2 * ref)
