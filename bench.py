@@ -306,6 +306,7 @@ def main():
     everything = args.profile_kernels or args.profile_detail
     capi.profile_begin(detail=args.profile_detail, only=None if everything else (
         'htd_conv2d_fwd', 'htd_conv2d_bwd_data', 'htd_conv2d_fwd_x3p', 'htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_weight',
+        'htd_conv2d_fwd_x3h', 'htd_conv2d_bwd_data_x3h', 'htd_conv2d_bwd_weight_h2',
         'htd_bgemm_nt', 'htd_conv2d_fwd_bf16',
         'htd_conv2d_dgrad_bf16', 'htd_conv2d_bwd_weight_bf16'))
     exchange = getattr(trainer, 'exchange', None)
@@ -374,11 +375,21 @@ def main():
                                  PEAK_BF16_MFMA_TFLOPS)
     if roof and roof.get('bound') == 'mfma' and 'bf16' not in roof['kernel']:
         roof['peak'] = round(roof['peak'], 1)
-        roof['math'] = ('fp32 = 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits, fp32 accumulate; peak = 2500 / 6 '
-                        'algorithmic TFLOP/s (the fp32-input MFMA peak, 157.3, is not the bound of this kernel)') if x3 else \
-            'v_mfma_f32_32x32x2_f32'
-        roof['issued_bf16_tflops'] = round(roof['achieved'] * 6.0, 1) if x3 else None
-        roof['frac_of_fp32_input_mfma_peak'] = round(roof['achieved'] / PEAK_F32_MFMA_TFLOPS, 4)      # 157.3: last round's yardstick
+        h2 = 'H2 form' in roof['kernel']
+        if h2:
+            roof['math'] = ('fp32 = 3 x v_mfma_f32_32x32x16_f16 on two block-scaled fp16 pieces per operand (a0 b0 + a0 b1 + a1 b0), fp32 '
+                            'accumulate; peak = 2500 / 3 algorithmic TFLOP/s.  Under the socket power cap the matrix pipe alone sustains '
+                            '539 algorithmic TFLOP/s in this form and 284 in the six-product bf16 form (tools/micro/mfma_split_products.hip, '
+                            'profiles/r04_mfma_split_products.txt)')
+            roof['power_capped_matrix_pipe_tflops'] = 539.2
+            roof['frac_of_power_capped_matrix_pipe'] = round(roof['achieved'] / 539.2, 4)
+            roof['frac_of_six_product_bf16_roof'] = round(roof['achieved'] / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4)    # rounds 2-3's yardstick
+        else:
+            roof['math'] = ('fp32 = 6 x v_mfma_f32_32x32x16_bf16 on exact 3-way bf16 splits, fp32 accumulate; peak = 2500 / 6 '
+                            'algorithmic TFLOP/s (the fp32-input MFMA peak, 157.3, is not the bound of this kernel)') if x3 else \
+                'v_mfma_f32_32x32x2_f32'
+        roof['issued_bf16_tflops'] = round(roof['achieved'] * (3.0 if h2 else 6.0), 1) if x3 else None
+        roof['frac_of_fp32_input_mfma_peak'] = round(roof['achieved'] / PEAK_F32_MFMA_TFLOPS, 4)      # 157.3: round 1's yardstick
     # HBM bytes per launch of the dominant kernel class come from separate rocprofv3 PMC passes (FETCH_SIZE,
     # WRITE_SIZE; gfx950 read correction applied) whose summary is committed under profiles/
     try:

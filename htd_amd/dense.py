@@ -708,7 +708,7 @@ def _wgrad_launch(x, g, weight, stride, padding, dilation, bias, amax=None):
         work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci, 4.0 * (x.numel() + g.numel() + aw.numel()))
         if amax is not None:
             capi.call('htd_conv2d_bwd_weight_h2', _P(x), _P(g), _P(amax[0]), _P(amax[1]), _P(aw), _P(ab), B, H, W, Ci, Co, kh, kw,
-                      stride, padding, dilation, 1, _P(ws), _S(), key='htd_conv2d_bwd_weight', work=work)
+                      stride, padding, dilation, 1, _P(ws), _S(), work=work)
         else:
             capi.call('htd_conv2d_bwd_weight_acc', _P(x), _P(g), _P(aw), _P(ab), B, H, W, Ci, Co, kh, kw, stride, padding,
                       dilation, _P(ws), _S(), key='htd_conv2d_bwd_weight', work=work)
@@ -728,7 +728,7 @@ def _wgrad_launch(x, g, weight, stride, padding, dilation, bias, amax=None):
     work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci, 4.0 * (x.numel() + g.numel() + gw.numel()))
     if amax is not None:
         capi.call('htd_conv2d_bwd_weight_h2', _P(x), _P(g), _P(amax[0]), _P(amax[1]), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw,
-                  stride, padding, dilation, 0, _P(ws), _S(), key='htd_conv2d_bwd_weight', work=work)
+                  stride, padding, dilation, 0, _P(ws), _S(), work=work)
     else:
         capi.call('htd_conv2d_bwd_weight', _P(x), _P(g), _P(gw), _P(gb), B, H, W, Ci, Co, kh, kw, stride, padding,
                   dilation, _P(ws), _S(), work=work)
@@ -1522,8 +1522,14 @@ def roofline_report(prof, peak_tflops, peak_gbs, peak_bf16_tflops=2500.0):
     if parts:                                        # same for the bf16 kernel
         prof['conv_bf16_kernel (htd_conv2d_fwd_bf16 + htd_conv2d_dgrad_bf16)'] = (
             sum(p[0] for p in parts), sum(p[1] for p in parts), 'flop', sum(p[3] for p in parts), sum(p[4] for p in parts))
+    parts = [prof.pop(k) for k in ('htd_conv2d_fwd_x3h', 'htd_conv2d_bwd_data_x3h') if k in prof]
+    if parts:                                        # the same kernel on the H2 arithmetic (three fp16 products per fp32 product)
+        prof['conv_x3p_kernel, H2 form (htd_conv2d_fwd_x3h + htd_conv2d_bwd_data_x3h)'] = (
+            sum(p[0] for p in parts), sum(p[1] for p in parts), 'flop', sum(p[3] for p in parts), sum(p[4] for p in parts))
     if 'htd_conv2d_bwd_weight' in prof:
         prof['conv_wgrad_kernel + splitk_reduce_kernel (htd_conv2d_bwd_weight)'] = prof.pop('htd_conv2d_bwd_weight')
+    if 'htd_conv2d_bwd_weight_h2' in prof:
+        prof['conv_wgrad_x3d / x3hd kernels, H2 form + splitk_reduce_kernel (htd_conv2d_bwd_weight_h2)'] = prof.pop('htd_conv2d_bwd_weight_h2')
     best = None
     for name, (calls, ms, kind, work, nbytes) in prof.items():
         if kind is None or ms <= 0:
@@ -1536,6 +1542,8 @@ def roofline_report(prof, peak_tflops, peak_gbs, peak_bf16_tflops=2500.0):
     if kind == 'flop':
         if 'bf16' in name:                       # bf16 matrix-core peak for the bf16 kernels
             peak_tflops = peak_bf16_tflops
+        elif 'H2 form' in name:                  # three fp16 products per fp32 product: the 16-bit matrix peak / 3
+            peak_tflops = peak_bf16_tflops / 3.0
         achieved = work / (ms * 1e-3) / 1e12
         out = dict(kernel=name, bound='mfma', achieved=round(achieved, 3), peak=peak_tflops, unit='TFLOP/s',
                    frac=round(achieved / peak_tflops, 4), traffic=None, launches=calls,
