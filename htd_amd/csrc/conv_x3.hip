@@ -167,7 +167,7 @@ struct X3Params {
 
 // the block's largest stored magnitude -> *out, one atomic per workgroup.
 // Bits of non-negative floats order like unsigned integers; NaN sorts above everything and stays.
-__device__ __forceinline__ void block_absmax_out(float mx, float *out, float *red)
+__device__ __forceinline__ void block_absmax_out(float mx, float *out, float *red, unsigned seen)
 {
     unsigned bits = (mx != mx) ? 0x7fc00000u : __float_as_uint(mx);
     for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
@@ -177,16 +177,18 @@ __device__ __forceinline__ void block_absmax_out(float mx, float *out, float *re
     if (threadIdx.x == 0) {
         const unsigned *r = reinterpret_cast<const unsigned *>(red);
         bits = max(max(r[0], r[1]), max(r[2], r[3]));
-        // (no read of the scalar first: the workgroup would wait a memory round trip for it; the atomic returns nothing)
-        if (bits != 0u) __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // `seen`: what the scalar held when this workgroup looked (early, off the critical path; possibly stale, which costs one
+        // atomic more).  Thousands of atomics on ONE address serialise in the L2 -- 16 K of them took 30 us -- so a workgroup
+        // that cannot raise the maximum stays away; the atomic itself returns nothing and nobody waits for it.
+        if (bits > seen) __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // the same per wavefront, no barrier: for the short reduce kernels, whose workgroups live for one element per thread
-__device__ __forceinline__ void wave_absmax_out(float mx, float *out)
+__device__ __forceinline__ void wave_absmax_out(float mx, float *out, unsigned seen)
 {
     unsigned bits = (mx != mx) ? 0x7fc00000u : __float_as_uint(mx);
     for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
-    if ((threadIdx.x & 63) == 0 && bits != 0u)
+    if ((threadIdx.x & 63) == 0 && bits > seen)
         __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float absmax4(float mx, float4 v)
@@ -236,6 +238,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
     const bool vec_ok = (p.Co & 3) == 0;
     constexpr int V = BN / 4, RPP = 256 / V;
     float omax = 0.f;                                  // largest stored magnitude (X3Params::amax_out)
+    const unsigned oseen = (p.amax_out != nullptr && !part) ? *reinterpret_cast<const volatile unsigned *>(p.amax_out) : 0u;
     // H2: column n of the accumulators carries sa sb[n] (exact powers of two)
     const bool scaled = p.wscale != nullptr;
     float4 cscale = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -396,7 +399,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
         }
         if (i + 1 < TM) __syncthreads();
     }
-    if (p.amax_out != nullptr && !part) block_absmax_out(omax, p.amax_out, le);
+    if (p.amax_out != nullptr && !part) block_absmax_out(omax, p.amax_out, le, oseen);
 }
 
 // MF16: the products run on v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  Its 32 k per instruction carry TWO of
@@ -1085,6 +1088,7 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
     const int64_t na = p.m_rem0 * p.Co, nb = (p.M - p.m_rem0) * p.Co;
     const float *pb = p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * na : 0);
     float omax = 0.f;
+    const unsigned oseen = p.amax_out != nullptr ? *reinterpret_cast<const volatile unsigned *>(p.amax_out) : 0u;
     for (int64_t o = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < hi; o += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
         if (o < na) {
@@ -1111,7 +1115,8 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
         p.y[o] = v;
         omax = absmax4(omax, make_float4(v, 0.f, 0.f, 0.f));
     }
-    if (p.amax_out != nullptr) wave_absmax_out(omax, p.amax_out);
+    __shared__ float ored[4];
+    if (p.amax_out != nullptr) block_absmax_out(omax, p.amax_out, ored, oseen);
 }
 
 // the same for Co % 4 == 0, four channels per thread: float4 loads of the partials (independent across the ranges), 32-bit
@@ -1124,6 +1129,7 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_vec_kernel(X3Par
     const float4 *pa = reinterpret_cast<const float4 *>(p.partial);
     const float4 *pb = pa + (p.splits_a > 1 ? (int64_t)p.splits_a * na : 0);
     float omax = 0.f;
+    const unsigned oseen = p.amax_out != nullptr ? *reinterpret_cast<const volatile unsigned *>(p.amax_out) : 0u;
     for (int64_t q = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < hi; q += (int64_t)gridDim.x * blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool in_a = q < na;
@@ -1163,7 +1169,8 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_vec_kernel(X3Par
         omax = absmax4(omax, v);
         if (p.yp != nullptr) emit_planes4(p.yp, p.yp_rows, (int64_t)m, (int)n, v);
     }
-    if (p.amax_out != nullptr) wave_absmax_out(omax, p.amax_out);
+    __shared__ float ored[4];
+    if (p.amax_out != nullptr) block_absmax_out(omax, p.amax_out, ored, oseen);
 }
 
 // ---- weight planes --------------------------------------------------------------------------------------------------
@@ -1724,10 +1731,11 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     if (pl.partial_floats > 0) {
         const int64_t rows = (p.splits_a > 1 ? p.m_rem0 : 0) + (p.splits_b > 1 ? p.M - p.m_rem0 : 0);
         if ((p.Co & 3) == 0) {      // (the main kernel writes its partial rows with float4 stores under the same condition)
-            const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * (p.Co >> 2), 256), 4096);
+            // (with amax_out: one atomic per workgroup on one address -- fewer, longer workgroups)
+            const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * (p.Co >> 2), 256), p.amax_out ? 1024 : 4096);
             hipLaunchKernelGGL(conv_x3p_splitk_epilogue_vec_kernel, dim3(rb), dim3(256), 0, s, p);
         } else {
-            const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * p.Co, 256), 4096);
+            const unsigned rb = (unsigned)std::min<int64_t>(htd::ceil_div(rows * p.Co, 256), p.amax_out ? 1024 : 4096);
             hipLaunchKernelGGL(conv_x3p_splitk_epilogue_kernel, dim3(rb), dim3(256), 0, s, p);
         }
     }
