@@ -250,11 +250,17 @@ def new_step():
 _AMAX_POOL = {}
 _AMAX_SLOTS = 1024
 _H2_FLAGS = {}                 # device index -> one int32 word the H2 kernels set when an element left fp16's range
-# The 1x1 layers run on H2 only when the maximum of their input comes for free -- left behind by the epilogue that wrote the
-# tensor (X3Params::amax_out, carried on the tensor object as `_htd_amax`); a pass of htd_absmax over the input would cost a
-# 1x1 layer more than the arithmetic saves.  The 3x3 layers fall back to that pass.  HTD_H2_1X1=0: 3x3 layers only.
+# The maximum of a layer's input normally comes for free -- left behind by the epilogue that wrote the tensor (X3Params::amax_out,
+# carried on the tensor object as `_htd_amax`); where it does not, see H2_ABSMAX_MIN_WORK.  HTD_H2_1X1=0: 3x3 layers only.
 H2_1X1 = os.environ.get('HTD_H2_1X1', '1') != '0'
 H2_CHECK = os.environ.get('HTD_H2_CHECK', '0') == '1'        # tests: every carried maximum is compared with a fresh htd_absmax
+# A tensor that carries no maximum gets a pass of htd_absmax when every element of it goes into at least this many multiply-adds
+# of the launch (filter taps x the OTHER side's channels); below it the layer runs on the three-piece bf16 form.  Measured on the
+# train step (headline / trained-like ms, two alternating runs each): never 31.70 / 43.4, from 512 on (1x1 into >= 512 channels,
+# the FC layers) 32.33 / 41.7, from 2304 on (the 3x3 layers of >= 256 channels) 31.68 / 40.9.
+H2_ABSMAX_MIN_WORK = int(os.environ.get('HTD_H2_ABSMAX_MIN_WORK', '2304'))
+# ... and only for tensors of at least this many elements: below it the pass is a launch (8 us and a slot in the queue), not bytes
+H2_ABSMAX_MIN_ELEMS = int(os.environ.get('HTD_H2_ABSMAX_MIN_ELEMS', str(1 << 20)))
 
 
 def _x3h_ok(Cred, Cout, kh, kw, stride, padding, dilation, dtype):
@@ -303,6 +309,18 @@ def h2_check(device=None):
             f.zero_()
             raise RuntimeError('htd_amd: an H2 convolution was given a maximum smaller than its input tensor holds (stale _htd_amax); '
                                'its output contains infinities')
+
+
+H2_TRACE = {} if os.environ.get('HTD_H2_TRACE', '0') == '1' else None      # diagnostics: which 1x1 launches found no carried maximum
+
+
+def _h2_trace(what, t, weight):
+    if H2_TRACE is not None:
+        import traceback
+        fr = [f for f in traceback.extract_stack(limit=12) if 'dense.py' not in f.filename]
+        key = (what, tuple(t.shape), tuple(weight.shape), f'{os.path.basename(fr[-1].filename)}:{fr[-1].lineno}' if fr else '?',
+               'grad_fn' if t.grad_fn is not None else ('attr-stale' if hasattr(t, '_htd_amax') else 'no-attr'))
+        H2_TRACE[key] = H2_TRACE.get(key, 0) + 1
 
 
 def tag_amax(t, slot):
@@ -559,7 +577,9 @@ def _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up
         out_slot = _amax_slot(x.device) if h2 else None          # the epilogue leaves max |y| for the layer behind this one
         if h2:
             am = carried_amax(x)
-            if am is None and kh == 3:
+            if am is None:
+                _h2_trace('fwd', x, weight)
+            if am is None and kh * kw * Co >= H2_ABSMAX_MIN_WORK and x.numel() >= H2_ABSMAX_MIN_ELEMS:
                 am = absmax(x)
             if am is not None:
                 capi.call('htd_conv2d_fwd_x3h', _P(x), _P(am), _P(x3_planes(weight, False, True)), _P(bias), _P(residual), rh, rw,
@@ -632,7 +652,9 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
         out_slot = _amax_slot(g.device) if h2 else None
         if h2:
             am = carried_amax(g)
-            if am is None and kh == 3:
+            if am is None:
+                _h2_trace('dgrad', g, weight)
+            if am is None and kh * kw * Ci >= H2_ABSMAX_MIN_WORK and g.numel() >= H2_ABSMAX_MIN_ELEMS:
                 am = absmax(g)
             if am is not None:
                 capi.call('htd_conv2d_bwd_data_x3h', _P(g), _P(am), _P(x3_planes(weight, True, True)), _P(mask_src), _P(accum), _P(gx),
@@ -688,7 +710,12 @@ def _wgrad_amax(x, g, weight, stride, padding, dilation):
             not capi.lib().htd_conv2d_bwd_weight_h2_supported(B, H, W, Ci, Co, kh, kw, stride, padding, dilation):
         return None
     ax, ag = carried_amax(x), carried_amax(g)
-    if (ax is None or ag is None) and kh != 3:
+    if ax is None:
+        _h2_trace('wgrad x', x, weight)
+    if ag is None:
+        _h2_trace('wgrad g', g, weight)
+    if (ax is None and (kh * kw * Co < H2_ABSMAX_MIN_WORK or x.numel() < H2_ABSMAX_MIN_ELEMS)) or \
+            (ag is None and (kh * kw * Ci < H2_ABSMAX_MIN_WORK or g.numel() < H2_ABSMAX_MIN_ELEMS)):
         return None
     return (ax if ax is not None else absmax(x)), (ag if ag is not None else absmax(g))
 
