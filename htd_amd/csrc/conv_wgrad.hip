@@ -562,14 +562,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradParams p)
 // conv_wgrad_x3_kernel: the results are bit-identical.
 constexpr int XD_KS = 16;                      // pixels per K slice
 constexpr int XD_PLANE = XD_KS * X3_ROW;       // half-words per plane image
-constexpr int XD_BUF = 6 * XD_PLANE;           // three gy planes + three x planes
 
 // TM x TN 32x32 blocks per wave (2 x 2 waves): 128x128 tiles, or 64x128 / 128x64 for layers with 64 output or 64 reduction-side
 // channels (layer1, the stem), where half of a 128-wide tile would multiply zeros.  p.mt / p.nt count tiles of THIS shape; the
 // split count and the K ranges are those of the 128x128 form (same summation order, same bits).
 template <int PIX, int TM, int TN, bool H2 = false>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
+__global__ __launch_bounds__(256, (H2 && PIX == PIX_POINTWISE ? 3 : 2)) void conv_wgrad_x3d_kernel(WgradParams p)
 {
+    constexpr int NPL = H2 ? 2 : 3;             // planes per operand: H2 keeps two, 40 KB of LDS, three workgroups per CU
     constexpr int WGN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32;
     constexpr int VA = BM / 4, VB = BN / 4, PA = XD_KS * VA / 256, PB = XD_KS * VB / 256;      // float4 per thread, operand and slice
     static_assert(PA >= 1 && PB >= 1 && (H2 || (6 * TM * TN) % (2 * (PA + PB)) == 0), "whole MFMAs per split chunk");
@@ -578,7 +578,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
         const H2ScaleW a = h2w_scale(p.amax_g), b = h2w_scale(p.amax_x);
         sg = a.s; sg_inv = a.inv; sx = b.s; sx_inv = b.inv;
     }
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * XD_BUF];
+    constexpr int XD_BUFX = 2 * NPL * XD_PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * XD_BUFX];
 
     // Workgroup -> (tile, split).  Consecutive workgroups go to consecutive XCDs, each with its own L2:
     //   splits % 8 == 0: XCD x owns the splits = x (mod 8) -- all tiles of a K range on one XCD, both operands' rows of that
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
             bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;      // every tile (a branch would cut the loop body in two)
         }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) put(buf + 3 * XD_PLANE, b_row[i], b_col, qb[i], sx);
+        for (int i = 0; i < PB; ++i) put(buf + NPL * XD_PLANE, b_row[i], b_col, qb[i], sx);
     };
 
     f32x16 acc[TM][TN];
@@ -737,7 +738,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
     // instructions) and MPC MFMAs (eight chunks of three for the 128x128 tile), pinned in this order by sched_barrier: left to itself hipcc moves all MFMAs behind
     // all of the vector work, and the matrix pipe idles through the split as it did in conv_wgrad_x3_kernel
     auto half = [&](const unsigned short *rd, unsigned short *wr, float4 (&qa)[PA], float4 (&qb)[PB]) {
-        constexpr int NPL = H2 ? 2 : 3;             // planes per operand
         bf16x8w fa[TM][3], fb[TN][3];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) fb[j][q] = tr_frag(rd + (3 + q) * XD_PLANE, 0, wn * TN * 32 + j * 32, lane);
+            for (int q = 0; q < NPL; ++q) fb[j][q] = tr_frag(rd + (NPL + q) * XD_PLANE, 0, wn * TN * 32 + j * 32, lane);
         __builtin_amdgcn_sched_barrier(0);
         // smallest terms first, as conv_wgrad_x3_kernel; H2: a1 b0, a0 b1, a0 b0
         constexpr int QA[6] = {H2 ? 1 : 2, 0, H2 ? 0 : 1, 1, 0, 0}, QB[6] = {0, H2 ? 1 : 2, H2 ? 0 : 1, 0, 1, 0};
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
             } else {
                 if constexpr (H2) split2w(v.z * sc, v.w * sc, h[1], l[1]);
                 else split3x2w(v.z, v.w, h[1], m[1], l[1]);
-                unsigned short *d = (is_a ? wr + a_row[u] * X3_ROW + a_col : wr + 3 * XD_PLANE + b_row[u - PA] * X3_ROW + b_col);
+                unsigned short *d = (is_a ? wr + a_row[u] * X3_ROW + a_col : wr + NPL * XD_PLANE + b_row[u - PA] * X3_ROW + b_col);
                 *reinterpret_cast<uint2 *>(d) = make_uint2(h[0], h[1]);
                 if constexpr (H2) {
                     *reinterpret_cast<uint2 *>(d + XD_PLANE) = make_uint2(l[0], l[1]);
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3d_kernel(WgradParams p)
     };
 
     // set 0: slices 0, 2, 4 ...; set 1: slices 1, 3, 5 ...  (loads past k_end return zeros)
-    unsigned short *buf0 = lds, *buf1 = lds + XD_BUF;
+    unsigned short *buf0 = lds, *buf1 = lds + XD_BUFX;
     load_slice(ra[0], rb[0]);
     load_slice(ra[1], rb[1]);
     store_slice(buf0, ra[0], rb[0]);

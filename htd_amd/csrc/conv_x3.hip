@@ -92,6 +92,9 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned
 #ifndef HTD_X3P_EARLY
 #define HTD_X3P_EARLY 1
 #endif
+#ifndef HTD_X3H_OCC4
+#define HTD_X3H_OCC4 0          // 1: the 128x128 H2 tile at four workgroups per CU (128 VGPRs)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm()
@@ -414,26 +417,28 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
 // for inside the loop (cdna_hip_programming.md section 5, "Pipelining across barriers").  Small tiles, whose tap is a few
 // hundred matrix-pipe cycles, need the distance: with one tap of prefetch every tap waited for its weights (~1 us).
 // resident workgroups per CU (= waves per SIMD of a 4-wave workgroup): by registers 3 (128x128) or 4, by the 160 KB of LDS
-template <int WGM, int WGN, int TM, int TN, int KW, int NB>
+template <int WGM, int WGN, int TM, int TN, int KW, int NB, bool H2 = false>
 constexpr int x3p_occupancy()
 {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    constexpr int main_bytes = (2 * NCH * Geo<BM, KW>::PITCH + NB * NCH * BN) * 16;
+    constexpr int NCHL = H2 ? 4 : NCH;               // chunk arrays in LDS: H2 keeps two planes
+    constexpr int main_bytes = (2 * NCHL * Geo<BM, KW>::PITCH + NB * NCHL * BN) * 16;
     constexpr int epi_bytes = WGM * 32 * (BN + 4) * 4;
     constexpr int by_lds = 163840 / (main_bytes > epi_bytes ? main_bytes : epi_bytes);
-    constexpr int by_regs = TM * TN >= 4 ? 3 : 4;
+    constexpr int by_regs = TM * TN >= 4 ? (H2 && HTD_X3H_OCC4 ? 4 : 3) : 4;
     return by_lds < by_regs ? by_lds : by_regs;
 }
 
 template <int WGM, int WGN, int TM, int TN, int KW, bool MF16, int NB, bool H2 = false>
-__global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) void conv_x3p_kernel(X3Params p)
+__global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>())) void conv_x3p_kernel(X3Params p)
 {
     static_assert(!(H2 && MF16), "H2: 32x32x16 form only");
+    constexpr int NCHL = H2 ? 4 : NCH;               // chunk arrays per LDS tile (the weight image in memory always has NCH)
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     using G = Geo<BM, KW>;
     constexpr int PADX = (KW - 1) / 2;
-    constexpr int A_VEC = NCH * G::PITCH;                         // uint4 per A buffer
-    constexpr int B_VEC = NCH * BN;                               // uint4 per B buffer
+    constexpr int A_VEC = NCHL * G::PITCH;                        // uint4 per A buffer
+    constexpr int B_VEC = NCHL * BN;                              // uint4 per B buffer
     constexpr int MAIN_VEC = 2 * A_VEC + NB * B_VEC;
     constexpr int EPI_STRIDE = BN + 4, EPI_ROWS = WGM * 32;
     constexpr int EPI_VEC = EPI_ROWS * EPI_STRIDE / 4;
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB>())) v
     const int s_end = part ? min(total_steps, s_begin + sps) : total_steps;
 
     // zero rows of both A buffers (never overwritten: the staging writes rows < RUN only)
-    if (tid < 2 * NCH) lA[(tid / NCH) * A_VEC + (tid % NCH) * G::PITCH + G::RUN] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 2 * NCHL) lA[(tid / NCHL) * A_VEC + (tid % NCHL) * G::PITCH + G::RUN] = make_uint4(0u, 0u, 0u, 0u);
 
     // ---- A staging registers.  A pass (64 rows x one float4 per thread) is IN FLIGHT FOR A WHOLE TAP: issued at the start of
     // one tap, waited for and split into LDS at the end of the NEXT one, so the matrix work of two taps (and of the

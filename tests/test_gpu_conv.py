@@ -151,10 +151,11 @@ def test_fpn_fused_top_down_matches_interpolate_add():
         res.append(([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
                     {n: p.grad.clone() for n, p in fpn.named_parameters()}))
     (o1, g1, p1), (o2, g2, p2) = res
+    # (the two formulations need not run a layer on the same product arithmetic -- H2 where the input carries its maximum: the fused
+    # laterals' outputs do, the sum torch makes in the unfused module does not and is too small for a pass of its own; the
+    # three-piece bf16 form elsewhere: both fp32-accurate, not bit-equal)
     for a, b in zip(o1, o2):
-        assert torch.equal(a, b)
-    # (the two formulations need not run the lateral layers' data gradient on the same product arithmetic -- H2 where the
-    # gradient map carries its maximum, the three-piece bf16 form where it does not: both fp32-accurate, not bit-equal)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
     for a, b in zip(g1, g2):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=4e-5)
     for n in p2:

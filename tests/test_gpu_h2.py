@@ -28,8 +28,13 @@ def h2():
 
 
 def _run(dense, x, w, gy, bias=None):
+    """Forward + data gradient with both inputs carrying their maxima (as tensors written by the package's epilogues do): small or
+    light layers take H2 only then (dense.H2_ABSMAX_MIN_WORK / _MIN_ELEMS)."""
     dense.new_step()
     xr = x.clone().requires_grad_()
+    gy = gy.clone()
+    dense.tag_amax(xr, dense.absmax(xr))
+    dense.tag_amax(gy, dense.absmax(gy))
     y = dense.conv2d(xr, w, bias, 1, 1, 1)
     y.backward(gy)
     return y.detach(), xr.grad
