@@ -139,7 +139,7 @@ def call(name, *args, work=None, key=None):
         return
     import torch
     if _DETAIL:
-        key = name + '(' + ','.join(str(a) for a in args if isinstance(a, int) and not isinstance(a, bool)) + ')'
+        key = key + '(' + ','.join(str(a) for a in args if isinstance(a, int) and not isinstance(a, bool)) + ')'
         # which pointer operands are present (residual / mask / accum select epilogue variants): 1 = given, 0 = NULL
         key += '[' + ''.join('0' if a is None else '1' for a in args if a is None or isinstance(a, ctypes.c_void_p)) + ']'
     rec = _PROFILE.setdefault(key, dict(events=[], kind=None, work=0.0, bytes=0.0))

@@ -1694,7 +1694,7 @@ void launch_tile_q(const X3Params &p, dim3 grid, hipStream_t s)
 int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
 {
     const int total_steps = p.ncs * p.kh;
-    const int epi = (p.residual ? 1 : 0) | (p.mask_src ? 2 : 0);
+    const int epi = (p.residual ? 1 : 0) | (p.mask_src ? 2 : 0) | (p.amax ? 4 : 0);          // bit 2: the H2 kernels have their own entries
     const int cfg = choose_cfg(p.M, p.Co, p.Ci, p.kh * kw, epi);
     const XPlan pl = plan_x3p(cfg, p.M, p.Co, total_steps, kw, workspace != nullptr);
     p.tiles_a = pl.tiles_a; p.splits_a = pl.splits_a; p.sps_a = pl.sps_a; p.splits_b = pl.splits_b; p.sps_b = pl.sps_b;
@@ -1777,10 +1777,10 @@ extern "C" int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stri
 }
 
 // Tuned tile table of conv_x3p_kernel (see choose_cfg).  cfg: 0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases the entry.
-// epi: bit 0 = residual / accum operand present, bit 1 = mask_src present.
+// epi: bit 0 = residual / accum operand present, bit 1 = mask_src present, bit 2 = the launch runs on the H2 arithmetic.
 extern "C" int htd_conv2d_x3p_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg)
 {
-    HTD_REQUIRE(M > 0 && Co > 0 && Ci > 0 && taps > 0 && epi >= 0 && epi < 4 && cfg < 4,
+    HTD_REQUIRE(M > 0 && Co > 0 && Ci > 0 && taps > 0 && epi >= 0 && epi < 8 && cfg < 4,
                 "x3p_tile_table_set: bad entry M=%lld Co=%d Ci=%d taps=%d epi=%d cfg=%d", (long long)M, Co, Ci, taps, epi, cfg);
     std::lock_guard<std::mutex> lock(g_xtable_mutex);
     if (cfg < 0) g_xtable.erase(XKey{M, Co, Ci, taps, epi});

@@ -290,7 +290,8 @@ int htd_conv2d_stem7_fwd(const float *x, const float *w, const float *bias, floa
  *       Same arithmetic as the default mode of those (six bf16 MFMAs on exact three-way splits, fp32 accumulation). */
 int htd_conv2d_x3p_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
 /* Tile table of conv_x3p_kernel, as htd_conv2d_tile_table_set for conv_igemm_kernel: problem (M, Co, Ci, taps, epi) ->
- * configuration id (0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases).  htd_amd/tuning loads the table measured on
+ * configuration id (0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases); epi bit 0: residual / accum operand, bit 1: mask_src,
+ * bit 2: the launch runs on the H2 arithmetic (its own entries).  htd_amd/tuning loads the table measured on
  * MI355X by tools/tune_conv_tiles.py --kernel x3p (cudnn_benchmark's role, mmdet/apis/train.py). */
 int htd_conv2d_x3p_tile_table_set(int64_t M, int Co, int Ci, int taps, int epi, int cfg);
 int htd_conv2d_x3p_tile_table_clear(void);

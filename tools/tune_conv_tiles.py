@@ -21,21 +21,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-KEY = re.compile(r'^(htd_conv2d_fwd|htd_conv2d_bwd_data|htd_conv2d_fwd_x3p|htd_conv2d_bwd_data_x3p)\(([-\d,]+)\)\[([01]+)\]$')
+KEY = re.compile(r'^(htd_conv2d_fwd|htd_conv2d_bwd_data|htd_conv2d_fwd_x3p|htd_conv2d_bwd_data_x3p|htd_conv2d_fwd_x3h|htd_conv2d_bwd_data_x3h)'
+                 r'\(([-\d,]+)\)\[([01]+)\]$')
 
 
 def signature(name, ints, mask):
     """(M, Co, Ci, taps, epi) as conv_fwd.hip::launch_conv keys the launch, or None when the table does not apply."""
-    # (calls of htd_conv2d_fwd_x3q / _bwd_data_x3q are accounted under the x3p names, dense.py; they carry two more pointer slots:
-    #  x, xplanes, wplanes, bias, residual, y, yplanes, ws, stream  /  gy, gyplanes, wplanesT, mask_src, accum, gx, gxplanes, ws, stream)
-    q = len(mask) == 9
-    if name == 'htd_conv2d_fwd_x3p':         # conv_x3.hip::launch_x3p
+    # (calls of htd_conv2d_fwd_x3q / _bwd_data_x3q are accounted under the x3p names, dense.py.  Pointer slots:
+    #  x3q  x, xplanes, wplanes, bias, residual, y, yplanes, amax_out, ws, stream  /  gy, gyplanes, wplanesT, mask_src, accum, gx, ...
+    #  x3h  x, amax, wplanes, bias, residual, y, yplanes, amax_out, h2_flag, ws, stream  /  gy, amax, wplanesT, mask_src, accum, gx, ...
+    #  x3p  x, wplanes, bias, residual, y, ws, stream  /  gy, wplanesT, mask_src, accum, gx, ws, stream)
+    q = len(mask) >= 9
+    h2 = 4 if name.endswith('x3h') else 0    # table key bit 2: the launch runs on the H2 arithmetic
+    if name in ('htd_conv2d_fwd_x3p', 'htd_conv2d_fwd_x3h'):         # conv_x3.hip::launch_x3p
         res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, relu = ints
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-        return (B * Ho * Wo, Co, Ci, kh * kw, int(mask[4 if q else 3] == '1'))
-    if name == 'htd_conv2d_bwd_data_x3p':
+        return (B * Ho * Wo, Co, Ci, kh * kw, int(mask[4 if q else 3] == '1') | h2)
+    if name in ('htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_data_x3h'):
         B, H, W, Ci, Co, kh, kw, pad = ints
-        return (B * H * W, Ci, Co, kh * kw, int(mask[4 if q else 3] == '1') | (int(mask[3 if q else 2] == '1') << 1))
+        return (B * H * W, Ci, Co, kh * kw, int(mask[4 if q else 3] == '1') | (int(mask[3 if q else 2] == '1') << 1) | h2)
     if name == 'htd_conv2d_fwd':
         res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, dil, relu = ints
         Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
@@ -88,7 +92,8 @@ def main():
             trainer.train_step(data)
 
     x3p = args.kernel == 'x3p'
-    only = ('htd_conv2d_fwd_x3p', 'htd_conv2d_bwd_data_x3p') if x3p else ('htd_conv2d_fwd', 'htd_conv2d_bwd_data')
+    only = ('htd_conv2d_fwd_x3p', 'htd_conv2d_bwd_data_x3p', 'htd_conv2d_fwd_x3h', 'htd_conv2d_bwd_data_x3h') if x3p else \
+        ('htd_conv2d_fwd', 'htd_conv2d_bwd_data')
     ids = (0, 1, 2, 3) if x3p else (0, 2, 3, 4, 5)
     force = 'HTD_X3P_FORCE_TILE' if x3p else 'HTD_CONV_FORCE_TILE'
     query = L.htd_conv2d_x3p_tile_query if x3p else L.htd_conv2d_tile_query
