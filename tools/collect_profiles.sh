@@ -12,6 +12,7 @@ B="python3 $R/bench.py"
 echo "== bench lines"
 $B --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 HTD_CONV_MATH=0 $B --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_fp32mfma.json 2>/dev/null
+HTD_CONV_H2=0 $B --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_bf16x6.json 2>/dev/null          # round 3's arithmetic everywhere
 $B --steps 20 --warmup 5 --no-cpu-baseline --trained-like --trained-like-steps 0 > $OUT/bench_trained_like.json 2>/dev/null
 $B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 > $OUT/bench_r101.json 2>/dev/null
 $B --steps 20 --warmup 5 --no-cpu-baseline --depth 101 --bf16 > $OUT/bench_r101_bf16.json 2>/dev/null
@@ -59,5 +60,10 @@ python3 $R/tools/bench_roi_align.py 512 4 --ba > $OUT/roi_align_ba_512.log 2>&1
 echo "== round 4: plane-fed 1x1 layers, bf16 LDS-DMA kernel"
 HTD_X3P_TUNE=1 python3 $R/tools/bench_planes.py > $OUT/bench_planes.log 2>&1
 HTD_BF16Q_TUNE=1 python3 $R/tools/bench_conv_bf16.py > $OUT/bench_conv_bf16q.log 2>&1
+echo "== round 4: H2 arithmetic"
+$R/tools/micro/mfma_split_products.bin > $OUT/mfma_split_products.txt 2>&1
+python3 $R/tools/x3_accuracy.py > $OUT/x3_accuracy.log 2>&1
+python3 $R/tools/h2_loss_trajectory.py 80 > $OUT/h2_loss_trajectory.txt 2>&1
+python3 $R/tools/h2_trace.py > $OUT/h2_trace.txt 2>&1
 python3 $R/tools/summarize_collection.py $OUT > $OUT/summary.txt 2>&1
 ls -la $OUT

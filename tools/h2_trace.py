@@ -1,6 +1,6 @@
 import os, sys
 os.environ['HTD_H2_TRACE'] = '1'
-sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/htd_amd') else os.environ.get('GRAFT_REPO_ROOT', '.'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from htd_amd import dense
 from htd_amd.configs import build_htd_detector

@@ -6,8 +6,10 @@ import os
 import sys
 
 d = sys.argv[1]
-for f in ('bench.json', 'bench_fp32mfma.json', 'bench_trained_like.json', 'bench_r101.json', 'bench_r101_bf16.json', 'bench_r101_dcn.json',
+for f in ('bench.json', 'bench_bf16x6.json', 'bench_fp32mfma.json', 'bench_trained_like.json', 'bench_r101.json', 'bench_r101_bf16.json', 'bench_r101_dcn.json',
           'bench_r101_dcn_bf16.json', 'bench_infer_r101_b64.json', 'bench_infer_r101_b64_bf16.json'):
+    if not os.path.exists(os.path.join(d, f)):
+        continue
     b = json.loads([l for l in open(os.path.join(d, f)) if l.startswith('{')][-1])
     r = b.get('roofline') or {}
     print(f"{f:34s} {b['value']:8.2f} img/s {b['ms_per_step']:8.2f} ms  {r.get('kernel', '')[:22]:22s} {r.get('achieved')} {r.get('frac')} "
