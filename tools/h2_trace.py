@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Which convolution launches of a train step found no carried maximum on their input (dense.carried_amax) -- and so took a pass of
+htd_absmax or stayed on the three-piece bf16 form.  One line per (kind, tensor shape, weight shape, provenance)."""
 import os, sys
 os.environ['HTD_H2_TRACE'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
