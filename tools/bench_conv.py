@@ -44,13 +44,19 @@ def timeit(fn, n=5):
 def device_rates(x, w, g, s, p, flop, n=8):
     """TF/s of the three C-ABI entry points from device events around each call (capi profile)."""
     xg, wg = x.clone().requires_grad_(), w.clone().requires_grad_()
+    if capi.lib().htd_conv2d_set_h2(-1) == 1 and x.dtype == torch.float32:
+        # inside the step a layer's input and gradient carry their maxima (left by the epilogues that wrote them): the same here, so
+        # that the table shows the arithmetic the step runs (H2 where the kernels have it)
+        g = g.clone()
+        dense.tag_amax(xg, dense.absmax(xg))
+        dense.tag_amax(g, dense.absmax(g))
     for it in range(n + 20):                 # 20 untimed iterations first: an idle device needs milliseconds to raise its clocks
         if it == 20:
             capi.profile_begin()
         dense.conv2d(xg, wg, None, s, p, 1).backward(g)
     prof = capi.profile_end()
     out = []
-    for ks in (('htd_conv2d_fwd_x3h', 'htd_conv2d_fwd_x3p', 'htd_conv2d_fwd'), ('htd_conv2d_bwd_data_x3h', 'htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_data'), ('htd_conv2d_bwd_weight', )):
+    for ks in (('htd_conv2d_fwd_x3h', 'htd_conv2d_fwd_x3p', 'htd_conv2d_fwd'), ('htd_conv2d_bwd_data_x3h', 'htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_data'), ('htd_conv2d_bwd_weight_h2', 'htd_conv2d_bwd_weight')):
         k = next(k for k in ks if k in prof)          # conv_x3p_kernel where it takes the layer, conv_igemm_kernel otherwise
         calls = max(prof[k][0] for k in ks if k in prof)
         ms = sum(prof[k][1] for k in ks if k in prof)

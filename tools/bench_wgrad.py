@@ -58,24 +58,30 @@ def main():
         layers = [l for l in POINTWISE + OTHER if key in l[0]]
     capi.lib()
     dev = torch.device('cuda', 0)
-    print(f'{"layer":28s} {"us":>9s} {"TF/s":>8s}  crc32(gw) crc32(gb)')
+    print(f'{"layer":34s} {"us":>9s} {"TF/s":>8s}  crc32(gw) crc32(gb)')
     for name, B, Ci, H, W, Co, k, s, p in layers:
         g0 = torch.Generator(device='cpu').manual_seed(1234)
         x = torch.randn(B, Ci, H, W, generator=g0).to(dev).contiguous(memory_format=CL)
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         gy = torch.randn(B, Co, Ho, Wo, generator=g0).to(dev).contiguous(memory_format=CL)
         w = torch.empty(Co, Ci, k, k, device=dev).contiguous(memory_format=CL)
+        # inside the step both operands carry their maxima (left by the epilogues that wrote them): the same here, so that the table
+        # shows the arithmetic the step runs -- H2 where the kernels have it (HTD_CONV_H2=0 / HTD_H2_WGRAD=0: the bf16 form)
+        dense.tag_amax(x, dense.absmax(x))
+        dense.tag_amax(gy, dense.absmax(gy))
+        amax = dense._wgrad_amax(x, gy, w, s, p, 1)
         for it in range(45):                 # 25 launches first: the clocks of an idle device take milliseconds to come up
             if it == 25:
                 capi.profile_begin()
-            gw, gb = dense._wgrad_launch(x, gy, w, s, p, 1, True)[:2]
+            gw, gb = dense._wgrad_launch(x, gy, w, s, p, 1, True, amax)[:2]
         prof = capi.profile_end()
-        n, ms = prof['htd_conv2d_bwd_weight'][:2]
+        n, ms = prof['htd_conv2d_bwd_weight_h2' if 'htd_conv2d_bwd_weight_h2' in prof else 'htd_conv2d_bwd_weight'][:2]
+        name = name + (' [H2]' if amax is not None else '')
         us = ms / n * 1e3
         flop = 2.0 * B * Ho * Wo * Co * k * k * Ci
         crc_w = zlib.crc32(gw.detach().cpu().contiguous(memory_format=CL).numpy().tobytes())
         crc_b = zlib.crc32(gb.detach().cpu().numpy().tobytes())
-        print(f'{name:28s} {us:9.1f} {flop / us / 1e6:8.1f}  {crc_w:08x} {crc_b:08x}')
+        print(f'{name:34s} {us:9.1f} {flop / us / 1e6:8.1f}  {crc_w:08x} {crc_b:08x}')
 
 
 if __name__ == '__main__':
