@@ -261,3 +261,66 @@ def test_h2_weight_gradient_accumulates_and_is_exact_on_integers(h2):
         capi.call('htd_conv2d_bwd_weight_h2', capi.ptr(x), capi.ptr(gy), capi.ptr(dense.absmax(x)), capi.ptr(dense.absmax(gy)),
                   capi.ptr(acc), None, 2, 17, 21, 64, 128, k, k, 1, k // 2, 1, 1, capi.ptr(ws), capi.current_stream_ptr())
         assert torch.equal(acc.double(), 2 * ref)
+
+
+def test_carried_maximum_contract(h2):
+    """dense.tag_amax / carried_amax: the tag is a Python attribute on the tensor OBJECT and is honoured only while address, size and
+    torch's version counter are what they were -- an in-place torch op voids it, a view or a copy never had it, drop_amax removes it
+    (for kernels that write behind torch's back), and it survives autograd's Function.apply and the save_for_backward of an intermediate (same object)."""
+    from htd_amd import dense
+    dev = torch.device('cuda:0')
+    dense.new_step()
+    x = torch.randn(2, 64, 9, 11, device=dev).contiguous(memory_format=CL)
+    w = torch.randn(64, 64, 3, 3, device=dev).contiguous(memory_format=CL) * 0.05
+    dense.tag_amax(x, dense.absmax(x))
+    y = dense._fwd_raw(x, w, None, None, 1, 1, 1, True)
+    am = dense.carried_amax(y)                                # left by the epilogue
+    assert am is not None and float(am) == float(y.abs().max())
+    assert dense.carried_amax(y.view_as(y)) is None and dense.carried_amax(y.clone()) is None
+    y.mul_(2.0)                                               # torch's version counter moved: stale
+    assert dense.carried_amax(y) is None
+    y2 = dense._fwd_raw(x, w, None, None, 1, 1, 1, True)
+    dense.drop_amax(y2)
+    assert dense.carried_amax(y2) is None
+
+    class Pass(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            mid = dense._fwd_raw(t, w, None, None, 1, 1, 1, True)         # an intermediate, saved as it is
+            out = dense._fwd_raw(mid, w, None, None, 1, 1, 1, False)
+            ctx.save_for_backward(mid, out)
+            return out
+
+        @staticmethod
+        def backward(ctx, g):
+            mid, out = ctx.saved_tensors
+            # (a saved OUTPUT is re-wrapped by autograd when it is unpacked -- a new object, no tag: the safe direction)
+            Pass.seen = (dense.carried_amax(mid) is not None, dense.carried_amax(out) is not None)
+            return g
+    xr = x.clone().requires_grad_()
+    dense.tag_amax(xr, dense.absmax(xr))
+    out = Pass.apply(xr)
+    assert dense.carried_amax(out) is not None
+    out.sum().backward()
+    assert Pass.seen[0] and Pass.seen in ((True, False), (True, True))
+    dense.new_step()
+
+
+def test_stale_maximum_is_caught_by_the_guard(h2, monkeypatch):
+    """A maximum that is NOT the tensor's (a caller's bug) puts infinities into the output; with the guard on (HTD_H2_GUARD / check
+    mode) the kernel raises the device flag and dense.h2_check() fails loudly."""
+    from htd_amd import capi, dense
+    dev = torch.device('cuda:0')
+    monkeypatch.setattr(dense, 'H2_GUARD', True)
+    dense.new_step()
+    x = torch.randn(1, 64, 16, 16, device=dev).contiguous(memory_format=CL)
+    w = torch.randn(64, 64, 3, 3, device=dev).contiguous(memory_format=CL) * 0.05
+    wrong = dense.absmax(x * 1e-3)                            # a thousand times too small
+    dense.tag_amax(x, wrong)
+    dense.h2_check()                                          # clean so far
+    y = dense._fwd_raw(x, w, None, None, 1, 1, 1, False)
+    assert not torch.isfinite(y).all()
+    with pytest.raises(RuntimeError, match='stale'):
+        dense.h2_check()
+    dense.h2_check()                                          # the flag was cleared
+    dense.new_step()
