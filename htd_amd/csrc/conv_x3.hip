@@ -161,11 +161,10 @@ struct X3Params {
     // 1 / sb[n] ([Cop] floats behind the planes).  NULL: the six-product bf16 form.
     const float *amax, *wscale;
     // amax_out != NULL: the epilogue also leaves max |y| of the values it stores in this device scalar (zero, or an earlier maximum,
-    // on entry) -- the `amax` of whoever consumes y on the H2 arithmetic, without a pass over y.
-    // h2_flag: set to 1 by an H2 launch that met a scaled element beyond fp16's range, i.e. an `amax` that was NOT the tensor's
-    // maximum (a caller's bug: the result then holds infinities); the host checks it once in a while and fails loudly.
+    // on entry) -- the `amax` of whoever consumes y on the H2 arithmetic, without a pass over y.  (An `amax` that was NOT the
+    // tensor's maximum -- a caller's bug -- overflows fp16 in the split, the output holds infinities and amax_out says so: NaN / inf
+    // from a finite input maximum is what dense.h2_check() looks for.)
     float *amax_out;
-    unsigned *h2_flag;
 };
 
 // the block's largest stored magnitude -> *out, one atomic per workgroup.
@@ -566,7 +565,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
 #pragma unroll
     for (int i = 0; i < 2 * NPT; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned ra_ok = 0u;
-    float h2s = 1.f, h2big = 0.f;                     // h2big: the largest scaled magnitude this thread split (overflow check)
+    float h2s = 1.f;
     if constexpr (H2) h2s = h2_scale(p.amax).s;
     // (no divisions inside the K loop: the step's channel slice / filter row and the prefetch pointers advance incrementally)
     auto load_pass = [&](int shift, int koff, int i, int slot, bool live) __attribute__((always_inline)) {   // pass i of the run at pixel shift `shift`
@@ -602,10 +601,8 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
         const unsigned d = lds_a0 + (unsigned)(buf * A_VEC * 16 + ((vcol >> 1) * G::PITCH + j) * 16 + (vcol & 1) * 8);
         if constexpr (H2) {
             unsigned h0, l0, h1, l1;
-            const float t0 = v.x * h2s, t1 = v.y * h2s, t2 = v.z * h2s, t3 = v.w * h2s;
-            if (p.h2_flag != nullptr) h2big = fmaxf(h2big, fmaxf(fmaxf(fabsf(t0), fabsf(t1)), fmaxf(fabsf(t2), fabsf(t3))));
-            split2hx2(t0, t1, h0, l0);
-            split2hx2(t2, t3, h1, l1);
+            split2hx2(v.x * h2s, v.y * h2s, h0, l0);
+            split2hx2(v.z * h2s, v.w * h2s, h1, l1);
             lds_store8<0>(d, h0, h1);
             lds_store8<2 * G::PITCH * 16>(d, l0, l1);
         } else {
@@ -883,11 +880,6 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
 #pragma unroll
     for (int i = 0; i < 2 * NPT; ++i) landed(ra[i]);
 
-    if constexpr (H2) {
-        // a finite element that left fp16's range: `amax` was not the tensor's maximum (infinities and NaNs of the INPUT are the
-        // caller's data and propagate like in fp32)
-        if (h2big > 65504.f && h2big < __builtin_inff() && p.h2_flag != nullptr) atomicOr(p.h2_flag, 1u);
-    }
     x3_epilogue<WGM, WGN, TM, TN, MF16>(p, acc, lds, m0, n0, part, region_b, split);
 }
 
@@ -1995,8 +1987,8 @@ extern "C" int htd_conv2d_bwd_data_x3p(const float *gy, const void *wplanesT, co
 // The 3x3 layers on the H2 arithmetic (two fp16 pieces per operand, three matrix instructions per product block instead of six;
 // see h2_scale above).  amax: device scalar >= max |x| of the whole input tensor (htd_absmax); wplanes: htd_conv2d_x3h_planes.
 extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void *wplanes, const float *bias, const float *residual,
-                                  int res_h, int res_w, float *y, void *yplanes, float *amax_out, void *h2_flag, int B, int H, int W,
-                                  int Ci, int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream)
+                                  int res_h, int res_w, float *y, void *yplanes, float *amax_out, int B, int H, int W, int Ci,
+                                  int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream)
 {
     HTD_REQUIRE(!yplanes || Co % XK == 0, "conv2d_fwd_x3h: output planes need Co %% 16 == 0 (Co=%d)", Co);
     HTD_REQUIRE(x && amax && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3h: bad arguments");
@@ -2015,7 +2007,7 @@ extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void 
     p.amax = amax;
     p.wscale = reinterpret_cast<const float *>(p.wp + planes_vec(kh * kw, Ci, p.Cop));
     p.yp = (uint4 *)yplanes; p.yp_rows = act_rows(p.M);
-    p.amax_out = amax_out; p.h2_flag = (unsigned *)h2_flag;
+    p.amax_out = amax_out;
     HTD_REQUIRE((int64_t)B * H * W * Ci < (1ll << 31) && p.M * Co < (1ll << 40), "conv2d_fwd_x3h: operand too large");
     if (res_h > 0) {
         p.res_H = res_h; p.res_W = res_w;
@@ -2025,8 +2017,8 @@ extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void 
 }
 
 extern "C" int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const void *wplanesT, const float *mask_src,
-                                       const float *accum, float *gx, void *gxplanes, float *amax_out, void *h2_flag, int B, int H,
-                                       int W, int Ci, int Co, int kh, int kw, int pad, void *workspace, void *stream)
+                                       const float *accum, float *gx, void *gxplanes, float *amax_out, int B, int H, int W,
+                                       int Ci, int Co, int kh, int kw, int pad, void *workspace, void *stream)
 {
     HTD_REQUIRE(!gxplanes || Ci % XK == 0, "conv2d_bwd_data_x3h: output planes need Ci %% 16 == 0 (Ci=%d)", Ci);
     HTD_REQUIRE(gy && amax && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3h: bad arguments");
@@ -2041,7 +2033,7 @@ extern "C" int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const
     p.amax = amax;
     p.wscale = reinterpret_cast<const float *>(p.wp + planes_vec(kh * kw, Co, p.Cop));
     p.yp = (uint4 *)gxplanes; p.yp_rows = act_rows(p.M);
-    p.amax_out = amax_out; p.h2_flag = (unsigned *)h2_flag;
+    p.amax_out = amax_out;
     HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3h: operand too large");
     return launch_x3p(p, kw, (hipStream_t)stream, workspace);
 }

@@ -249,7 +249,6 @@ def new_step():
 # (one fill per step, no host read).  Never cached per tensor: the allocator hands the same address to different tensors.
 _AMAX_POOL = {}
 _AMAX_SLOTS = 1024
-_H2_FLAGS = {}                 # device index -> one int32 word the H2 kernels set when an element left fp16's range
 # The maximum of a layer's input normally comes for free -- left behind by the epilogue that wrote the tensor (X3Params::amax_out,
 # carried on the tensor object as `_htd_amax`); where it does not, see H2_ABSMAX_MIN_WORK.  HTD_H2_1X1=0: 3x3 layers only.
 H2_1X1 = os.environ.get('HTD_H2_1X1', '1') != '0'
@@ -285,30 +284,31 @@ def absmax(x):
     return slot
 
 
-# HTD_H2_GUARD=1 (and the check mode): every H2 launch also verifies that no finite element left fp16's range and raises the
-# device flag if one did (h2_check()).  Off by default: two more vector instructions per staged float4, and an overflow is not
-# silent anyway -- it puts infinities into the layer's output and a NaN into the loss.
+# HTD_H2_GUARD=1 (and the check mode): every H2 launch is remembered as (maximum it was given, maximum its epilogue left), and
+# dense.h2_check() -- a device read -- raises when an output maximum is NaN / inf although the input's was finite: the input
+# maximum was not the tensor's (a stale `_htd_amax`), the split overflowed fp16.  Off by default (an overflow is not silent
+# anyway: infinities in the output, NaN in the loss).
 H2_GUARD = H2_CHECK or os.environ.get('HTD_H2_GUARD', '0') == '1'
+_H2_LAUNCHES = []
 
 
-def h2_flag(device):
-    if not H2_GUARD:
-        return None
-    f = _H2_FLAGS.get(device.index)
-    if f is None:
-        f = _H2_FLAGS[device.index] = torch.zeros(1, device=device, dtype=torch.int32)
-    return f
+def _h2_guard(am_in, out_slot):
+    if H2_GUARD and out_slot is not None:
+        _H2_LAUNCHES.append((am_in, out_slot))
 
 
 def h2_check(device=None):
-    """Raise if an H2 launch since the last call met an element beyond its tensor's `amax` (reads the device: a sync)."""
-    for idx, f in list(_H2_FLAGS.items()):
-        if device is not None and idx != device.index:
-            continue
-        if int(f.item()) != 0:
-            f.zero_()
-            raise RuntimeError('htd_amd: an H2 convolution was given a maximum smaller than its input tensor holds (stale _htd_amax); '
-                               'its output contains infinities')
+    """Raise if an H2 launch since the last call (guard mode) overflowed: see H2_GUARD.  Reads the device."""
+    pairs, _H2_LAUNCHES[:] = list(_H2_LAUNCHES), []
+    if not pairs:
+        return
+    a = torch.cat([p[0].reshape(1) for p in pairs])
+    b = torch.cat([p[1].reshape(1) for p in pairs])
+    bad = torch.isfinite(a) & ~torch.isfinite(b)
+    if bool(bad.any()):
+        i = int(torch.nonzero(bad)[0])
+        raise RuntimeError(f'htd_amd: H2 convolution launch {i} of {len(pairs)} was given a maximum ({float(a[i])}) smaller than its input '
+                           'tensor holds (stale _htd_amax): its output contains infinities')
 
 
 H2_TRACE = {} if os.environ.get('HTD_H2_TRACE', '0') == '1' else None      # diagnostics: which 1x1 launches found no carried maximum
@@ -583,9 +583,10 @@ def _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up
                 am = absmax(x)
             if am is not None:
                 capi.call('htd_conv2d_fwd_x3h', _P(x), _P(am), _P(x3_planes(weight, False, True)), _P(bias), _P(residual), rh, rw,
-                          _P(y), _P(yp), _P(out_slot), _P(h2_flag(x.device)), B, H, W, Ci, Co, kh, kw, stride, padding,
+                          _P(y), _P(yp), _P(out_slot), B, H, W, Ci, Co, kh, kw, stride, padding,
                           int(bool(relu)), _P(ws), _S(), work=work)
                 tag_amax(y, out_slot)
+                _h2_guard(am, out_slot)
                 return (y, yp) if emit else y
         # (algorithmic bytes stay those of the fp32 operands: the planes are this implementation's traffic, not the layer's)
         capi.call('htd_conv2d_fwd_x3q', _P(x), _P(x_planes) if use_xp else None, _P(x3_planes(weight, False, False)), _P(bias),
@@ -658,8 +659,9 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
                 am = absmax(g)
             if am is not None:
                 capi.call('htd_conv2d_bwd_data_x3h', _P(g), _P(am), _P(x3_planes(weight, True, True)), _P(mask_src), _P(accum), _P(gx),
-                          _P(gxp), _P(out_slot), _P(h2_flag(g.device)), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(), work=work)
+                          _P(gxp), _P(out_slot), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(), work=work)
                 tag_amax(gx, out_slot)
+                _h2_guard(am, out_slot)
                 return (gx, gxp) if emit else gx
         capi.call('htd_conv2d_bwd_data_x3q', _P(g), _P(g_planes) if use_gp else None, _P(x3_planes(weight, True, False)), _P(mask_src),
                   _P(accum), _P(gx), _P(gxp), _P(out_slot), B, H, W, Ci, Co, kh, kw, padding, _P(ws), _S(),

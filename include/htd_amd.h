@@ -344,8 +344,8 @@ int htd_conv2d_bwd_data_x3q(const float *gy, const void *gyplanes, const void *w
  *   htd_conv2d_x3h_planes_many  desc: { const float *w; void *planes; int Co, taps, Ci, transposed; int64_t block0, row0; }
  *   htd_conv2d_fwd_x3h / htd_conv2d_bwd_data_x3h   = htd_conv2d_fwd_x3q / htd_conv2d_bwd_data_x3q with `amax` of the input
  *     amax_out (also on the x3q entry points): the epilogue leaves max |y| of what it stores in this device scalar (zero or
- *     an earlier maximum on entry) -- the consumer's `amax` without a pass over y; h2_flag: device word set to 1 when a
- *     finite scaled element left fp16's range, i.e. `amax` was NOT the tensor's maximum (the caller's bug; check and fail)
+ *     an earlier maximum on entry) -- the consumer's `amax` without a pass over y.  An `amax` that is NOT the tensor's maximum
+ *     (the caller's bug) overflows fp16: the output then holds infinities and amax_out says so
  *   htd_conv2d_set_h2        0 / 1 switches the arithmetic off / on (-1: query), returns the previous setting */
 int htd_conv2d_set_h2(int on);
 /* the weight gradient on the same arithmetic: amax_x / amax_g = max |x| / max |gy| of the two tensors (device scalars);
@@ -359,11 +359,11 @@ int htd_absmax(const float *x, int64_t n, float *amax, void *stream);
 int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);
 int htd_conv2d_x3h_planes_many(const void *desc, int n, int64_t total_blocks, int64_t total_rows, void *stream);
 int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void *wplanes, const float *bias, const float *residual,
-                       int res_h, int res_w, float *y, void *yplanes, float *amax_out, void *h2_flag, int B, int H, int W,
-                       int Ci, int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream);
+                       int res_h, int res_w, float *y, void *yplanes, float *amax_out, int B, int H, int W, int Ci,
+                       int Co, int kh, int kw, int stride, int pad, int relu, void *workspace, void *stream);
 int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const void *wplanesT, const float *mask_src,
-                            const float *accum, float *gx, void *gxplanes, float *amax_out, void *h2_flag, int B, int H,
-                            int W, int Ci, int Co, int kh, int kw, int pad, void *workspace, void *stream);
+                            const float *accum, float *gx, void *gxplanes, float *amax_out, int B, int H, int W,
+                            int Ci, int Co, int kh, int kw, int pad, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Deformable convolution v1 / v2 (mask == NULL => v1 = the 'DCN' the HTD config uses,

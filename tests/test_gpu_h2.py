@@ -308,7 +308,7 @@ def test_carried_maximum_contract(h2):
 
 def test_stale_maximum_is_caught_by_the_guard(h2, monkeypatch):
     """A maximum that is NOT the tensor's (a caller's bug) puts infinities into the output; with the guard on (HTD_H2_GUARD / check
-    mode) the kernel raises the device flag and dense.h2_check() fails loudly."""
+    mode) dense.h2_check() finds the launch whose epilogue left a non-finite maximum from a finite input maximum and fails loudly."""
     from htd_amd import capi, dense
     dev = torch.device('cuda:0')
     monkeypatch.setattr(dense, 'H2_GUARD', True)
