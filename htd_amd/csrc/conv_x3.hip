@@ -1420,8 +1420,26 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x
     const int64_t n4 = n >> 2;
     float mx = 0.f;
     unsigned nan = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {            // four loads in flight per thread
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        const float m0 = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+        const float m1 = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)));
+        const float m2 = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
+        const float m3 = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        mx = fmaxf(fmaxf(mx, fmaxf(m0, m1)), fmaxf(m2, m3));
+        // (fmaxf drops NaNs.  x - x is NaN exactly when x is NaN or infinite: sum the lot, test once, look closer only then)
+        const float t = (a.x - a.x) + (a.y - a.y) + (a.z - a.z) + (a.w - a.w) + (b.x - b.x) + (b.y - b.y) + (b.z - b.z) + (b.w - b.w) +
+                        (c.x - c.x) + (c.y - c.y) + (c.z - c.z) + (c.w - c.w) + (d.x - d.x) + (d.y - d.y) + (d.z - d.z) + (d.w - d.w);
+        if (t != t) {
+            nan |= (a.x != a.x) | (a.y != a.y) | (a.z != a.z) | (a.w != a.w) | (b.x != b.x) | (b.y != b.y) | (b.z != b.z) | (b.w != b.w) |
+                   (c.x != c.x) | (c.y != c.y) | (c.z != c.z) | (c.w != c.w) | (d.x != d.x) | (d.y != d.y) | (d.z != d.z) | (d.w != d.w);
+        }
+    }
+    for (; i < n4; i += stride) {
+        const float4 v = x4[i];
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
     }

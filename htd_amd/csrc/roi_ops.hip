@@ -349,8 +349,10 @@ __global__ __launch_bounds__(256) void chunk_sums_kernel(const float *__restrict
 template <int PREG>
 __global__ void gn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                               const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ mean,
-                              float *__restrict__ rstd, int P, int C, int G, float eps, int relu)
+                              float *__restrict__ rstd, int P, int C, int G, float eps, int relu, float *__restrict__ amax_out)
 {
+    __shared__ unsigned mxs[16];
+    float omax = 0.f;                     // largest |y| stored (amax_out: for an H2 consumer of y, conv_x3.hip)
     const int64_t i = blockIdx.x;
     const int c = threadIdx.x;
     const int cpg = C / G;
@@ -380,7 +382,7 @@ __global__ void gn_fwd_kernel(const float *__restrict__ x, const float *__restri
     }
     for (int o = 1; o < cpg; o <<= 1) v += __shfl_xor(v, o, 64);
     const float rs = rsqrtf(v / (float)(P * cpg) + eps);
-    if (!act) return;
+    if (act) {
     if (c % cpg == 0) { mean[i * G + c / cpg] = mu; rstd[i * G + c / cpg] = rs; }
     const float ga = gamma[c] * rs, be = beta[c] - mu * gamma[c] * rs;
     float *yp = y + i * P * C + c;
@@ -391,12 +393,26 @@ __global__ void gn_fwd_kernel(const float *__restrict__ x, const float *__restri
                 float t = xr[q] * ga + be;
                 if (relu) t = fmaxf(t, 0.f);
                 yp[(int64_t)q * C] = t;
+                omax = (t != t) ? t : ((omax != omax) ? omax : fmaxf(omax, fabsf(t)));
             }
     } else {
         for (int q = 0; q < P; ++q) {
             float t = xp[(int64_t)q * C] * ga + be;
             if (relu) t = fmaxf(t, 0.f);
             yp[(int64_t)q * C] = t;
+            omax = (t != t) ? t : ((omax != omax) ? omax : fmaxf(omax, fabsf(t)));
+        }
+    }
+    }   // act
+    if (amax_out != nullptr) {            // one atomic per tile (NaN sorts above everything)
+        unsigned bits = (omax != omax) ? 0x7fc00000u : __float_as_uint(omax);
+        for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
+        if ((threadIdx.x & 63) == 0) mxs[threadIdx.x >> 6] = bits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nw = (blockDim.x + 63) >> 6;
+            for (int w = 1; w < nw; ++w) bits = max(bits, mxs[w]);
+            if (bits != 0u) atomicMax(reinterpret_cast<unsigned *>(amax_out), bits);
         }
     }
 }
@@ -477,6 +493,134 @@ __global__ void gn_bwd_kernel(const float *__restrict__ x, const float *__restri
             gxp[(int64_t)q * C] = rs * (d * ga - a - xh * b);
         }
     }
+}
+
+
+// ---- GroupNorm backward of a tile, bandwidth form (round 4) ------------------------------------------------------------------
+// gn_bwd_kernel gives a thread ONE channel and all P positions of it: 147 registers of cached operands at P = 49, nine waves per
+// tile, one tile per CU in flight, 4-byte loads -- 0.31 TB/s on the regression branch's 58 MB tiles (561 us per launch in the
+// trained-like step).  Here a thread is (four channels, every R-th position): 16-byte loads that run through the tile's
+// contiguous [P][C] block, PQ <= 8 positions cached per thread, the per-channel sums of the R position groups meet in LDS in
+// a fixed order, the group sums (cpg / 4 float4 columns) likewise.  Same formulas; the sums are taken in another (fixed) order.
+// amax_out (may be NULL): the largest |gx| stored, for an H2 consumer (conv_x3.hip).
+template <int PQ>
+__global__ __launch_bounds__(1024) void gn_bwd_tile_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                           const float *__restrict__ rstd, const float *__restrict__ gy,
+                                                           float *__restrict__ gx, float *__restrict__ ggamma,
+                                                           float *__restrict__ gbeta, int P, int C, int G, int relu,
+                                                           float *__restrict__ partial, int V, int R, float *__restrict__ amax_out)
+{
+    __shared__ float4 red[2][1024];
+    __shared__ float grp[2][256];
+    __shared__ unsigned mxs[16];
+    const int64_t i = blockIdx.x;
+    const int tid = threadIdx.x, c4 = tid % V, r = tid / V;
+    const int cpg = C / G, cpg4 = cpg >> 2;
+    const int g = (c4 * 4) / cpg;
+    const float mu = mean[i * G + g], rs = rstd[i * G + g];
+    const float4 ga = ld4(gamma + c4 * 4);
+    const int64_t base = i * P * C + c4 * 4;
+    float4 dr[PQ], xc[PQ];
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgx = sg;
+#pragma unroll
+    for (int k = 0; k < PQ; ++k) {
+        const int q = r + k * R;
+        const bool in = q < P;
+        const int64_t o = base + (int64_t)(in ? q : 0) * C;
+        float4 d = ld4(gy + o), yv = ld4(y + o), xv = ld4(x + o);
+        if (!in) d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (relu) {
+            d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f; d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+        }
+        xv = make_float4(xv.x - mu, xv.y - mu, xv.z - mu, xv.w - mu);
+        dr[k] = d; xc[k] = xv;
+        sg.x += d.x; sg.y += d.y; sg.z += d.z; sg.w += d.w;
+        sgx.x += d.x * xv.x * rs; sgx.y += d.y * xv.y * rs; sgx.z += d.z * xv.z * rs; sgx.w += d.w * xv.w * rs;
+    }
+    red[0][r * V + c4] = sg;
+    red[1][r * V + c4] = sgx;
+    __syncthreads();
+    if (r == 0) {
+        float4 tg = red[0][c4], tx = red[1][c4];
+        for (int rr = 1; rr < R; ++rr) {
+            const float4 a = red[0][rr * V + c4], b = red[1][rr * V + c4];
+            tg.x += a.x; tg.y += a.y; tg.z += a.z; tg.w += a.w;
+            tx.x += b.x; tx.y += b.y; tx.z += b.z; tx.w += b.w;
+        }
+        // partial != NULL: this tile's sums go to partial[tile][c] (gamma) and partial[n + tile][c] (beta), added up in a fixed
+        // order by colsum_rows_kernel; NULL: float atomics into ggamma / gbeta
+        if (partial) {
+            st4(partial + i * C + c4 * 4, tx);
+            st4(partial + ((int64_t)gridDim.x + i) * C + c4 * 4, tg);
+        } else {
+            atomicAdd(ggamma + c4 * 4, tx.x); atomicAdd(ggamma + c4 * 4 + 1, tx.y); atomicAdd(ggamma + c4 * 4 + 2, tx.z); atomicAdd(ggamma + c4 * 4 + 3, tx.w);
+            atomicAdd(gbeta + c4 * 4, tg.x); atomicAdd(gbeta + c4 * 4 + 1, tg.y); atomicAdd(gbeta + c4 * 4 + 2, tg.z); atomicAdd(gbeta + c4 * 4 + 3, tg.w);
+        }
+        grp[0][c4] = tg.x * ga.x + tg.y * ga.y + tg.z * ga.z + tg.w * ga.w;
+        grp[1][c4] = tx.x * ga.x + tx.y * ga.y + tx.z * ga.z + tx.w * ga.w;
+    }
+    __syncthreads();
+    float a = 0.f, b = 0.f;
+    const int g0 = (c4 / cpg4) * cpg4;
+    for (int j = 0; j < cpg4; ++j) { a += grp[0][g0 + j]; b += grp[1][g0 + j]; }
+    const float m = 1.f / (float)(P * cpg);
+    a *= m; b *= m;
+    float omax = 0.f;
+#pragma unroll
+    for (int k = 0; k < PQ; ++k) {
+        const int q = r + k * R;
+        if (q < P) {
+            float4 o;
+            o.x = rs * (dr[k].x * ga.x - a - xc[k].x * rs * b);
+            o.y = rs * (dr[k].y * ga.y - a - xc[k].y * rs * b);
+            o.z = rs * (dr[k].z * ga.z - a - xc[k].z * rs * b);
+            o.w = rs * (dr[k].w * ga.w - a - xc[k].w * rs * b);
+            st4(gx + base + (int64_t)q * C, o);
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            if (o.x != o.x || o.y != o.y || o.z != o.z || o.w != o.w) omax = __uint_as_float(0x7fc00000u);
+        }
+    }
+    if (amax_out != nullptr) {            // one atomic per tile (NaN sorts above everything)
+        unsigned bits = (omax != omax) ? 0x7fc00000u : __float_as_uint(omax);
+        for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
+        if ((tid & 63) == 0) mxs[tid >> 6] = bits;
+        __syncthreads();
+        if (tid == 0) {
+            const int nw = (blockDim.x + 63) >> 6;
+            for (int w = 1; w < nw; ++w) bits = max(bits, mxs[w]);
+            if (bits != 0u) atomicMax(reinterpret_cast<unsigned *>(amax_out), bits);
+        }
+    }
+}
+
+// host: -> true when the tile form took the launch
+static bool gn_tile_off()
+{
+    static const bool off = getenv("HTD_GN_TILE") && atoi(getenv("HTD_GN_TILE")) == 0;
+    return off;
+}
+
+static bool launch_gn_bwd_tile(const float *x, const float *y, const float *gamma, const float *mean, const float *rstd, const float *gy,
+                               float *gx, float *ggamma, float *gbeta, int64_t n, int P, int C, int G, int relu, float *partial,
+                               float *amax_out, hipStream_t s)
+{
+    const int cpg = C / G;
+    if (gn_tile_off() || (C & 3) || (cpg & 3) || C / 4 > 256 || P < 1) return false;
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)gamma | (uintptr_t)partial) & 15) != 0) return false;
+    const int V = C / 4;
+    const int R = std::min(1024 / V, P);
+    const int PQ = (int)htd::ceil_div(P, R);
+    if (PQ > 8) return false;
+    const dim3 grid((unsigned)n), block((unsigned)(R * V));
+#define HTD_GN_TILE_CASE(K) \
+    case K: hipLaunchKernelGGL(gn_bwd_tile_kernel<K>, grid, block, 0, s, x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta, P, C, G, relu, partial, V, R, amax_out); break;
+    switch (PQ) {
+        HTD_GN_TILE_CASE(1) HTD_GN_TILE_CASE(2) HTD_GN_TILE_CASE(3) HTD_GN_TILE_CASE(4)
+        HTD_GN_TILE_CASE(5) HTD_GN_TILE_CASE(6) HTD_GN_TILE_CASE(7) HTD_GN_TILE_CASE(8)
+    }
+#undef HTD_GN_TILE_CASE
+    return true;
 }
 
 // ------------------------------------------------------------------ SGD momentum
@@ -783,8 +927,8 @@ extern "C" int htd_global_avg_pool_bwd_acc(const float *g, float *gx, int64_t B,
     return htd::check_launch("global_avg_pool_bwd_acc");
 }
 
-extern "C" int htd_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
-                                       float *rstd, int64_t n, int P, int C, int G, float eps, int relu, void *stream)
+static int gn_fwd_impl(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd, int64_t n, int P,
+                       int C, int G, float eps, int relu, float *amax_out, void *stream)
 {
     HTD_REQUIRE(G > 0 && C % G == 0, "group_norm: C=%d not divisible by G=%d", C, G);
     const int cpg = C / G;
@@ -795,11 +939,26 @@ extern "C" int htd_group_norm_relu_fwd(const float *x, const float *gamma, const
     const int threads = (int)htd::ceil_div(C, 64) * 64;
     if (P <= 49)
         hipLaunchKernelGGL(gn_fwd_kernel<49>, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, P, C, G, eps, relu);
+                           mean, rstd, P, C, G, eps, relu, amax_out);
     else
         hipLaunchKernelGGL(gn_fwd_kernel<0>, dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, gamma, beta, y,
-                           mean, rstd, P, C, G, eps, relu);
+                           mean, rstd, P, C, G, eps, relu, amax_out);
     return htd::check_launch("group_norm_fwd");
+}
+
+extern "C" int htd_group_norm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                                       float *rstd, int64_t n, int P, int C, int G, float eps, int relu, void *stream)
+{
+    return gn_fwd_impl(x, gamma, beta, y, mean, rstd, n, P, C, G, eps, relu, nullptr, stream);
+}
+
+// the same, and max |y| of what it stores is left in *amax_out (zero or an earlier maximum on entry): the `amax` of the
+// convolution that consumes y on the H2 arithmetic (conv_x3.hip)
+extern "C" int htd_group_norm_relu_fwd_amax(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                                            float *rstd, int64_t n, int P, int C, int G, float eps, int relu, float *amax_out,
+                                            void *stream)
+{
+    return gn_fwd_impl(x, gamma, beta, y, mean, rstd, n, P, C, G, eps, relu, amax_out, stream);
 }
 
 extern "C" int htd_group_norm_relu_bwd(const float *x, const float *y, const float *gamma, const float *mean,
@@ -813,6 +972,8 @@ extern "C" int htd_group_norm_relu_bwd(const float *x, const float *y, const flo
     if (n == 0) return HTD_OK;
     HTD_REQUIRE(x && y && gamma && mean && rstd && gy && gx && ggamma && gbeta, "group_norm_bwd: null pointer");
     const int threads = (int)htd::ceil_div(C, 64) * 64;
+    if (launch_gn_bwd_tile(x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta, n, P, C, G, relu, nullptr, nullptr, (hipStream_t)stream))
+        return htd::check_launch("group_norm_bwd");
     hipLaunchKernelGGL((P <= 49 ? gn_bwd_kernel<49> : gn_bwd_kernel<0>), dim3((unsigned)n), dim3(threads), 0, (hipStream_t)stream, x, y, gamma, mean,
                        rstd, gy, gx, ggamma, gbeta, P, C, G, relu, (float *)nullptr);
     return htd::check_launch("group_norm_bwd");
@@ -820,9 +981,9 @@ extern "C" int htd_group_norm_relu_bwd(const float *x, const float *y, const flo
 
 // The same with bit-reproducible parameter gradients: per-tile sums go through `workspace` (2 * n * C floats) and are
 // added in a fixed order; ggamma / gbeta are overwritten (no zero-initialisation needed).
-extern "C" int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const float *gamma, const float *mean,
-                                          const float *rstd, const float *gy, float *gx, float *ggamma, float *gbeta,
-                                          int64_t n, int P, int C, int G, int relu, void *workspace, void *stream)
+static int gn_bwd_ws_impl(const float *x, const float *y, const float *gamma, const float *mean, const float *rstd, const float *gy,
+                          float *gx, float *ggamma, float *gbeta, int64_t n, int P, int C, int G, int relu, void *workspace,
+                          float *amax_out, void *stream)
 {
     HTD_REQUIRE(G > 0 && C % G == 0, "group_norm: C=%d not divisible by G=%d", C, G);
     const int cpg = C / G;
@@ -838,11 +999,38 @@ extern "C" int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const 
     HTD_REQUIRE(x && y && gamma && mean && rstd && gy && gx && workspace, "group_norm_bwd: null pointer");
     const int threads = (int)htd::ceil_div(C, 64) * 64;
     float *ws = (float *)workspace;
-    hipLaunchKernelGGL((P <= 49 ? gn_bwd_kernel<49> : gn_bwd_kernel<0>), dim3((unsigned)n), dim3(threads), 0, s, x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta,
-                       P, C, G, relu, ws);
+    if (!launch_gn_bwd_tile(x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta, n, P, C, G, relu, ws, amax_out, s)) {
+        HTD_REQUIRE(amax_out == nullptr, "group_norm_bwd: this shape (C=%d, P=%d) runs on the kernel that leaves no maximum", C, P);
+        hipLaunchKernelGGL((P <= 49 ? gn_bwd_kernel<49> : gn_bwd_kernel<0>), dim3((unsigned)n), dim3(threads), 0, s, x, y, gamma, mean, rstd, gy, gx,
+                           ggamma, gbeta, P, C, G, relu, ws);
+    }
     hipLaunchKernelGGL(colsum_rows_kernel, dim3((unsigned)htd::ceil_div(C, 16), 2), dim3(256), 0, s, (const float *)ws, ggamma,
                        gbeta, C, (int)n);
     return htd::check_launch("group_norm_bwd_ws");
+}
+
+extern "C" int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const float *gamma, const float *mean,
+                                          const float *rstd, const float *gy, float *gx, float *ggamma, float *gbeta,
+                                          int64_t n, int P, int C, int G, int relu, void *workspace, void *stream)
+{
+    return gn_bwd_ws_impl(x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta, n, P, C, G, relu, workspace, nullptr, stream);
+}
+
+// 1 when htd_group_norm_relu_bwd_amax can leave the maximum of gx for this shape (the tile form of the kernel takes it)
+extern "C" int htd_group_norm_bwd_amax_supported(int P, int C, int G)
+{
+    if (gn_tile_off() || G <= 0 || C % G != 0 || (C & 3) || ((C / G) & 3) || C / 4 > 256 || P < 1) return 0;
+    const int V = C / 4, R = std::min(1024 / V, P);
+    return htd::ceil_div(P, R) <= 8 ? 1 : 0;
+}
+
+// htd_group_norm_relu_bwd_ws that also leaves max |gx| in *amax_out (zero or an earlier maximum on entry): the `amax` of the
+// convolution data gradient that consumes gx on the H2 arithmetic (conv_x3.hip)
+extern "C" int htd_group_norm_relu_bwd_amax(const float *x, const float *y, const float *gamma, const float *mean,
+                                            const float *rstd, const float *gy, float *gx, float *ggamma, float *gbeta,
+                                            int64_t n, int P, int C, int G, int relu, void *workspace, float *amax_out, void *stream)
+{
+    return gn_bwd_ws_impl(x, y, gamma, mean, rstd, gy, gx, ggamma, gbeta, n, P, C, G, relu, workspace, amax_out, stream);
 }
 
 extern "C" int htd_sgd_momentum_step(float *param, const float *grad, float *momentum_buf, int64_t n,

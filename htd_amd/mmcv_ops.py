@@ -762,8 +762,15 @@ class GroupNormReLUFunction(Function):
         y = torch.empty_like(x, memory_format=CL)
         mean = torch.empty(n, num_groups, device=x.device, dtype=x.dtype)
         rstd = torch.empty_like(mean)
-        capi.call('htd_group_norm_relu_fwd', _P(x), _P(weight), _P(bias), _P(y), _P(mean), _P(rstd), n, h * w, C,
-                  int(num_groups), float(eps), int(bool(relu)), _S())
+        from . import dense
+        slot = dense._amax_slot(x.device) if (n > 0 and capi.lib().htd_conv2d_set_h2(-1) == 1) else None
+        if slot is not None:              # max |y| for the convolution behind this layer (H2 arithmetic, dense.carried_amax)
+            capi.call('htd_group_norm_relu_fwd_amax', _P(x), _P(weight), _P(bias), _P(y), _P(mean), _P(rstd), n, h * w, C,
+                      int(num_groups), float(eps), int(bool(relu)), _P(slot), _S())
+            dense.tag_amax(y, slot)
+        else:
+            capi.call('htd_group_norm_relu_fwd', _P(x), _P(weight), _P(bias), _P(y), _P(mean), _P(rstd), n, h * w, C,
+                      int(num_groups), float(eps), int(bool(relu)), _S())
         ctx.save_for_backward(x, y, weight, mean, rstd)
         ctx.meta = (int(num_groups), int(bool(relu)))
         ctx.bias_ref = bias                   # only its address is used (gradient sink lookup)
@@ -781,8 +788,15 @@ class GroupNormReLUFunction(Function):
         gw = dense.grad_out(weight)           # straight into the flat gradient buffer when the parameters are registered there
         gb = dense.grad_out(ctx.bias_ref) if ctx.bias_ref is not None and ctx.bias_ref.shape == weight.shape else torch.empty_like(weight)
         ws = torch.empty(2 * max(n, 1) * C, device=x.device, dtype=torch.float32)      # per-tile sums, added in a fixed order
-        capi.call('htd_group_norm_relu_bwd_ws', _P(x), _P(y), _P(weight), _P(mean), _P(rstd), _P(gy), _P(gx), _P(gw),
-                  _P(gb), n, h * w, C, G, relu, _P(ws), _S())
+        L = capi.lib()
+        if n > 0 and L.htd_conv2d_set_h2(-1) == 1 and L.htd_group_norm_bwd_amax_supported(h * w, C, G):
+            slot = dense._amax_slot(x.device)
+            capi.call('htd_group_norm_relu_bwd_amax', _P(x), _P(y), _P(weight), _P(mean), _P(rstd), _P(gy), _P(gx), _P(gw),
+                      _P(gb), n, h * w, C, G, relu, _P(ws), _P(slot), _S(), key='htd_group_norm_relu_bwd_ws')
+            dense.tag_amax(gx, slot)
+        else:
+            capi.call('htd_group_norm_relu_bwd_ws', _P(x), _P(y), _P(weight), _P(mean), _P(rstd), _P(gy), _P(gx), _P(gw),
+                      _P(gb), n, h * w, C, G, relu, _P(ws), _S())
         return gx, gw, gb, None, None, None
 
 

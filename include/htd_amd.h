@@ -422,6 +422,16 @@ int htd_group_norm_relu_bwd(const float *x, const float *y, const float *gamma, 
 int htd_group_norm_relu_bwd_ws(const float *x, const float *y, const float *gamma, const float *mean, const float *rstd,
                                const float *gy, float *gx, float *ggamma, float *gbeta, int64_t n, int P, int C, int G,
                                int relu, void *workspace, void *stream);
+/* Round 4: the same two passes leaving the largest magnitude of what they store in a device scalar (zero or an earlier maximum on
+ * entry) -- the `amax` operand of the H2 convolution that consumes the tensor (htd_conv2d_fwd_x3h / htd_conv2d_bwd_data_x3h /
+ * htd_conv2d_bwd_weight_h2), without a pass of htd_absmax.  The backward leaves it on the shapes its bandwidth-form kernel takes
+ * (htd_group_norm_bwd_amax_supported; the 7x7 x 576-channel tiles of htd_bbox_head.py:77-113 are one). */
+int htd_group_norm_relu_fwd_amax(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                                 int64_t n, int P, int C, int G, float eps, int relu, float *amax_out, void *stream);
+int htd_group_norm_bwd_amax_supported(int P, int C, int G);
+int htd_group_norm_relu_bwd_amax(const float *x, const float *y, const float *gamma, const float *mean, const float *rstd,
+                                 const float *gy, float *gx, float *ggamma, float *gbeta, int64_t n, int P, int C, int G,
+                                 int relu, void *workspace, float *amax_out, void *stream);
 int htd_fuse_global_bwd_global_ws(const float *grad, const float *rois, float *grad_global, int64_t n, int P, int C, int B,
                                   void *workspace, void *stream);
 

@@ -312,6 +312,7 @@ def test_stale_maximum_is_caught_by_the_guard(h2, monkeypatch):
     from htd_amd import capi, dense
     dev = torch.device('cuda:0')
     monkeypatch.setattr(dense, 'H2_GUARD', True)
+    monkeypatch.setattr(dense, 'H2_CHECK', False)          # (check mode would refuse the wrong tag before the launch)
     dense.new_step()
     x = torch.randn(1, 64, 16, 16, device=dev).contiguous(memory_format=CL)
     w = torch.randn(64, 64, 3, 3, device=dev).contiguous(memory_format=CL) * 0.05
