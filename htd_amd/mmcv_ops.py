@@ -25,8 +25,9 @@ CL = torch.channels_last
 
 
 def _drop_amax(t):
-    if t is not None and hasattr(t, '_htd_amax'):
-        del t._htd_amax
+    """t is about to be modified in place by a kernel torch does not see: a maximum carried on it is void (dense.drop_amax)."""
+    from . import dense
+    dense.drop_amax(t)
 
 
 def _need_gpu(t, name):
