@@ -92,6 +92,9 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned
 #ifndef HTD_X3P_EARLY
 #define HTD_X3P_EARLY 1
 #endif
+#ifndef HTD_X3H_FRAG_FIRST
+#define HTD_X3H_FRAG_FIRST 1     // H2: a tap's fragment reads ahead of its bookkeeping (0: where the MFMAs are)
+#endif
 #ifndef HTD_X3H_OCC4
 #define HTD_X3H_OCC4 0          // 1: the 128x128 H2 tile at four workgroups per CU (128 VGPRs)
 #endif
@@ -677,7 +680,10 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
             for (int r = 0; r < (MF16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
     // the matrix work of one tap: fragments of A buffer `abuf` at row shift kx against B buffer `bbuf`
-    auto mma_tap = [&](int abuf, int bbuf, int kx, int tap0) __attribute__((always_inline)) {
+    // H2: the fragment reads of a tap are issued FIRST in the tap (phase 0), ahead of the tile / pass bookkeeping and the wait for
+    // the staged pass, so that their LDS latency runs under those ~100 scalar and vector instructions; the MFMAs (phase 1) follow
+    f16x8 hfa[RB][2], hfb[CB][2];
+    auto mma_tap = [&](int abuf, int bbuf, int kx, int tap0, int phase = 2) __attribute__((always_inline)) {
         const char *la = reinterpret_cast<const char *>(lA + abuf * A_VEC);
         const char *lb = reinterpret_cast<const char *>(lB + bbuf * B_VEC);
         int arow[RB];
@@ -706,25 +712,28 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
                 }
             }
         } else if constexpr (H2) {
-            f16x8 fa[RB][2], fb[CB][2];
+            if (phase != 1) {
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+                for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    fa[i][q] = *reinterpret_cast<const f16x8 *>(la + arow[i] + a_c0 + q * 2 * G::PITCH * 16);
+                    for (int q = 0; q < 2; ++q)
+                        hfa[i][q] = *reinterpret_cast<const f16x8 *>(la + arow[i] + a_c0 + q * 2 * G::PITCH * 16);
 #pragma unroll
-            for (int j = 0; j < CB; ++j)
+                for (int j = 0; j < CB; ++j)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    fb[j][q] = *reinterpret_cast<const f16x8 *>(lb + b_c0 + j * 32 * 16 + q * 2 * BN * 16);
+                    for (int q = 0; q < 2; ++q)
+                        hfb[j][q] = *reinterpret_cast<const f16x8 *>(lb + b_c0 + j * 32 * 16 + q * 2 * BN * 16);
+            }
+            if (phase != 0) {
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+                for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int j = 0; j < CB; ++j) {      // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < CB; ++j) {      // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hfa[i][1], hfb[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hfa[i][0], hfb[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hfa[i][0], hfb[j][0], acc[i][j], 0, 0, 0);
+                    }
+            }
         } else {
             bf16x8 fa[RB][3], fb[CB][3];
 #pragma unroll
@@ -800,6 +809,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
     // (TAIL: the split's last tap when their number is odd -- it has nothing to put in flight)
     auto tap = [&](int P, bool TAIL) __attribute__((always_inline)) {
         const bool more = s + 1 < s_end, more2 = s + 2 < s_end;
+        if constexpr (H2 && HTD_X3H_FRAG_FIRST) mma_tap(abuf, bbuf, kx, ky * KW, 0);
         const bool issued = issue_b();
         if (!TAIL) {
             if constexpr (KW == 1) {
@@ -819,7 +829,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
             else wait_vm<NPT>();
 #pragma unroll
             for (int i = 0; i < NPT; ++i) landed(ra[(P ^ 1) * NPT + i]);
-            mma_tap(abuf, bbuf, kx, ky * KW);
+            mma_tap(abuf, bbuf, kx, ky * KW, (H2 && HTD_X3H_FRAG_FIRST) ? 1 : 2);
             // (not under `if (more)`: a predicated region cannot take MFMAs; in the last step the stores put unused rows into the idle buffer)
             if constexpr (KW == 1) {
 #pragma unroll
@@ -837,7 +847,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
             }
             if (!TAIL) wait_vm<NPT>();   // the next tap's B tile has landed (this tap's A passes stay in flight)
         } else {
-            mma_tap(abuf, bbuf, kx, ky * KW);
+            mma_tap(abuf, bbuf, kx, ky * KW, (H2 && HTD_X3H_FRAG_FIRST) ? 1 : 2);
             // the other set (issued one tap ago) and the next tap's B tile have landed
             if (TAIL) wait_vm<0>();
             else wait_tap(issued);
