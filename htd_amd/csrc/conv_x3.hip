@@ -92,6 +92,9 @@ __device__ __forceinline__ void split3x2(float a, float b, unsigned &h, unsigned
 #ifndef HTD_X3P_EARLY
 #define HTD_X3P_EARLY 1
 #endif
+#ifndef HTD_X3H_NB
+#define HTD_X3H_NB 2             // weight-tile buffers of the H2 kernels (prefetch distance + 1)
+#endif
 #ifndef HTD_X3H_FRAG_FIRST
 #define HTD_X3H_FRAG_FIRST 1     // H2: a tap's fragment reads ahead of its bookkeeping (0: where the MFMAs are)
 #endif
@@ -845,7 +848,12 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
             }
-            if (!TAIL) wait_vm<NPT>();   // the next tap's B tile has landed (this tap's A passes stay in flight)
+            // the next tap's B tile has landed; this tap's A passes stay in flight, and with two taps of prefetch (DIST >= 2) so
+            // does the tile this tap issued (it is younger than the one needed next: vector-memory operations retire in order)
+            if (!TAIL) {
+                if (DIST >= 2 && issued) wait_vm<NPT + NI_MIN>();
+                else wait_vm<NPT>();
+            }
         } else {
             mma_tap(abuf, bbuf, kx, ky * KW, (H2 && HTD_X3H_FRAG_FIRST) ? 1 : 2);
             // the other set (issued one tap ago) and the next tap's B tile have landed
@@ -1726,17 +1734,17 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     const dim3 grid((unsigned)pl.grid);
     if (p.amax != nullptr && kw == 3) {        // H2 arithmetic
         switch (cfg) {
-        case 0: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 1, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 2, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 1, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 2, 3, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        case 0: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 1, 3, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 2, 3, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 1, 3, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 2, 3, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
         }
     } else if (p.amax != nullptr) {
         switch (cfg) {
-        case 0: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 1, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 2, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 1, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 2, 1, false, 2, true>), grid, dim3(256), 0, s, p); break;
+        case 0: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 1, 1, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 2, 1, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 2, 1, 1, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_x3p_kernel<2, 2, 1, 2, 1, false, HTD_X3H_NB, true>), grid, dim3(256), 0, s, p); break;
         }
     } else if (p.xp != nullptr) {   // A operand pre-split: conv_x3q_kernel (1x1, stride 1)
         switch (cfg) {
