@@ -355,7 +355,8 @@ def _planes_key(w, transposed):
     return _flip_key(w) + (bool(transposed), )
 
 
-_ALSO_WANTED = set()          # (weight address, shape, transposed, h2): images that a step asked for outside its table launch
+_ALSO_WANTED = set()          # (weight shape, transposed, h2): images that a step asked for outside its table launch (by shape: the
+                              # folded weights of a stage live at another address every step)
 
 
 def _planes_h2(w, transposed):
@@ -377,7 +378,7 @@ def x3_planes(weight, transposed, h2=None):
         return hit[1]
     # made on demand, one launch (two for H2) for this weight alone: remember the request, the next steps' table launch
     # (planes_many) makes this image too
-    _ALSO_WANTED.add((weight.data_ptr(), tuple(weight.shape), bool(transposed), bool(h2)))
+    _ALSO_WANTED.add((tuple(weight.shape), bool(transposed), bool(h2)))
     Co, Ci, kh, kw = weight.shape
     nbytes = capi.lib().htd_conv2d_x3_planes_bytes(Co, kh, kw, Ci, int(transposed))
     planes = torch.empty(nbytes // 4, device=weight.device, dtype=torch.int32)
@@ -405,7 +406,7 @@ def planes_many(items):
         if not _planes_wanted(w4, tr):
             continue
         h2 = _planes_h2(w4, tr)
-        for v in ((h2, ) if (w4.data_ptr(), tuple(w4.shape), bool(tr), not h2) not in _ALSO_WANTED else (h2, not h2)):
+        for v in ((h2, ) if (tuple(w4.shape), bool(tr), not h2) not in _ALSO_WANTED else (h2, not h2)):
             key = _planes_key(w4, tr) + (v, )
             if key not in _STEP_PLANES and key not in seen:
                 seen.add(key)
