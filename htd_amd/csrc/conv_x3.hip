@@ -1299,9 +1299,12 @@ __device__ __forceinline__ void x3h_rowmax_part(const float *__restrict__ w, flo
         for (int r = 0; r < 16; ++r) {
             const int n = n0 + wave * 16 + r;
             float mx = 0.f;
-            if (n < N) {
-                const float *row = w + (int64_t)n * taps * Ci;
-                for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, fabsf(row[e]));
+            if (n < N) {            // (rows and chunks are whole float4s: Ci % 4 == 0, chunk bounds multiples of 4)
+                const float4 *row = reinterpret_cast<const float4 *>(w + (int64_t)n * taps * Ci);
+                for (int e = (e0 >> 2) + lane; e < (e1 >> 2); e += 64) {
+                    const float4 v = row[e];
+                    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                }
             }
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
             if (lane == 0) red[wave * 16 + r] = mx;
