@@ -45,6 +45,23 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// Largest magnitude a launch stores, left in a device scalar for an H2 consumer of the tensor (conv_x3.hip, h2_scale): magnitudes
+// order like their bit patterns, NaN is put above everything and stays.  mag_bits: one value; mag_bits4: folded into a running
+// maximum; wave_mag_out: the wavefront's maximum -> *out with at most one atomic, and none when the scalar already holds as much
+// (thousands of atomics on one address serialise in the L2).
+__device__ __forceinline__ unsigned mag_bits(float v) { return (v != v) ? 0x7fc00000u : (__float_as_uint(v) & 0x7fffffffu); }
+__device__ __forceinline__ unsigned mag_bits4(unsigned mx, float4 v)
+{
+    return max(max(mx, max(mag_bits(v.x), mag_bits(v.y))), max(mag_bits(v.z), mag_bits(v.w)));
+}
+__device__ __forceinline__ void wave_mag_out(unsigned bits, float *out)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+    if ((threadIdx.x & 63) == 0 && bits > *reinterpret_cast<volatile unsigned *>(out))
+        __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace htd

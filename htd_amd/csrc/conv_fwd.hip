@@ -112,6 +112,9 @@ struct ConvParams {
     // one BK-channel slice back to back: a tile re-reads its own footprint from L1/L2 instead of streaming the whole
     // input once per tap through an L2 that the concurrent tiles of the XCD overflow)
     int cmajor;
+    // amax_out != NULL: the epilogues also leave the largest magnitude they store in this device scalar (zero or an earlier maximum
+    // on entry) -- the `amax` of an H2 consumer of y (conv_x3.hip), without a pass over y
+    float *amax_out;
 };
 
 // BK: floats of K per slice; WGM x WGN: wave grid of the block; TM x TN: 32x32 MFMA blocks per wave
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
     // Accumulators go through LDS (one 32-row band per wave row per round) so that global stores -- and the
     // residual / mask loads -- are 16 B per lane along full output rows instead of 4 B column fragments.
     const bool vec_ok = (p.Co & 3) == 0;
+    unsigned omx = 0u;                                // largest magnitude stored to y (p.amax_out)
     constexpr int V = T::BN / 4;                      // float4 per staged row
     constexpr int RPP = 256 / V;                      // staged rows written per pass
 #pragma unroll
@@ -484,7 +488,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
                 }
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
-                    if (ok[u]) *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
+                    if (ok[u]) {
+                        *reinterpret_cast<float4 *>(p.y + o[u]) = v[u];
+                        omx = htd::mag_bits4(omx, v[u]);
+                    }
             }
             if (i + 1 < TM) __syncthreads();
             continue;
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
                     v.z = mv.z > 0.f ? v.z : 0.f; v.w = mv.w > 0.f ? v.w : 0.f;
                 }
                 *reinterpret_cast<float4 *>(p.y + o) = v;
+                omx = htd::mag_bits4(omx, v);
             } else {
                 auto put = [&](int e, float t) {
                     if (n + e >= p.Co) return;
@@ -552,17 +560,20 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 3 : 4)) void conv_igemm_kernel
                     if (p.relu) t = fmaxf(t, 0.f);
                     if (p.mask_src) t = p.mask_src[o + e] > 0.f ? t : 0.f;
                     p.y[o + e] = t;
+                    omx = max(omx, htd::mag_bits(t));
                 };
                 put(0, v.x); put(1, v.y); put(2, v.z); put(3, v.w);
             }
         }
         if (i + 1 < TM) __syncthreads();
     }
+    if (p.amax_out != nullptr && tail_split < 0 && p.splits <= 1) htd::wave_mag_out(omx, p.amax_out);
 }
 
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvParams p)
 {
     const int64_t total = p.M * p.Co;
+    unsigned omx = 0u;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int k = 0; k < p.splits; ++k) v += p.partial[(int64_t)k * total + o];
@@ -583,13 +594,16 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(ConvParams p)
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
         p.y[o] = v;
+        omx = max(omx, htd::mag_bits(v));
     }
+    if (p.amax_out != nullptr) htd::wave_mag_out(omx, p.amax_out);
 }
 
 // sums the partial tiles of the balanced tail and applies the epilogue; one thread per output element of a tail tile
 __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvParams p, int BM, int BN)
 {
     const int64_t per_tile = (int64_t)BM * BN, total = (int64_t)(p.mt * p.nt - p.tail_first) * per_tile;
+    unsigned omx = 0u;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(e / per_tile), within = (int)(e - (int64_t)t * per_tile);
         const int tile = p.tail_first + t, tile_m = tile / p.nt, tile_n = tile % p.nt;
@@ -615,7 +629,9 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(ConvParams p, i
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
         p.y[o] = v;
+        omx = max(omx, htd::mag_bits(v));
     }
+    if (p.amax_out != nullptr) htd::wave_mag_out(omx, p.amax_out);
 }
 
 int g_conv_math = getenv("HTD_CONV_MATH") ? atoi(getenv("HTD_CONV_MATH")) : 1;
@@ -850,9 +866,9 @@ int conv_math() { return g_conv_math; }      // conv_x3.hip: its kernels exist f
 
 // res_h / res_w > 0: residual is a [B][res_h][res_w][Co] map added through nearest-neighbour up-sampling to the
 // output size (0, 0: residual has the output's shape).
-extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, int res_h,
-                              int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
-                              int pad, int dil, int relu, void *workspace, void *stream)
+static int conv2d_fwd_impl(const float *x, const float *w, const float *bias, const float *residual, int res_h, int res_w, float *y,
+                           int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, int relu,
+                           float *amax_out, void *workspace, void *stream)
 {
     HTD_REQUIRE((res_h > 0) == (res_w > 0) && res_h >= 0 && (res_h == 0 || ((Co & 3) == 0 && residual)),
                 "conv2d_fwd: bad residual up-sampling arguments");
@@ -868,12 +884,32 @@ extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias,
     p.Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) / stride + 1;
     HTD_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d_fwd: empty output");
     p.Hx = H; p.Wx = W; p.relu = relu;
+    p.amax_out = amax_out;
     p.M = (int64_t)B * p.Ho * p.Wo;
     if (res_h > 0) {
         p.res_H = res_h; p.res_W = res_w;
         p.res_sh = (float)res_h / (float)p.Ho; p.res_sw = (float)res_w / (float)p.Wo;
     }
     return launch_conv(p, (hipStream_t)stream, workspace);
+}
+
+extern "C" int htd_conv2d_fwd(const float *x, const float *w, const float *bias, const float *residual, int res_h,
+                              int res_w, float *y, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride,
+                              int pad, int dil, int relu, void *workspace, void *stream)
+{
+    return conv2d_fwd_impl(x, w, bias, residual, res_h, res_w, y, B, H, W, Ci, Co, kh, kw, stride, pad, dil, relu, nullptr, workspace,
+                           stream);
+}
+
+// htd_conv2d_fwd that also leaves max |y| in *amax_out (a device scalar holding zero or an earlier maximum on entry): the layers
+// this kernel keeps (strided, dilated, skinny) hand their output to layers that run on the H2 arithmetic (htd_conv2d_fwd_x3h)
+extern "C" int htd_conv2d_fwd_amax(const float *x, const float *w, const float *bias, const float *residual, int res_h, int res_w,
+                                   float *y, float *amax_out, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                                   int dil, int relu, void *workspace, void *stream)
+{
+    HTD_REQUIRE(amax_out, "conv2d_fwd: null maximum");
+    return conv2d_fwd_impl(x, w, bias, residual, res_h, res_w, y, B, H, W, Ci, Co, kh, kw, stride, pad, dil, relu, amax_out, workspace,
+                           stream);
 }
 
 // bytes of split-K workspace htd_conv2d_fwd / htd_conv2d_bwd_data may use for this problem (0 = none needed);
@@ -970,9 +1006,9 @@ extern "C" int htd_bgemm_nt_counts(const float *a, const float *b, float *c, int
 // channel-transposed weights (htd_conv2d_flip_weights).  mask_src (may be NULL): gx is zeroed where
 // mask_src <= 0 -- the ReLU of the layer that produced the conv input, fused into this epilogue.
 // accum (may be NULL; stride 1 only): added to the data gradient before the mask (the other branch of a residual join).
-extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx,
-                                   int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
-                                   void *workspace, void *stream)
+static int conv2d_bwd_data_impl(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx, int B, int H,
+                                int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil, float *amax_out, void *workspace,
+                                void *stream)
 {
     HTD_REQUIRE(!accum || stride == 1, "conv2d_bwd_data: accum needs stride 1");
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
@@ -984,6 +1020,7 @@ extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float
     ConvParams p{};
     p.x = gy; p.w = wT; p.bias = nullptr; p.residual = accum; p.mask_src = mask_src; p.y = gx;
     p.B = B; p.Ci = Co; p.Co = Ci; p.kh = kh; p.kw = kw; p.dil = dil; p.relu = 0;
+    p.amax_out = amax_out;               // (strided form: every parity class's launch raises the same scalar; the rest is zeros)
     p.Hx = Ho; p.Wx = Wo;
     HTD_REQUIRE(kh == kw, "conv2d_bwd_data: square kernels only");
     if (stride == 1) {
@@ -1042,6 +1079,22 @@ extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float
         if (st) return st;
     }
     return HTD_OK;
+}
+
+extern "C" int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx,
+                                   int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
+                                   void *workspace, void *stream)
+{
+    return conv2d_bwd_data_impl(gy, wT, mask_src, accum, gx, B, H, W, Ci, Co, kh, kw, stride, pad, dil, nullptr, workspace, stream);
+}
+
+// htd_conv2d_bwd_data that also leaves max |gx| in *amax_out (zero or an earlier maximum on entry), see htd_conv2d_fwd_amax
+extern "C" int htd_conv2d_bwd_data_amax(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx,
+                                        float *amax_out, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                                        int dil, void *workspace, void *stream)
+{
+    HTD_REQUIRE(amax_out, "conv2d_bwd_data: null maximum");
+    return conv2d_bwd_data_impl(gy, wT, mask_src, accum, gx, B, H, W, Ci, Co, kh, kw, stride, pad, dil, amax_out, workspace, stream);
 }
 
 namespace {

@@ -1388,32 +1388,42 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restric
 
 // column sums of a [rows][C] matrix (bias gradient), optionally fused with the ReLU-mask of the incoming
 // gradient:  gm = g * (y > 0) written back, gbias[c] = sum_rows gm.  Deterministic two-stage reduction.
+// amax_out (may be NULL): max |gm| of what the launch stores (max |g| without a mask) is left in this device scalar -- zero or an
+// earlier maximum on entry -- for an H2 consumer of the gradient (conv_x3.hip).  Magnitudes order like their bits; NaN above all.
+using htd::mag_bits;
+using htd::wave_mag_out;
+
 __global__ __launch_bounds__(256) void colsum_mask_kernel(const float *__restrict__ g, const float *__restrict__ y,
                                                           float *__restrict__ gm, float *__restrict__ partial,
-                                                          int64_t rows, int C, int64_t rows_per_block)
+                                                          int64_t rows, int C, int64_t rows_per_block, float *__restrict__ amax_out)
 {
     const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        float v = g[r * C + c];
-        if (y) {
-            v = y[r * C + c] > 0.f ? v : 0.f;
-            gm[r * C + c] = v;
+    unsigned mx = 0u;
+    if (c < C)
+        for (int64_t r = r0; r < r1; ++r) {
+            float v = g[r * C + c];
+            if (y) {
+                v = y[r * C + c] > 0.f ? v : 0.f;
+                gm[r * C + c] = v;
+            }
+            mx = max(mx, mag_bits(v));
+            s += v;
         }
-        s += v;
-    }
-    if (partial) partial[(int64_t)blockIdx.x * C + c] = s;
+    if (amax_out) wave_mag_out(mx, amax_out);
+    if (partial && c < C) partial[(int64_t)blockIdx.x * C + c] = s;
 }
 
 // float4 version for C % 4 == 0: a block's 256 threads cover R = 256 / (C/4) rows per iteration with 16-byte
 // accesses (full-rate streaming), then fold their R partial rows through LDS.
 __global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__restrict__ g, const float *__restrict__ y,
                                                               float *__restrict__ gm, float *__restrict__ partial,
-                                                              int64_t rows, int C, int64_t rows_per_block)
+                                                              int64_t rows, int C, int64_t rows_per_block,
+                                                              float *__restrict__ amax_out)
 {
     __shared__ float4 red[256];
+    unsigned mx = 0u;
     const int C4 = C >> 2;
     const int cbase = blockIdx.y * 256;                         // float4 column chunk of this block
     const int cw = min(256, C4 - cbase);                        // float4 columns handled here
@@ -1440,6 +1450,7 @@ __global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__res
                     v[u].z = yv[u].z > 0.f ? v[u].z : 0.f; v[u].w = yv[u].w > 0.f ? v[u].w : 0.f;
                     *reinterpret_cast<float4 *>(gm + o) = v[u];
                 }
+                mx = htd::mag_bits4(mx, v[u]);
                 s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
             }
         }
@@ -1452,9 +1463,11 @@ __global__ __launch_bounds__(256) void colsum_mask_vec_kernel(const float *__res
                 v.z = yv.z > 0.f ? v.z : 0.f; v.w = yv.w > 0.f ? v.w : 0.f;
                 *reinterpret_cast<float4 *>(gm + o) = v;
             }
+            mx = htd::mag_bits4(mx, v);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
+    if (amax_out) wave_mag_out(mx, amax_out);
     if (!partial) return;                                       // mask-only call: no column sums wanted
     red[threadIdx.x] = s;
     __syncthreads();
@@ -1723,8 +1736,8 @@ extern "C" int htd_conv2d_bwd_weight_h2(const float *x, const float *gy, const f
 }
 
 // g [rows][C], y (may be NULL) [rows][C]; gm (out, required iff y) ; gbias [C]; workspace >= 2048*C*4 bytes
-extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows, int C,
-                                       void *workspace, void *stream)
+static int bias_grad_relu_mask_impl(const float *g, const float *y, float *gm, float *gbias, int64_t rows, int C, void *workspace,
+                                    float *amax_out, void *stream)
 {
     HTD_REQUIRE(rows >= 0 && C > 0, "bias_grad: bad sizes");
     HTD_REQUIRE(g && (gbias || y) && (!gbias || workspace) && (!y || gm), "bias_grad: null pointer");
@@ -1735,12 +1748,27 @@ extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm
     float *partial = gbias ? (float *)workspace : nullptr;          // gbias == NULL: ReLU mask only
     if ((C & 3) == 0 && (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gm | (uintptr_t)partial) & 15) == 0)
         hipLaunchKernelGGL(colsum_mask_vec_kernel, dim3(nb, (unsigned)htd::ceil_div(C / 4, 256)), dim3(256), 0, s, g, y,
-                           gm, partial, rows, C, rpb);
+                           gm, partial, rows, C, rpb, amax_out);
     else
         hipLaunchKernelGGL(colsum_mask_kernel, dim3(nb, (unsigned)htd::ceil_div(C, 256)), dim3(256), 0, s, g, y, gm,
-                           partial, rows, C, rpb);
+                           partial, rows, C, rpb, amax_out);
     if (gbias)
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)htd::ceil_div(C, 16)), dim3(256), 0, s,
                            (const float *)partial, gbias, C, nb);
     return htd::check_launch("bias_grad");
+}
+
+extern "C" int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows, int C,
+                                       void *workspace, void *stream)
+{
+    return bias_grad_relu_mask_impl(g, y, gm, gbias, rows, C, workspace, nullptr, stream);
+}
+
+// the same, and the largest magnitude of gm (of g when y is NULL) is left in *amax_out (zero or an earlier maximum on entry): the
+// `amax` of the data- and weight-gradient launches that read the masked gradient on the H2 arithmetic
+extern "C" int htd_bias_grad_relu_mask_amax(const float *g, const float *y, float *gm, float *gbias, int64_t rows, int C,
+                                            void *workspace, float *amax_out, void *stream)
+{
+    HTD_REQUIRE(amax_out, "bias_grad: null maximum");
+    return bias_grad_relu_mask_impl(g, y, gm, gbias, rows, C, workspace, amax_out, stream);
 }

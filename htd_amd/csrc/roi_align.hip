@@ -235,11 +235,14 @@ struct LevelTable {
 __global__ __launch_bounds__(256) void roi_align_levels_fwd_kernel(LevelTable tab, const float *__restrict__ rois,
                                                                    const int64_t *__restrict__ roi_level, float *__restrict__ out,
                                                                    int64_t n, int B, int C, int L, int ph, int pw,
-                                                                   int sampling_ratio, int aligned, int chunks, int64_t tasks)
+                                                                   int sampling_ratio, int aligned, int chunks, int64_t tasks,
+                                                                   float *__restrict__ amax_out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t task = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (task >= tasks) return;
+    // amax_out: what the scalar holds now (read early; a wavefront that cannot raise it stays away from the atomic)
+    const unsigned seen = amax_out ? *reinterpret_cast<const volatile unsigned *>(amax_out) : 0u;
     const int chunk = (int)(task % chunks);
     const int64_t t2 = task / chunks;
     const int bin = (int)(t2 % (ph * pw));
@@ -284,6 +287,14 @@ __global__ __launch_bounds__(256) void roi_align_levels_fwd_kernel(LevelTable ta
     if (act) {
         acc.x *= g.inv_count; acc.y *= g.inv_count; acc.z *= g.inv_count; acc.w *= g.inv_count;
         *reinterpret_cast<float4 *>(out + bin_off + ch) = acc;
+    }
+    if (amax_out) {                                       // wave-uniform: max |out| of the launch (NaN sorts above everything)
+        const bool nan = act && ((acc.x != acc.x) | (acc.y != acc.y) | (acc.z != acc.z) | (acc.w != acc.w));
+        const float m = act ? fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))) : 0.f;
+        unsigned bits = nan ? 0x7fc00000u : __float_as_uint(m);
+        for (int o = 32; o > 0; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o));
+        if (lane == 0 && bits > seen)
+            __hip_atomic_fetch_max(reinterpret_cast<unsigned *>(amax_out), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -862,9 +873,9 @@ extern "C" int htd_roi_align_fwd(const float *feat, const float *rois, const int
 
 // feats[l] [B][H[l]][W[l]][C] for l < L (L <= 8); every RoI is pooled from level roi_level[i] (RoIs with a level outside
 // [0, L) get zeros): SingleRoIExtractor.forward (single_level_roi_extractor.py:81-99) in one launch.
-extern "C" int htd_roi_align_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
-                                        const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph,
-                                        int pw, int sampling_ratio, int aligned, void *stream)
+static int roi_align_levels_fwd_impl(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                                     const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph,
+                                     int pw, int sampling_ratio, int aligned, float *amax_out, void *stream)
 {
     HTD_REQUIRE(L > 0 && L <= 8 && n >= 0 && B > 0 && C > 0 && ph > 0 && pw > 0, "roi_align_levels: bad sizes");
     HTD_REQUIRE(C % 4 == 0, "roi_align_levels: C=%d must be a multiple of 4", C);
@@ -880,8 +891,27 @@ extern "C" int htd_roi_align_levels_fwd(const float *const *feats, const int *H,
     const int64_t blocks = htd::ceil_div(tasks, 4);
     HTD_REQUIRE(blocks < (1ll << 31), "roi_align_levels: too many tasks");
     hipLaunchKernelGGL(roi_align_levels_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab, rois, roi_level, out,
-                       n, B, C, L, ph, pw, sampling_ratio, aligned, chunks, tasks);
+                       n, B, C, L, ph, pw, sampling_ratio, aligned, chunks, tasks, amax_out);
     return htd::check_launch("roi_align_levels");
+}
+
+extern "C" int htd_roi_align_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                                        const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph,
+                                        int pw, int sampling_ratio, int aligned, void *stream)
+{
+    return roi_align_levels_fwd_impl(feats, H, W, scales, L, rois, roi_level, out, n, B, C, ph, pw, sampling_ratio, aligned, nullptr,
+                                     stream);
+}
+
+// the same, and max |out| is left in *amax_out (a device scalar holding zero or an earlier maximum on entry): the pooled tiles go
+// straight into the RoI heads' first FC layer, whose H2 launches (htd_conv2d_fwd_x3h, htd_conv2d_bwd_weight_h2) scale by it
+extern "C" int htd_roi_align_levels_fwd_amax(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                                             const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C,
+                                             int ph, int pw, int sampling_ratio, int aligned, float *amax_out, void *stream)
+{
+    HTD_REQUIRE(amax_out, "roi_align_levels: null maximum");
+    return roi_align_levels_fwd_impl(feats, H, W, scales, L, rois, roi_level, out, n, B, C, ph, pw, sampling_ratio, aligned, amax_out,
+                                     stream);
 }
 
 // Every RoI pooled from every level (AdptRoIExtractor): outs[l] (n, ph, pw, C) <- RoIAlign(feats[l], rois), l < L, ONE launch.

@@ -17,8 +17,9 @@ __global__ __launch_bounds__(256) void fuse_global_fwd_kernel(const float *__res
                                                               const float *__restrict__ g,
                                                               const float *__restrict__ extra, float alpha,
                                                               float *__restrict__ out, int64_t total4, int P,
-                                                              int C4, int B)
+                                                              int C4, int B, float *__restrict__ amax_out)
 {
+    unsigned mx = 0u;                     // amax_out (may be NULL): max |out| of the launch, for an H2 consumer (common.h)
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % C4);
@@ -33,14 +34,17 @@ __global__ __launch_bounds__(256) void fuse_global_fwd_kernel(const float *__res
             v.x += alpha * e.x; v.y += alpha * e.y; v.z += alpha * e.z; v.w += alpha * e.w;
         }
         st4(out + idx * 4, v);
+        mx = htd::mag_bits4(mx, v);
     }
+    if (amax_out) htd::wave_mag_out(mx, amax_out);
 }
 
 // both[0 .. n) = x, both[n .. 2n) = x + g[img(roi)]: the two batches the HTD classification FCs run on, one read of x
 __global__ __launch_bounds__(256) void plain_and_fused_kernel(const float *__restrict__ x, const float *__restrict__ rois,
                                                               const float *__restrict__ g, float *__restrict__ both,
-                                                              int64_t total4, int P, int C4, int B)
+                                                              int64_t total4, int P, int C4, int B, float *__restrict__ amax_out)
 {
+    unsigned mx = 0u;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % C4);
         const int64_t i = idx / ((int64_t)P * C4);
@@ -48,10 +52,13 @@ __global__ __launch_bounds__(256) void plain_and_fused_kernel(const float *__res
         b = b < 0 ? 0 : (b >= B ? B - 1 : b);
         float4 v = ld4(x + idx * 4);
         st4(both + idx * 4, v);
+        mx = htd::mag_bits4(mx, v);
         const float4 gv = ld4(g + ((int64_t)b * C4 + c4) * 4);
         v.x += gv.x; v.y += gv.y; v.z += gv.z; v.w += gv.w;
         st4(both + (total4 + idx) * 4, v);
+        mx = htd::mag_bits4(mx, v);
     }
+    if (amax_out) htd::wave_mag_out(mx, amax_out);
 }
 
 // grad_global[b][c] += sum_{i in image b} sum_p grad[i][p][c]; a block walks ROIS_PER_BLOCK
@@ -795,9 +802,8 @@ inline unsigned grid_for(int64_t work, int block = 256, int cap = 4096)
 
 }  // namespace
 
-extern "C" int htd_fuse_global_fwd(const float *roi_feats, const float *rois, const float *global_feat,
-                                   const float *extra, float alpha, float *out, int64_t n, int P, int C, int B,
-                                   void *stream)
+static int fuse_global_fwd_impl(const float *roi_feats, const float *rois, const float *global_feat, const float *extra, float alpha,
+                                float *out, int64_t n, int P, int C, int B, float *amax_out, void *stream)
 {
     HTD_REQUIRE(C % 4 == 0 && P > 0 && B > 0 && n >= 0, "fuse_global: bad sizes n=%lld P=%d C=%d B=%d",
                 (long long)n, P, C, B);
@@ -805,21 +811,51 @@ extern "C" int htd_fuse_global_fwd(const float *roi_feats, const float *rois, co
     HTD_REQUIRE(roi_feats && rois && global_feat && out, "fuse_global: null pointer");
     const int64_t total4 = n * P * (C / 4);
     hipLaunchKernelGGL(fuse_global_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, roi_feats,
-                       rois, global_feat, extra, alpha, out, total4, P, C / 4, B);
+                       rois, global_feat, extra, alpha, out, total4, P, C / 4, B, amax_out);
     return htd::check_launch("fuse_global_fwd");
 }
 
+extern "C" int htd_fuse_global_fwd(const float *roi_feats, const float *rois, const float *global_feat,
+                                   const float *extra, float alpha, float *out, int64_t n, int P, int C, int B,
+                                   void *stream)
+{
+    return fuse_global_fwd_impl(roi_feats, rois, global_feat, extra, alpha, out, n, P, C, B, nullptr, stream);
+}
+
+// htd_fuse_global_fwd / htd_plain_and_fused_fwd that also leave the largest magnitude they store in *amax_out (a device scalar
+// holding zero or an earlier maximum on entry): their outputs are what the RoI heads' first FC layers read, and those layers' H2
+// launches (htd_conv2d_fwd_x3h, htd_conv2d_bwd_weight_h2) scale by it.
+extern "C" int htd_fuse_global_fwd_amax(const float *roi_feats, const float *rois, const float *global_feat, const float *extra,
+                                        float alpha, float *out, int64_t n, int P, int C, int B, float *amax_out, void *stream)
+{
+    HTD_REQUIRE(amax_out, "fuse_global: null maximum");
+    return fuse_global_fwd_impl(roi_feats, rois, global_feat, extra, alpha, out, n, P, C, B, amax_out, stream);
+}
+
 // both [2n][P][C]: rows [0, n) = roi_feats, rows [n, 2n) = roi_feats + global_feat[image of the RoI] (htd_bbox_head.py:198,201)
-extern "C" int htd_plain_and_fused_fwd(const float *roi_feats, const float *rois, const float *global_feat, float *both,
-                                       int64_t n, int P, int C, int B, void *stream)
+static int plain_and_fused_impl(const float *roi_feats, const float *rois, const float *global_feat, float *both, int64_t n, int P,
+                                int C, int B, float *amax_out, void *stream)
 {
     HTD_REQUIRE(C % 4 == 0 && P > 0 && B > 0 && n >= 0, "plain_and_fused: bad sizes n=%lld P=%d C=%d B=%d", (long long)n, P, C, B);
     if (n == 0) return HTD_OK;
     HTD_REQUIRE(roi_feats && rois && global_feat && both, "plain_and_fused: null pointer");
     const int64_t total4 = n * P * (C / 4);
     hipLaunchKernelGGL(plain_and_fused_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, roi_feats, rois,
-                       global_feat, both, total4, P, C / 4, B);
+                       global_feat, both, total4, P, C / 4, B, amax_out);
     return htd::check_launch("plain_and_fused_fwd");
+}
+
+extern "C" int htd_plain_and_fused_fwd(const float *roi_feats, const float *rois, const float *global_feat, float *both,
+                                       int64_t n, int P, int C, int B, void *stream)
+{
+    return plain_and_fused_impl(roi_feats, rois, global_feat, both, n, P, C, B, nullptr, stream);
+}
+
+extern "C" int htd_plain_and_fused_fwd_amax(const float *roi_feats, const float *rois, const float *global_feat, float *both,
+                                            int64_t n, int P, int C, int B, float *amax_out, void *stream)
+{
+    HTD_REQUIRE(amax_out, "plain_and_fused: null maximum");
+    return plain_and_fused_impl(roi_feats, rois, global_feat, both, n, P, C, B, amax_out, stream);
 }
 
 extern "C" int htd_fuse_global_bwd_global(const float *grad, const float *rois, float *grad_global, int64_t n, int P,
@@ -1098,9 +1134,10 @@ namespace {
 
 __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                            int *__restrict__ idx, int B, int H, int W, int C4, int Ho,
-                                                           int Wo, int k, int s, int p)
+                                                           int Wo, int k, int s, int p, float *__restrict__ amax_out)
 {
     const int64_t total = (int64_t)B * Ho * Wo * C4;
+    unsigned mx = 0u;                     // amax_out (may be NULL): max |y| of the launch, for an H2 consumer (common.h)
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(t % C4);
         int64_t r = t / C4;
@@ -1126,7 +1163,9 @@ __global__ __launch_bounds__(256) void max_pool_fwd_kernel(const float *__restri
         }
         reinterpret_cast<float4 *>(y)[t] = m;
         if (idx) reinterpret_cast<int4 *>(idx)[t] = am;
+        mx = htd::mag_bits4(mx, m);
     }
+    if (amax_out) htd::wave_mag_out(mx, amax_out);
 }
 
 // gather form of the backward: an input pixel sums the gradients of the (at most ceil(k/s)^2) windows that contain
@@ -1250,8 +1289,8 @@ extern "C" int htd_upsample_nearest_bwd(const float *g, float *out, int B, int H
     return htd::check_launch("upsample_nearest_bwd");
 }
 
-extern "C" int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride,
-                                  int pad, void *stream)
+static int max_pool2d_fwd_impl(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride, int pad,
+                               float *amax_out, void *stream)
 {
     HTD_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k,
                 "max_pool2d: bad sizes");
@@ -1263,8 +1302,23 @@ extern "C" int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int
     const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
     const unsigned blocks = (unsigned)std::min<int64_t>(htd::ceil_div(total, 256), 65536);
     hipLaunchKernelGGL(max_pool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, idx, B, H, W, C / 4,
-                       Ho, Wo, k, stride, pad);
+                       Ho, Wo, k, stride, pad, amax_out);
     return htd::check_launch("max_pool2d_fwd");
+}
+
+extern "C" int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride,
+                                  int pad, void *stream)
+{
+    return max_pool2d_fwd_impl(x, y, idx, B, H, W, C, k, stride, pad, nullptr, stream);
+}
+
+// the same, and max |y| is left in *amax_out (device scalar, zero or an earlier maximum on entry) for the H2 launches of the 1x1
+// layers that read the pooled map (htd_conv2d_fwd_x3h: the first block of the ResNet's first stage)
+extern "C" int htd_max_pool2d_fwd_amax(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride, int pad,
+                                       float *amax_out, void *stream)
+{
+    HTD_REQUIRE(amax_out, "max_pool2d: null maximum");
+    return max_pool2d_fwd_impl(x, y, idx, B, H, W, C, k, stride, pad, amax_out, stream);
 }
 
 extern "C" int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, int W, int C, int k,

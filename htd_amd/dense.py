@@ -13,6 +13,7 @@ import os
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
+from torch.multiprocessing.reductions import StorageWeakRef as _StorageWeakRef
 
 from . import capi
 
@@ -241,6 +242,7 @@ def new_step():
     _STEP_FLIPS.clear()
     _STEP_PLANES.clear()
     _AMAX_POOL.clear()
+    _AMAX_BY_PTR.clear()
     _drop_temp_sinks()
 
 
@@ -323,19 +325,50 @@ def _h2_trace(what, t, weight):
         H2_TRACE[key] = H2_TRACE.get(key, 0) + 1
 
 
+# A tagged tensor reaches its consumer as ANOTHER tensor object when views lie between them (linear()'s (M, K) <-> (M, K, 1, 1), the
+# view nodes autograd runs on the way back, a saved tensor unpacked in backward): the maxima are therefore also kept by ADDRESS,
+# each with a weak reference to the storage it was written into -- while that storage lives the allocator cannot hand the address to
+# anybody else, and a dense tensor of the same address, element count and version counter over the same storage holds the same
+# elements.  HTD_H2_VIEWS=0: tensor objects only.
+H2_VIEWS = os.environ.get('HTD_H2_VIEWS', '1') != '0'
+_AMAX_BY_PTR = {}
+
+
+def _dense_layout(t):
+    """Does t cover numel() distinct consecutive elements from data_ptr() on (a permutation of a contiguous tensor)?"""
+    if t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=CL)):
+        return True
+    want = 1
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.shape, t.stride()) if sz != 1), key=lambda p: p[1]):
+        if stride != want:
+            return False
+        want *= size
+    return True
+
+
 def tag_amax(t, slot):
-    """Remember on the tensor object that `slot` holds max |t| (written by the kernel that is filling t)."""
+    """Remember that `slot` holds max |t| (written by the kernel that is filling t): on the tensor object, and by address."""
     t._htd_amax = (slot, t.data_ptr(), t.numel(), t._version)
+    if H2_VIEWS:
+        st = t.untyped_storage()
+        _AMAX_BY_PTR[t.data_ptr()] = (slot, t.numel(), t._version, st._cdata, _StorageWeakRef(st))
 
 
 def drop_amax(t):
     """t is about to be modified in place by a kernel torch does not see: its carried maximum is void."""
-    if t is not None and hasattr(t, '_htd_amax'):
-        del t._htd_amax
+    if t is not None:
+        if hasattr(t, '_htd_amax'):
+            del t._htd_amax
+        _AMAX_BY_PTR.pop(t.data_ptr(), None)
 
 
 def carried_amax(t):
     a = getattr(t, '_htd_amax', None)
+    if a is None and H2_VIEWS:
+        e = _AMAX_BY_PTR.get(t.data_ptr())
+        if e is not None and e[1] == t.numel() and e[2] == t._version and not e[4].expired() and \
+                t.untyped_storage()._cdata == e[3] and _dense_layout(t):
+            a = (e[0], t.data_ptr(), e[1], e[2])
     if a is None or a[1] != t.data_ptr() or a[2] != t.numel() or a[3] != t._version:
         return None
     if H2_CHECK:
@@ -596,10 +629,24 @@ def _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up
         if out_slot is not None:
             tag_amax(y, out_slot)
         return (y, yp) if emit else y
+    work = ('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0)))
+    if _igemm_emits(y, Co):
+        # (a strided / dilated layer between layers that run on H2: its output's maximum rides along like theirs)
+        slot = _amax_slot(x.device)
+        capi.call('htd_conv2d_fwd_amax', _P(x), _P(weight), _P(bias), _P(residual), rh, rw, _P(y), _P(slot), B, H, W, Ci, Co, kh, kw,
+                  stride, padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
+                  key='htd_conv2d_fwd', work=work)
+        tag_amax(y, slot)
+        return y
     capi.call('htd_conv2d_fwd', _P(x), _P(weight), _P(bias), _P(residual), rh, rw, _P(y), B, H, W, Ci, Co, kh, kw, stride,
-              padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(),
-              work=('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0))))
+              padding, dilation, int(bool(relu)), _P(_splitk_ws(B * Ho * Wo, Co, Ci, kh, kw, x.device)), _S(), work=work)
     return y
+
+
+def _igemm_emits(y, C):
+    """Does a conv_igemm_kernel launch leave the maximum of its output?  fp32 maps of at least 64 channels (what an H2 layer can
+    read; the skinny heads' outputs go into losses) while H2 is on."""
+    return y.dtype == torch.float32 and C >= 64 and emits('igemm')
 
 
 def _colsum_raw(g, y=None, bias=None):
@@ -610,9 +657,30 @@ def _colsum_raw(g, y=None, bias=None):
     if g.numel() == 0:
         return gm, gb.zero_()
     ws = torch.empty(2048 * Co, device=g.device, dtype=g.dtype)
-    capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm) if y is not None else None, _P(gb), B * Ho * Wo, Co,
-              _P(ws), _S(), work=('byte', 4.0 * B * Ho * Wo * Co * (3 if y is not None else 1)))
+    work = ('byte', 4.0 * B * Ho * Wo * Co * (3 if y is not None else 1))
+    if _mask_emits(g):
+        slot = _amax_slot(g.device)
+        capi.call('htd_bias_grad_relu_mask_amax', _P(g), _P(y), _P(gm) if y is not None else None, _P(gb), B * Ho * Wo, Co,
+                  _P(ws), _P(slot), _S(), key='htd_bias_grad_relu_mask', work=work)
+        tag_amax(gm, slot)
+    else:
+        capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm) if y is not None else None, _P(gb), B * Ho * Wo, Co,
+                  _P(ws), _S(), work=work)
     return gm, gb
+
+
+# HTD_H2_EMIT_OFF=mask,igemm,roi,pool: producers that do NOT leave their output's maximum (A/B runs and bisection): the ReLU-mask /
+# bias-gradient pass, conv_igemm_kernel's epilogues, RoIAlign and the global-context fusions, the stem's max pooling.
+H2_EMIT_OFF = frozenset(v for v in os.environ.get('HTD_H2_EMIT_OFF', '').split(',') if v)
+
+
+def emits(kind):
+    return kind not in H2_EMIT_OFF and capi.lib().htd_conv2d_set_h2(-1) == 1
+
+
+def _mask_emits(g):
+    """The masked gradient goes into a data- and a weight-gradient launch: its maximum rides along when those can use it."""
+    return g.dtype == torch.float32 and emits('mask')
 
 
 def _mask_raw(g, y):
@@ -621,8 +689,14 @@ def _mask_raw(g, y):
     gm = torch.empty_like(g, memory_format=CL)
     if g.numel() == 0:
         return gm
-    capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm), None, B * Ho * Wo, Co, None, _S(),
-              work=('byte', 12.0 * B * Ho * Wo * Co))
+    if _mask_emits(g):
+        slot = _amax_slot(g.device)
+        capi.call('htd_bias_grad_relu_mask_amax', _P(g), _P(y), _P(gm), None, B * Ho * Wo, Co, None, _P(slot), _S(),
+                  key='htd_bias_grad_relu_mask', work=('byte', 12.0 * B * Ho * Wo * Co))
+        tag_amax(gm, slot)
+    else:
+        capi.call('htd_bias_grad_relu_mask', _P(g), _P(y), _P(gm), None, B * Ho * Wo, Co, None, _S(),
+                  work=('byte', 12.0 * B * Ho * Wo * Co))
     return gm
 
 
@@ -688,10 +762,17 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
                 capi.call('htd_conv2d_flip_weights', _P(weight), _P(wT), Co, kh, kw, Ci, _S())
                 _STEP_FLIPS[key] = (weight, wT)
     gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+    work = ('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
+            4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None))))
+    if _igemm_emits(gx, Ci):
+        slot = _amax_slot(g.device)
+        capi.call('htd_conv2d_bwd_data_amax', _P(gd), _P(wT), _P(mask_src), _P(accum), _P(gx), _P(slot), B, H, W, Ci, Cod, kh, kw,
+                  stride, padding, dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(),
+                  key='htd_conv2d_bwd_data', work=work)
+        tag_amax(gx, slot)
+        return gx
     capi.call('htd_conv2d_bwd_data', _P(gd), _P(wT), _P(mask_src), _P(accum), _P(gx), B, H, W, Ci, Cod, kh, kw, stride,
-              padding, dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(),
-              work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
-                    4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None) + (accum is not None)))))
+              padding, dilation, _P(_splitk_ws(B * H * W, Ci, Cod, kh, kw, g.device)), _S(), work=work)
     return gx
 
 

@@ -282,8 +282,17 @@ class _RoIAlignLevels(Function):
             Hs = (ctypes.c_int * L)(*[s_[2] for s_ in shapes])
             Ws = (ctypes.c_int * L)(*[s_[3] for s_ in shapes])
             sc = (ctypes.c_float * L)(*[float(v) for v in scales])
-            capi.call('htd_roi_align_levels_fwd', ptrs, Hs, Ws, sc, L, _P(rois), _P(lvls), _P(out), n, shapes[0][0], C, ph, pw,
-                      int(sampling_ratio), int(bool(aligned)), _S(), work=('byte', n * C * 4.0 * (ph * pw + 21 * 21)))
+            work = ('byte', n * C * 4.0 * (ph * pw + 21 * 21))
+            from . import dense
+            if dense.emits('roi'):
+                # the tiles go into the head's first FC layer: their maximum rides along for its H2 launches (dense.carried_amax)
+                slot = dense._amax_slot(out.device)
+                capi.call('htd_roi_align_levels_fwd_amax', ptrs, Hs, Ws, sc, L, _P(rois), _P(lvls), _P(out), n, shapes[0][0], C, ph,
+                          pw, int(sampling_ratio), int(bool(aligned)), _P(slot), _S(), key='htd_roi_align_levels_fwd', work=work)
+                dense.tag_amax(out, slot)
+            else:
+                capi.call('htd_roi_align_levels_fwd', ptrs, Hs, Ws, sc, L, _P(rois), _P(lvls), _P(out), n, shapes[0][0], C, ph, pw,
+                          int(sampling_ratio), int(bool(aligned)), _S(), work=work)
         ctx.save_for_backward(rois, lvls)
         ctx.args = (shapes, ph, pw, scales, int(sampling_ratio), int(bool(aligned)))
         ctx.chain = bool(chain)
@@ -424,7 +433,14 @@ class MaxPool2dFunction(Function):
         y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=CL)
         need = ctx.needs_input_grad[0]
         idx = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.int32) if need else None
-        capi.call('htd_max_pool2d_fwd', _P(x), _P(y), _P(idx), B, H, W, C, kernel, stride, padding, _S())
+        from . import dense
+        if dense.emits('pool'):                              # the 1x1 layers behind the pool read y on H2: its maximum rides along
+            slot = dense._amax_slot(y.device)
+            capi.call('htd_max_pool2d_fwd_amax', _P(x), _P(y), _P(idx), B, H, W, C, kernel, stride, padding, _P(slot), _S(),
+                      key='htd_max_pool2d_fwd')
+            dense.tag_amax(y, slot)
+        else:
+            capi.call('htd_max_pool2d_fwd', _P(x), _P(y), _P(idx), B, H, W, C, kernel, stride, padding, _S())
         ctx.save_for_backward(idx)
         ctx.args = ((B, C, H, W), kernel, stride, padding)
         return y
@@ -539,7 +555,14 @@ class FuseGlobalFunction(Function):
         e = nhwc(extra) if extra is not None else None
         rois = rois.contiguous()
         out = torch.empty_like(x, memory_format=CL)
-        capi.call('htd_fuse_global_fwd', _P(x), _P(rois), _P(g), _P(e), float(alpha), _P(out), n, ph * pw, C, B, _S())
+        from . import dense
+        if n and dense.emits('roi'):                         # the FC layer behind this reads `out` on H2: its maximum rides along
+            slot = dense._amax_slot(out.device)
+            capi.call('htd_fuse_global_fwd_amax', _P(x), _P(rois), _P(g), _P(e), float(alpha), _P(out), n, ph * pw, C, B, _P(slot), _S(),
+                      key='htd_fuse_global_fwd')
+            dense.tag_amax(out, slot)
+        else:
+            capi.call('htd_fuse_global_fwd', _P(x), _P(rois), _P(g), _P(e), float(alpha), _P(out), n, ph * pw, C, B, _S())
         ctx.save_for_backward(rois)
         ctx.meta = (tuple(global_feat.shape), float(alpha), extra is not None)
         return out
@@ -601,7 +624,14 @@ class PlainAndFusedFunction(Function):
         g = global_feat.reshape(B, C).contiguous()
         rois = rois.contiguous()
         both = torch.empty((2 * n, C, ph, pw), device=x.device, dtype=x.dtype, memory_format=CL)
-        capi.call('htd_plain_and_fused_fwd', _P(x), _P(rois), _P(g), _P(both), n, ph * pw, C, B, _S())
+        from . import dense
+        if n and dense.emits('roi'):
+            slot = dense._amax_slot(both.device)
+            capi.call('htd_plain_and_fused_fwd_amax', _P(x), _P(rois), _P(g), _P(both), n, ph * pw, C, B, _P(slot), _S(),
+                      key='htd_plain_and_fused_fwd')
+            dense.tag_amax(both, slot)
+        else:
+            capi.call('htd_plain_and_fused_fwd', _P(x), _P(rois), _P(g), _P(both), n, ph * pw, C, B, _S())
         ctx.save_for_backward(rois)
         ctx.meta = (tuple(global_feat.shape), n, tuple(x.shape))
         ctx.stash = stash

@@ -66,6 +66,11 @@ int htd_roi_align_bwd(const float *grad_out, const float *rois, const int64_t *r
 int htd_roi_align_levels_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int L,
                              const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph, int pw,
                              int sampling_ratio, int aligned, void *stream);
+/* The same, and max |out| is left in *amax_out (device scalar, zero or an earlier maximum on entry) for the H2 launches of the
+ * FC layer the tiles go into (htd_conv2d_fwd_x3h / htd_conv2d_bwd_weight_h2). */
+int htd_roi_align_levels_fwd_amax(const float *const *feats, const int *H, const int *W, const float *scales, int L,
+                                  const float *rois, const int64_t *roi_level, float *out, int64_t n, int B, int C, int ph,
+                                  int pw, int sampling_ratio, int aligned, float *amax_out, void *stream);
 /* Gather-form RoIAlign backward of all pyramid levels of a SingleRoIExtractor in one launch (coarsest level first, so the
  * long per-strip RoI lists of the small maps overlap the many short strips of the large ones).  grad_feats[l] == NULL
  * skips level l; accumulate[l] != 0 adds into a map another consumer has already written.
@@ -173,6 +178,12 @@ int htd_fuse_global_fwd(const float *roi_feats, const float *rois, const float *
  * both[0..n) = roi_feats, both[n..2n) = roi_feats + global_feat[image of the RoI].  both: [2n][P][C] floats. */
 int htd_plain_and_fused_fwd(const float *roi_feats, const float *rois, const float *global_feat, float *both,
                             int64_t n, int P, int C, int B, void *stream);
+/* The two above, also leaving the largest magnitude they store in *amax_out (device scalar, zero or an earlier maximum on
+ * entry): the `amax` of the H2 launches of the FC layer that reads the tiles (htd_conv2d_fwd_x3h, htd_conv2d_bwd_weight_h2). */
+int htd_fuse_global_fwd_amax(const float *roi_feats, const float *rois, const float *global_feat, const float *extra,
+                             float alpha, float *out, int64_t n, int P, int C, int B, float *amax_out, void *stream);
+int htd_plain_and_fused_fwd_amax(const float *roi_feats, const float *rois, const float *global_feat, float *both,
+                                 int64_t n, int P, int C, int B, float *amax_out, void *stream);
 int htd_fuse_global_bwd_global(const float *grad, const float *rois, float *grad_global,
                                int64_t n, int P, int C, int B, void *stream);
 
@@ -254,6 +265,14 @@ int htd_pad_channels(const float *x, float *y, int64_t rows, int C, int C_padded
 int htd_conv2d_bwd_data(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx,
                         int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad, int dil,
                         void *workspace, void *stream);
+/* htd_conv2d_fwd / htd_conv2d_bwd_data that also leave the largest magnitude of what they store in *amax_out (device scalar, zero
+ * or an earlier maximum on entry): the `amax` of the H2 launches (htd_conv2d_fwd_x3h ...) that read the output next. */
+int htd_conv2d_fwd_amax(const float *x, const float *w, const float *bias, const float *residual, int res_h, int res_w,
+                        float *y, float *amax_out, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                        int dil, int relu, void *workspace, void *stream);
+int htd_conv2d_bwd_data_amax(const float *gy, const float *wT, const float *mask_src, const float *accum, float *gx,
+                             float *amax_out, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                             int dil, void *workspace, void *stream);
 int64_t htd_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw,
                                          int stride, int pad, int dil);
 int htd_conv2d_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H, int W,
@@ -266,6 +285,10 @@ int htd_conv2d_bwd_weight_acc(const float *x, const float *gy, float *gw, float 
                               int Co, int kh, int kw, int stride, int pad, int dil, void *workspace, void *stream);
 int htd_bias_grad_relu_mask(const float *g, const float *y, float *gm, float *gbias, int64_t rows,
                             int C, void *workspace, void *stream);
+/* The same, and max |gm| (max |g| when y is NULL) is left in *amax_out, a device scalar holding zero or an earlier maximum on
+ * entry: the `amax` of the H2 data- / weight-gradient launches that read the masked gradient (htd_conv2d_bwd_data_x3h). */
+int htd_bias_grad_relu_mask_amax(const float *g, const float *y, float *gm, float *gbias, int64_t rows, int C,
+                                 void *workspace, float *amax_out, void *stream);
 /* The ResNet stem (backbones/resnet.py:596-607 `conv1`: 7x7, stride 2, padding 3, 3 -> 64 channels; what cuDNN's
  * small-channel first-layer algorithm is to the reference): x [B][H][W][4] fp32 NHWC with the fourth channel zero,
  * w [64][7][7][4] fp32 KRSC, bias [64] or NULL, y [B][Ho][Wo][64], Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1; relu != 0 applies
@@ -536,6 +559,10 @@ int htd_rpn_loss(const float *cls, const float *reg, const float *anchors, const
 int htd_upsample_nearest_bwd(const float *g, float *out, int B, int H, int W, int h, int w, int C, void *stream);
 int htd_max_pool2d_fwd(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride, int pad,
                        void *stream);
+/* The same, also leaving max |y| in *amax_out (device scalar, zero or an earlier maximum on entry) for the H2 launches that read
+ * the pooled map (htd_conv2d_fwd_x3h). */
+int htd_max_pool2d_fwd_amax(const float *x, float *y, int *idx, int B, int H, int W, int C, int k, int stride, int pad,
+                            float *amax_out, void *stream);
 int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int B, int H, int W, int C, int k, int stride,
                        int pad, void *stream);
 

@@ -264,9 +264,11 @@ def test_h2_weight_gradient_accumulates_and_is_exact_on_integers(h2):
 
 
 def test_carried_maximum_contract(h2):
-    """dense.tag_amax / carried_amax: the tag is a Python attribute on the tensor OBJECT and is honoured only while address, size and
-    torch's version counter are what they were -- an in-place torch op voids it, a view or a copy never had it, drop_amax removes it
-    (for kernels that write behind torch's back), and it survives autograd's Function.apply and the save_for_backward of an intermediate (same object)."""
+    """dense.tag_amax / carried_amax: the maximum is remembered on the tensor object and by address (with a weak reference to the
+    storage), and honoured only while address, element count and torch's version counter are what they were and the storage is
+    the one that was written -- views of the whole tensor keep it (linear()'s reshapes, autograd's view nodes), an in-place torch
+    op voids it, a copy or a partial / strided view never had it, drop_amax removes it (for kernels that write behind torch's back),
+    a new tensor at the freed address does not inherit it; and it survives Function.apply and save_for_backward."""
     from htd_amd import dense
     dev = torch.device('cuda:0')
     dense.new_step()
@@ -276,12 +278,39 @@ def test_carried_maximum_contract(h2):
     y = dense._fwd_raw(x, w, None, None, 1, 1, 1, True)
     am = dense.carried_amax(y)                                # left by the epilogue
     assert am is not None and float(am) == float(y.abs().max())
-    assert dense.carried_amax(y.view_as(y)) is None and dense.carried_amax(y.clone()) is None
+    assert dense.carried_amax(y.clone()) is None
+    for v in (y.view_as(y), y.permute(0, 2, 3, 1), y.permute(0, 2, 3, 1).reshape(2, -1), y.detach()):
+        got = dense.carried_amax(v)                           # the same elements under another shape
+        assert got is not None and got.data_ptr() == am.data_ptr()
+    assert dense.carried_amax(y[:1]) is None and dense.carried_amax(y[:, :32]) is None        # a part of the elements
+    flat = y.permute(0, 2, 3, 1).reshape(-1)
+    assert dense.carried_amax(flat[::2]) is None and dense.carried_amax(flat[1:]) is None
+    big = torch.empty(4 * y.numel(), device=dev)
+    half = big[:y.numel()]
+    dense.tag_amax(half, dense.absmax(half.zero_()))
+    assert dense.carried_amax(big[:2 * y.numel():2]) is None  # same address and element count, other elements
+    # the address handed to another tensor: the weak reference to the storage that was written has expired
+    ptr, shape = y.data_ptr(), y.shape
+    keep = am.clone()
+    del y, v, got, flat
+    z = torch.empty(shape, device=dev).contiguous(memory_format=CL)
+    if z.data_ptr() == ptr:
+        assert dense.carried_amax(z) is None
+    monkey = dense.H2_VIEWS
+    try:
+        dense.H2_VIEWS = False
+        y = dense._fwd_raw(x, w, None, None, 1, 1, 1, True)
+        assert dense.carried_amax(y) is not None and dense.carried_amax(y.view_as(y)) is None      # tensor objects only
+    finally:
+        dense.H2_VIEWS = monkey
+    y = dense._fwd_raw(x, w, None, None, 1, 1, 1, True)
+    assert float(keep) == float(dense.carried_amax(y))
     y.mul_(2.0)                                               # torch's version counter moved: stale
     assert dense.carried_amax(y) is None
+    assert dense.carried_amax(y.view_as(y)) is None
     y2 = dense._fwd_raw(x, w, None, None, 1, 1, 1, True)
     dense.drop_amax(y2)
-    assert dense.carried_amax(y2) is None
+    assert dense.carried_amax(y2) is None and dense.carried_amax(y2.view_as(y2)) is None
 
     class Pass(torch.autograd.Function):
         @staticmethod
@@ -294,7 +323,7 @@ def test_carried_maximum_contract(h2):
         @staticmethod
         def backward(ctx, g):
             mid, out = ctx.saved_tensors
-            # (a saved OUTPUT is re-wrapped by autograd when it is unpacked -- a new object, no tag: the safe direction)
+            # (a saved OUTPUT is re-wrapped by autograd when it is unpacked -- a new object: found by address)
             Pass.seen = (dense.carried_amax(mid) is not None, dense.carried_amax(out) is not None)
             return g
     xr = x.clone().requires_grad_()
@@ -302,7 +331,7 @@ def test_carried_maximum_contract(h2):
     out = Pass.apply(xr)
     assert dense.carried_amax(out) is not None
     out.sum().backward()
-    assert Pass.seen[0] and Pass.seen in ((True, False), (True, True))
+    assert Pass.seen == (True, True)
     dense.new_step()
 
 
@@ -324,4 +353,176 @@ def test_stale_maximum_is_caught_by_the_guard(h2, monkeypatch):
     with pytest.raises(RuntimeError, match='stale'):
         dense.h2_check()
     dense.h2_check()                                          # the flag was cleared
+    dense.new_step()
+
+
+@pytest.mark.parametrize('rows,C,with_y,with_bias', [(1000, 256, True, True), (777, 1024, True, False), (513, 30, True, True),
+                                                      (2048, 1024, False, True), (64, 81, False, True)])
+def test_masked_gradient_leaves_its_maximum(h2, rows, C, with_y, with_bias):
+    """htd_bias_grad_relu_mask_amax: the same gm / gbias as htd_bias_grad_relu_mask, and max |gm| bit for bit (both kernels: 16-byte
+    and scalar columns); a NaN in the gradient comes out as NaN."""
+    from htd_amd import capi
+    dev = torch.device('cuda:0')
+    torch.manual_seed(rows + C)
+    g = torch.randn(rows, C, device=dev) * 3
+    y = torch.randn(rows, C, device=dev) if with_y else None
+    for nan in (False, True):
+        if nan:
+            g[rows // 2, C // 3] = float('nan')
+            if with_y:
+                y[rows // 2, C // 3] = 1.0
+        out = []
+        for name in ('htd_bias_grad_relu_mask', 'htd_bias_grad_relu_mask_amax'):
+            gm = torch.empty_like(g) if with_y else None
+            gb = torch.empty(C, device=dev) if with_bias else None
+            ws = torch.empty(2048 * C, device=dev) if with_bias else None
+            slot = torch.zeros(1, device=dev)
+            extra = (capi.ptr(slot), ) if name.endswith('_amax') else ()
+            capi.call(name, capi.ptr(g), capi.ptr(y), capi.ptr(gm), capi.ptr(gb), rows, C, capi.ptr(ws), *extra, capi.current_stream_ptr())
+            out.append((gm, gb, slot))
+        (gm0, gb0, _), (gm1, gb1, slot) = out
+        if with_y:
+            assert torch.equal(gm0.nan_to_num(7.0), gm1.nan_to_num(7.0))
+        if with_bias:
+            assert torch.equal(gb0.nan_to_num(7.0), gb1.nan_to_num(7.0))
+        ref = (gm1 if with_y else g).abs().max()
+        assert torch.isnan(slot).item() if nan else float(slot) == float(ref)
+
+
+def test_roi_align_levels_leaves_its_maximum(h2):
+    """htd_roi_align_levels_fwd_amax: the tiles of htd_roi_align_levels_fwd and max |out| bit for bit; through mmcv_ops the tag reaches
+    the FC layer behind the flatten (a view) and that layer runs on H2 -- forward and weight gradient."""
+    from htd_amd import capi, dense, mmcv_ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    feats = [torch.randn(2, 64, 80 >> l, 96 >> l, device=dev).contiguous(memory_format=CL).requires_grad_() for l in range(4)]
+    n = 300
+    xy = torch.rand(n, 2, device=dev) * torch.tensor([300.0, 250.0], device=dev)
+    wh = torch.rand(n, 2, device=dev) * 120 + 4
+    rois = torch.cat([torch.randint(0, 2, (n, 1), device=dev).float(), xy, xy + wh], 1)
+    lv = torch.randint(0, 4, (n, ), device=dev)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    h2.htd_conv2d_set_h2(0)
+    ref = mmcv_ops._RoIAlignLevels.apply(rois, lv, 7, scales, 2, True, False, *[f.detach() for f in feats])
+    assert dense.carried_amax(ref) is None
+    h2.htd_conv2d_set_h2(1)
+    dense.new_step()
+    out = mmcv_ops._RoIAlignLevels.apply(rois, lv, 7, scales, 2, True, False, *feats)
+    assert torch.equal(out, ref)
+    am = dense.carried_amax(out)
+    assert am is not None and float(am) == float(out.detach().abs().max())
+    fc = torch.nn.Linear(64 * 49, 256).to(dev)
+    xf = out.permute(0, 2, 3, 1).reshape(n, -1)
+    assert dense.carried_amax(xf) is not None
+    capi.profile_begin()
+    yfc = dense.linear(xf, fc.weight, fc.bias, relu=True)
+    yfc.square().sum().backward()
+    prof = capi.profile_end()
+    assert 'htd_conv2d_fwd_x3h' in prof and 'htd_conv2d_bwd_weight_h2' in prof and 'htd_conv2d_bwd_data_x3h' in prof, sorted(prof)
+    dense.new_step()
+
+
+def test_fused_roi_tiles_leave_their_maximum(h2):
+    """htd_fuse_global_fwd_amax / htd_plain_and_fused_fwd_amax: the outputs of the plain entry points and their largest magnitude bit
+    for bit (what the heads' first FC layers scale by); through mmcv_ops the outputs come back tagged."""
+    from htd_amd import capi, dense, mmcv_ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(11)
+    n, C, P, B = 333, 64, 49, 3
+    x = (torch.randn(n, C, 7, 7, device=dev) * 4).contiguous(memory_format=CL)
+    rois = torch.cat([torch.randint(0, B, (n, 1), device=dev).float(), torch.rand(n, 4, device=dev) * 100], 1)
+    g = torch.randn(B, C, device=dev) * 9
+    extra = torch.randn_like(x).contiguous(memory_format=CL)
+    S = capi.current_stream_ptr
+    for e in (None, extra):
+        a, b, slot = torch.empty_like(x), torch.empty_like(x), torch.zeros(1, device=dev)
+        capi.call('htd_fuse_global_fwd', capi.ptr(x), capi.ptr(rois), capi.ptr(g), capi.ptr(e), 0.5, capi.ptr(a), n, P, C, B, S())
+        capi.call('htd_fuse_global_fwd_amax', capi.ptr(x), capi.ptr(rois), capi.ptr(g), capi.ptr(e), 0.5, capi.ptr(b), n, P, C, B,
+                  capi.ptr(slot), S())
+        assert torch.equal(a, b) and float(slot) == float(a.abs().max())
+    a = torch.empty(2 * n, C, 7, 7, device=dev).contiguous(memory_format=CL)
+    b, slot = torch.empty_like(a), torch.zeros(1, device=dev)
+    capi.call('htd_plain_and_fused_fwd', capi.ptr(x), capi.ptr(rois), capi.ptr(g), capi.ptr(a), n, P, C, B, S())
+    capi.call('htd_plain_and_fused_fwd_amax', capi.ptr(x), capi.ptr(rois), capi.ptr(g), capi.ptr(b), n, P, C, B, capi.ptr(slot), S())
+    assert torch.equal(a, b) and float(slot) == float(a.abs().max())
+    x[5, 3, 2, 1] = float('nan')
+    slot.zero_()
+    capi.call('htd_plain_and_fused_fwd_amax', capi.ptr(x), capi.ptr(rois), capi.ptr(g), capi.ptr(b), n, P, C, B, capi.ptr(slot), S())
+    assert torch.isnan(slot).item()
+    x[5, 3, 2, 1] = 0.0
+    dense.new_step()
+    out = mmcv_ops.fuse_global(x, rois, g.view(B, C, 1, 1))
+    both = mmcv_ops.PlainAndFusedFunction.apply(x, rois, g.view(B, C, 1, 1))
+    for t in (out, both):
+        am = dense.carried_amax(t.permute(0, 2, 3, 1).reshape(t.size(0), -1))
+        assert am is not None and float(am) == float(t.abs().max())
+    dense.new_step()
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,k,stride,relu,res', [
+    (2, 40, 56, 128, 128, 3, 2, 1, False),        # the stride-2 3x3 of a stage's first block
+    (4, 100, 168, 64, 64, 3, 2, 0, False),
+    (4, 50, 84, 256, 1024, 1, 1, 0, False),       # 1056 tiles of 128x128: the balanced tail and its epilogue kernel
+    (1, 13, 21, 256, 256, 3, 1, 1, True),         # few tiles: split-K and its epilogue kernel
+    (2, 25, 33, 64, 78, 1, 1, 0, False),          # Co % 4 != 0: the scalar epilogue
+    (2, 31, 45, 64, 128, 1, 2, 0, False),         # stride-2 1x1 shortcut
+])
+def test_igemm_kernels_leave_their_maximum(h2, B, H, W, Ci, Co, k, stride, relu, res):
+    """htd_conv2d_fwd_amax / htd_conv2d_bwd_data_amax: outputs of the plain entry points, and their largest magnitude bit for bit
+    (every epilogue of conv_igemm_kernel: in-kernel, split-K, balanced tail, scalar columns; the strided data gradient's parity
+    classes raise one scalar)."""
+    from htd_amd import capi, dense
+    dev = torch.device('cuda:0')
+    torch.manual_seed(B * H + Co)
+    pad = k // 2
+    x = torch.randn(B, Ci, H, W, device=dev).contiguous(memory_format=CL)
+    w = (torch.randn(Co, Ci, k, k, device=dev) * 0.1).contiguous(memory_format=CL)
+    bias = torch.randn(Co, device=dev)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    r = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL) if res else None
+    S = capi.current_stream_ptr
+    ws = dense._splitk_ws(B * Ho * Wo, Co, Ci, k, k, dev)
+    y0, y1, slot = [torch.empty(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL) for _ in range(2)] + [torch.zeros(1, device=dev)]
+    capi.call('htd_conv2d_fwd', capi.ptr(x), capi.ptr(w), capi.ptr(bias), capi.ptr(r), 0, 0, capi.ptr(y0), B, H, W, Ci, Co, k, k, stride,
+              pad, 1, relu, capi.ptr(ws), S())
+    capi.call('htd_conv2d_fwd_amax', capi.ptr(x), capi.ptr(w), capi.ptr(bias), capi.ptr(r), 0, 0, capi.ptr(y1), capi.ptr(slot), B, H, W,
+              Ci, Co, k, k, stride, pad, 1, relu, capi.ptr(ws), S())
+    assert torch.equal(y0, y1) and float(slot) == float(y0.abs().max())
+    if Co % 8:
+        return
+    # data gradient of the same layer: gy (B, Co, Ho, Wo) -> gx (B, Ci, H, W), masked by x > 0
+    gy = torch.randn(B, Co, Ho, Wo, device=dev).contiguous(memory_format=CL)
+    wT = torch.empty(Ci * k * k * Co, device=dev)
+    capi.call('htd_conv2d_flip_weights', capi.ptr(w), capi.ptr(wT), Co, k, k, Ci, S())
+    ws = dense._splitk_ws(B * H * W, Ci, Co, k, k, dev)
+    g0, g1 = [torch.empty(B, Ci, H, W, device=dev).contiguous(memory_format=CL) for _ in range(2)]
+    slot.zero_()
+    capi.call('htd_conv2d_bwd_data', capi.ptr(gy), capi.ptr(wT), capi.ptr(x), None, capi.ptr(g0), B, H, W, Ci, Co, k, k, stride, pad, 1,
+              capi.ptr(ws), S())
+    capi.call('htd_conv2d_bwd_data_amax', capi.ptr(gy), capi.ptr(wT), capi.ptr(x), None, capi.ptr(g1), capi.ptr(slot), B, H, W, Ci, Co, k,
+              k, stride, pad, 1, capi.ptr(ws), S())
+    assert torch.equal(g0, g1) and float(slot) == float(g0.abs().max())
+    # through dense: the outputs come back tagged
+    dense.new_step()
+    y = dense._fwd_raw(x, w, bias, r, stride, pad, 1, bool(relu))
+    gx = dense._dgrad_raw(gy, w, x.shape, stride, pad, 1, mask_src=x)
+    for t in (y, gx):          # (whichever kernel dense gives the layer to)
+        am = dense.carried_amax(t)
+        assert am is not None and float(am) == float(t.abs().max())
+    dense.new_step()
+
+
+def test_max_pool_leaves_its_maximum(h2):
+    from htd_amd import capi, dense, mmcv_ops
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 57, 83, device=dev).contiguous(memory_format=CL)
+    dense.new_step()
+    y = mmcv_ops.MaxPool2dFunction.apply(x, 3, 2, 1)
+    assert torch.equal(y, F.max_pool2d(x, 3, 2, 1))
+    am = dense.carried_amax(y)
+    assert am is not None and float(am) == float(y.abs().max())
+    x[1, 7, 20, 30] = float('nan')
+    y = mmcv_ops.MaxPool2dFunction.apply(x, 3, 2, 1)
+    assert torch.isnan(dense.carried_amax(y)).item()
     dense.new_step()

@@ -28,6 +28,11 @@ LAYERS = [  # name, Ci, H, W, Co, k, stride, pad
     ('fpn P6 3x3 256', 256, 13, 21, 256, 3, 1, 1),
     ('l3.conv3 1x1 256-1024', 256, 50, 84, 1024, 1, 1, 0),
     ('l4.conv3 1x1 512-2048', 512, 25, 42, 2048, 1, 1, 0),
+    # the RoI heads' FC layers as 1x1 convolutions over (rows, C, 1, 1): last element = rows
+    ('fc 12544-1024 x2048', 12544, 1, 1, 1024, 1, 1, 0, 2048),
+    ('fc 12544-1024 x4096', 12544, 1, 1, 1024, 1, 1, 0, 4096),
+    ('fc 1024-1024 x2048', 1024, 1, 1, 1024, 1, 1, 0, 2048),
+    ('fc 1024-1024 x4096', 1024, 1, 1, 1024, 1, 1, 0, 4096),
 ]
 
 
@@ -69,9 +74,10 @@ def main():
     dev = torch.device('cuda:0')
     only = sys.argv[1] if len(sys.argv) > 1 else None
     print(f'{"layer":26s} {"GFLOP":>8s} | {"fwd":>7s} {"dgrad":>7s} {"wgrad":>7s} TF/s (htd) | {"fwd":>7s} {"bwd":>7s} TF/s (ATen)')
-    for name, Ci, H, W, Co, k, s, p in LAYERS:
+    for name, Ci, H, W, Co, k, s, p, *rows in LAYERS:
         if only and only not in name:
             continue
+        B = rows[0] if rows else 4
         x = torch.randn(B, Ci, H, W, device=dev).contiguous(memory_format=CL)
         w = (torch.randn(Co, Ci, k, k, device=dev) / (Ci * k * k) ** 0.5).contiguous(memory_format=CL)
         y = dense.conv2d(x, w, None, s, p, 1)
