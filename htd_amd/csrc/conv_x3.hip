@@ -142,6 +142,11 @@ struct X3Params {
     int Ci, Co, Cop;
     int kh;                    // filter rows; the filter width is the template parameter KW
     int stride;                // kw == 1 only
+    // kw == 1, ntl > 0: TAP-LIST mode (strided 3x3 layers and the parity classes of their data gradients on the 1x1 loop): the
+    // step's kh "rows" are ntl = kh taps; tap t multiplies input pixel (ho * stride + tl_dy[t], wo * stride + tl_dx[t]) -- zeros
+    // outside the map -- with tap tl_w[t] of the weight image (whose tiles are [tap][slice] for every filter shape)
+    int ntl;
+    int tl_dy[9], tl_dx[9], tl_w[9];
     int relu;
     int res_H, res_W;          // > 0: residual is a coarser map read through nearest up-sampling (FPN top-down)
     float res_sh, res_sw;
@@ -488,9 +493,11 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
     const int a_g0 = (int)m0 + vrow - PADX;
     unsigned a_off[KW > 1 ? 1 : G::PASSES];            // element offsets mod 2^32
     bool a_in[KW > 1 ? 1 : G::PASSES];
+    unsigned a_tm[KW > 1 ? 1 : G::PASSES];             // tap-list mode: bit t = tap t of this row lies inside the map
     if constexpr (KW > 1) {
         a_off[0] = (unsigned)a_g0 * (unsigned)p.Ci + vcol * 4;
         a_in[0] = true;
+        a_tm[0] = 0u;
     } else {
 #pragma unroll
         for (int i = 0; i < G::PASSES; ++i) {
@@ -501,6 +508,14 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
             const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
             a_off[i] = ((b * (unsigned)p.Hx + ho * (unsigned)p.stride) * (unsigned)p.Wx + wo * (unsigned)p.stride) *
                            (unsigned)p.Ci + vcol * 4;
+            unsigned tm = 0x1ffu;
+            if (p.ntl > 0) {
+                tm = 0u;
+                const int hb = (int)(ho * (unsigned)p.stride), wb = (int)(wo * (unsigned)p.stride);
+                for (int q = 0; q < p.ntl; ++q)
+                    tm |= ((unsigned)(hb + p.tl_dy[q]) < (unsigned)p.Hx && (unsigned)(wb + p.tl_dx[q]) < (unsigned)p.Wx) ? (1u << q) : 0u;
+            }
+            a_tm[i] = tm;
         }
     }
 
@@ -574,6 +589,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
     float h2s = 1.f;
     if constexpr (H2) h2s = h2_scale(p.amax).s;
     // (no divisions inside the K loop: the step's channel slice / filter row and the prefetch pointers advance incrementally)
+    // (kw == 1: `shift` is the step's tap index -- tap-list mode looks its validity up -- and koff holds the tap's pixel offset)
     auto load_pass = [&](int shift, int koff, int i, int slot, bool live) __attribute__((always_inline)) {   // pass i of the run at pixel shift `shift`
         bool ok;
         unsigned off;
@@ -583,8 +599,9 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
             off = a_off[0] + (unsigned)(64 * i) * (unsigned)p.Ci + (unsigned)koff;
             ra_ok = ok ? (ra_ok | (1u << i)) : (ra_ok & ~(1u << i));
         } else {
-            ok = live && a_in[i];
+            ok = live && a_in[i] && ((a_tm[i] >> shift) & 1u);
             off = a_off[i] + (unsigned)koff;
+            ra_ok = ok ? (ra_ok | (1u << slot)) : (ra_ok & ~(1u << slot));
         }
         // out of range / not live: element 0, zeroed or dropped at store time.  Inline asm: hipcc must not count this load (see NB above)
         asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(ra[slot]) : "v"(p.x + (off & (0u - (unsigned)ok))) : "memory");
@@ -601,7 +618,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
         }
         bool ok;
         if constexpr (KW > 1) ok = (ra_ok >> i) & 1u;
-        else ok = a_in[i];
+        else ok = (ra_ok >> slot) & 1u;
         const float4 v = make_float4(ok ? ra[slot][0] : 0.f, ok ? ra[slot][1] : 0.f, ok ? ra[slot][2] : 0.f, ok ? ra[slot][3] : 0.f);
         // chunk = plane * 2 + (vcol >> 1); 8 bytes at half (vcol & 1) of the row's 16
         const unsigned d = lds_a0 + (unsigned)(buf * A_VEC * 16 + ((vcol >> 1) * G::PITCH + j) * 16 + (vcol & 1) * 8);
@@ -661,7 +678,8 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
     const unsigned tile_stride = (unsigned)(NCH * p.Cop);         // uint4 per (tap, slice) tile
     int ps = s_begin, pbuf = 0;
     int pcs = s_begin / p.kh, ptap = (s_begin - pcs * p.kh) * KW;
-    unsigned poff = (unsigned)(ptap * p.ncs + pcs) * tile_stride;
+    const bool tap_list = KW == 1 && p.ntl > 0;
+    unsigned poff = (unsigned)((tap_list ? p.tl_w[ptap] : ptap) * p.ncs + pcs) * tile_stride;
     auto issue_b = [&]() -> bool {
         const bool any = ps < s_end;
         if (any) load_b(poff, pbuf);
@@ -670,7 +688,15 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
         poff += (unsigned)p.ncs * tile_stride;
         if (ptap % KW == 0) ++ps;
         if (ptap == ntap) { ptap = 0; ++pcs; poff = (unsigned)pcs * tile_stride; }
+        if constexpr (KW == 1)
+            if (tap_list) poff = (unsigned)(p.tl_w[ptap] * p.ncs + pcs) * tile_stride;
         return any;
+    };
+    // element offset of (tap / filter row t, channel slice c) relative to the run's base pixel
+    auto tap_koff = [&](int t, int c) -> int {
+        if constexpr (KW == 1)
+            if (tap_list) return (p.tl_dy[t] * p.Wx + p.tl_dx[t]) * p.Ci + c * XK;
+        return (t - PADY) * p.Wx * p.Ci + c * XK;
     };
 
     using acc_t = typename std::conditional<MF16, f32x4, f32x16>::type;
@@ -774,17 +800,17 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
 #pragma unroll
     for (int d = 0; d < DIST; ++d) issue_b();
     {
-        const int shift0 = (ky - PADY) * p.Wx, koff0 = shift0 * p.Ci + cs * XK;
+        const int shift0 = (ky - PADY) * p.Wx, koff0 = tap_koff(ky, cs);
         if constexpr (KW == 1) {
 #pragma unroll
-            for (int i = 0; i < NP; ++i) load_pass(0, koff0, i, i, true);
+            for (int i = 0; i < NP; ++i) load_pass(ky, koff0, i, i, true);
             wait_vm<0>();
 #pragma unroll
             for (int i = 0; i < NP; ++i) landed(ra[i]);
 #pragma unroll
             for (int i = 0; i < NP; ++i) store_pass(0, i, i);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) load_pass(0, (s_begin + 1) * XK, i, NP + i, s_begin + 1 < s_end);
+            for (int i = 0; i < NP; ++i) load_pass(ky1, tap_koff(ky1, cs1), i, NP + i, s_begin + 1 < s_end);
         } else {
             load_pass(shift0, koff0, 0, 0, true);
             load_pass(shift0, koff0, 1, 1, true);
@@ -806,8 +832,8 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
     lds_barrier();
 
     int bbuf = 0, abuf = 0, kx = 0;
-    int n1shift = (ky1 - PADY) * p.Wx, n1koff = n1shift * p.Ci + cs1 * XK;
-    int n2shift = (ky2 - PADY) * p.Wx, n2koff = n2shift * p.Ci + cs2 * XK;
+    int n1shift = (ky1 - PADY) * p.Wx, n1koff = tap_koff(ky1, cs1);
+    int n2shift = (ky2 - PADY) * p.Wx, n2koff = tap_koff(ky2, cs2);
     // one tap; P (a literal at the call sites) is the register set this tap LOADS into, the other one is stored
     // (TAIL: the split's last tap when their number is odd -- it has nothing to put in flight)
     auto tap = [&](int P, bool TAIL) __attribute__((always_inline)) {
@@ -817,7 +843,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
         if (!TAIL) {
             if constexpr (KW == 1) {
 #pragma unroll
-                for (int i = 0; i < NP; ++i) load_pass(0, n2koff, i, P * NP + i, more2);
+                for (int i = 0; i < NP; ++i) load_pass(ky2, n2koff, i, P * NP + i, more2);
             } else {
                 const bool last = kx == KW - 1;
                 load_pass(last ? n2shift : n1shift, last ? n2koff : n1koff, last ? 0 : kx + 1, P, last ? more2 : more);
@@ -881,7 +907,7 @@ __global__ __launch_bounds__(256, (x3p_occupancy<WGM, WGN, TM, TN, KW, NB, H2>()
             if (++ky2 == p.kh) { ky2 = 0; ++cs2; }
             n1shift = n2shift; n1koff = n2koff;
             n2shift = (ky2 - PADY) * p.Wx;
-            n2koff = n2shift * p.Ci + cs2 * XK;
+            n2koff = tap_koff(ky2, cs2);
         }
     };
     const int taps_total = (s_end - s_begin) * KW;
@@ -1778,6 +1804,13 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
     return htd::check_launch("conv2d_x3p");
 }
 
+// strided 3x3 layers (the first block of a ResNet stage, backbones/resnet.py:260-300 `conv2` at stride 2): H2 only, tap-list mode
+bool x3h_strided_ok(int Ci, int Co, int kh, int kw, int stride, int pad)
+{
+    static const bool on = !(getenv("HTD_X3H_STRIDED") && atoi(getenv("HTD_X3H_STRIDED")) == 0);
+    return on && Ci % XK == 0 && Co >= 33 && kh == 3 && kw == 3 && stride == 2 && pad == 1;
+}
+
 bool x3p_shape_ok(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
 {
     if (Ci % XK != 0 || Co < 33 || dil != 1 || kh != kw) return false;
@@ -1805,6 +1838,13 @@ extern "C" int htd_conv2d_set_h2(int on)
 extern "C" int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
 {
     return (g_conv_h2 == 1 && htd_conv2d_x3p_supported(Ci, Co, kh, kw, stride, pad, dil)) ? 1 : 0;
+}
+// 1 when htd_conv2d_fwd_x3h also takes this STRIDED layer (3x3, stride 2, pad 1: nine taps on the kernel's 1x1 loop; workspace:
+// htd_conv2d_x3p_workspace_bytes(M, Co, Ci, 9, 1)).  The six-product form has no such path: without a maximum for the input the
+// layer stays on htd_conv2d_fwd.
+extern "C" int htd_conv2d_x3h_strided_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
+{
+    return (g_conv_h2 == 1 && !x3p_off() && htd::conv_math() == 1 && dil == 1 && x3h_strided_ok(Ci, Co, kh, kw, stride, pad)) ? 1 : 0;
 }
 
 // Tuned tile table of conv_x3p_kernel (see choose_cfg).  cfg: 0 64x64, 1 128x128, 2 128x64, 3 64x128; < 0 erases the entry.
@@ -2031,8 +2071,10 @@ extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void 
 {
     HTD_REQUIRE(!yplanes || Co % XK == 0, "conv2d_fwd_x3h: output planes need Co %% 16 == 0 (Co=%d)", Co);
     HTD_REQUIRE(x && amax && wplanes && y && B > 0 && H > 0 && W > 0, "conv2d_fwd_x3h: bad arguments");
-    HTD_REQUIRE(x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3h: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d", Ci, Co,
-                kh, kw, stride, pad);
+    const bool taps = x3h_strided_ok(Ci, Co, kh, kw, stride, pad);      // 3x3 / stride 2: nine taps on the 1x1 loop
+    HTD_REQUIRE(taps || x3p_shape_ok(Ci, Co, kh, kw, stride, pad, 1), "conv2d_fwd_x3h: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d",
+                Ci, Co, kh, kw, stride, pad);
+    HTD_REQUIRE(!taps || (!yplanes && res_h == 0), "conv2d_fwd_x3h: strided 3x3 layers write no planes and take no up-sampled residual");
     HTD_REQUIRE((res_h > 0) == (res_w > 0) && res_h >= 0 && (res_h == 0 || ((Co & 3) == 0 && residual)),
                 "conv2d_fwd_x3h: bad residual up-sampling arguments");
     X3Params p{};
@@ -2051,6 +2093,11 @@ extern "C" int htd_conv2d_fwd_x3h(const float *x, const float *amax, const void 
     if (res_h > 0) {
         p.res_H = res_h; p.res_W = res_w;
         p.res_sh = (float)res_h / (float)p.Ho; p.res_sw = (float)res_w / (float)p.Wo;
+    }
+    if (taps) {
+        p.kh = p.ntl = kh * kw;
+        for (int t = 0; t < p.ntl; ++t) { p.tl_dy[t] = t / kw - pad; p.tl_dx[t] = t % kw - pad; p.tl_w[t] = t; }
+        return launch_x3p(p, 1, (hipStream_t)stream, workspace);
     }
     return launch_x3p(p, kw, (hipStream_t)stream, workspace);
 }

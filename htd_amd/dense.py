@@ -630,6 +630,23 @@ def _fwd_raw_(x, weight, bias, residual, stride, padding, dilation, relu, res_up
             tag_amax(y, out_slot)
         return (y, yp) if emit else y
     work = ('flop', flops, 4.0 * (x.numel() + weight.numel() + y.numel() + (y.numel() if residual is not None else 0)))
+    if x.dtype == torch.float32 and rh == 0 and \
+            capi.lib().htd_conv2d_x3h_strided_supported(Ci, Co, kh, kw, stride, padding, dilation):
+        # the strided 3x3 of a stage's first block: nine taps on the H2 kernel's 1x1 loop when the input's maximum is known
+        am = carried_amax(x)
+        if am is None:
+            _h2_trace('fwd', x, weight)
+            if kh * kw * Co >= H2_ABSMAX_MIN_WORK and x.numel() >= H2_ABSMAX_MIN_ELEMS:
+                am = absmax(x)
+        if am is not None:
+            nb = capi.lib().htd_conv2d_x3p_workspace_bytes(B * Ho * Wo, Co, Ci, kh * kw, 1)
+            ws = torch.empty(nb // 4, device=x.device, dtype=torch.float32) if nb > 0 else None
+            out_slot = _amax_slot(x.device)
+            capi.call('htd_conv2d_fwd_x3h', _P(x), _P(am), _P(x3_planes(weight, False, True)), _P(bias), _P(residual), 0, 0, _P(y), None,
+                      _P(out_slot), B, H, W, Ci, Co, kh, kw, stride, padding, int(bool(relu)), _P(ws), _S(), work=work)
+            tag_amax(y, out_slot)
+            _h2_guard(am, out_slot)
+            return y
     if _igemm_emits(y, Co):
         # (a strided / dilated layer between layers that run on H2: its output's maximum rides along like theirs)
         slot = _amax_slot(x.device)

@@ -378,6 +378,9 @@ int htd_conv2d_bwd_weight_h2(const float *x, const float *gy, const float *amax_
                              float *gbias, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
                              int dil, int accumulate, void *workspace, void *stream);
 int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+/* 1 when htd_conv2d_fwd_x3h also takes this strided layer (3x3, stride 2, pad 1 -- `conv2` of a ResNet stage's first block,
+ * backbones/resnet.py:260-300): nine taps on the kernel's 1x1 loop.  Workspace: htd_conv2d_x3p_workspace_bytes(M, Co, Ci, 9, 1). */
+int htd_conv2d_x3h_strided_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
 int htd_absmax(const float *x, int64_t n, float *amax, void *stream);
 int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);
 int htd_conv2d_x3h_planes_many(const void *desc, int n, int64_t total_blocks, int64_t total_rows, void *stream);

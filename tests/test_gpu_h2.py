@@ -526,3 +526,46 @@ def test_max_pool_leaves_its_maximum(h2):
     y = mmcv_ops.MaxPool2dFunction.apply(x, 3, 2, 1)
     assert torch.isnan(dense.carried_amax(y)).item()
     dense.new_step()
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 40, 56, 128, 128), (1, 33, 47, 64, 96), (3, 25, 42, 256, 512), (2, 7, 9, 48, 64)])
+def test_strided_3x3_on_the_tap_list_loop(h2, B, H, W, Ci, Co):
+    """The stride-2 3x3 layer of a stage's first block on conv_x3p_kernel's 1x1 loop (tap-list mode, H2): integer-exact on small
+    integers -- odd sizes, borders, bias, residual, ReLU -- the maximum it leaves is its output's, and on wide-range data its error
+    against fp64 is within RMS_BOUND of the fp32-input matrix instructions' (conv_igemm_kernel with set_math(0))."""
+    from htd_amd import capi, dense
+    dev = torch.device('cuda:0')
+    if not h2.htd_conv2d_x3h_strided_supported(Ci, Co, 3, 3, 2, 1, 1):
+        pytest.skip('strided H2 path switched off')
+    torch.manual_seed(H * W + Ci)
+    xi = torch.randint(-4, 5, (B, Ci, H, W), device=dev).float().contiguous(memory_format=CL)
+    wi = torch.randint(-2, 3, (Co, Ci, 3, 3), device=dev).float().contiguous(memory_format=CL)
+    bi = torch.randint(-8, 9, (Co, ), device=dev).float()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ri = torch.randint(-16, 17, (B, Co, Ho, Wo), device=dev).float().contiguous(memory_format=CL)
+    dense.new_step()
+    dense.tag_amax(xi, dense.absmax(xi))
+    capi.profile_begin()
+    y = dense._fwd_raw(xi, wi, bi, ri, 2, 1, 1, True)
+    prof = capi.profile_end()
+    assert 'htd_conv2d_fwd_x3h' in prof and 'htd_conv2d_fwd' not in prof, sorted(prof)
+    ref = torch.relu(F.conv2d(xi.double(), wi.double(), bi.double(), 2, 1) + ri.double())
+    assert torch.equal(y.double(), ref)
+    am = dense.carried_amax(y)
+    assert am is not None and float(am) == float(y.abs().max())
+    # wide dynamic range
+    x = (torch.randn(B, Ci, H, W, device=dev) * torch.exp2(torch.randint(-6, 7, (B, Ci, 1, 1), device=dev).float())).contiguous(memory_format=CL)
+    w = (torch.randn(Co, Ci, 3, 3, device=dev) * 0.05 * torch.exp2(torch.randint(-3, 4, (Co, 1, 1, 1), device=dev).float())).contiguous(memory_format=CL)
+    ref = F.conv2d(x.double(), w.double(), None, 2, 1)
+    dense.new_step()
+    dense.tag_amax(x, dense.absmax(x))
+    y = dense._fwd_raw(x, w, None, None, 2, 1, 1, False)
+    h2.htd_conv2d_set_h2(0)
+    h2.htd_conv2d_set_math(0)
+    yn = dense._fwd_raw(x, w, None, None, 2, 1, 1, False)
+    h2.htd_conv2d_set_math(1)
+    h2.htd_conv2d_set_h2(1)
+    e, en = (y.double() - ref), (yn.double() - ref)
+    assert float(e.square().mean().sqrt()) <= RMS_BOUND * float(en.square().mean().sqrt()) + 1e-12
+    assert float(e.abs().max()) <= MAX_BOUND * 2 * float(en.abs().max()) + 1e-12
+    dense.new_step()
