@@ -147,6 +147,9 @@ struct X3Params {
     // outside the map -- with tap tl_w[t] of the weight image (whose tiles are [tap][slice] for every filter shape)
     int ntl;
     int tl_dy[9], tl_dx[9], tl_w[9];
+    // o_step > 0: output row m = pixel (ho, wo) of the launch's Ho x Wo sub-grid is written to pixel (o_h0 + o_step ho, o_w0 +
+    // o_step wo) of an oH x oW map (one parity class of a strided data gradient); residual / mask_src are read there too
+    int o_step, o_h0, o_w0, oH, oW;
     int relu;
     int res_H, res_W;          // > 0: residual is a coarser map read through nearest up-sampling (FPN top-down)
     float res_sh, res_sw;
@@ -234,6 +237,15 @@ struct Geo {
 // ---- epilogue (conv_fwd.hip): accumulators through LDS, 16-byte stores along output rows, fused bias / residual / ReLU /
 // producer's ReLU mask (+ the bf16 planes of the stored values for a 1x1 consumer, X3Params::yp).  Shared by conv_x3p_kernel and
 // conv_x3q_kernel.  D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// element offset of output row m, column n in y (and in residual / mask_src)
+__device__ __forceinline__ int64_t x3_out_off(const X3Params &p, int64_t m, int n)
+{
+    if (p.o_step == 0) return m * p.Co + n;
+    const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
+    const unsigned ho = t % (unsigned)p.Ho, b = t / (unsigned)p.Ho;
+    return (((int64_t)b * p.oH + p.o_h0 + p.o_step * (int)ho) * p.oW + p.o_w0 + p.o_step * (int)wo) * p.Co + n;
+}
+
 template <int WGM, int WGN, int TM, int TN, bool MF16, typename Acc>
 __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *lds, int64_t m0, int n0, bool part, bool region_b,
                                             int split)
@@ -302,7 +314,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
                     const int row = tid / V + (pass0 + u) * RPP;
                     const int64_t m = m0 + ((row >> 5) * TM + i) * 32 + (row & 31);
                     ok[u] = m < p.M && col_ok;
-                    o[u] = (m * p.Co + n) & -(int64_t)ok[u];          // rows / columns past the end: element 0, read and dropped
+                    o[u] = x3_out_off(p, ok[u] ? m : 0, n) & -(int64_t)ok[u];   // rows / columns past the end: element 0, read and dropped
                     v[u] = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
                     if (scaled) { v[u].x *= cscale.x; v[u].y *= cscale.y; v[u].z *= cscale.z; v[u].w *= cscale.w; }
                 }
@@ -357,7 +369,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params &p, Acc &acc, uint4 *
             if (m >= p.M || n >= p.Co) continue;
             float4 v = *reinterpret_cast<const float4 *>(le + row * EPI_STRIDE + c4 * 4);
             if (scaled) { v.x *= cscale.x; v.y *= cscale.y; v.z *= cscale.z; v.w *= cscale.w; }
-            const int64_t o = m * p.Co + n;
+            const int64_t o = x3_out_off(p, m, n);
             if (part) {
                 float *dst = region_b ? p.partial + (p.splits_a > 1 ? (int64_t)p.splits_a * p.m_rem0 * p.Co : 0) +
                                             ((int64_t)split * (p.M - p.m_rem0) + (m - p.m_rem0)) * p.Co + n
@@ -1140,7 +1152,7 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
         const int n = (int)(o % p.Co);
         if (p.bias) v += p.bias[n];
         if (p.residual) {
-            int64_t ro = o;
+            int64_t ro = p.o_step == 0 ? o : x3_out_off(p, o / p.Co, n);
             if (p.res_H > 0) {
                 const int64_t m = o / p.Co;
                 const unsigned mm = (unsigned)m, wo = mm % (unsigned)p.Wo, t = mm / (unsigned)p.Wo;
@@ -1152,8 +1164,9 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_kernel(X3Params 
             v += p.residual[ro];
         }
         if (p.relu) v = fmaxf(v, 0.f);
-        if (p.mask_src) v = p.mask_src[o] > 0.f ? v : 0.f;
-        p.y[o] = v;
+        const int64_t oo = p.o_step == 0 ? o : x3_out_off(p, o / p.Co, n);
+        if (p.mask_src) v = p.mask_src[oo] > 0.f ? v : 0.f;
+        p.y[oo] = v;
         omax = absmax4(omax, make_float4(v, 0.f, 0.f, 0.f));
     }
     __shared__ float ored[4];
@@ -1183,7 +1196,7 @@ __global__ __launch_bounds__(256) void conv_x3p_splitk_epilogue_vec_kernel(X3Par
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
         const unsigned m = (unsigned)(q / C4), n = (unsigned)(q - (int64_t)m * C4) * 4u;
-        const int64_t o = (int64_t)m * p.Co + n;
+        const int64_t o = x3_out_off(p, (int64_t)m, (int)n);
         if (p.bias) {
             const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -1752,7 +1765,8 @@ int launch_x3p(X3Params p, int kw, hipStream_t s, void *workspace)
 {
     const int total_steps = p.ncs * p.kh;
     const int epi = (p.residual ? 1 : 0) | (p.mask_src ? 2 : 0) | (p.amax ? 4 : 0);          // bit 2: the H2 kernels have their own entries
-    const int cfg = choose_cfg(p.M, p.Co, p.Ci, p.kh * kw, epi);
+    // (tap-list launches key the table with taps + 100: a strided 3x3 layer has the M, Co, Ci and tap count of its stride-1 neighbour)
+    const int cfg = choose_cfg(p.M, p.Co, p.Ci, p.kh * kw + (p.ntl > 0 ? 100 : 0), epi);
     const XPlan pl = plan_x3p(cfg, p.M, p.Co, total_steps, kw, workspace != nullptr);
     p.tiles_a = pl.tiles_a; p.splits_a = pl.splits_a; p.sps_a = pl.sps_a; p.splits_b = pl.splits_b; p.sps_b = pl.sps_b;
     p.m_rem0 = pl.m_rem0;
@@ -2123,3 +2137,107 @@ extern "C" int htd_conv2d_bwd_data_x3h(const float *gy, const float *amax, const
     HTD_REQUIRE((int64_t)B * H * W * Co < (1ll << 31), "conv2d_bwd_data_x3h: operand too large");
     return launch_x3p(p, kw, (hipStream_t)stream, workspace);
 }
+
+// ---- strided data gradients on the H2 kernel (tap-list mode of conv_x3p_kernel's 1x1 loop) -----------------------------------
+// gx [B][H][W][Ci] of a stride-s layer falls into s*s parity classes of output pixels; class (ph, pw) receives only the filter taps
+// with (ph + pad - ky) % s == 0 (likewise kx), and those form a dense stride-1 problem on the sub-grid hi = ph + s i over gy:
+// one launch per class with its tap list and a strided output map (X3Params::o_step), classes without taps are zeros
+// (conv_fwd.hip::htd_conv2d_bwd_data does the same on conv_igemm_kernel).  Reference role: cuDNN's backward-data behind the
+// strided `conv2` and `downsample` convolutions of backbones/resnet.py:260-300,330-350.
+namespace {
+struct StridedClass { int ntaps; int dy[9], dx[9], w[9]; int Ho, Wo; };
+int strided_classes(int H, int W, int kh, int kw, int stride, int pad, StridedClass *cls)          // -> number of classes with taps
+{
+    int n = 0;
+    for (int c = 0; c < stride * stride; ++c) {
+        const int ph = c / stride, pw = c % stride;
+        StridedClass &q = cls[c];
+        q.ntaps = 0;
+        q.Ho = ph < H ? (H - ph + stride - 1) / stride : 0;
+        q.Wo = pw < W ? (W - pw + stride - 1) / stride : 0;
+        if (q.Ho == 0 || q.Wo == 0) continue;
+        for (int ky = 0; ky < kh; ++ky) {
+            const int ry = ph + pad - ky;
+            if (((ry % stride) + stride) % stride != 0) continue;
+            for (int kx = 0; kx < kw; ++kx) {
+                const int rx = pw + pad - kx;
+                if (((rx % stride) + stride) % stride != 0) continue;
+                q.dy[q.ntaps] = ry >= 0 ? ry / stride : -((-ry) / stride);
+                q.dx[q.ntaps] = rx >= 0 ? rx / stride : -((-rx) / stride);
+                q.w[q.ntaps] = (kh - 1 - ky) * kw + (kw - 1 - kx);          // tap of the flipped / transposed image
+                ++q.ntaps;
+            }
+        }
+        n += q.ntaps > 0;
+    }
+    return n;
+}
+bool x3h_strided_dgrad_ok(int Ci, int Co, int kh, int kw, int stride, int pad)
+{
+    static const bool on = !(getenv("HTD_X3H_STRIDED") && atoi(getenv("HTD_X3H_STRIDED")) == 0);
+    return on && Co % XK == 0 && Ci >= 33 && stride == 2 && ((kh == 3 && kw == 3 && pad == 1) || (kh == 1 && kw == 1 && pad == 0));
+}
+}  // namespace
+
+extern "C" int htd_conv2d_bwd_data_x3h_strided_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil)
+{
+    return (g_conv_h2 == 1 && !x3p_off() && htd::conv_math() == 1 && dil == 1 && x3h_strided_dgrad_ok(Ci, Co, kh, kw, stride, pad)) ? 1 : 0;
+}
+
+extern "C" int64_t htd_conv2d_bwd_data_x3h_strided_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad)
+{
+    if (!x3h_strided_dgrad_ok(Ci, Co, kh, kw, stride, pad) || B <= 0 || H <= 0 || W <= 0) return 0;
+    StridedClass cls[4];
+    strided_classes(H, W, kh, kw, stride, pad, cls);
+    int64_t need = 0;
+    for (int c = 0; c < stride * stride; ++c)
+        if (cls[c].ntaps > 0)
+            need = std::max(need, htd_conv2d_x3p_workspace_bytes((int64_t)B * cls[c].Ho * cls[c].Wo, Ci, Co, cls[c].ntaps, 1));
+    return need;
+}
+
+// gy [B][Ho][Wo][Co] (Ho, Wo = the layer's output size), amax: device scalar holding max |gy|, wplanesT: the transposed H2 image of
+// the layer's weights (htd_conv2d_x3h_planes, transposed = 1), mask_src (may be NULL): gx is zeroed where mask_src <= 0,
+// amax_out (may be NULL): max |gx| is left there.  workspace: htd_conv2d_bwd_data_x3h_strided_workspace_bytes (NULL: no K ranges).
+extern "C" int htd_conv2d_bwd_data_x3h_strided(const float *gy, const float *amax, const void *wplanesT, const float *mask_src,
+                                               float *gx, float *amax_out, int B, int H, int W, int Ci, int Co, int kh, int kw,
+                                               int stride, int pad, void *workspace, void *stream)
+{
+    HTD_REQUIRE(gy && amax && wplanesT && gx && B > 0 && H > 0 && W > 0, "conv2d_bwd_data_x3h_strided: bad arguments");
+    HTD_REQUIRE(x3h_strided_dgrad_ok(Ci, Co, kh, kw, stride, pad), "conv2d_bwd_data_x3h_strided: unsupported layer Ci=%d Co=%d k=%dx%d s=%d p=%d",
+                Ci, Co, kh, kw, stride, pad);
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    HTD_REQUIRE(Ho > 0 && Wo > 0 && (int64_t)B * Ho * Wo * Co < (1ll << 31) && (int64_t)B * H * W * Ci < (1ll << 40),
+                "conv2d_bwd_data_x3h_strided: bad sizes");
+    StridedClass cls[4];
+    const int live = strided_classes(H, W, kh, kw, stride, pad, cls);
+    if (live < stride * stride) {       // classes without taps (the 1x1 shortcut: three of four) are plain zeros
+        if (hipMemsetAsync(gx, 0, (size_t)B * H * W * Ci * 4, (hipStream_t)stream) != hipSuccess) {
+            htd::set_error("conv2d_bwd_data_x3h_strided: memset failed");
+            return HTD_ERR_LAUNCH;
+        }
+    }
+    X3Params p{};
+    p.x = gy; p.wp = (const uint4 *)wplanesT; p.mask_src = mask_src; p.y = gx;
+    p.Hx = Ho; p.Wx = Wo;
+    p.Ci = Co; p.Co = Ci; p.Cop = planes_np(Ci); p.stride = 1;
+    p.ncs = Co / XK;
+    p.amax = amax;
+    p.wscale = reinterpret_cast<const float *>(p.wp + planes_vec(kh * kw, Co, p.Cop));
+    p.amax_out = amax_out;
+    p.o_step = stride; p.oH = H; p.oW = W;
+    for (int c = 0; c < stride * stride; ++c) {
+        const StridedClass &q = cls[c];
+        if (q.ntaps == 0) continue;
+        X3Params r = p;
+        r.Ho = q.Ho; r.Wo = q.Wo;
+        r.M = (int64_t)B * q.Ho * q.Wo;
+        r.kh = r.ntl = q.ntaps;
+        for (int t = 0; t < q.ntaps; ++t) { r.tl_dy[t] = q.dy[t]; r.tl_dx[t] = q.dx[t]; r.tl_w[t] = q.w[t]; }
+        r.o_h0 = c / stride; r.o_w0 = c % stride;
+        const int st = launch_x3p(r, 1, (hipStream_t)stream, workspace);
+        if (st) return st;
+    }
+    return HTD_OK;
+}
+

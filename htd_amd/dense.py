@@ -761,6 +761,26 @@ def _dgrad_raw_(g, weight, x_shape, stride, padding, dilation, mask_src, accum, 
         if out_slot is not None:
             tag_amax(gx, out_slot)
         return (gx, gxp) if emit else gx
+    if stride != 1 and accum is None and g.dtype == torch.float32 and \
+            capi.lib().htd_conv2d_bwd_data_x3h_strided_supported(Ci, Co, kh, kw, stride, padding, dilation):
+        # the strided layers of a stage's first block: one H2 launch per parity class of gx's pixels when max |g| is known
+        am = carried_amax(g)
+        if am is None:
+            _h2_trace('dgrad', g, weight)
+            if kh * kw * Ci >= H2_ABSMAX_MIN_WORK and g.numel() >= H2_ABSMAX_MIN_ELEMS:
+                am = absmax(g)
+        if am is not None:
+            gx = torch.empty((B, Ci, H, W), device=g.device, dtype=g.dtype, memory_format=CL)
+            nb = capi.lib().htd_conv2d_bwd_data_x3h_strided_workspace_bytes(B, H, W, Ci, Co, kh, kw, stride, padding)
+            ws = torch.empty(nb // 4, device=g.device, dtype=torch.float32) if nb > 0 else None
+            out_slot = _amax_slot(g.device)
+            capi.call('htd_conv2d_bwd_data_x3h_strided', _P(g), _P(am), _P(x3_planes(weight, True, True)), _P(mask_src), _P(gx),
+                      _P(out_slot), B, H, W, Ci, Co, kh, kw, stride, padding, _P(ws), _S(), key='htd_conv2d_bwd_data_x3h',
+                      work=('flop', 2.0 * B * Ho * Wo * Co * kh * kw * Ci,
+                            4.0 * (g.numel() + weight.numel() + gx.numel() * (1 + (mask_src is not None)))))
+            tag_amax(gx, out_slot)
+            _h2_guard(am, out_slot)
+            return gx
     gd, Cod = g, Co
     if Co % 8 != 0:      # skinny heads (RPN cls+reg Co=15, fc_cls 81, fc_reg 4): zero-pad the reduction channels
         Cod = Co + (-Co) % 8

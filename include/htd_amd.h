@@ -381,6 +381,15 @@ int htd_conv2d_x3h_supported(int Ci, int Co, int kh, int kw, int stride, int pad
 /* 1 when htd_conv2d_fwd_x3h also takes this strided layer (3x3, stride 2, pad 1 -- `conv2` of a ResNet stage's first block,
  * backbones/resnet.py:260-300): nine taps on the kernel's 1x1 loop.  Workspace: htd_conv2d_x3p_workspace_bytes(M, Co, Ci, 9, 1). */
 int htd_conv2d_x3h_strided_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+/* Strided data gradients on the H2 kernel: one launch per parity class of gx's pixels with that class's tap list (what
+ * htd_conv2d_bwd_data does on conv_igemm_kernel); 3x3 / stride 2 / pad 1 and 1x1 / stride 2 / pad 0 (`conv2` and `downsample` of a
+ * ResNet stage's first block, backbones/resnet.py:260-300).  gy [B][Ho][Wo][Co], amax = device scalar with max |gy|, wplanesT =
+ * htd_conv2d_x3h_planes(transposed = 1) of the layer's weights, mask_src / amax_out may be NULL. */
+int htd_conv2d_bwd_data_x3h_strided_supported(int Ci, int Co, int kh, int kw, int stride, int pad, int dil);
+int64_t htd_conv2d_bwd_data_x3h_strided_workspace_bytes(int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad);
+int htd_conv2d_bwd_data_x3h_strided(const float *gy, const float *amax, const void *wplanesT, const float *mask_src, float *gx,
+                                    float *amax_out, int B, int H, int W, int Ci, int Co, int kh, int kw, int stride, int pad,
+                                    void *workspace, void *stream);
 int htd_absmax(const float *x, int64_t n, float *amax, void *stream);
 int htd_conv2d_x3h_planes(const float *w, void *planes, int Co, int kh, int kw, int Ci, int transposed, void *stream);
 int htd_conv2d_x3h_planes_many(const void *desc, int n, int64_t total_blocks, int64_t total_rows, void *stream);

@@ -569,3 +569,46 @@ def test_strided_3x3_on_the_tap_list_loop(h2, B, H, W, Ci, Co):
     assert float(e.square().mean().sqrt()) <= RMS_BOUND * float(en.square().mean().sqrt()) + 1e-12
     assert float(e.abs().max()) <= MAX_BOUND * 2 * float(en.abs().max()) + 1e-12
     dense.new_step()
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co,k', [(2, 40, 56, 128, 128, 3), (1, 33, 47, 64, 96, 3), (3, 25, 42, 256, 512, 3), (2, 7, 9, 48, 64, 3),
+                                            (2, 31, 45, 64, 128, 1), (4, 50, 84, 512, 1024, 1), (1, 1, 1, 64, 64, 3)])
+def test_strided_data_gradient_on_the_tap_list_loop(h2, B, H, W, Ci, Co, k):
+    """htd_conv2d_bwd_data_x3h_strided: the stride-2 layers' data gradient as one H2 launch per parity class of gx's pixels (tap lists,
+    strided output map): integer-exact on small integers with the producer's ReLU mask, odd sizes and borders; the maximum it
+    leaves is gx's; error against fp64 within RMS_BOUND of the fp32-input matrix instructions' on wide-range data."""
+    from htd_amd import capi, dense
+    dev = torch.device('cuda:0')
+    pad = k // 2
+    if not h2.htd_conv2d_bwd_data_x3h_strided_supported(Ci, Co, k, k, 2, pad, 1):
+        pytest.skip('strided H2 path switched off')
+    torch.manual_seed(H * W + Co + k)
+    Ho, Wo = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
+    gi = torch.randint(-4, 5, (B, Co, Ho, Wo), device=dev).float().contiguous(memory_format=CL)
+    wi = torch.randint(-2, 3, (Co, Ci, k, k), device=dev).float().contiguous(memory_format=CL)
+    mask = torch.randn(B, Ci, H, W, device=dev).contiguous(memory_format=CL)
+    dense.new_step()
+    dense.tag_amax(gi, dense.absmax(gi))
+    capi.profile_begin()
+    gx = dense._dgrad_raw(gi, wi, (B, Ci, H, W), 2, pad, 1, mask_src=mask)
+    prof = capi.profile_end()
+    assert 'htd_conv2d_bwd_data_x3h' in prof and 'htd_conv2d_bwd_data' not in prof, sorted(prof)
+    ref = torch.nn.grad.conv2d_input((B, Ci, H, W), wi.double(), gi.double(), 2, pad) * (mask > 0)
+    assert torch.equal(gx.double(), ref)
+    am = dense.carried_amax(gx)
+    assert am is not None and float(am) == float(gx.abs().max())
+    g = (torch.randn(B, Co, Ho, Wo, device=dev) * torch.exp2(torch.randint(-6, 7, (B, Co, 1, 1), device=dev).float())).contiguous(memory_format=CL)
+    w = (torch.randn(Co, Ci, k, k, device=dev) * 0.05 * torch.exp2(torch.randint(-3, 4, (1, Ci, 1, 1), device=dev).float())).contiguous(memory_format=CL)
+    ref = torch.nn.grad.conv2d_input((B, Ci, H, W), w.double(), g.double(), 2, pad)
+    dense.new_step()
+    dense.tag_amax(g, dense.absmax(g))
+    gx = dense._dgrad_raw(g, w, (B, Ci, H, W), 2, pad, 1)
+    h2.htd_conv2d_set_h2(0)
+    h2.htd_conv2d_set_math(0)
+    gn = dense._dgrad_raw(g, w, (B, Ci, H, W), 2, pad, 1)
+    h2.htd_conv2d_set_math(1)
+    h2.htd_conv2d_set_h2(1)
+    e, en = (gx.double() - ref), (gn.double() - ref)
+    assert float(e.square().mean().sqrt()) <= RMS_BOUND * float(en.square().mean().sqrt()) + 1e-12
+    assert float(e.abs().max()) <= MAX_BOUND * 2 * float(en.abs().max()) + 1e-12
+    dense.new_step()

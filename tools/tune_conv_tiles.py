@@ -36,8 +36,11 @@ def signature(name, ints, mask):
     if name in ('htd_conv2d_fwd_x3p', 'htd_conv2d_fwd_x3h'):         # conv_x3.hip::launch_x3p
         res_h, res_w, B, H, W, Ci, Co, kh, kw, stride, pad, relu = ints
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-        return (B * Ho * Wo, Co, Ci, kh * kw, int(mask[4 if q else 3] == '1') | h2)
+        taps = kh * kw + (100 if (kh == 3 and stride == 2) else 0)          # conv_x3.hip::launch_x3p: tap-list launches key with + 100
+        return (B * Ho * Wo, Co, Ci, taps, int(mask[4 if q else 3] == '1') | h2)
     if name in ('htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_data_x3h'):
+        if len(ints) != 8:
+            return None                      # htd_conv2d_bwd_data_x3h_strided: one launch per parity class, scored
         B, H, W, Ci, Co, kh, kw, pad = ints
         return (B * H * W, Ci, Co, kh * kw, int(mask[4 if q else 3] == '1') | (int(mask[3 if q else 2] == '1') << 1) | h2)
     if name == 'htd_conv2d_fwd':
