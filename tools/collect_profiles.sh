@@ -65,5 +65,7 @@ $R/tools/micro/mfma_split_products.bin > $OUT/mfma_split_products.txt 2>&1
 python3 $R/tools/x3_accuracy.py > $OUT/x3_accuracy.log 2>&1
 python3 $R/tools/h2_loss_trajectory.py 80 > $OUT/h2_loss_trajectory.txt 2>&1
 python3 $R/tools/h2_trace.py > $OUT/h2_trace.txt 2>&1
+python3 $R/tools/conv_layers.py 50 110 > $OUT/conv_layers.txt 2>&1
+python3 $R/tools/fixture_margin.py > $OUT/fixture_margin.txt 2>&1
 python3 $R/tools/summarize_collection.py $OUT > $OUT/summary.txt 2>&1
 ls -la $OUT
