@@ -794,6 +794,28 @@ __global__ __launch_bounds__(256) void bn_fold_many_bwd_kernel(const FoldBwdDesc
     }
 }
 
+// out[i] = x[rows[i]] / gx[rows[i]] += g[i] for rows of F floats (F % 4 == 0), one float4 per thread: the stage-2 positives' rows of
+// the RoI tiles (htd_roi_head.py:163-166 `bbox_feats[pos_inds]` and its adjoint; ATen's index_select / index_add_ ran these 26 MB
+// at 0.1 TB/s)
+__global__ __launch_bounds__(256) void rows_gather_kernel(const float4 *__restrict__ x, const int64_t *__restrict__ rows,
+                                                          float4 *__restrict__ out, int64_t total, int F4)
+{
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / F4;
+        out[t] = x[rows[i] * F4 + (t - i * F4)];
+    }
+}
+__global__ __launch_bounds__(256) void rows_add_kernel(const float4 *__restrict__ g, const int64_t *__restrict__ rows,
+                                                       float4 *__restrict__ gx, int64_t total, int F4)
+{
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / F4;
+        const int64_t o = rows[i] * F4 + (t - i * F4);
+        const float4 a = gx[o], b = g[t];
+        gx[o] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
 inline unsigned grid_for(int64_t work, int block = 256, int cap = 4096)
 {
     int64_t b = htd::ceil_div(work, block);
@@ -1334,3 +1356,28 @@ extern "C" int htd_max_pool2d_bwd(const float *g, const int *idx, float *gx, int
                        Ho, Wo, k, stride, pad);
     return htd::check_launch("max_pool2d_bwd");
 }
+
+// Row selection and its adjoint: out[i][:] = x[rows[i]][:], i < n / gx[rows[i]][:] += g[i][:] (rows distinct: plain sums, bit-
+// reproducible); rows of F floats, F % 4 == 0, every rows[i] in [0, N).  torch.index_select(x, 0, rows) / x.index_add_(0, rows, g).
+extern "C" int htd_rows_gather(const float *x, const int64_t *rows, float *out, int64_t n, int64_t N, int F, void *stream)
+{
+    HTD_REQUIRE(n >= 0 && N >= 0 && F > 0 && F % 4 == 0, "rows_gather: bad sizes n=%lld N=%lld F=%d", (long long)n, (long long)N, F);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(x && rows && out, "rows_gather: null pointer");
+    const int64_t total = n * (F / 4);
+    hipLaunchKernelGGL(rows_gather_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const float4 *)x, rows,
+                       (float4 *)out, total, F / 4);
+    return htd::check_launch("rows_gather");
+}
+
+extern "C" int htd_rows_add(const float *g, const int64_t *rows, float *gx, int64_t n, int64_t N, int F, void *stream)
+{
+    HTD_REQUIRE(n >= 0 && N >= 0 && F > 0 && F % 4 == 0, "rows_add: bad sizes n=%lld N=%lld F=%d", (long long)n, (long long)N, F);
+    if (n == 0) return HTD_OK;
+    HTD_REQUIRE(g && rows && gx, "rows_add: null pointer");
+    const int64_t total = n * (F / 4);
+    hipLaunchKernelGGL(rows_add_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const float4 *)g, rows,
+                       (float4 *)gx, total, F / 4);
+    return htd::check_launch("rows_add");
+}
+

@@ -662,7 +662,15 @@ class PlainAndFusedFunction(Function):
             if stash.grad is not None and ctx.needs_input_grad[0]:
                 if gx is None:
                     gx = torch.zeros(xshape, device=stash.grad.device, dtype=stash.grad.dtype).contiguous(memory_format=CL)
-                gx.index_add_(0, stash.rows, stash.grad)          # distinct rows: plain sums, deterministic
+                sg = stash.grad
+                if gx.is_cuda and gx.dtype == torch.float32 and gx.is_contiguous(memory_format=CL) and sg.dtype == torch.float32 and \
+                        (gx[0].numel() % 4) == 0:
+                    sg = nhwc(sg)
+                    _drop_amax(gx)                                # written behind torch's back
+                    capi.call('htd_rows_add', _P(sg), _P(stash.rows.to(torch.int64).contiguous()), _P(gx), sg.size(0), gx.size(0),
+                              gx[0].numel(), _S(), work=('byte', 12.0 * sg.numel()))
+                else:
+                    gx.index_add_(0, stash.rows, stash.grad)      # distinct rows: plain sums, deterministic
             stash.rows = stash.grad = None
         return gx, None, gg, None
 
@@ -672,6 +680,13 @@ class _SelectRowsVia(Function):
     def forward(ctx, alias, rows, stash):
         ctx.stash, ctx.rows = stash, rows
         stash.pending = True
+        if alias.is_cuda and alias.dtype == torch.float32 and alias.dim() == 4 and alias.is_contiguous(memory_format=CL) and \
+                (alias[0].numel() % 4) == 0:
+            rows = rows.to(torch.int64).contiguous()
+            out = torch.empty((rows.numel(), ) + tuple(alias.shape[1:]), device=alias.device, dtype=alias.dtype, memory_format=CL)
+            capi.call('htd_rows_gather', _P(alias), _P(rows), _P(out), rows.numel(), alias.size(0), alias[0].numel(), _S(),
+                      work=('byte', 8.0 * out.numel()))
+            return out
         return torch.index_select(alias, 0, rows)
 
     @staticmethod

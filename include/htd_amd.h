@@ -697,6 +697,11 @@ int htd_pgraph_gather(const float *x, const int64_t *rows, const unsigned char *
 int htd_pgraph_scatter(const float *g, const int64_t *rows, const unsigned char *valid, float *gx, int64_t n_out, int64_t N,
                        int F, int Fo, int G, int transposed, void *stream);
 
+/* Row selection and its adjoint for the stage-2 positives of the RoI tiles (`bbox_feats[pos_inds]`, roi_heads/htd_roi_head.py:163-166):
+ * out[i] = x[rows[i]], i < n / gx[rows[i]] += g[i] (distinct rows).  Rows of F floats, F % 4 == 0, rows[i] in [0, N). */
+int htd_rows_gather(const float *x, const int64_t *rows, float *out, int64_t n, int64_t N, int F, void *stream);
+int htd_rows_add(const float *g, const int64_t *rows, float *gx, int64_t n, int64_t N, int F, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

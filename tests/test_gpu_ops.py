@@ -610,3 +610,43 @@ def test_static_samples_finish_kernel_equals_the_tensor_formulation(add_gt, P, S
         x, y = getattr(a, name), getattr(b, name)
         assert x.shape == y.shape and x.dtype == y.dtype and torch.equal(x, y), name
     assert int(b.npos.sum()) > 0 and bool((b.valid.sum(1) <= S).all())
+
+
+@pytest.mark.parametrize('N,n,shape', [(2048, 512, (256, 7, 7)), (96, 16, (64, 7, 7)), (33, 33, (8, 1, 1)), (10, 0, (16, 3, 3))])
+def test_row_selection_and_its_adjoint(N, n, shape):
+    """htd_rows_gather / htd_rows_add (the stage-2 positives' rows of the RoI tiles, htd_roi_head.py:163-166) against
+    torch.index_select / index_add_, bit for bit; and through mmcv_ops.select_rows_via the gradient of the selected rows joins
+    the PlainAndFused node's sum exactly as the dense autograd formulation's."""
+    from htd_amd import capi, mmcv_ops as M
+    dev = torch.device('cuda:0')
+    CL = torch.channels_last
+    g = torch.Generator().manual_seed(N + n)
+    x = torch.randn(N, *shape, generator=g).to(dev).contiguous(memory_format=CL)
+    rows = torch.randperm(N, generator=g)[:n].to(dev)
+    F = x[0].numel()
+    out = torch.empty((n, ) + shape, device=dev).contiguous(memory_format=CL)
+    capi.call('htd_rows_gather', capi.ptr(x), capi.ptr(rows), capi.ptr(out), n, N, F, capi.current_stream_ptr())
+    assert torch.equal(out, torch.index_select(x, 0, rows))
+    upd = torch.randn(n, *shape, generator=g).to(dev).contiguous(memory_format=CL)
+    gx = x.clone(memory_format=torch.preserve_format)
+    capi.call('htd_rows_add', capi.ptr(upd), capi.ptr(rows), capi.ptr(gx), n, N, F, capi.current_stream_ptr())
+    assert torch.equal(gx, x.clone().index_add_(0, rows, upd))
+    if n == 0 or shape[0] % 4:
+        return
+    B = 2
+    rois = torch.cat([torch.randint(0, B, (N, 1), generator=g).float(), torch.rand(N, 4, generator=g) * 50], 1).to(dev)
+    glob = torch.randn(B, shape[0], 1, 1, generator=g).to(dev)
+    w = torch.randn(n, *shape, generator=g).to(dev)
+    grads = []
+    for via in (True, False):
+        xr = x.clone(memory_format=torch.preserve_format).requires_grad_()
+        if via:
+            stash = M.RowStash()
+            both = M.plain_and_fused(xr, rois, glob, stash)
+            sel = M.select_rows_via(stash, rows)
+        else:
+            both = M.plain_and_fused(xr, rois, glob)
+            sel = torch.index_select(xr, 0, rows)
+        (both.square().sum() + (sel * w).sum()).backward()
+        grads.append(xr.grad.clone())
+    assert torch.equal(grads[0], grads[1])
