@@ -44,10 +44,15 @@ print('after warm-up: allocated %.1f MB, reserved %.1f MB' % (torch.cuda.memory_
 t0 = time.perf_counter()
 for i in range(steps):
     out = tr.train_step(datas[i % 4])
+    last_loss = out['loss'].detach()
     del out
     if (i + 1) % chunk == 0:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        from htd_amd import dense
+        if dense.H2_GUARD:              # HTD_H2_GUARD=1: no H2 launch of the chunk's last step overflowed its split (dense.h2_check)
+            dense.h2_check()
+        print('             loss %.4f%s' % (float(last_loss), '  (H2 guard clean)' if dense.H2_GUARD else ''), flush=True)
         print('steps %5d: %.2f ms/step in this chunk, allocated %.1f MB, peak %.1f MB, reserved %.1f MB' %
               (i + 1, (t1 - t0) / chunk * 1e3, torch.cuda.memory_allocated() / 1e6, torch.cuda.max_memory_allocated() / 1e6,
                torch.cuda.memory_reserved() / 1e6), flush=True)
