@@ -342,7 +342,8 @@ def main():
     trained = None
     if not args.infer and not args.trained_like and args.trained_like_steps > 0:
         trained_like_proposals(model, data, args.batch)
-        for _ in range(2):
+        TL_WARMUP = 4          # (the regression branch's tensors are new sizes for the allocator: two steps did not always cover them)
+        for _ in range(TL_WARMUP):
             trainer.train_step(data)
         sync()
         t1 = time.perf_counter()
@@ -356,7 +357,7 @@ def main():
             el = t.item()
         npos_t = int(model.roi_head._last_static[1].npos.sum()) if hasattr(model.roi_head, '_last_static') else None
         trained = dict(img_s=round(args.batch * n_ranks * args.trained_like_steps / el, 3),
-                       ms_per_step=round(el / args.trained_like_steps * 1e3, 3), steps=args.trained_like_steps, warmup=2,
+                       ms_per_step=round(el / args.trained_like_steps * 1e3, 3), steps=args.trained_like_steps, warmup=TL_WARMUP,
                        stage2_positives=npos_t, reg_branch_gflop=round(npos_t * 1.2355, 1) if npos_t is not None else None,
                        proposals='jittered gt boxes injected into the last 600 proposal slots of every image: 128 positives / '
                                  'image / stage (bench.py trained_like_proposals)')
