@@ -1503,7 +1503,10 @@ Cfg choose(int Co, int Ntot, int64_t K)
     c.mt = (int)htd::ceil_div(Co, c.bm);
     c.nt = (int)htd::ceil_div(Ntot, c.bn);
     const int64_t slices = htd::ceil_div(K, BKW);
-    int64_t want = htd::ceil_div(2304, (int64_t)c.mt * c.nt);       // ~9 workgroups per CU (measured 768..6144: flat from 2304)
+    // ~6 workgroups per CU.  Round 2 measured 768..6144 on the fp32-input kernels: flat from 2304; with the H2 kernels the reduce
+    // pass weighs more and 768..1536 is 1.4 % less weight-gradient time per step than 2304 (tools/sweep_wgrad_units.sh)
+    static const int units = getenv("HTD_WGRAD_UNITS") ? atoi(getenv("HTD_WGRAD_UNITS")) : 1536;
+    int64_t want = htd::ceil_div(units, (int64_t)c.mt * c.nt);
     const int64_t tiles = (int64_t)c.mt * c.nt;
     int64_t cap = std::max<int64_t>(1, slices / 20);                 // at least 20 slices (640 pixels) per split ...
     if (tiles * cap < 256)                                           // ... unless that leaves CUs idle (short reductions)
