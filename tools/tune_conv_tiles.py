@@ -40,7 +40,19 @@ def signature(name, ints, mask):
         return (B * Ho * Wo, Co, Ci, taps, int(mask[4 if q else 3] == '1') | h2)
     if name in ('htd_conv2d_bwd_data_x3p', 'htd_conv2d_bwd_data_x3h'):
         if len(ints) != 8:
-            return None                      # htd_conv2d_bwd_data_x3h_strided: one launch per parity class, scored
+            # htd_conv2d_bwd_data_x3h_strided (gy, amax, wplanesT, mask_src, gx, amax_out, ws, stream): one launch per parity class
+            # of gx's pixels, timed together -- ('strided', key of class 0, key of class 1, ...), all classes get the call's best tile
+            B, H, W, Ci, Co, kh, kw, stride, pad = ints
+            epi = (int(mask[3] == '1') << 1) | 4
+            keys = []
+            for c in range(stride * stride):
+                ph, pw = c // stride, c % stride
+                ny = sum(1 for ky in range(kh) if (ph + pad - ky) % stride == 0)
+                nx = sum(1 for kx in range(kw) if (pw + pad - kx) % stride == 0)
+                Hc, Wc = (H - ph + stride - 1) // stride if ph < H else 0, (W - pw + stride - 1) // stride if pw < W else 0
+                if ny * nx and Hc * Wc:
+                    keys.append((B * Hc * Wc, Ci, Co, ny * nx + 100, epi))
+            return ('strided', ) + tuple(keys)
         B, H, W, Ci, Co, kh, kw, pad = ints
         return (B * H * W, Ci, Co, kh * kw, int(mask[4 if q else 3] == '1') | (int(mask[3 if q else 2] == '1') << 1) | h2)
     if name == 'htd_conv2d_fwd':
@@ -131,6 +143,22 @@ def main():
           ' | pick   us/call')
     for sig in sorted(times[-1], key=lambda s_: -times[-1][s_][0]):
         auto_ms, calls = times[-1][sig]
+        if sig[0] == 'strided':             # the parity classes of one strided data gradient: one measurement, one pick for all of them
+            cand = {c: times[c][sig][0] for c in ids if sig in times[c]}
+            best = min(cand, key=cand.get)
+            pick = best if cand[best] < auto_ms * (1.0 - args.margin) else None
+            for key in sig[1:]:
+                if pick is not None and query(*key) != pick:
+                    table[key] = pick
+                elif pick is None and key in table:
+                    del table[key]
+            if pick is not None:
+                gained += (auto_ms - cand[best]) / args.steps
+            k0 = sig[1]
+            print(f'{k0[0]:8d} {k0[1]:5d} {k0[2]:5d} {k0[3]:4d} {k0[4]:3d} | {auto_ms / calls * 1e3:8.1f} ' +
+                  ' '.join(f'{cand[c] / calls * 1e3:8.1f}' if c in cand else f'{"-":>8s}' for c in ids) +
+                  f' | {("cfg" + str(pick)) if pick is not None else "auto":7s} x{calls // args.steps} (strided data gradient, {len(sig) - 1} classes)')
+            continue
         auto_cfg = query(*sig)
         cand = {}
         for c in ids:
